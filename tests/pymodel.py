@@ -1,0 +1,164 @@
+"""Pure-Python (big-int) model of the dusk-schnorr verify/sign path.  TEST INFRASTRUCTURE.
+
+Independent second restatement used to cross-check the C oracle (oracle/schnorr_oracle.c) on
+small cases: it uses the *affine* complete twisted-Edwards addition law and Python's modular
+inverse, not the extended-coordinate formulas of the oracle, so a slip in either shows up as a
+disagreement.  Follows the same reference call sites:
+
+  verify            /root/reference/src/keys/public.rs:121-130, 222-244, 401-415
+  challenge hashes  /root/reference/src/signatures.rs:127-134, 275-290
+  sign              /root/reference/src/keys/secret.rs:150-168, 217-240, 433-451
+
+Hash constants: same published recipe as oracle/gen_constants.py (PARITY UNPINNED).
+"""
+import hashlib
+
+Q = 0x73EDA753299D7D483339D80809A1D80553BDA402FFFE5BFEFFFFFFFF00000001
+R_ORDER = 0x0E7DB4EA6533AFA906673B0101343B00A6682093CCC81082D0970E5ED6F72CB7
+D = (-10240 * pow(10241, -1, Q)) % Q
+GEN = (0x3FD2814C43AC65A6F1FBF02D0FD6CCE62E3EBB21FD6C54ED4DF7B7FFEC7BEACA, 0x12)
+GEN_NUMS = (
+    0x5E67B8F316F414F7BD9514C773FD4456931E316A39FE4541921710179DF76377,
+    0x43D80EB3B2F3EB1B7B162DBEEB3B34FD9949BA0F82A5507A6705B707162E3EF8,
+)
+IDENTITY = (0, 1)
+WIDTH, FULL, PARTIAL = 5, 8, 59
+
+
+def on_curve(p):
+    u, v = p
+    return (-u * u + v * v - 1 - D * u * u * v * v) % Q == 0
+
+
+def padd(p, q):
+    u1, v1 = p
+    u2, v2 = q
+    k = D * u1 * u2 * v1 * v2 % Q
+    u3 = (u1 * v2 + v1 * u2) * pow(1 + k, -1, Q) % Q
+    v3 = (v1 * v2 + u1 * u2) * pow(1 - k, -1, Q) % Q
+    return (u3, v3)
+
+
+def pneg(p):
+    return ((-p[0]) % Q, p[1])
+
+
+def pmul(p, k):
+    acc = IDENTITY
+    for bit in range(k.bit_length() - 1, -1, -1):
+        acc = padd(acc, acc)
+        if (k >> bit) & 1:
+            acc = padd(acc, p)
+    return acc
+
+
+_RC = None
+_MDS = None
+
+
+def _consts():
+    global _RC, _MDS
+    if _RC is None:
+        rc, p, data = [], 1, b"poseidon-for-plonk"
+        for _ in range((FULL + PARTIAL) * WIDTH):
+            data = hashlib.sha512(data).digest()
+            p = (int.from_bytes(data, "little") + p) % Q
+            rc.append(p)
+        _RC = rc
+        _MDS = [[pow(i + j + WIDTH, -1, Q) for j in range(WIDTH)] for i in range(WIDTH)]
+    return _RC, _MDS
+
+
+def hades_permute(state):
+    rc, mds = _consts()
+    s = list(state)
+    ci = 0
+    for rnd in range(FULL + PARTIAL):
+        full = rnd < FULL // 2 or rnd >= FULL // 2 + PARTIAL
+        s = [(x + rc[ci + k]) % Q for k, x in enumerate(s)]
+        ci += WIDTH
+        if full:
+            s = [pow(x, 5, Q) for x in s]
+        else:
+            s[4] = pow(s[4], 5, Q)
+        s = [sum(mds[k][j] * s[j] for j in range(WIDTH)) % Q for k in range(WIDTH)]
+    return s
+
+
+def sponge_hash(msgs):
+    st = [0] * WIDTH
+    rate = WIDTH - 1
+    chunks = [msgs[i : i + rate] for i in range(0, len(msgs), rate)]
+    for ci, ch in enumerate(chunks):
+        for k, x in enumerate(ch):
+            st[1 + k] = (st[1 + k] + x) % Q
+        if ci == len(chunks) - 1:
+            if len(ch) < rate:
+                st[len(ch) + 1] = (st[len(ch) + 1] + 1) % Q
+            else:
+                st = hades_permute(st)
+                st[1] = (st[1] + 1) % Q
+        st = hades_permute(st)
+    return st[1]
+
+
+def truncated_hash(msgs):
+    return sponge_hash(msgs) & ((1 << 250) - 1)
+
+
+def challenge(R, m):
+    return truncated_hash([R[0], R[1], m])
+
+
+def challenge_double(R, Rp, m):
+    return truncated_hash([R[0], R[1], Rp[0], Rp[1], m])
+
+
+def verify_single(u, R, PK, m):
+    c = challenge(R, m)
+    return padd(pmul(GEN, u), pmul(PK, c)) == R
+
+
+def verify_double(u, R, Rp, PK, PKp, m):
+    c = challenge_double(R, Rp, m)
+    return padd(pmul(GEN, u), pmul(PK, c)) == R and padd(pmul(GEN_NUMS, u), pmul(PKp, c)) == Rp
+
+
+def verify_vargen(u, R, PK, Gen, m):
+    c = challenge(R, m)
+    return padd(pmul(Gen, u), pmul(PK, c)) == R
+
+
+def sign_single(sk, m, r):
+    R = pmul(GEN, r)
+    c = challenge(R, m)
+    return (r - c * sk) % R_ORDER, R
+
+
+def sign_double(sk, m, r):
+    R, Rp = pmul(GEN, r), pmul(GEN_NUMS, r)
+    c = challenge_double(R, Rp, m)
+    return (r - c * sk) % R_ORDER, R, Rp
+
+
+def sign_vargen(sk, gen, m, r):
+    R = pmul(gen, r)
+    c = challenge(R, m)
+    return (r - c * sk) % R_ORDER, R
+
+
+def compress(p):
+    u, v = p
+    return (v | ((u & 1) << 255)).to_bytes(32, "little")
+
+
+def le32(x):
+    return int(x).to_bytes(32, "little")
+
+
+def from_le(b):
+    return int.from_bytes(bytes(b), "little")
+
+
+def point_bytes(p):
+    return le32(p[0]) + le32(p[1])
