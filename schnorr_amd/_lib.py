@@ -1,0 +1,55 @@
+"""ctypes binding of libdsv.so (include/dsv.h).  There is NO CPU fallback: if the library is
+missing or a call fails, an exception is raised."""
+import ctypes
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libdsv.so")
+
+# every extern "C" symbol include/dsv.h declares
+SYMBOLS = [
+    "dsv_init", "dsv_shutdown", "dsv_version", "dsv_last_error", "dsv_device_count",
+    "dsv_verify_single", "dsv_verify_double", "dsv_verify_vargen", "dsv_verify_single_ext",
+    "dsv_workspace_bytes", "dsv_verify_single_dev", "dsv_verify_double_dev",
+    "dsv_verify_vargen_dev", "dsv_challenge_single", "dsv_challenge_double",
+    "dsv_challenge_single_dev", "dsv_challenge_double_dev", "dsv_sign_single", "dsv_sign_double",
+    "dsv_sign_vargen", "dsv_public_keys", "dsv_sign_single_dev", "dsv_sign_double_dev",
+    "dsv_public_keys_dev", "dsv_debug_table_entry", "dsv_debug_fq_mul",
+]
+
+
+class DsvError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def load():
+    """Load libdsv.so (building it first if hipcc is available and it is missing)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        from . import build as _build  # raises if hipcc is absent
+
+        _build.build()
+    try:
+        L = ctypes.CDLL(LIB_PATH)
+    except OSError as e:  # pragma: no cover
+        raise DsvError("cannot load the HIP engine %s: %s" % (LIB_PATH, e))
+    L.dsv_version.restype = ctypes.c_char_p
+    L.dsv_last_error.restype = ctypes.c_char_p
+    L.dsv_workspace_bytes.restype = ctypes.c_size_t
+    L.dsv_workspace_bytes.argtypes = [ctypes.c_size_t]
+    for name in SYMBOLS:
+        fn = getattr(L, name)  # AttributeError if a declared symbol is not exported
+        if name not in ("dsv_version", "dsv_last_error", "dsv_workspace_bytes"):
+            fn.restype = ctypes.c_int
+    _lib = L
+    return L
+
+
+def check(rc):
+    if rc != 0:
+        raise DsvError("dsv error %d: %s" % (rc, load().dsv_last_error().decode()))

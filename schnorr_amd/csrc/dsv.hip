@@ -1,0 +1,1003 @@
+// dsv.hip — MI355X (gfx950) batch Schnorr verification engine: kernels + C ABI (include/dsv.h).
+//
+// Pipeline per batch (one lane = one signature, 64 signatures per wavefront, no cross-lane
+// traffic, no LDS, no MFMA — integer modular arithmetic on 29-bit limbs, see fe29.h):
+//
+//   k_challenge     c = trunc250(Poseidon(R.u, R.v[, R'.u, R'.v], m))      (~20 % of the work)
+//   k_verify_fixed  ok &= [ u*G + c*PK == R ]                               (~80 %)
+//                   u*G   : 32 mixed additions from an 8-bit-window table of G (or G'),
+//                           896 KiB, built once on the device, L2-resident (4 MiB L2 per XCD)
+//                   c*PK  : 4-bit fixed windows, 16-entry per-lane table in scratch,
+//                           250 doublings + 63 additions
+//   k_verify_var    both bases variable (PublicKeyVarGen): Straus — one doubling chain shared
+//                   by the two 4-bit-window tables
+//
+// PublicKeyDouble::verify runs k_challenge<double> then k_verify_fixed twice (G/PK/R and
+// G'/PK'/R'), AND-ing into ok[].  HBM traffic per signature is 193 B (single) / 321 B
+// (double) / 257 B (vargen) in, 1 B out, plus 33 B of c/valid between the two kernels: the
+// path is VALU-bound by four orders of magnitude, not HBM-bound.
+#include <hip/hip_runtime.h>
+
+#include <atomic>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/dsv.h"
+#include "fe29.h"
+#include "fr.h"
+#include "hades29.h"
+#include "jubjub29.h"
+
+namespace dsv {
+
+// ------------------------------------------------------------------------------------------
+// device helpers
+// ------------------------------------------------------------------------------------------
+#ifndef DSV_WAVES_VERIFY
+#define DSV_WAVES_VERIFY 2
+#endif
+#ifndef DSV_WAVES_HASH
+#define DSV_WAVES_HASH 2
+#endif
+constexpr int kFixedWindows = 32;           // 8-bit windows over a 256-bit scalar
+constexpr int kFixedEntries = 256;
+constexpr int kEntryWords = 28;             // 27 used (3 x 9 limbs) + 1 pad: 7 x 16 B
+constexpr size_t kTableBytes = (size_t)kFixedWindows * kFixedEntries * kEntryWords * 4;
+
+DSV_DEV void load_words8(u32 (&w)[8], const uint8_t* base, size_t idx) {
+  const uint4* p = reinterpret_cast<const uint4*>(base + idx * 32);
+  uint4 a = p[0], b = p[1];
+  w[0] = a.x; w[1] = a.y; w[2] = a.z; w[3] = a.w;
+  w[4] = b.x; w[5] = b.y; w[6] = b.z; w[7] = b.w;
+}
+DSV_DEV void store_words8(uint8_t* base, size_t idx, const u32 (&w)[8]) {
+  uint4* p = reinterpret_cast<uint4*>(base + idx * 32);
+  p[0] = make_uint4(w[0], w[1], w[2], w[3]);
+  p[1] = make_uint4(w[4], w[5], w[6], w[7]);
+}
+// canonical LE bytes -> Montgomery fe29; returns false if the encoding is >= q
+DSV_DEV bool load_fq(Fe& out, const uint8_t* base, size_t idx) {
+  u32 w[8];
+  load_words8(w, base, idx);
+  bool ok = words_lt(w, kQ32);
+  out = fe_to_mont(fe_from_words_plain(w));
+  return ok;
+}
+DSV_DEV void store_fq(uint8_t* base, size_t idx, const Fe& mont) {
+  u32 w[8];
+  fe_to_words_plain(w, fe_from_mont(mont));
+  store_words8(base, idx, w);
+}
+
+DSV_DEV ANiels load_aniels(const u32* __restrict__ table, int window, u32 digit) {
+  const uint4* p = reinterpret_cast<const uint4*>(table + ((size_t)window * kFixedEntries + digit) * kEntryWords);
+  u32 w[kEntryWords];
+#pragma unroll
+  for (int i = 0; i < kEntryWords / 4; i++) {
+    uint4 v = p[i];
+    w[4 * i] = v.x; w[4 * i + 1] = v.y; w[4 * i + 2] = v.z; w[4 * i + 3] = v.w;
+  }
+  ANiels n;
+#pragma unroll
+  for (int i = 0; i < NL; i++) {
+    n.vpu.l[i] = w[i];
+    n.vmu.l[i] = w[NL + i];
+    n.t2d.l[i] = w[2 * NL + i];
+  }
+  return n;
+}
+
+// a^(q-2) (Fermat) — init-time and the *_ext entry points only
+DSV_DEV Fe fe_invert(const Fe& a) {
+  // q - 2: the low word of q is 1, so the subtraction borrows from word 1
+  const u32 e[8] = {0xffffffffu, kQ32[1] - 1, kQ32[2], kQ32[3], kQ32[4], kQ32[5], kQ32[6], kQ32[7]};
+  Fe acc = fe_one();
+#pragma unroll 1
+  for (int bit = 254; bit >= 0; bit--) {
+    acc = fe_sqr(acc);
+    if ((e[bit >> 5] >> (bit & 31)) & 1) acc = fe_mul(acc, a);
+  }
+  return acc;
+}
+
+// generic double-and-add over a 256-bit LE scalar (init-time table construction only)
+DSV_DEV Ext ext_mul_words(const Ext& p, const u32 (&s)[8]) {
+  Niels n = ext_to_niels(p);
+  Niels id = niels_identity();
+  Ext acc = ext_identity();
+#pragma unroll 1
+  for (int bit = 255; bit >= 0; bit--) {
+    acc = ext_double(acc);
+    bool b = (s[bit >> 5] >> (bit & 31)) & 1;
+    Niels sel;
+    sel.vpu = fe_select(b, n.vpu, id.vpu);
+    sel.vmu = fe_select(b, n.vmu, id.vmu);
+    sel.z = fe_select(b, n.z, id.z);
+    sel.t2d = fe_select(b, n.t2d, id.t2d);
+    acc = ext_add_niels(acc, sel);
+  }
+  return acc;
+}
+
+// ------------------------------------------------------------------------------------------
+// init: fixed-base tables.  table[w][d] = affine niels of (d * 2^(8w)) * Gen, canonical limbs.
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(64) k_build_fixed_table(u32* __restrict__ table, int which) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= kFixedWindows * kFixedEntries) return;
+  const int w = idx / kFixedEntries, d = idx % kFixedEntries;
+  const u32 gu[NL] = DSV_GEN_U, gv[NL] = DSV_GEN_V, nu[NL] = DSV_GENN_U, nv[NL] = DSV_GENN_V;
+  Ext g = which == 0 ? ext_from_affine(fe_const(gu), fe_const(gv))
+                     : ext_from_affine(fe_const(nu), fe_const(nv));
+  u32 s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  s[w >> 2] = (u32)d << (8 * (w & 3));
+  Ext p = ext_mul_words(g, s);
+  Fe zi = fe_invert(p.z);
+  Fe u = fe_mul(p.u, zi), v = fe_mul(p.v, zi);
+  Fe vpu = fe_canon(fe_add(v, u));
+  Fe vmu = fe_canon(fe_sub2(v, u));
+  Fe t2d = fe_canon(fe_mul(fe_mul(u, v), fe_const(kD2)));
+  u32* e = table + (size_t)idx * kEntryWords;
+#pragma unroll
+  for (int i = 0; i < NL; i++) {
+    e[i] = vpu.l[i];
+    e[NL + i] = vmu.l[i];
+    e[2 * NL + i] = t2d.l[i];
+  }
+  e[27] = 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// challenge hash
+// ------------------------------------------------------------------------------------------
+template <bool DOUBLE>
+__global__ void __launch_bounds__(256, DSV_WAVES_HASH)
+k_challenge(const uint8_t* __restrict__ R_uv, const uint8_t* __restrict__ Rp_uv,
+            const uint8_t* __restrict__ m, size_t n, uint8_t* __restrict__ c_out,
+            uint8_t* __restrict__ valid) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  Fe ru, rv, mm;
+  bool ok = load_fq(ru, R_uv, 2 * i);
+  ok &= load_fq(rv, R_uv, 2 * i + 1);
+  ok &= load_fq(mm, m, i);
+  Fe h;
+  if (DOUBLE) {
+    Fe pu, pv;
+    ok &= load_fq(pu, Rp_uv, 2 * i);
+    ok &= load_fq(pv, Rp_uv, 2 * i + 1);
+    h = poseidon_hash5(ru, rv, pu, pv, mm);
+  } else {
+    h = poseidon_hash3(ru, rv, mm);
+  }
+  u32 c[8];
+  poseidon_truncate(c, h);
+  store_words8(c_out, i, c);
+  if (valid) valid[i] = ok ? 1 : 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// scalar multiplications
+// ------------------------------------------------------------------------------------------
+// acc += u * Gen from the 8-bit-window table: 32 mixed additions, no doubling.  The running
+// accumulator is passed in so that u*G + c*PK needs no separate final addition (and no second
+// live point: register pressure, not arithmetic, is what limits occupancy here).
+DSV_DEV Ext fixed_base_accumulate(Ext acc, const u32 (&s)[8], const u32* __restrict__ table) {
+#pragma unroll 1
+  for (int w = 0; w < kFixedWindows; w++) {
+    u32 digit = (s[w >> 2] >> (8 * (w & 3))) & 0xff;
+    ANiels e = load_aniels(table, w, digit);
+    acc = ext_add_aniels(acc, e);
+  }
+  return acc;
+}
+
+constexpr int kVarDigits = 63;  // 4-bit windows over 252 bits
+
+DSV_DEV void build_var_table(Niels (&tbl)[16], const Fe& pu, const Fe& pv) {
+  Ext p = ext_from_affine(pu, pv);
+  Niels n1 = ext_to_niels(p);
+  tbl[0] = niels_identity();
+  tbl[1] = n1;
+  Ext cur = p;
+#pragma unroll 1
+  for (int i = 2; i < 16; i++) {
+    cur = ext_add_niels(cur, n1);
+    tbl[i] = ext_to_niels(cur);
+  }
+}
+DSV_DEV u32 digit4(const u32 (&s)[8], int k) { return (s[k >> 3] >> (4 * (k & 7))) & 0xf; }
+
+// acc = 16 * acc: three doublings that skip the (t1, t2) outputs nobody reads, then a full one
+DSV_DEV Ext ext_mul16(const Ext& p) {
+  Fe u = p.u, v = p.v, z = p.z;
+#pragma unroll 1
+  for (int j = 0; j < 3; j++) ext_double_uvz(u, v, z);
+  Ext q;
+  q.u = u;
+  q.v = v;
+  q.z = z;
+  return ext_double(q);
+}
+
+// c * P, 4-bit fixed windows (MSB first): acc = 16*acc + T[digit]
+DSV_DEV Ext var_base_mul(const u32 (&s)[8], const Niels (&tbl)[16]) {
+  Ext acc = ext_identity();
+#pragma unroll 1
+  for (int k = kVarDigits - 1; k >= 0; k--) {
+    acc = ext_mul16(acc);
+    acc = ext_add_niels(acc, tbl[digit4(s, k)]);
+  }
+  return acc;
+}
+// a*P + b*Q with one shared doubling chain (Straus)
+DSV_DEV Ext var_base_mul2(const u32 (&a)[8], const Niels (&tp)[16], const u32 (&b)[8],
+                          const Niels (&tq)[16]) {
+  Ext acc = ext_identity();
+#pragma unroll 1
+  for (int k = kVarDigits - 1; k >= 0; k--) {
+    acc = ext_mul16(acc);
+    acc = ext_add_niels(acc, tp[digit4(a, k)]);
+    acc = ext_add_niels(acc, tq[digit4(b, k)]);
+  }
+  return acc;
+}
+
+// ------------------------------------------------------------------------------------------
+// verify kernels
+// ------------------------------------------------------------------------------------------
+// ok[i] = ok_in & [ u*Gen + c*PK == R ]   with Gen given by its fixed-base table.
+// ACCUM = false: first pass, ok_in = valid[i];  ACCUM = true: ok_in = ok[i] (double scheme).
+// Order of work is chosen for register pressure: PK -> table (scratch) -> c*PK -> += u*Gen ->
+// compare with R; each input is loaded right before its only use.
+template <bool ACCUM>
+__global__ void __launch_bounds__(256, DSV_WAVES_VERIFY)
+k_verify_fixed(const uint8_t* __restrict__ u, const uint8_t* __restrict__ c,
+               const uint8_t* __restrict__ PK_uv, const uint8_t* __restrict__ R_uv,
+               const u32* __restrict__ table, const uint8_t* __restrict__ valid, size_t n,
+               uint8_t* __restrict__ ok) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  bool good = ACCUM ? (ok[i] != 0) : (valid[i] != 0);
+  Niels tbl[16];
+  {
+    Fe pku, pkv;
+    good &= load_fq(pku, PK_uv, 2 * i);
+    good &= load_fq(pkv, PK_uv, 2 * i + 1);
+    build_var_table(tbl, pku, pkv);
+  }
+  Ext acc;
+  {
+    u32 cs[8];
+    load_words8(cs, c, i);
+    acc = var_base_mul(cs, tbl);
+  }
+  {
+    u32 us[8];
+    load_words8(us, u, i);
+    good &= words_lt(us, kR32);
+    acc = fixed_base_accumulate(acc, us, table);
+  }
+  Fe ru, rv;
+  good &= load_fq(ru, R_uv, 2 * i);
+  good &= load_fq(rv, R_uv, 2 * i + 1);
+  bool eq = ext_eq_affine(acc, ru, rv);
+  ok[i] = (good & eq) ? 1 : 0;
+}
+
+__global__ void __launch_bounds__(256, DSV_WAVES_VERIFY)
+k_verify_var(const uint8_t* __restrict__ u, const uint8_t* __restrict__ c,
+             const uint8_t* __restrict__ PK_uv, const uint8_t* __restrict__ Gen_uv,
+             const uint8_t* __restrict__ R_uv, const uint8_t* __restrict__ valid, size_t n,
+             uint8_t* __restrict__ ok) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  bool good = valid[i] != 0;
+  Niels tp[16], tq[16];
+  {
+    Fe gu, gv;
+    good &= load_fq(gu, Gen_uv, 2 * i);
+    good &= load_fq(gv, Gen_uv, 2 * i + 1);
+    build_var_table(tp, gu, gv);
+  }
+  {
+    Fe pku, pkv;
+    good &= load_fq(pku, PK_uv, 2 * i);
+    good &= load_fq(pkv, PK_uv, 2 * i + 1);
+    build_var_table(tq, pku, pkv);
+  }
+  Ext acc;
+  {
+    u32 us[8], cs[8];
+    load_words8(us, u, i);
+    load_words8(cs, c, i);
+    good &= words_lt(us, kR32);
+    acc = var_base_mul2(us, tp, cs, tq);
+  }
+  Fe ru, rv;
+  good &= load_fq(ru, R_uv, 2 * i);
+  good &= load_fq(rv, R_uv, 2 * i + 1);
+  bool eq = ext_eq_affine(acc, ru, rv);
+  ok[i] = (good & eq) ? 1 : 0;
+}
+
+// (u, v, z) -> affine (u/z, v/z), canonical bytes; flags z == 0 / non-canonical as invalid
+__global__ void __launch_bounds__(256)
+k_normalize_uvz(const uint8_t* __restrict__ uvz, size_t n, uint8_t* __restrict__ uv,
+                uint8_t* __restrict__ valid, int accumulate) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  Fe x, y, z;
+  bool ok = load_fq(x, uvz, 3 * i);
+  ok &= load_fq(y, uvz, 3 * i + 1);
+  ok &= load_fq(z, uvz, 3 * i + 2);
+  Fe zc = fe_canon(z);
+  ok &= !fe_is_zero_canon(zc);
+  Fe zi = fe_invert(z);
+  store_fq(uv, 2 * i, fe_mul(x, zi));
+  store_fq(uv, 2 * i + 1, fe_mul(y, zi));
+  if (accumulate) ok &= valid[i] != 0;
+  valid[i] = ok ? 1 : 0;
+}
+__global__ void k_and_bytes(uint8_t* __restrict__ ok, const uint8_t* __restrict__ valid, size_t n) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) ok[i] = ok[i] & valid[i];
+}
+
+// ------------------------------------------------------------------------------------------
+// signing / key derivation ("next" row of the scope table: the step that precedes verify)
+// ------------------------------------------------------------------------------------------
+DSV_DEV void store_affine(uint8_t* out_uv, size_t i, const Ext& p) {
+  Fe zi = fe_invert(p.z);
+  store_fq(out_uv, 2 * i, fe_mul(p.u, zi));
+  store_fq(out_uv, 2 * i + 1, fe_mul(p.v, zi));
+}
+// out = scalar * Gen (fixed-base table), affine.  R = r*G, PK = sk*G
+// (/root/reference/src/keys/secret.rs:159, public.rs:61-67)
+__global__ void __launch_bounds__(256, DSV_WAVES_VERIFY)
+k_fixed_base_points(const uint8_t* __restrict__ scalar, const u32* __restrict__ table, size_t n,
+                    uint8_t* __restrict__ out_uv) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  u32 s[8];
+  load_words8(s, scalar, i);
+  Ext acc = fixed_base_accumulate(ext_identity(), s, table);
+  store_affine(out_uv, i, acc);
+}
+// out = scalar * P for a per-item base P (var-generator scheme: secret.rs:442, public.rs:337-344)
+__global__ void __launch_bounds__(256, DSV_WAVES_VERIFY)
+k_var_base_points(const uint8_t* __restrict__ scalar, const uint8_t* __restrict__ P_uv, size_t n,
+                  uint8_t* __restrict__ out_uv) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  Niels tbl[16];
+  {
+    Fe pu, pv;
+    load_fq(pu, P_uv, 2 * i);
+    load_fq(pv, P_uv, 2 * i + 1);
+    build_var_table(tbl, pu, pv);
+  }
+  u32 s[8];
+  load_words8(s, scalar, i);
+  Ext acc = var_base_mul(s, tbl);
+  store_affine(out_uv, i, acc);
+}
+// u = r - c * sk  in Fr  (secret.rs:165)
+__global__ void __launch_bounds__(256)
+k_sign_finish(const uint8_t* __restrict__ r, const uint8_t* c,  // c may alias u_out
+              const uint8_t* __restrict__ sk, size_t n, uint8_t* u_out) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  u32 rs[8], cs[8], ks[8], t[8], u[8];
+  load_words8(rs, r, i);
+  load_words8(cs, c, i);
+  load_words8(ks, sk, i);
+  fr_mul(t, cs, ks);
+  fr_sub(u, rs, t);
+  store_words8(u_out, i, u);
+}
+
+__global__ void __launch_bounds__(256)
+k_debug_fq_mul(const uint8_t* __restrict__ a, const uint8_t* __restrict__ b, size_t n,
+               uint8_t* __restrict__ out) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  Fe x, y;
+  load_fq(x, a, i);
+  load_fq(y, b, i);
+  // exercise mul, sqr, add, sub paths: out = a*b  (computed as ((a+b)^2 - a^2 - b^2) / 2 cross-checked)
+  Fe p = fe_mul(x, y);
+  Fe s = fe_sqr(fe_add(x, y));
+  Fe t = fe_sub4(fe_sub4(s, fe_sqr(x)), fe_sqr(y));  // 2ab, < 9.2 q
+  t = fe_mul(t, fe_one());                           // back to < 1.2 q before the comparison
+  bool same = fe_equal(t, fe_dbl(p));
+  u32 w[8];
+  fe_to_words_plain(w, fe_from_mont(p));
+  if (!same) w[7] |= 0x80000000u;  // poison: can never be canonical
+  store_words8(out, i, w);
+}
+
+}  // namespace dsv
+
+// ==========================================================================================
+// host side: context + C ABI
+// ==========================================================================================
+namespace {
+
+using namespace dsv;
+
+thread_local std::string g_err;
+int fail(int code, const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  g_err = buf;
+  return code;
+}
+#define HIP_TRY(expr)                                                                         \
+  do {                                                                                        \
+    hipError_t e_ = (expr);                                                                   \
+    if (e_ != hipSuccess)                                                                     \
+      return fail(DSV_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, \
+                  __LINE__);                                                                  \
+  } while (0)
+
+struct Context {
+  int device = -1;
+  u32* table[2] = {nullptr, nullptr};  // fixed-base tables for G, G'
+  // staging for the host-pointer entry points (grown on demand, guarded by mu)
+  std::mutex mu;
+  uint8_t* stage = nullptr;
+  size_t stage_bytes = 0;
+};
+Context g_ctx;
+std::mutex g_init_mu;
+std::atomic<bool> g_ready{false};
+
+int ensure_stage(size_t bytes) {
+  if (g_ctx.stage_bytes >= bytes) return DSV_OK;
+  if (g_ctx.stage) HIP_TRY(hipFree(g_ctx.stage));
+  g_ctx.stage = nullptr;
+  g_ctx.stage_bytes = 0;
+  size_t want = bytes + bytes / 4;
+  HIP_TRY(hipMalloc(&g_ctx.stage, want));
+  g_ctx.stage_bytes = want;
+  return DSV_OK;
+}
+
+inline unsigned grid_for(size_t n, unsigned block = 256) { return (unsigned)((n + block - 1) / block); }
+inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+int check_ready() {
+  if (!g_ready.load(std::memory_order_acquire))
+    return fail(DSV_ERR_NOT_INITIALIZED, "dsv_init() has not been called");
+  return DSV_OK;
+}
+int check_n(size_t n) {
+  if (n > DSV_MAX_BATCH) return fail(DSV_ERR_TOO_LARGE, "batch of %zu exceeds DSV_MAX_BATCH", n);
+  return DSV_OK;
+}
+
+// workspace layout for the *_dev verify entry points: c[n][32] | valid[n]
+struct Workspace {
+  uint8_t* c;
+  uint8_t* valid;
+};
+Workspace carve(void* ws, size_t n) {
+  Workspace w;
+  w.c = static_cast<uint8_t*>(ws);
+  w.valid = w.c + align_up(n * 32, 256);
+  return w;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* dsv_version(void) { return "dsv 0.1.0 (gfx950, fe29)"; }
+const char* dsv_last_error(void) { return g_err.c_str(); }
+
+int dsv_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+int dsv_init(int device) {
+  std::lock_guard<std::mutex> lk(g_init_mu);
+  if (g_ready.load()) {
+    if (g_ctx.device == device) return DSV_OK;
+    return fail(DSV_ERR_INVALID_ARGUMENT, "already initialised on device %d", g_ctx.device);
+  }
+  int count = 0;
+  if (hipGetDeviceCount(&count) != hipSuccess || count == 0)
+    return fail(DSV_ERR_NO_DEVICE, "no HIP device visible");
+  if (device < 0 || device >= count)
+    return fail(DSV_ERR_INVALID_ARGUMENT, "device %d out of range (count %d)", device, count);
+  HIP_TRY(hipSetDevice(device));
+  HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(c_hades_rc), DSV_HADES_RC_HOST, sizeof(DSV_HADES_RC_HOST)));
+  HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(c_hades_mds), DSV_HADES_MDS_HOST, sizeof(DSV_HADES_MDS_HOST)));
+  for (int g = 0; g < 2; g++) {
+    HIP_TRY(hipMalloc(&g_ctx.table[g], kTableBytes));
+    const int total = kFixedWindows * kFixedEntries;
+    hipLaunchKernelGGL(k_build_fixed_table, dim3((total + 63) / 64), dim3(64), 0, 0,
+                       g_ctx.table[g], g);
+    HIP_TRY(hipGetLastError());
+  }
+  HIP_TRY(hipDeviceSynchronize());
+  g_ctx.device = device;
+  g_ready.store(true, std::memory_order_release);
+  return DSV_OK;
+}
+
+int dsv_shutdown(void) {
+  std::lock_guard<std::mutex> lk(g_init_mu);
+  if (!g_ready.load()) return DSV_OK;
+  hipSetDevice(g_ctx.device);
+  hipDeviceSynchronize();
+  for (int g = 0; g < 2; g++) {
+    if (g_ctx.table[g]) hipFree(g_ctx.table[g]);
+    g_ctx.table[g] = nullptr;
+  }
+  if (g_ctx.stage) hipFree(g_ctx.stage);
+  g_ctx.stage = nullptr;
+  g_ctx.stage_bytes = 0;
+  g_ctx.device = -1;
+  g_ready.store(false);
+  return DSV_OK;
+}
+
+size_t dsv_workspace_bytes(size_t n) { return align_up(n * 32, 256) + align_up(n, 256) + 256; }
+
+// ---- device-pointer entry points --------------------------------------------------------
+int dsv_challenge_single_dev(const void* R_uv, const void* m, size_t n, void* c, void* valid,
+                             void* stream) {
+  if (int r = check_ready()) return r;
+  if (int r = check_n(n)) return r;
+  if (n == 0) return DSV_OK;
+  if (!R_uv || !m || !c) return fail(DSV_ERR_INVALID_ARGUMENT, "null pointer");
+  hipLaunchKernelGGL(k_challenge<false>, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream,
+                     (const uint8_t*)R_uv, (const uint8_t*)nullptr, (const uint8_t*)m, n,
+                     (uint8_t*)c, (uint8_t*)valid);
+  HIP_TRY(hipGetLastError());
+  return DSV_OK;
+}
+int dsv_challenge_double_dev(const void* R_uv, const void* Rp_uv, const void* m, size_t n, void* c,
+                             void* valid, void* stream) {
+  if (int r = check_ready()) return r;
+  if (int r = check_n(n)) return r;
+  if (n == 0) return DSV_OK;
+  if (!R_uv || !Rp_uv || !m || !c) return fail(DSV_ERR_INVALID_ARGUMENT, "null pointer");
+  hipLaunchKernelGGL(k_challenge<true>, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream,
+                     (const uint8_t*)R_uv, (const uint8_t*)Rp_uv, (const uint8_t*)m, n,
+                     (uint8_t*)c, (uint8_t*)valid);
+  HIP_TRY(hipGetLastError());
+  return DSV_OK;
+}
+
+int dsv_verify_single_dev(const void* u, const void* R_uv, const void* PK_uv, const void* m,
+                          size_t n, void* ok, void* workspace, void* stream) {
+  if (int r = check_ready()) return r;
+  if (int r = check_n(n)) return r;
+  if (n == 0) return DSV_OK;
+  if (!u || !R_uv || !PK_uv || !m || !ok || !workspace)
+    return fail(DSV_ERR_INVALID_ARGUMENT, "null pointer");
+  Workspace w = carve(workspace, n);
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(k_challenge<false>, dim3(grid_for(n)), dim3(256), 0, s, (const uint8_t*)R_uv,
+                     (const uint8_t*)nullptr, (const uint8_t*)m, n, w.c, w.valid);
+  hipLaunchKernelGGL(k_verify_fixed<false>, dim3(grid_for(n)), dim3(256), 0, s, (const uint8_t*)u,
+                     (const uint8_t*)w.c, (const uint8_t*)PK_uv, (const uint8_t*)R_uv,
+                     (const u32*)g_ctx.table[0], (const uint8_t*)w.valid, n, (uint8_t*)ok);
+  HIP_TRY(hipGetLastError());
+  return DSV_OK;
+}
+
+int dsv_verify_double_dev(const void* u, const void* R_uv, const void* Rp_uv, const void* PK_uv,
+                          const void* PKp_uv, const void* m, size_t n, void* ok, void* workspace,
+                          void* stream) {
+  if (int r = check_ready()) return r;
+  if (int r = check_n(n)) return r;
+  if (n == 0) return DSV_OK;
+  if (!u || !R_uv || !Rp_uv || !PK_uv || !PKp_uv || !m || !ok || !workspace)
+    return fail(DSV_ERR_INVALID_ARGUMENT, "null pointer");
+  Workspace w = carve(workspace, n);
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(k_challenge<true>, dim3(grid_for(n)), dim3(256), 0, s, (const uint8_t*)R_uv,
+                     (const uint8_t*)Rp_uv, (const uint8_t*)m, n, w.c, w.valid);
+  hipLaunchKernelGGL(k_verify_fixed<false>, dim3(grid_for(n)), dim3(256), 0, s, (const uint8_t*)u,
+                     (const uint8_t*)w.c, (const uint8_t*)PK_uv, (const uint8_t*)R_uv,
+                     (const u32*)g_ctx.table[0], (const uint8_t*)w.valid, n, (uint8_t*)ok);
+  hipLaunchKernelGGL(k_verify_fixed<true>, dim3(grid_for(n)), dim3(256), 0, s, (const uint8_t*)u,
+                     (const uint8_t*)w.c, (const uint8_t*)PKp_uv, (const uint8_t*)Rp_uv,
+                     (const u32*)g_ctx.table[1], (const uint8_t*)w.valid, n, (uint8_t*)ok);
+  HIP_TRY(hipGetLastError());
+  return DSV_OK;
+}
+
+int dsv_verify_vargen_dev(const void* u, const void* R_uv, const void* PK_uv, const void* Gen_uv,
+                          const void* m, size_t n, void* ok, void* workspace, void* stream) {
+  if (int r = check_ready()) return r;
+  if (int r = check_n(n)) return r;
+  if (n == 0) return DSV_OK;
+  if (!u || !R_uv || !PK_uv || !Gen_uv || !m || !ok || !workspace)
+    return fail(DSV_ERR_INVALID_ARGUMENT, "null pointer");
+  Workspace w = carve(workspace, n);
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(k_challenge<false>, dim3(grid_for(n)), dim3(256), 0, s, (const uint8_t*)R_uv,
+                     (const uint8_t*)nullptr, (const uint8_t*)m, n, w.c, w.valid);
+  hipLaunchKernelGGL(k_verify_var, dim3(grid_for(n)), dim3(256), 0, s, (const uint8_t*)u,
+                     (const uint8_t*)w.c, (const uint8_t*)PK_uv, (const uint8_t*)Gen_uv,
+                     (const uint8_t*)R_uv, (const uint8_t*)w.valid, n, (uint8_t*)ok);
+  HIP_TRY(hipGetLastError());
+  return DSV_OK;
+}
+
+// ---- host-pointer entry points ----------------------------------------------------------
+namespace {
+struct Stager {
+  uint8_t* base;
+  size_t off = 0;
+  explicit Stager(uint8_t* b) : base(b) {}
+  uint8_t* take(size_t bytes) {
+    uint8_t* p = base + off;
+    off += align_up(bytes, 256);
+    return p;
+  }
+};
+}  // namespace
+
+#define H2D(dst, src, bytes) HIP_TRY(hipMemcpyAsync((dst), (src), (bytes), hipMemcpyHostToDevice, 0))
+#define D2H(dst, src, bytes) HIP_TRY(hipMemcpyAsync((dst), (src), (bytes), hipMemcpyDeviceToHost, 0))
+
+int dsv_verify_single(const uint8_t* u, const uint8_t* R_uv, const uint8_t* PK_uv,
+                      const uint8_t* m, size_t n, uint8_t* ok) {
+  if (int r = check_ready()) return r;
+  if (int r = check_n(n)) return r;
+  if (n == 0) return DSV_OK;
+  if (!u || !R_uv || !PK_uv || !m || !ok) return fail(DSV_ERR_INVALID_ARGUMENT, "null pointer");
+  std::lock_guard<std::mutex> lk(g_ctx.mu);
+  HIP_TRY(hipSetDevice(g_ctx.device));
+  size_t need = align_up(n * 32, 256) * 2 + align_up(n * 64, 256) * 2 + align_up(n, 256) +
+                dsv_workspace_bytes(n);
+  if (int r = ensure_stage(need)) return r;
+  Stager st(g_ctx.stage);
+  uint8_t *du = st.take(n * 32), *dR = st.take(n * 64), *dPK = st.take(n * 64),
+          *dm = st.take(n * 32), *dok = st.take(n), *ws = st.take(dsv_workspace_bytes(n));
+  H2D(du, u, n * 32);
+  H2D(dR, R_uv, n * 64);
+  H2D(dPK, PK_uv, n * 64);
+  H2D(dm, m, n * 32);
+  if (int r = dsv_verify_single_dev(du, dR, dPK, dm, n, dok, ws, nullptr)) return r;
+  D2H(ok, dok, n);
+  HIP_TRY(hipStreamSynchronize(0));
+  return DSV_OK;
+}
+
+int dsv_verify_double(const uint8_t* u, const uint8_t* R_uv, const uint8_t* Rp_uv,
+                      const uint8_t* PK_uv, const uint8_t* PKp_uv, const uint8_t* m, size_t n,
+                      uint8_t* ok) {
+  if (int r = check_ready()) return r;
+  if (int r = check_n(n)) return r;
+  if (n == 0) return DSV_OK;
+  if (!u || !R_uv || !Rp_uv || !PK_uv || !PKp_uv || !m || !ok)
+    return fail(DSV_ERR_INVALID_ARGUMENT, "null pointer");
+  std::lock_guard<std::mutex> lk(g_ctx.mu);
+  HIP_TRY(hipSetDevice(g_ctx.device));
+  size_t need = align_up(n * 32, 256) * 2 + align_up(n * 64, 256) * 4 + align_up(n, 256) +
+                dsv_workspace_bytes(n);
+  if (int r = ensure_stage(need)) return r;
+  Stager st(g_ctx.stage);
+  uint8_t *du = st.take(n * 32), *dR = st.take(n * 64), *dRp = st.take(n * 64),
+          *dPK = st.take(n * 64), *dPKp = st.take(n * 64), *dm = st.take(n * 32),
+          *dok = st.take(n), *ws = st.take(dsv_workspace_bytes(n));
+  H2D(du, u, n * 32);
+  H2D(dR, R_uv, n * 64);
+  H2D(dRp, Rp_uv, n * 64);
+  H2D(dPK, PK_uv, n * 64);
+  H2D(dPKp, PKp_uv, n * 64);
+  H2D(dm, m, n * 32);
+  if (int r = dsv_verify_double_dev(du, dR, dRp, dPK, dPKp, dm, n, dok, ws, nullptr)) return r;
+  D2H(ok, dok, n);
+  HIP_TRY(hipStreamSynchronize(0));
+  return DSV_OK;
+}
+
+int dsv_verify_vargen(const uint8_t* u, const uint8_t* R_uv, const uint8_t* PK_uv,
+                      const uint8_t* Gen_uv, const uint8_t* m, size_t n, uint8_t* ok) {
+  if (int r = check_ready()) return r;
+  if (int r = check_n(n)) return r;
+  if (n == 0) return DSV_OK;
+  if (!u || !R_uv || !PK_uv || !Gen_uv || !m || !ok)
+    return fail(DSV_ERR_INVALID_ARGUMENT, "null pointer");
+  std::lock_guard<std::mutex> lk(g_ctx.mu);
+  HIP_TRY(hipSetDevice(g_ctx.device));
+  size_t need = align_up(n * 32, 256) * 2 + align_up(n * 64, 256) * 3 + align_up(n, 256) +
+                dsv_workspace_bytes(n);
+  if (int r = ensure_stage(need)) return r;
+  Stager st(g_ctx.stage);
+  uint8_t *du = st.take(n * 32), *dR = st.take(n * 64), *dPK = st.take(n * 64),
+          *dG = st.take(n * 64), *dm = st.take(n * 32), *dok = st.take(n),
+          *ws = st.take(dsv_workspace_bytes(n));
+  H2D(du, u, n * 32);
+  H2D(dR, R_uv, n * 64);
+  H2D(dPK, PK_uv, n * 64);
+  H2D(dG, Gen_uv, n * 64);
+  H2D(dm, m, n * 32);
+  if (int r = dsv_verify_vargen_dev(du, dR, dPK, dG, dm, n, dok, ws, nullptr)) return r;
+  D2H(ok, dok, n);
+  HIP_TRY(hipStreamSynchronize(0));
+  return DSV_OK;
+}
+
+int dsv_verify_single_ext(const uint8_t* u, const uint8_t* R_uvz, const uint8_t* PK_uvz,
+                          const uint8_t* m, size_t n, uint8_t* ok) {
+  if (int r = check_ready()) return r;
+  if (int r = check_n(n)) return r;
+  if (n == 0) return DSV_OK;
+  if (!u || !R_uvz || !PK_uvz || !m || !ok) return fail(DSV_ERR_INVALID_ARGUMENT, "null pointer");
+  std::lock_guard<std::mutex> lk(g_ctx.mu);
+  HIP_TRY(hipSetDevice(g_ctx.device));
+  size_t need = align_up(n * 32, 256) * 2 + align_up(n * 96, 256) * 2 + align_up(n * 64, 256) * 2 +
+                align_up(n, 256) * 2 + dsv_workspace_bytes(n);
+  if (int r = ensure_stage(need)) return r;
+  Stager st(g_ctx.stage);
+  uint8_t *du = st.take(n * 32), *dRz = st.take(n * 96), *dPKz = st.take(n * 96),
+          *dR = st.take(n * 64), *dPK = st.take(n * 64), *dm = st.take(n * 32), *dok = st.take(n),
+          *dvalid = st.take(n), *ws = st.take(dsv_workspace_bytes(n));
+  H2D(du, u, n * 32);
+  H2D(dRz, R_uvz, n * 96);
+  H2D(dPKz, PK_uvz, n * 96);
+  H2D(dm, m, n * 32);
+  hipLaunchKernelGGL(k_normalize_uvz, dim3(grid_for(n)), dim3(256), 0, 0, (const uint8_t*)dRz, n,
+                     dR, dvalid, 0);
+  hipLaunchKernelGGL(k_normalize_uvz, dim3(grid_for(n)), dim3(256), 0, 0, (const uint8_t*)dPKz, n,
+                     dPK, dvalid, 1);
+  if (int r = dsv_verify_single_dev(du, dR, dPK, dm, n, dok, ws, nullptr)) return r;
+  hipLaunchKernelGGL(k_and_bytes, dim3(grid_for(n)), dim3(256), 0, 0, dok, (const uint8_t*)dvalid, n);
+  HIP_TRY(hipGetLastError());
+  D2H(ok, dok, n);
+  HIP_TRY(hipStreamSynchronize(0));
+  return DSV_OK;
+}
+
+int dsv_challenge_single(const uint8_t* R_uv, const uint8_t* m, size_t n, uint8_t* c) {
+  if (int r = check_ready()) return r;
+  if (int r = check_n(n)) return r;
+  if (n == 0) return DSV_OK;
+  if (!R_uv || !m || !c) return fail(DSV_ERR_INVALID_ARGUMENT, "null pointer");
+  std::lock_guard<std::mutex> lk(g_ctx.mu);
+  HIP_TRY(hipSetDevice(g_ctx.device));
+  if (int r = ensure_stage(align_up(n * 64, 256) + 2 * align_up(n * 32, 256))) return r;
+  Stager st(g_ctx.stage);
+  uint8_t *dR = st.take(n * 64), *dm = st.take(n * 32), *dc = st.take(n * 32);
+  H2D(dR, R_uv, n * 64);
+  H2D(dm, m, n * 32);
+  if (int r = dsv_challenge_single_dev(dR, dm, n, dc, nullptr, nullptr)) return r;
+  D2H(c, dc, n * 32);
+  HIP_TRY(hipStreamSynchronize(0));
+  return DSV_OK;
+}
+int dsv_challenge_double(const uint8_t* R_uv, const uint8_t* Rp_uv, const uint8_t* m, size_t n,
+                         uint8_t* c) {
+  if (int r = check_ready()) return r;
+  if (int r = check_n(n)) return r;
+  if (n == 0) return DSV_OK;
+  if (!R_uv || !Rp_uv || !m || !c) return fail(DSV_ERR_INVALID_ARGUMENT, "null pointer");
+  std::lock_guard<std::mutex> lk(g_ctx.mu);
+  HIP_TRY(hipSetDevice(g_ctx.device));
+  if (int r = ensure_stage(2 * align_up(n * 64, 256) + 2 * align_up(n * 32, 256))) return r;
+  Stager st(g_ctx.stage);
+  uint8_t *dR = st.take(n * 64), *dRp = st.take(n * 64), *dm = st.take(n * 32),
+          *dc = st.take(n * 32);
+  H2D(dR, R_uv, n * 64);
+  H2D(dRp, Rp_uv, n * 64);
+  H2D(dm, m, n * 32);
+  if (int r = dsv_challenge_double_dev(dR, dRp, dm, n, dc, nullptr, nullptr)) return r;
+  D2H(c, dc, n * 32);
+  HIP_TRY(hipStreamSynchronize(0));
+  return DSV_OK;
+}
+
+// ---- signing / key derivation -----------------------------------------------------------
+int dsv_public_keys_dev(const void* sk, int which, size_t n, void* PK_uv, void* stream) {
+  if (int r = check_ready()) return r;
+  if (int r = check_n(n)) return r;
+  if (n == 0) return DSV_OK;
+  if (!sk || !PK_uv || which < 0 || which > 1) return fail(DSV_ERR_INVALID_ARGUMENT, "bad argument");
+  hipLaunchKernelGGL(k_fixed_base_points, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream,
+                     (const uint8_t*)sk, (const u32*)g_ctx.table[which], n, (uint8_t*)PK_uv);
+  HIP_TRY(hipGetLastError());
+  return DSV_OK;
+}
+// scratch use: c is written to u (32 B per item) before k_sign_finish overwrites it in place
+int dsv_sign_single_dev(const void* sk, const void* m, const void* r, size_t n, void* u, void* R_uv,
+                        void* stream) {
+  if (int rc = check_ready()) return rc;
+  if (int rc = check_n(n)) return rc;
+  if (n == 0) return DSV_OK;
+  if (!sk || !m || !r || !u || !R_uv) return fail(DSV_ERR_INVALID_ARGUMENT, "null pointer");
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(k_fixed_base_points, dim3(grid_for(n)), dim3(256), 0, s, (const uint8_t*)r,
+                     (const u32*)g_ctx.table[0], n, (uint8_t*)R_uv);
+  hipLaunchKernelGGL(k_challenge<false>, dim3(grid_for(n)), dim3(256), 0, s, (const uint8_t*)R_uv,
+                     (const uint8_t*)nullptr, (const uint8_t*)m, n, (uint8_t*)u, (uint8_t*)nullptr);
+  hipLaunchKernelGGL(k_sign_finish, dim3(grid_for(n)), dim3(256), 0, s, (const uint8_t*)r,
+                     (const uint8_t*)u, (const uint8_t*)sk, n, (uint8_t*)u);
+  HIP_TRY(hipGetLastError());
+  return DSV_OK;
+}
+int dsv_sign_double_dev(const void* sk, const void* m, const void* r, size_t n, void* u, void* R_uv,
+                        void* Rp_uv, void* stream) {
+  if (int rc = check_ready()) return rc;
+  if (int rc = check_n(n)) return rc;
+  if (n == 0) return DSV_OK;
+  if (!sk || !m || !r || !u || !R_uv || !Rp_uv) return fail(DSV_ERR_INVALID_ARGUMENT, "null pointer");
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(k_fixed_base_points, dim3(grid_for(n)), dim3(256), 0, s, (const uint8_t*)r,
+                     (const u32*)g_ctx.table[0], n, (uint8_t*)R_uv);
+  hipLaunchKernelGGL(k_fixed_base_points, dim3(grid_for(n)), dim3(256), 0, s, (const uint8_t*)r,
+                     (const u32*)g_ctx.table[1], n, (uint8_t*)Rp_uv);
+  hipLaunchKernelGGL(k_challenge<true>, dim3(grid_for(n)), dim3(256), 0, s, (const uint8_t*)R_uv,
+                     (const uint8_t*)Rp_uv, (const uint8_t*)m, n, (uint8_t*)u, (uint8_t*)nullptr);
+  hipLaunchKernelGGL(k_sign_finish, dim3(grid_for(n)), dim3(256), 0, s, (const uint8_t*)r,
+                     (const uint8_t*)u, (const uint8_t*)sk, n, (uint8_t*)u);
+  HIP_TRY(hipGetLastError());
+  return DSV_OK;
+}
+
+int dsv_public_keys(const uint8_t* sk, int which, const uint8_t* gen_uv, size_t n, uint8_t* PK_uv) {
+  if (int r = check_ready()) return r;
+  if (int r = check_n(n)) return r;
+  if (n == 0) return DSV_OK;
+  if (!sk || !PK_uv || which < 0 || which > 1) return fail(DSV_ERR_INVALID_ARGUMENT, "bad argument");
+  std::lock_guard<std::mutex> lk(g_ctx.mu);
+  HIP_TRY(hipSetDevice(g_ctx.device));
+  if (int r = ensure_stage(align_up(n * 32, 256) + 2 * align_up(n * 64, 256))) return r;
+  Stager st(g_ctx.stage);
+  uint8_t *dsk = st.take(n * 32), *dg = st.take(n * 64), *dpk = st.take(n * 64);
+  H2D(dsk, sk, n * 32);
+  if (gen_uv) {
+    H2D(dg, gen_uv, n * 64);
+    hipLaunchKernelGGL(k_var_base_points, dim3(grid_for(n)), dim3(256), 0, 0, (const uint8_t*)dsk,
+                       (const uint8_t*)dg, n, dpk);
+    HIP_TRY(hipGetLastError());
+  } else {
+    if (int r = dsv_public_keys_dev(dsk, which, n, dpk, nullptr)) return r;
+  }
+  D2H(PK_uv, dpk, n * 64);
+  HIP_TRY(hipStreamSynchronize(0));
+  return DSV_OK;
+}
+int dsv_sign_single(const uint8_t* sk, const uint8_t* m, const uint8_t* r, size_t n, uint8_t* u,
+                    uint8_t* R_uv) {
+  if (int rc = check_ready()) return rc;
+  if (int rc = check_n(n)) return rc;
+  if (n == 0) return DSV_OK;
+  if (!sk || !m || !r || !u || !R_uv) return fail(DSV_ERR_INVALID_ARGUMENT, "null pointer");
+  std::lock_guard<std::mutex> lk(g_ctx.mu);
+  HIP_TRY(hipSetDevice(g_ctx.device));
+  if (int rc = ensure_stage(4 * align_up(n * 32, 256) + align_up(n * 64, 256))) return rc;
+  Stager st(g_ctx.stage);
+  uint8_t *dsk = st.take(n * 32), *dm = st.take(n * 32), *dr = st.take(n * 32),
+          *du = st.take(n * 32), *dR = st.take(n * 64);
+  H2D(dsk, sk, n * 32);
+  H2D(dm, m, n * 32);
+  H2D(dr, r, n * 32);
+  if (int rc = dsv_sign_single_dev(dsk, dm, dr, n, du, dR, nullptr)) return rc;
+  D2H(u, du, n * 32);
+  D2H(R_uv, dR, n * 64);
+  HIP_TRY(hipStreamSynchronize(0));
+  return DSV_OK;
+}
+int dsv_sign_double(const uint8_t* sk, const uint8_t* m, const uint8_t* r, size_t n, uint8_t* u,
+                    uint8_t* R_uv, uint8_t* Rp_uv) {
+  if (int rc = check_ready()) return rc;
+  if (int rc = check_n(n)) return rc;
+  if (n == 0) return DSV_OK;
+  if (!sk || !m || !r || !u || !R_uv || !Rp_uv) return fail(DSV_ERR_INVALID_ARGUMENT, "null pointer");
+  std::lock_guard<std::mutex> lk(g_ctx.mu);
+  HIP_TRY(hipSetDevice(g_ctx.device));
+  if (int rc = ensure_stage(4 * align_up(n * 32, 256) + 2 * align_up(n * 64, 256))) return rc;
+  Stager st(g_ctx.stage);
+  uint8_t *dsk = st.take(n * 32), *dm = st.take(n * 32), *dr = st.take(n * 32),
+          *du = st.take(n * 32), *dR = st.take(n * 64), *dRp = st.take(n * 64);
+  H2D(dsk, sk, n * 32);
+  H2D(dm, m, n * 32);
+  H2D(dr, r, n * 32);
+  if (int rc = dsv_sign_double_dev(dsk, dm, dr, n, du, dR, dRp, nullptr)) return rc;
+  D2H(u, du, n * 32);
+  D2H(R_uv, dR, n * 64);
+  D2H(Rp_uv, dRp, n * 64);
+  HIP_TRY(hipStreamSynchronize(0));
+  return DSV_OK;
+}
+int dsv_sign_vargen(const uint8_t* sk, const uint8_t* Gen_uv, const uint8_t* m, const uint8_t* r,
+                    size_t n, uint8_t* u, uint8_t* R_uv) {
+  if (int rc = check_ready()) return rc;
+  if (int rc = check_n(n)) return rc;
+  if (n == 0) return DSV_OK;
+  if (!sk || !Gen_uv || !m || !r || !u || !R_uv) return fail(DSV_ERR_INVALID_ARGUMENT, "null pointer");
+  std::lock_guard<std::mutex> lk(g_ctx.mu);
+  HIP_TRY(hipSetDevice(g_ctx.device));
+  if (int rc = ensure_stage(4 * align_up(n * 32, 256) + 2 * align_up(n * 64, 256))) return rc;
+  Stager st(g_ctx.stage);
+  uint8_t *dsk = st.take(n * 32), *dm = st.take(n * 32), *dr = st.take(n * 32),
+          *du = st.take(n * 32), *dG = st.take(n * 64), *dR = st.take(n * 64);
+  H2D(dsk, sk, n * 32);
+  H2D(dm, m, n * 32);
+  H2D(dr, r, n * 32);
+  H2D(dG, Gen_uv, n * 64);
+  hipLaunchKernelGGL(k_var_base_points, dim3(grid_for(n)), dim3(256), 0, 0, (const uint8_t*)dr,
+                     (const uint8_t*)dG, n, dR);
+  hipLaunchKernelGGL(k_challenge<false>, dim3(grid_for(n)), dim3(256), 0, 0, (const uint8_t*)dR,
+                     (const uint8_t*)nullptr, (const uint8_t*)dm, n, du, (uint8_t*)nullptr);
+  hipLaunchKernelGGL(k_sign_finish, dim3(grid_for(n)), dim3(256), 0, 0, (const uint8_t*)dr,
+                     (const uint8_t*)du, (const uint8_t*)dsk, n, du);
+  HIP_TRY(hipGetLastError());
+  D2H(u, du, n * 32);
+  D2H(R_uv, dR, n * 64);
+  HIP_TRY(hipStreamSynchronize(0));
+  return DSV_OK;
+}
+
+int dsv_debug_table_entry(int which, int window, int digit, uint8_t out96[96]) {
+  if (int r = check_ready()) return r;
+  if (which < 0 || which > 1 || window < 0 || window >= kFixedWindows || digit < 0 ||
+      digit >= kFixedEntries || !out96)
+    return fail(DSV_ERR_INVALID_ARGUMENT, "bad table coordinates");
+  u32 e[kEntryWords];
+  HIP_TRY(hipSetDevice(g_ctx.device));
+  HIP_TRY(hipMemcpy(e, g_ctx.table[which] + ((size_t)window * kFixedEntries + digit) * kEntryWords,
+                    sizeof e, hipMemcpyDeviceToHost));
+  // entries are Montgomery (R = 2^261) canonical limbs; hand back the raw limbs as 3 x 9 x 29-bit
+  // packed LE integers so the test can undo the Montgomery factor with Python integers.
+  for (int f = 0; f < 3; f++) {
+    unsigned __int128 acc = 0;
+    int bits = 0, o = 0;
+    uint8_t* dst = out96 + 32 * f;
+    memset(dst, 0, 32);
+    for (int i = 0; i < NL; i++) {
+      acc |= (unsigned __int128)e[f * NL + i] << bits;
+      bits += 29;
+      while (bits >= 8 && o < 32) {
+        dst[o++] = (uint8_t)acc;
+        acc >>= 8;
+        bits -= 8;
+      }
+    }
+    while (o < 32) {
+      dst[o++] = (uint8_t)acc;
+      acc >>= 8;
+    }
+  }
+  return DSV_OK;
+}
+
+int dsv_debug_fq_mul(const uint8_t* a, const uint8_t* b, size_t n, uint8_t* out) {
+  if (int r = check_ready()) return r;
+  if (int r = check_n(n)) return r;
+  if (n == 0) return DSV_OK;
+  if (!a || !b || !out) return fail(DSV_ERR_INVALID_ARGUMENT, "null pointer");
+  std::lock_guard<std::mutex> lk(g_ctx.mu);
+  HIP_TRY(hipSetDevice(g_ctx.device));
+  if (int r = ensure_stage(3 * align_up(n * 32, 256))) return r;
+  Stager st(g_ctx.stage);
+  uint8_t *da = st.take(n * 32), *db = st.take(n * 32), *dout = st.take(n * 32);
+  H2D(da, a, n * 32);
+  H2D(db, b, n * 32);
+  hipLaunchKernelGGL(k_debug_fq_mul, dim3(grid_for(n)), dim3(256), 0, 0, (const uint8_t*)da,
+                     (const uint8_t*)db, n, dout);
+  HIP_TRY(hipGetLastError());
+  D2H(out, dout, n * 32);
+  HIP_TRY(hipStreamSynchronize(0));
+  return DSV_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,290 @@
+// fe29.h — BLS12-381 scalar field (= JubJub base field Fq) arithmetic for gfx950 lanes.
+//
+// Representation.  One field element lives in ONE lane as 9 limbs of 29 bits in 9 VGPRs
+// (value = sum l[i] 2^(29 i)), Montgomery form with R = 2^261.  Why not 8 x 32 saturated
+// limbs: measured on MI355X (tools/microbench/valu_rates.hip, profiles/r01_valu_rates.txt)
+// v_mad_u64_u32 issues at the SAME ~4 cycles per wave64 as v_add_co_u32 / v_addc_co_u32,
+// so what costs is the carry bookkeeping, not the multiplier.  With 29-bit limbs a whole
+// 9x9 schoolbook product plus the interleaved Montgomery reduction accumulates in 64-bit
+// column registers with NO carry instruction at all: each step is one in-place
+// v_mad_u64_u32 (D = S0*S1 + D).  A multiply is 81 + 72 MADs + 72 carry/normalise ops = 225
+// VALU instructions (a squaring 189); hipcc emits exactly that from the plain C++ below.
+// R = 2^261 leaves 6 spare bits over q (255 bits), so products of lazily-added operands
+// never need a conditional subtraction: values stay below ~8q between reductions.
+//
+// Contracts (checked by tests/test_fe29_model.py on a bit-exact Python model of this file):
+//   fe_mul/fe_sqr(a, b): max_limb(a) * max_limb(b) <= 1.5 * 2^60  and  a*b < 2^261 * q * 0.5
+//                        -> result limbs < 2^29 (limb 8 < 2^25), value < a*b/2^261 + q
+//   fe_add(a, b)       : limb-wise, no carry; caller keeps limbs < 2^31
+//   fe_sub2/4/8(a, b)  : a + k*q - b with a redundant-limb k*q whose limbs dominate b's
+//                        (b limbs <= 2^30 - 2, b < (k - 0.01) q), then one parallel carry pass
+//                        -> limbs < 2^29 + 8
+// "dot5" (5-term dot product with ONE reduction) is used by the Hades MDS layer.
+//
+// Reference semantics being reproduced: dusk-bls12_381 `BlsScalar` mul/add/sub/square as used
+// by the verify path (/root/reference/src/keys/public.rs:121-130 via dusk-jubjub operators);
+// only values mod q are observable, never the representation.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "dsv_constants.h"
+
+namespace dsv {
+
+typedef uint32_t u32;
+typedef uint64_t u64;
+
+constexpr int NL = 9;
+constexpr u32 M29 = (1u << 29) - 1;
+
+struct Fe {
+  u32 l[NL];
+};
+
+#define DSV_DEV __device__ __forceinline__
+
+__device__ constexpr u32 kQ29[NL] = DSV_Q29;
+__device__ constexpr u32 kBias2[NL] = DSV_BIAS2;
+__device__ constexpr u32 kBias4[NL] = DSV_BIAS4;
+__device__ constexpr u32 kBias8[NL] = DSV_BIAS8;
+__device__ constexpr u32 kQx1[NL] = DSV_Q29_X1;
+__device__ constexpr u32 kQx2[NL] = DSV_Q29_X2;
+__device__ constexpr u32 kQx4[NL] = DSV_Q29_X4;
+__device__ constexpr u32 kQx8[NL] = DSV_Q29_X8;
+__device__ constexpr u32 kR2[NL] = DSV_R2;
+__device__ constexpr u32 kOne[NL] = DSV_ONE;
+__device__ constexpr u32 kD2[NL] = DSV_D2;
+__device__ constexpr u32 kQ32[8] = DSV_Q32;
+__device__ constexpr u32 kR32[8] = DSV_R32;
+
+DSV_DEV Fe fe_const(const u32 (&c)[NL]) {
+  Fe r;
+#pragma unroll
+  for (int i = 0; i < NL; i++) r.l[i] = c[i];
+  return r;
+}
+DSV_DEV Fe fe_zero() {
+  Fe r;
+#pragma unroll
+  for (int i = 0; i < NL; i++) r.l[i] = 0;
+  return r;
+}
+DSV_DEV Fe fe_one() { return fe_const(kOne); }
+
+// ---- Montgomery reduction of 17 column sums c[0..16] (c[17] scratch), R = 2^261 ----------
+// q = 1 (mod 2^29)  =>  -q^-1 = -1 (mod 2^29): the quotient digit is just the negated low limb,
+// and digit * q[0] only contributes the carry that clears that limb.
+DSV_DEV Fe fe_reduce_cols(u64 (&c)[18]) {
+  u64 k = 0;
+#pragma unroll
+  for (int i = 0; i < NL; i++) {
+    u64 s = c[i] + k;
+    u32 m = (0u - (u32)s) & M29;
+    k = (s + m) >> 29;
+#pragma unroll
+    for (int j = 1; j < NL; j++) c[i + j] += (u64)m * kQ29[j];
+  }
+  Fe r;
+#pragma unroll
+  for (int i = 0; i < NL - 1; i++) {
+    u64 s = c[NL + i] + k;
+    r.l[i] = (u32)s & M29;
+    k = s >> 29;
+  }
+  r.l[NL - 1] = (u32)k;
+  return r;
+}
+
+DSV_DEV Fe fe_mul(const Fe& a, const Fe& b) {
+  u64 c[18];
+#pragma unroll
+  for (int k = 0; k < 17; k++) {
+    u64 s = 0;
+#pragma unroll
+    for (int i = 0; i < NL; i++) {
+      const int j = k - i;
+      if (j >= 0 && j < NL) s += (u64)a.l[i] * b.l[j];
+    }
+    c[k] = s;
+  }
+  c[17] = 0;
+  return fe_reduce_cols(c);
+}
+
+// squaring: cross terms once, against a pre-doubled operand (45 MADs instead of 81)
+DSV_DEV Fe fe_sqr(const Fe& a) {
+  u32 d[NL];
+#pragma unroll
+  for (int i = 0; i < NL; i++) d[i] = a.l[i] << 1;
+  u64 c[18];
+#pragma unroll
+  for (int k = 0; k < 17; k++) {
+    u64 s = 0;
+#pragma unroll
+    for (int i = 0; i < NL; i++) {
+      const int j = k - i;
+      if (j > i && j < NL) s += (u64)d[i] * a.l[j];
+    }
+    if ((k & 1) == 0) s += (u64)a.l[k / 2] * a.l[k / 2];
+    c[k] = s;
+  }
+  c[17] = 0;
+  return fe_reduce_cols(c);
+}
+
+// sum_{t<5} a[t]*b[t] with one reduction (b limbs < 2^29: constants)
+DSV_DEV Fe fe_dot5(const Fe (&a)[5], const Fe (&b)[5]) {
+  u64 c[18];
+#pragma unroll
+  for (int k = 0; k < 17; k++) {
+    u64 s = 0;
+#pragma unroll
+    for (int t = 0; t < 5; t++) {
+#pragma unroll
+      for (int i = 0; i < NL; i++) {
+        const int j = k - i;
+        if (j >= 0 && j < NL) s += (u64)a[t].l[i] * b[t].l[j];
+      }
+    }
+    c[k] = s;
+  }
+  c[17] = 0;
+  return fe_reduce_cols(c);
+}
+
+DSV_DEV Fe fe_add(const Fe& a, const Fe& b) {
+  Fe r;
+#pragma unroll
+  for (int i = 0; i < NL; i++) r.l[i] = a.l[i] + b.l[i];
+  return r;
+}
+DSV_DEV Fe fe_dbl(const Fe& a) {
+  Fe r;
+#pragma unroll
+  for (int i = 0; i < NL; i++) r.l[i] = a.l[i] << 1;
+  return r;
+}
+// one parallel carry pass: limbs < 2^32 in -> limbs 0..7 < 2^29 + 8 out (limb 8 absorbs)
+DSV_DEV Fe fe_carry(const Fe& a) {
+  Fe r;
+  r.l[0] = a.l[0] & M29;
+#pragma unroll
+  for (int i = 1; i < NL - 1; i++) r.l[i] = (a.l[i] & M29) + (a.l[i - 1] >> 29);
+  r.l[NL - 1] = a.l[NL - 1] + (a.l[NL - 2] >> 29);
+  return r;
+}
+template <int K>
+DSV_DEV Fe fe_sub_bias(const Fe& a, const Fe& b) {
+  Fe r;
+#pragma unroll
+  for (int i = 0; i < NL; i++) {
+    const u32 bias = (K == 2) ? kBias2[i] : (K == 4) ? kBias4[i] : kBias8[i];
+    r.l[i] = a.l[i] + (bias - b.l[i]);
+  }
+  return fe_carry(r);
+}
+DSV_DEV Fe fe_sub2(const Fe& a, const Fe& b) { return fe_sub_bias<2>(a, b); }
+DSV_DEV Fe fe_sub4(const Fe& a, const Fe& b) { return fe_sub_bias<4>(a, b); }
+DSV_DEV Fe fe_sub8(const Fe& a, const Fe& b) { return fe_sub_bias<8>(a, b); }
+DSV_DEV Fe fe_neg2(const Fe& b) { return fe_sub_bias<2>(fe_zero(), b); }
+
+DSV_DEV Fe fe_select(bool c, const Fe& a, const Fe& b) {  // c ? a : b
+  Fe r;
+#pragma unroll
+  for (int i = 0; i < NL; i++) r.l[i] = c ? a.l[i] : b.l[i];
+  return r;
+}
+
+// ---- canonical form ------------------------------------------------------------------------
+// full ripple carry; value unchanged, limbs 0..7 < 2^29
+DSV_DEV Fe fe_ripple(const Fe& a) {
+  Fe r;
+  u32 k = 0;
+#pragma unroll
+  for (int i = 0; i < NL - 1; i++) {
+    u32 s = a.l[i] + k;  // callers keep a.l[i] < 2^31
+    r.l[i] = s & M29;
+    k = s >> 29;
+  }
+  r.l[NL - 1] = a.l[NL - 1] + k;
+  return r;
+}
+// r = a - m if a >= m else a   (both ripple-normalised)
+DSV_DEV Fe fe_cond_sub(const Fe& a, const u32 (&m)[NL]) {
+  Fe d;
+  u32 borrow = 0;
+#pragma unroll
+  for (int i = 0; i < NL; i++) {
+    u32 s = a.l[i] - m[i] - borrow;
+    borrow = s >> 31;  // limbs < 2^30 so bit 31 set iff negative
+    d.l[i] = (i < NL - 1) ? (s & M29) : s;
+  }
+  return fe_select(borrow != 0, a, d);
+}
+// unique representative in [0, q) of a value < 16 q (plain integer, not a Montgomery op)
+DSV_DEV Fe fe_canon(const Fe& a) {
+  Fe r = fe_ripple(a);
+  r = fe_cond_sub(r, kQx8);
+  r = fe_cond_sub(r, kQx4);
+  r = fe_cond_sub(r, kQx2);
+  r = fe_cond_sub(r, kQx1);
+  return r;
+}
+DSV_DEV bool fe_is_zero_canon(const Fe& a) {
+  u32 o = 0;
+#pragma unroll
+  for (int i = 0; i < NL; i++) o |= a.l[i];
+  return o == 0;
+}
+// a == b (mod q) for lazily reduced a, b (limbs <= 2^30 - 2, b < 7.9 q)
+DSV_DEV bool fe_equal(const Fe& a, const Fe& b) {
+  return fe_is_zero_canon(fe_canon(fe_sub8(a, b)));
+}
+
+// ---- conversions: 8 x u32 little-endian words (canonical integer) <-> fe29 -----------------
+DSV_DEV Fe fe_from_words_plain(const u32 (&w)[8]) {
+  Fe r;
+#pragma unroll
+  for (int i = 0; i < NL; i++) {
+    const int bit = 29 * i;
+    const int wi = bit >> 5, sh = bit & 31;
+    u32 lo = w[wi] >> sh;
+    if (sh > 3 && wi + 1 < 8) lo |= w[wi + 1] << (32 - sh);
+    r.l[i] = lo & M29;
+  }
+  return r;
+}
+DSV_DEV void fe_to_words_plain(u32 (&w)[8], const Fe& a) {  // a canonical (limbs < 2^29)
+#pragma unroll
+  for (int k = 0; k < 8; k++) {
+    // word k covers bits [32k, 32k+32)
+    const int lo_limb = (32 * k) / 29, off = (32 * k) % 29;
+    u32 v = a.l[lo_limb] >> off;
+    int have = 29 - off;
+    if (lo_limb + 1 < NL) v |= a.l[lo_limb + 1] << have;
+    have += 29;
+    if (have < 32 && lo_limb + 2 < NL) v |= a.l[lo_limb + 2] << have;
+    w[k] = v;
+  }
+}
+DSV_DEV Fe fe_to_mont(const Fe& plain) { return fe_mul(plain, fe_const(kR2)); }
+// Montgomery -> canonical plain integer limbs
+DSV_DEV Fe fe_from_mont(const Fe& a) {
+  Fe one = fe_zero();
+  one.l[0] = 1;
+  return fe_canon(fe_mul(a, one));
+}
+
+// words < modulus ?  (8 x u32 LE)
+DSV_DEV bool words_lt(const u32 (&w)[8], const u32 (&m)[8]) {
+  u32 borrow = 0;
+#pragma unroll
+  for (int i = 0; i < 8; i++) {
+    u64 d = (u64)w[i] - m[i] - borrow;
+    borrow = (u32)(d >> 63);
+  }
+  return borrow != 0;
+}
+
+}  // namespace dsv

@@ -1,0 +1,138 @@
+// jubjub29.h — JubJub (twisted Edwards a = -1 over Fq) group law on fe29 lanes.
+//
+// Formulas are the extended-coordinate ones dusk-jubjub's operators implement (SURVEY.md
+// Appendix A.3), i.e. what `GENERATOR_EXTENDED * u`, `pk * c`, `+` and `==` evaluate at
+// /root/reference/src/keys/public.rs:127-129, :236-243, :411-414:
+//   double : 4S + 3M     add (extended niels) : 8M     add (affine niels, z = 1) : 7M
+// They are complete on the whole curve (a = -1 is a square, d is not), so identity, small-order
+// and repeated points need no special case — same as the reference.
+//
+// Lazy-reduction bookkeeping (bounds in units of q, "N" = output of fe_mul, < 1.5 q,
+// limbs < 2^29): every fe_add result feeds a multiply directly (limbs < 2^30); every
+// subtraction goes through a biased subtract + one carry pass.  The worst case of each
+// formula is annotated inline and re-checked numerically by tests/test_fe29_model.py.
+#pragma once
+#include "fe29.h"
+
+namespace dsv {
+
+struct Ext {  // (u, v, z, t1, t2): u = U/Z, v = V/Z, t1*t2 = UV/Z
+  Fe u, v, z, t1, t2;
+};
+struct Niels {  // (v+u, v-u, z, 2d*t)
+  Fe vpu, vmu, z, t2d;
+};
+struct ANiels {  // affine niels: z = 1
+  Fe vpu, vmu, t2d;
+};
+
+DSV_DEV Ext ext_identity() {
+  Ext r;
+  r.u = fe_zero();
+  r.v = fe_one();
+  r.z = fe_one();
+  r.t1 = fe_zero();
+  r.t2 = fe_zero();
+  return r;
+}
+DSV_DEV Ext ext_from_affine(const Fe& u, const Fe& v) {
+  Ext r;
+  r.u = u;
+  r.v = v;
+  r.z = fe_one();
+  r.t1 = u;
+  r.t2 = v;
+  return r;
+}
+DSV_DEV Niels niels_identity() {
+  Niels n;
+  n.vpu = fe_one();
+  n.vmu = fe_one();
+  n.z = fe_one();
+  n.t2d = fe_zero();
+  return n;
+}
+
+// in : u, v, z  N (< 1.5q)            (t1, t2 unused)
+// out: u, v, z  N;  t1 < 5.2q (carried limbs), t2 < 2.1q (limbs < 2^30)
+DSV_DEV Ext ext_double(const Ext& p) {
+  Fe uu = fe_sqr(p.u);                      // < 1.04
+  Fe vv = fe_sqr(p.v);                      // < 1.04
+  Fe zz2 = fe_dbl(fe_sqr(p.z));             // < 2.1, limbs < 2^30
+  Fe uv2 = fe_sqr(fe_add(p.u, p.v));        // (3q)^2 -> < 1.13
+  Fe vpu = fe_add(vv, uu);                  // < 2.1, limbs < 2^30
+  Fe vmu = fe_sub2(vv, uu);                 // < 3.1
+  Fe cu = fe_sub4(uv2, vpu);                // < 5.2
+  Fe ct = fe_sub4(zz2, vmu);                // < 6.1
+  Ext r;
+  r.u = fe_mul(cu, ct);                     // 5.2*6.1*0.01414+1 = 1.45
+  r.v = fe_mul(vpu, vmu);                   // < 1.1
+  r.z = fe_mul(vmu, ct);                    // < 1.3
+  r.t1 = cu;
+  r.t2 = vpu;
+  return r;
+}
+
+// doubling that keeps only (u, v, z): inside a run of doublings nobody reads t1/t2
+DSV_DEV void ext_double_uvz(Fe& u, Fe& v, Fe& z) {
+  Fe uu = fe_sqr(u);
+  Fe vv = fe_sqr(v);
+  Fe zz2 = fe_dbl(fe_sqr(z));
+  Fe uv2 = fe_sqr(fe_add(u, v));
+  Fe vpu = fe_add(vv, uu);
+  Fe vmu = fe_sub2(vv, uu);
+  Fe cu = fe_sub4(uv2, vpu);
+  Fe ct = fe_sub4(zz2, vmu);
+  u = fe_mul(cu, ct);
+  v = fe_mul(vpu, vmu);
+  z = fe_mul(vmu, ct);
+}
+
+// shared tail of both additions.  a, b, c < 1.2 (N);  d < 3.0 with limbs < 2^30
+DSV_DEV Ext ext_add_tail(const Fe& a, const Fe& b, const Fe& c, const Fe& d) {
+  Fe cu = fe_sub2(b, a);                    // < 3.2
+  Fe cv = fe_add(b, a);                     // < 2.4, limbs < 2^30
+  Fe cz = fe_carry(fe_add(d, c));           // < 4.2, carried
+  Fe ct = fe_sub2(d, c);                    // < 5.0
+  Ext r;
+  r.u = fe_mul(cu, ct);                     // < 1.23
+  r.v = fe_mul(cv, cz);                     // < 1.15
+  r.z = fe_mul(cz, ct);                     // < 1.3
+  r.t1 = cu;
+  r.t2 = cv;
+  return r;
+}
+// p: u,v,z N; t1 < 5.2 carried, t2 < 2.4 limbs < 2^30.   n: all N, limbs < 2^29
+DSV_DEV Ext ext_add_niels(const Ext& p, const Niels& n) {
+  Fe a = fe_mul(fe_sub2(p.v, p.u), n.vmu);  // 3.5*1.5 -> < 1.08
+  Fe b = fe_mul(fe_add(p.v, p.u), n.vpu);   // 3.0*1.5 -> < 1.07
+  Fe c = fe_mul(fe_mul(p.t1, p.t2), n.t2d); // (5.2*2.4 -> 1.18) * 1.5 -> < 1.03
+  Fe d = fe_dbl(fe_mul(p.z, n.z));          // < 2.1, limbs < 2^30
+  return ext_add_tail(a, b, c, d);
+}
+DSV_DEV Ext ext_add_aniels(const Ext& p, const ANiels& n) {
+  Fe a = fe_mul(fe_sub2(p.v, p.u), n.vmu);
+  Fe b = fe_mul(fe_add(p.v, p.u), n.vpu);
+  Fe c = fe_mul(fe_mul(p.t1, p.t2), n.t2d);
+  Fe d = fe_dbl(p.z);                       // < 3.0, limbs < 2^30
+  return ext_add_tail(a, b, c, d);
+}
+// to_niels: (v+u, v-u, z, t1*t2*2d), all brought to N / carried form for table storage
+DSV_DEV Niels ext_to_niels(const Ext& p) {
+  Niels n;
+  n.vpu = fe_carry(fe_add(p.v, p.u));       // < 3.0, limbs < 2^29 + 8
+  n.vmu = fe_sub2(p.v, p.u);                // < 3.5
+  n.z = p.z;
+  n.t2d = fe_mul(fe_mul(p.t1, p.t2), fe_const(kD2));
+  return n;
+}
+
+// projective equality against an affine point (Ru, Rv), i.e. `point_1.eq(&sig.R())` with
+// R.z = 1: u1 * 1 == Ru * z1  and  v1 * 1 == Rv * z1
+DSV_DEV bool ext_eq_affine(const Ext& p, const Fe& ru, const Fe& rv) {
+  bool e1 = fe_equal(p.u, fe_mul(ru, p.z));
+  bool e2 = fe_equal(p.v, fe_mul(rv, p.z));
+  return e1 & e2;
+}
+
+}  // namespace dsv

@@ -1,0 +1,243 @@
+"""Batch entry points of the MI355X engine over numpy (host buffers) and torch (HBM-resident)
+arrays.  Thin marshalling only — all arithmetic happens in libdsv.so's HIP kernels.
+
+Array conventions (see include/dsv.h): uint8, C-contiguous,
+  scalars  [n, 32]   points [n, 64] (affine u || v)   ext points [n, 96] (u || v || z)
+Returns uint8 verdict vectors [n] (1 = the reference's verify() would return true).
+"""
+import ctypes
+
+import numpy as np
+
+from . import _lib
+
+_initialised_device = None
+
+
+def init(device=0):
+    """dsv_init: select the GPU and build the fixed-base tables (idempotent)."""
+    global _initialised_device
+    if _initialised_device is not None:
+        if _initialised_device != device:
+            raise _lib.DsvError("engine already initialised on device %d" % _initialised_device)
+        return
+    L = _lib.load()
+    _lib.check(L.dsv_init(ctypes.c_int(device)))
+    _initialised_device = device
+
+
+def shutdown():
+    global _initialised_device
+    if _initialised_device is not None:
+        _lib.check(_lib.load().dsv_shutdown())
+        _initialised_device = None
+
+
+def version():
+    return _lib.load().dsv_version().decode()
+
+
+def _arr(a, width):
+    a = np.ascontiguousarray(a, dtype=np.uint8)
+    if a.ndim == 1 and a.shape[0] == width:
+        a = a.reshape(1, width)
+    if a.ndim != 2 or a.shape[1] != width:
+        raise ValueError("expected uint8 array of shape [n, %d], got %r" % (width, a.shape))
+    return a
+
+
+def _p(a):
+    return ctypes.c_void_p(a.ctypes.data)
+
+
+def _same_n(*arrs):
+    n = arrs[0].shape[0]
+    for a in arrs:
+        if a.shape[0] != n:
+            raise ValueError("batch arrays disagree on n: %r" % [x.shape for x in arrs])
+    return n
+
+
+# ------------------------------------------------------------------ host-buffer path
+def verify_single(u, R, PK, m):
+    u, R, PK, m = _arr(u, 32), _arr(R, 64), _arr(PK, 64), _arr(m, 32)
+    n = _same_n(u, R, PK, m)
+    ok = np.zeros(n, dtype=np.uint8)
+    _lib.check(_lib.load().dsv_verify_single(_p(u), _p(R), _p(PK), _p(m), ctypes.c_size_t(n), _p(ok)))
+    return ok
+
+
+def verify_double(u, R, Rp, PK, PKp, m):
+    u, R, Rp, PK, PKp, m = (_arr(u, 32), _arr(R, 64), _arr(Rp, 64), _arr(PK, 64), _arr(PKp, 64),
+                            _arr(m, 32))
+    n = _same_n(u, R, Rp, PK, PKp, m)
+    ok = np.zeros(n, dtype=np.uint8)
+    _lib.check(_lib.load().dsv_verify_double(_p(u), _p(R), _p(Rp), _p(PK), _p(PKp), _p(m),
+                                             ctypes.c_size_t(n), _p(ok)))
+    return ok
+
+
+def verify_vargen(u, R, PK, Gen, m):
+    u, R, PK, Gen, m = _arr(u, 32), _arr(R, 64), _arr(PK, 64), _arr(Gen, 64), _arr(m, 32)
+    n = _same_n(u, R, PK, Gen, m)
+    ok = np.zeros(n, dtype=np.uint8)
+    _lib.check(_lib.load().dsv_verify_vargen(_p(u), _p(R), _p(PK), _p(Gen), _p(m),
+                                             ctypes.c_size_t(n), _p(ok)))
+    return ok
+
+
+def verify_single_ext(u, R_uvz, PK_uvz, m):
+    u, R, PK, m = _arr(u, 32), _arr(R_uvz, 96), _arr(PK_uvz, 96), _arr(m, 32)
+    n = _same_n(u, R, PK, m)
+    ok = np.zeros(n, dtype=np.uint8)
+    _lib.check(_lib.load().dsv_verify_single_ext(_p(u), _p(R), _p(PK), _p(m), ctypes.c_size_t(n),
+                                                 _p(ok)))
+    return ok
+
+
+def challenge_single(R, m):
+    R, m = _arr(R, 64), _arr(m, 32)
+    n = _same_n(R, m)
+    c = np.zeros((n, 32), dtype=np.uint8)
+    _lib.check(_lib.load().dsv_challenge_single(_p(R), _p(m), ctypes.c_size_t(n), _p(c)))
+    return c
+
+
+def challenge_double(R, Rp, m):
+    R, Rp, m = _arr(R, 64), _arr(Rp, 64), _arr(m, 32)
+    n = _same_n(R, Rp, m)
+    c = np.zeros((n, 32), dtype=np.uint8)
+    _lib.check(_lib.load().dsv_challenge_double(_p(R), _p(Rp), _p(m), ctypes.c_size_t(n), _p(c)))
+    return c
+
+
+def sign_single(sk, m, r):
+    sk, m, r = _arr(sk, 32), _arr(m, 32), _arr(r, 32)
+    n = _same_n(sk, m, r)
+    u = np.zeros((n, 32), dtype=np.uint8)
+    R = np.zeros((n, 64), dtype=np.uint8)
+    _lib.check(_lib.load().dsv_sign_single(_p(sk), _p(m), _p(r), ctypes.c_size_t(n), _p(u), _p(R)))
+    return u, R
+
+
+def sign_double(sk, m, r):
+    sk, m, r = _arr(sk, 32), _arr(m, 32), _arr(r, 32)
+    n = _same_n(sk, m, r)
+    u = np.zeros((n, 32), dtype=np.uint8)
+    R = np.zeros((n, 64), dtype=np.uint8)
+    Rp = np.zeros((n, 64), dtype=np.uint8)
+    _lib.check(_lib.load().dsv_sign_double(_p(sk), _p(m), _p(r), ctypes.c_size_t(n), _p(u), _p(R),
+                                           _p(Rp)))
+    return u, R, Rp
+
+
+def sign_vargen(sk, Gen, m, r):
+    sk, Gen, m, r = _arr(sk, 32), _arr(Gen, 64), _arr(m, 32), _arr(r, 32)
+    n = _same_n(sk, Gen, m, r)
+    u = np.zeros((n, 32), dtype=np.uint8)
+    R = np.zeros((n, 64), dtype=np.uint8)
+    _lib.check(_lib.load().dsv_sign_vargen(_p(sk), _p(Gen), _p(m), _p(r), ctypes.c_size_t(n),
+                                           _p(u), _p(R)))
+    return u, R
+
+
+def public_keys(sk, which=0, Gen=None):
+    sk = _arr(sk, 32)
+    n = sk.shape[0]
+    PK = np.zeros((n, 64), dtype=np.uint8)
+    g = None
+    if Gen is not None:
+        g = _arr(Gen, 64)
+        _same_n(sk, g)
+    _lib.check(_lib.load().dsv_public_keys(_p(sk), ctypes.c_int(which),
+                                           _p(g) if g is not None else ctypes.c_void_p(0),
+                                           ctypes.c_size_t(n), _p(PK)))
+    return PK
+
+
+def debug_table_entry(which, window, digit):
+    out = np.zeros(96, dtype=np.uint8)
+    _lib.check(_lib.load().dsv_debug_table_entry(ctypes.c_int(which), ctypes.c_int(window),
+                                                 ctypes.c_int(digit), _p(out)))
+    return out
+
+
+def debug_fq_mul(a, b):
+    a, b = _arr(a, 32), _arr(b, 32)
+    n = _same_n(a, b)
+    out = np.zeros((n, 32), dtype=np.uint8)
+    _lib.check(_lib.load().dsv_debug_fq_mul(_p(a), _p(b), ctypes.c_size_t(n), _p(out)))
+    return out
+
+
+# ------------------------------------------------------------------ HBM-resident path (torch)
+def _tp(t, width):
+    import torch
+
+    if not (isinstance(t, torch.Tensor) and t.is_cuda and t.dtype == torch.uint8 and
+            t.is_contiguous()):
+        raise ValueError("expected a contiguous uint8 CUDA tensor")
+    if t.dim() != 2 or t.shape[1] != width:
+        raise ValueError("expected shape [n, %d], got %r" % (width, tuple(t.shape)))
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def workspace_bytes(n):
+    return int(_lib.load().dsv_workspace_bytes(ctypes.c_size_t(n)))
+
+
+def _stream_ptr(stream):
+    import torch
+
+    s = stream if stream is not None else torch.cuda.current_stream()
+    return ctypes.c_void_p(s.cuda_stream)
+
+
+def verify_single_dev(u, R, PK, m, ok, workspace, stream=None):
+    """Enqueue on `stream` (default: torch's current stream); does not synchronise."""
+    n = u.shape[0]
+    _lib.check(_lib.load().dsv_verify_single_dev(
+        _tp(u, 32), _tp(R, 64), _tp(PK, 64), _tp(m, 32), ctypes.c_size_t(n),
+        ctypes.c_void_p(ok.data_ptr()), ctypes.c_void_p(workspace.data_ptr()), _stream_ptr(stream)))
+
+
+def verify_double_dev(u, R, Rp, PK, PKp, m, ok, workspace, stream=None):
+    n = u.shape[0]
+    _lib.check(_lib.load().dsv_verify_double_dev(
+        _tp(u, 32), _tp(R, 64), _tp(Rp, 64), _tp(PK, 64), _tp(PKp, 64), _tp(m, 32),
+        ctypes.c_size_t(n), ctypes.c_void_p(ok.data_ptr()), ctypes.c_void_p(workspace.data_ptr()),
+        _stream_ptr(stream)))
+
+
+def verify_vargen_dev(u, R, PK, Gen, m, ok, workspace, stream=None):
+    n = u.shape[0]
+    _lib.check(_lib.load().dsv_verify_vargen_dev(
+        _tp(u, 32), _tp(R, 64), _tp(PK, 64), _tp(Gen, 64), _tp(m, 32), ctypes.c_size_t(n),
+        ctypes.c_void_p(ok.data_ptr()), ctypes.c_void_p(workspace.data_ptr()), _stream_ptr(stream)))
+
+
+def challenge_single_dev(R, m, c, valid=None, stream=None):
+    n = m.shape[0]
+    _lib.check(_lib.load().dsv_challenge_single_dev(
+        _tp(R, 64), _tp(m, 32), ctypes.c_size_t(n), ctypes.c_void_p(c.data_ptr()),
+        ctypes.c_void_p(valid.data_ptr() if valid is not None else 0), _stream_ptr(stream)))
+
+
+def sign_single_dev(sk, m, r, u, R, stream=None):
+    n = sk.shape[0]
+    _lib.check(_lib.load().dsv_sign_single_dev(
+        _tp(sk, 32), _tp(m, 32), _tp(r, 32), ctypes.c_size_t(n), _tp(u, 32), _tp(R, 64),
+        _stream_ptr(stream)))
+
+
+def sign_double_dev(sk, m, r, u, R, Rp, stream=None):
+    n = sk.shape[0]
+    _lib.check(_lib.load().dsv_sign_double_dev(
+        _tp(sk, 32), _tp(m, 32), _tp(r, 32), ctypes.c_size_t(n), _tp(u, 32), _tp(R, 64),
+        _tp(Rp, 64), _stream_ptr(stream)))
+
+
+def public_keys_dev(sk, which, PK, stream=None):
+    n = sk.shape[0]
+    _lib.check(_lib.load().dsv_public_keys_dev(
+        _tp(sk, 32), ctypes.c_int(which), ctypes.c_size_t(n), _tp(PK, 64), _stream_ptr(stream)))
