@@ -1,0 +1,256 @@
+#!/usr/bin/env python3
+"""bench.py — Schnorr verifies/sec on MI355X (BASELINE.json metric).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--log2-batch B]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+One "step" = one pass of the verify hot path over one batch of 2^20 synthetic single signatures
+per GPU (BASELINE.json configs[1]), inputs already resident in HBM: k_challenge (Poseidon) then
+k_verify_fixed (u*G + c*PK == R).  Batches are generated on the GPU by the engine's own sign
+kernels and every 16th item is corrupted, so the expected verdict vector is non-trivial; it is
+checked after the timed region (and a sample is re-verified by the CPU oracle at N = 1).
+
+N > 1: one process per GPU, each rank verifies its own 2^20-item shard (weak scaling) and the
+verdict bytes are all-gathered over RCCL inside the timed region.
+
+Prints ONE JSON line on rank 0.  `roofline` is for the dominant kernel (k_verify_fixed), whose
+bound is VALU issue — see DESIGN.md §4 for the instruction model; HBM figures ride along.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+# ---- work model of k_verify_fixed: VALU lane-instructions per verdict --------
+FE_MUL, FE_SQR = 225, 189            # fe29.h: 153 / 117 MADs + carry & normalise ops
+CHEAP = 9                            # one limb-wise add
+SUB = 18 + 26                        # biased subtract + parallel carry pass
+DOUBLE_UVZ = 4 * FE_SQR + 3 * FE_MUL + 3 * CHEAP + 3 * SUB
+ADD_NIELS = 8 * FE_MUL + 4 * CHEAP + 26 + 3 * SUB
+ADD_ANIELS = 7 * FE_MUL + 4 * CHEAP + 26 + 3 * SUB
+TO_NIELS = 2 * FE_MUL + CHEAP + 26 + SUB
+VERIFY_FIXED_INSTR = (
+    4 * FE_MUL                                     # PK, R to Montgomery form
+    + 14 * (ADD_NIELS + TO_NIELS) + TO_NIELS       # 16-entry window table of PK
+    + 63 * (4 * DOUBLE_UVZ + ADD_NIELS)            # c*PK: 252 doublings + 63 additions
+    + 32 * ADD_ANIELS                              # += u*G from the 8-bit-window table
+    + 2 * FE_MUL + 2 * 150                         # projective compare
+)
+ALGO_BYTES_SINGLE = 193                            # 192 B in + 1 B out
+CORE_BYTES = 32 + 32 + 1 + 64 + 64 + 1             # what k_verify_fixed itself moves per item
+VALU_CYCLES_PER_INSTR = 4.05                       # measured: profiles/r01_valu_rates.txt
+N_CU, SIMD_PER_CU, CLOCK_HZ = 256, 4, 2.4e9
+VALU_PEAK_LANE_INSTR = N_CU * SIMD_PER_CU * CLOCK_HZ / VALU_CYCLES_PER_INSTR * 64
+HBM_PEAK_GBS = 8000.0
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--log2-batch", type=int, default=20)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-double", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the HIP engine has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = "cuda:%d" % local_rank
+
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        dist.init_process_group("nccl", device_id=torch.device(dev))
+
+    from schnorr_amd import engine as E
+    from schnorr_amd import workload as W
+
+    E.init(local_rank)
+    n = 1 << args.log2_batch
+    batch = W.gen_single(n, seed=2321 + rank, device=dev)
+    ok = torch.zeros(n, dtype=torch.uint8, device=dev)
+    ws = torch.empty(E.workspace_bytes(n), dtype=torch.uint8, device=dev)
+    c = torch.empty((n, 32), dtype=torch.uint8, device=dev)
+    valid = torch.empty(n, dtype=torch.uint8, device=dev)
+    gathered = torch.empty(world * n, dtype=torch.uint8, device=dev) if world > 1 else None
+
+    def step(events=None):
+        # the two launches dsv_verify_single_dev makes, issued separately so the dominant
+        # kernel can be bracketed by events on the stream it runs on
+        if events is not None:
+            events[0].record()
+        E.challenge_single_dev(batch["R"], batch["m"], c, valid)
+        if events is not None:
+            events[1].record()
+        E.verify_core_dev(batch["u"], c, valid, batch["PK"], batch["R"], ok)
+        if events is not None:
+            events[2].record()
+        if world > 1:
+            dist.all_gather_into_tensor(gathered, ok)
+
+    def sync_all():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    # the public entry point must agree with the split launches
+    E.verify_single_dev(batch["u"], batch["R"], batch["PK"], batch["m"], ok, ws)
+    torch.cuda.synchronize()
+    ok_api = ok.clone()
+
+    for _ in range(args.warmup):
+        step()
+    evs = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(args.steps)]
+    sync_all()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        step(evs[k])
+    sync_all()
+    dt = time.perf_counter() - t0
+
+    t = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dt = float(t.item())
+    hash_ms = sum(e[0].elapsed_time(e[1]) for e in evs) / args.steps
+    core_ms = sum(e[1].elapsed_time(e[2]) for e in evs) / args.steps
+
+    # ---- correctness of what was timed
+    mism = int((ok != batch["expected"]).sum().item())
+    mism_api = int((ok_api != batch["expected"]).sum().item())
+    if world > 1:
+        mine = gathered[rank * n:(rank + 1) * n]
+        mism += int((mine != batch["expected"]).sum().item())
+    if mism or mism_api:
+        raise SystemExit("rank %d: %d / %d verdicts differ from the expected pattern"
+                         % (rank, mism, mism_api))
+
+    total = n * world
+    value = total * args.steps / dt
+    out = {
+        "metric": "schnorr_single_verifies_per_sec",
+        "value": value,
+        "unit": "verifies/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": dt / args.steps * 1e3,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "u32x9 (29-bit limbs, u64 accumulate)",
+        "data": "synthetic: GPU-signed random (sk, m, nonce), every 16th item corrupted",
+        "config": {"workload": "2^%d single-signature batch verify per GPU (BASELINE configs[1])"
+                               % args.log2_batch,
+                   "batch_per_gpu": n, "parallelism": "dp%d" % world,
+                   "collective": "all_gather of verdict bytes" if world > 1 else "none"},
+    }
+
+    if rank == 0:
+        core_s = core_ms * 1e-3
+        lane_instr = VERIFY_FIXED_INSTR * n
+        achieved = lane_instr / core_s
+        out["roofline"] = {
+            "kernel": "k_verify_fixed",
+            "bound": "valu",
+            "achieved": achieved / 1e12,
+            "peak": VALU_PEAK_LANE_INSTR / 1e12,
+            "unit": "T lane-instr/s",
+            "frac": achieved / VALU_PEAK_LANE_INSTR,
+            "traffic": None,
+            "model": {"valu_lane_instr_per_verdict": VERIFY_FIXED_INSTR,
+                      "cycles_per_wave_instr": VALU_CYCLES_PER_INSTR,
+                      "kernel_ms": core_ms, "hash_kernel_ms": hash_ms},
+            "hbm": {"bound": "hbm", "achieved": CORE_BYTES * n / core_s / 1e9,
+                    "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": CORE_BYTES * n / core_s / 1e9 / HBM_PEAK_GBS,
+                    "algorithmic_bytes_per_verdict": ALGO_BYTES_SINGLE,
+                    "kernel_bytes_per_verdict": CORE_BYTES},
+        }
+
+    # ---- secondary figure: double signatures (BASELINE configs[2]), outside the timed region
+    if not args.no_double and world == 1:
+        nd = n
+        bd = W.gen_double(nd, seed=4242, device=dev)
+        okd = torch.zeros(nd, dtype=torch.uint8, device=dev)
+        E.verify_double_dev(bd["u"], bd["R"], bd["Rp"], bd["PK"], bd["PKp"], bd["m"], okd, ws)
+        torch.cuda.synchronize()
+        td0 = time.perf_counter()
+        reps = max(1, args.steps // 2)
+        for _ in range(reps):
+            E.verify_double_dev(bd["u"], bd["R"], bd["Rp"], bd["PK"], bd["PKp"], bd["m"], okd, ws)
+        torch.cuda.synchronize()
+        tdd = time.perf_counter() - td0
+        if int((okd != bd["expected"]).sum().item()):
+            raise SystemExit("double-signature verdicts differ from the expected pattern")
+        out["double"] = {"value": nd * reps / tdd, "unit": "verifies/s",
+                         "workload": "2^%d double-signature batch (BASELINE configs[2])"
+                                     % args.log2_batch}
+        del bd, okd
+
+    # ---- CPU baseline: the oracle (port of the reference algorithm) on the host cores
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import oracle_lib as O
+
+        try:
+            cores = len(os.sched_getaffinity(0))
+        except AttributeError:
+            cores = os.cpu_count() or 1
+        cores = max(1, min(cores, 16))  # the GPU box's CPU share for one GPU
+        sample = 4096 * cores
+        hu = batch["u"][:sample].cpu().numpy()
+        hR = batch["R"][:sample].cpu().numpy()
+        hPK = batch["PK"][:sample].cpu().numpy()
+        hm = batch["m"][:sample].cpu().numpy()
+        O.verify_single(hu[:64], hR[:64], hPK[:64], hm[:64])  # warm
+        tc0 = time.perf_counter()
+        cpu_ok = O.verify_single(hu, hR, hPK, hm, nthreads=cores)
+        tc = time.perf_counter() - tc0
+        want = batch["expected"][:sample].cpu().numpy()
+        if (cpu_ok != want).any() or (cpu_ok != ok[:sample].cpu().numpy()).any():
+            raise SystemExit("CPU oracle disagrees with the GPU verdicts on the sample")
+        one = min(sample, 2048)
+        t10 = time.perf_counter()
+        O.verify_single(hu[:one], hR[:one], hPK[:one], hm[:one], nthreads=1)
+        t1 = time.perf_counter() - t10
+        out["cpu_baseline"] = {
+            "value": sample / tc, "unit": "verifies/s", "cores": cores, "kind": "port",
+            "sample": "first %d items of the same batch, %d threads, %.1f s wall; "
+                      "1 thread: %.0f verifies/s on %d items" % (sample, cores, tc, one / t1, one),
+        }
+        # host-buffer path of the C ABI (PCIe-inclusive), never the headline value
+        hs = min(n, 1 << 18)
+        hu = batch["u"][:hs].cpu().numpy(); hR = batch["R"][:hs].cpu().numpy()
+        hPK = batch["PK"][:hs].cpu().numpy(); hm = batch["m"][:hs].cpu().numpy()
+        E.verify_single(hu[:1024], hR[:1024], hPK[:1024], hm[:1024])
+        th0 = time.perf_counter()
+        E.verify_single(hu, hR, hPK, hm)
+        th = time.perf_counter() - th0
+        out["host_path"] = {"value": hs / th, "unit": "verifies/s",
+                            "note": "dsv_verify_single on %d host-resident items incl. PCIe staging" % hs}
+
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

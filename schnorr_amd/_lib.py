@@ -11,7 +11,7 @@ SYMBOLS = [
     "dsv_init", "dsv_shutdown", "dsv_version", "dsv_last_error", "dsv_device_count",
     "dsv_verify_single", "dsv_verify_double", "dsv_verify_vargen", "dsv_verify_single_ext",
     "dsv_workspace_bytes", "dsv_verify_single_dev", "dsv_verify_double_dev",
-    "dsv_verify_vargen_dev", "dsv_challenge_single", "dsv_challenge_double",
+    "dsv_verify_vargen_dev", "dsv_verify_core_dev", "dsv_challenge_single", "dsv_challenge_double",
     "dsv_challenge_single_dev", "dsv_challenge_double_dev", "dsv_sign_single", "dsv_sign_double",
     "dsv_sign_vargen", "dsv_public_keys", "dsv_sign_single_dev", "dsv_sign_double_dev",
     "dsv_public_keys_dev", "dsv_debug_table_entry", "dsv_debug_fq_mul",

@@ -599,6 +599,29 @@ int dsv_verify_single_dev(const void* u, const void* R_uv, const void* PK_uv, co
   return DSV_OK;
 }
 
+// second stage alone (c and valid already computed): lets callers time / profile the dominant
+// kernel separately, and re-use one challenge for several key pairs
+int dsv_verify_core_dev(const void* u, const void* c, const void* valid, const void* PK_uv,
+                        const void* R_uv, int which, int accumulate, size_t n, void* ok,
+                        void* stream) {
+  if (int r = check_ready()) return r;
+  if (int r = check_n(n)) return r;
+  if (n == 0) return DSV_OK;
+  if (!u || !c || !valid || !PK_uv || !R_uv || !ok || which < 0 || which > 1)
+    return fail(DSV_ERR_INVALID_ARGUMENT, "bad argument");
+  hipStream_t s = (hipStream_t)stream;
+  if (accumulate)
+    hipLaunchKernelGGL(k_verify_fixed<true>, dim3(grid_for(n)), dim3(256), 0, s, (const uint8_t*)u,
+                       (const uint8_t*)c, (const uint8_t*)PK_uv, (const uint8_t*)R_uv,
+                       (const u32*)g_ctx.table[which], (const uint8_t*)valid, n, (uint8_t*)ok);
+  else
+    hipLaunchKernelGGL(k_verify_fixed<false>, dim3(grid_for(n)), dim3(256), 0, s, (const uint8_t*)u,
+                       (const uint8_t*)c, (const uint8_t*)PK_uv, (const uint8_t*)R_uv,
+                       (const u32*)g_ctx.table[which], (const uint8_t*)valid, n, (uint8_t*)ok);
+  HIP_TRY(hipGetLastError());
+  return DSV_OK;
+}
+
 int dsv_verify_double_dev(const void* u, const void* R_uv, const void* Rp_uv, const void* PK_uv,
                           const void* PKp_uv, const void* m, size_t n, void* ok, void* workspace,
                           void* stream) {
