@@ -1,0 +1,235 @@
+"""Bit-exact Python model of schnorr_amd/csrc/fe29.h + jubjub29.h (limb level), with the
+64-bit / 32-bit overflow conditions of the device code turned into assertions.  TEST INFRA.
+
+Every function mirrors the device function of the same name; `Fe` is a list of 9 ints.
+"""
+import re
+import os
+
+Q = 0x73EDA753299D7D483339D80809A1D80553BDA402FFFE5BFEFFFFFFFF00000001
+NL, LB = 9, 29
+M29 = (1 << LB) - 1
+RBITS = NL * LB
+RMONT = (1 << RBITS) % Q
+U32, U64 = 1 << 32, 1 << 64
+
+_HDR = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "schnorr_amd", "csrc",
+                    "dsv_constants.h")
+
+
+def _load(name):
+    text = open(_HDR).read()
+    m = re.search(r"#define %s \{([^}]*)\}" % name, text)
+    return [int(x.strip().rstrip("u"), 16) for x in m.group(1).split(",")]
+
+
+Q29 = _load("DSV_Q29")
+BIAS = {2: _load("DSV_BIAS2"), 4: _load("DSV_BIAS4"), 8: _load("DSV_BIAS8")}
+QX = {1: _load("DSV_Q29_X1"), 2: _load("DSV_Q29_X2"), 4: _load("DSV_Q29_X4"), 8: _load("DSV_Q29_X8")}
+R2 = _load("DSV_R2")
+ONE = _load("DSV_ONE")
+D2 = _load("DSV_D2")
+
+stats = {"max_col": 0, "max_limb_in": 0}
+
+
+def val(a):
+    return sum(l << (LB * i) for i, l in enumerate(a))
+
+
+def from_int(x):
+    assert 0 <= x < (1 << RBITS)
+    return [(x >> (LB * i)) & M29 for i in range(NL)]
+
+
+def to_mont_int(x):
+    return from_int(x * RMONT % Q)
+
+
+def reduce_cols(c):
+    k = 0
+    c = list(c) + [0]
+    for i in range(NL):
+        s = c[i] + k
+        assert s < U64
+        m = (-s) & M29
+        t = s + m
+        assert t < U64 and t & M29 == 0
+        k = t >> LB
+        for j in range(1, NL):
+            c[i + j] += m * Q29[j]
+            assert c[i + j] < U64, "column overflow in reduction"
+            stats["max_col"] = max(stats["max_col"], c[i + j])
+    r = []
+    for i in range(NL - 1):
+        s = c[NL + i] + k
+        assert s < U64
+        r.append(s & M29)
+        k = s >> LB
+    assert k < U32
+    r.append(k)
+    return r
+
+
+def mul(a, b):
+    for l in a + b:
+        assert 0 <= l < U32
+        stats["max_limb_in"] = max(stats["max_limb_in"], l)
+    c = [0] * 17
+    for i in range(NL):
+        for j in range(NL):
+            c[i + j] += a[i] * b[j]
+    for x in c:
+        assert x < U64, "column overflow in product"
+        stats["max_col"] = max(stats["max_col"], x)
+    return reduce_cols(c)
+
+
+def sqr(a):
+    for l in a:
+        assert 2 * l < U32
+    return mul(a, a)
+
+
+def dot(avec, bvec):
+    c = [0] * 17
+    for a, b in zip(avec, bvec):
+        for l in a + b:
+            assert 0 <= l < U32
+        for i in range(NL):
+            for j in range(NL):
+                c[i + j] += a[i] * b[j]
+    for x in c:
+        assert x < U64, "column overflow in dot product"
+        stats["max_col"] = max(stats["max_col"], x)
+    return reduce_cols(c)
+
+
+def add(a, b):
+    r = [x + y for x, y in zip(a, b)]
+    assert all(x < U32 for x in r)
+    return r
+
+
+def dbl(a):
+    return add(a, a)
+
+
+def carry(a):
+    r = [a[0] & M29]
+    for i in range(1, NL - 1):
+        r.append((a[i] & M29) + (a[i - 1] >> LB))
+    r.append(a[NL - 1] + (a[NL - 2] >> LB))
+    assert all(x < U32 for x in r)
+    return r
+
+
+def sub(a, b, k):
+    bias = BIAS[k]
+    r = []
+    for i in range(NL):
+        assert bias[i] >= b[i], "bias does not dominate subtrahend limb %d" % i
+        x = a[i] + (bias[i] - b[i])
+        assert x < U32
+        r.append(x)
+    return carry(r)
+
+
+def ripple(a):
+    r, k = [], 0
+    for i in range(NL - 1):
+        s = a[i] + k
+        assert s < U32
+        r.append(s & M29)
+        k = s >> LB
+    r.append(a[NL - 1] + k)
+    return r
+
+
+def cond_sub(a, m):
+    d, borrow = [], 0
+    for i in range(NL):
+        s = a[i] - m[i] - borrow
+        borrow = 1 if s < 0 else 0
+        if i < NL - 1:
+            assert -(1 << 30) < s < (1 << 30)
+            d.append(s & M29)
+        else:
+            d.append(s)
+    return a if borrow else d
+
+
+def canon(a):
+    r = ripple(a)
+    assert val(r) < 16 * Q
+    for k in (8, 4, 2, 1):
+        r = cond_sub(r, QX[k])
+    assert val(r) < Q and all(0 <= l <= M29 for l in r)
+    return r
+
+
+def from_mont(a):
+    one = [1] + [0] * (NL - 1)
+    return canon(mul(a, one))
+
+
+def to_mont(plain):
+    return mul(plain, R2)
+
+
+def equal(a, b):
+    return val(canon(sub(a, b, 8))) == 0
+
+
+# ---- points ------------------------------------------------------------------------------
+def ext_identity():
+    return {"u": [0] * NL, "v": list(ONE), "z": list(ONE), "t1": [0] * NL, "t2": [0] * NL}
+
+
+def ext_from_affine(u, v):
+    return {"u": u, "v": v, "z": list(ONE), "t1": u, "t2": v}
+
+
+def ext_double(p):
+    uu, vv = sqr(p["u"]), sqr(p["v"])
+    zz2 = dbl(sqr(p["z"]))
+    uv2 = sqr(add(p["u"], p["v"]))
+    vpu = add(vv, uu)
+    vmu = sub(vv, uu, 2)
+    cu = sub(uv2, vpu, 4)
+    ct = sub(zz2, vmu, 4)
+    return {"u": mul(cu, ct), "v": mul(vpu, vmu), "z": mul(vmu, ct), "t1": cu, "t2": vpu}
+
+
+def _add_tail(a, b, c, d):
+    cu = sub(b, a, 2)
+    cv = add(b, a)
+    cz = carry(add(d, c))
+    ct = sub(d, c, 2)
+    return {"u": mul(cu, ct), "v": mul(cv, cz), "z": mul(cz, ct), "t1": cu, "t2": cv}
+
+
+def ext_add_niels(p, n):
+    a = mul(sub(p["v"], p["u"], 2), n["vmu"])
+    b = mul(add(p["v"], p["u"]), n["vpu"])
+    c = mul(mul(p["t1"], p["t2"]), n["t2d"])
+    d = dbl(mul(p["z"], n["z"]))
+    return _add_tail(a, b, c, d)
+
+
+def ext_add_aniels(p, n):
+    a = mul(sub(p["v"], p["u"], 2), n["vmu"])
+    b = mul(add(p["v"], p["u"]), n["vpu"])
+    c = mul(mul(p["t1"], p["t2"]), n["t2d"])
+    d = dbl(p["z"])
+    return _add_tail(a, b, c, d)
+
+
+def ext_to_niels(p):
+    return {"vpu": carry(add(p["v"], p["u"])), "vmu": sub(p["v"], p["u"], 2), "z": p["z"],
+            "t2d": mul(mul(p["t1"], p["t2"]), D2)}
+
+
+def affine_of(p):
+    zi = pow(val(from_mont(p["z"])), -1, Q)
+    return (val(from_mont(p["u"])) * zi % Q, val(from_mont(p["v"])) * zi % Q)

@@ -1,0 +1,70 @@
+"""CPU tests of the multi-GPU host logic: shard arithmetic and a world_size-2 gloo run of the
+shard -> verify -> all_gather path (verify_fn = the CPU oracle here; on the GPU box the same
+code runs with the HIP engine and backend "nccl")."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import harness as H
+import oracle_lib as O
+from schnorr_amd import distributed as D
+
+
+def test_shard_bounds_partition_everything():
+    for n in (0, 1, 7, 64, 1000, (1 << 20) + 3):
+        for world in (1, 2, 3, 8):
+            spans = [D.shard_bounds(n, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            for a, b in zip(spans, spans[1:]):
+                assert a[1] == b[0]
+            sizes = D.shard_sizes(n, world)
+            assert sum(sizes) == n and max(sizes) - min(sizes) <= 1
+    with pytest.raises(ValueError):
+        D.shard_bounds(10, 2, 2)
+
+
+def test_split_mixed():
+    s, d = D.split_mixed([0, 1, 0, 1, 1, 0])
+    assert list(s) == [0, 2, 5] and list(d) == [1, 3, 4]
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, n, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank),
+                      WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    d = O.keygen_sign_single(n, 2321)
+    H.tamper(d, period=5)
+    full = D.verify_single_sharded(d["u"], d["R"], d["PK"], d["m"],
+                                   verify_fn=lambda *a: O.verify_single(*a),
+                                   to_tensor=lambda a: torch.from_numpy(a))
+    want = O.verify_single(d["u"], d["R"], d["PK"], d["m"])
+    q.put((rank, bool(np.array_equal(full.numpy(), want)), int(full.sum())))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n", [37, 64])  # ragged and even shards
+def test_world_size_2_gloo_gather(n):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, n, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(ok for _, ok, _ in res), res
+    assert res[0][2] == res[1][2] > 0

@@ -1,0 +1,84 @@
+"""The lazy-reduction contracts of fe29.h / jubjub29.h / hades29.h, checked on a bit-exact Python
+model (tests/fe29_model.py) whose every 32/64-bit overflow condition is an assertion: random
+inputs, adversarial all-ones limbs, and long chains of the exact formula sequences the kernels run."""
+import random
+
+import fe29_model as F
+import pymodel as M
+
+rnd = random.Random(1234)
+
+
+def rand_fe():
+    return F.to_mont_int(rnd.randrange(F.Q))
+
+
+def test_mul_sqr_add_sub_values():
+    for _ in range(300):
+        x, y = rnd.randrange(F.Q), rnd.randrange(F.Q)
+        a, b = F.to_mont_int(x), F.to_mont_int(y)
+        assert F.val(F.from_mont(F.mul(a, b))) == x * y % F.Q
+        assert F.val(F.from_mont(F.sqr(a))) == x * x % F.Q
+        assert F.val(F.from_mont(F.mul(F.add(a, b), F.sub(a, b, 2)))) == (x + y) * (x - y) % F.Q
+        assert F.equal(F.sub(a, b, 4), F.to_mont_int((x - y) % F.Q))
+    for x in (0, 1, F.Q - 1, (1 << 254), F.M29, 1 << 29):
+        a = F.to_mont(F.from_int(x))
+        assert F.val(F.from_mont(a)) == x % F.Q
+
+
+def test_worst_case_limbs_do_not_overflow_columns():
+    """limbs at the contract ceiling: a < 2^30 (sum of two normalised), b < 1.5*2^30 (d + c)"""
+    a = [(1 << 30) - 2] * 8 + [(1 << 26)]
+    b = [3 * (1 << 29)] * 8 + [(1 << 26)]
+    F.mul(a, b)
+    F.mul(b, a)
+    F.sqr(a)
+    five = [[F.M29 + 8] * 8 + [1 << 25]] * 5
+    mds = [[F.M29] * 8 + [(F.Q >> 232)]] * 5
+    F.dot(five, mds)
+    assert F.stats["max_col"] < (1 << 64)
+
+
+def test_group_law_chain_matches_affine_model_and_keeps_bounds():
+    """the exact op sequence of var_base_mul / fixed_base_accumulate for a random scalar"""
+    for trial in range(2):
+        k = rnd.randrange(1 << 250)
+        P = M.pmul(M.GEN, rnd.randrange(1, M.R_ORDER))
+        pu, pv = F.to_mont_int(P[0]), F.to_mont_int(P[1])
+        p = F.ext_from_affine(pu, pv)
+        n1 = F.ext_to_niels(p)
+        tbl = [{"vpu": list(F.ONE), "vmu": list(F.ONE), "z": list(F.ONE), "t2d": [0] * 9}, n1]
+        cur = p
+        for _ in range(2, 16):
+            cur = F.ext_add_niels(cur, n1)
+            tbl.append(F.ext_to_niels(cur))
+        acc = F.ext_identity()
+        for d in range(62, -1, -1):
+            for _ in range(4):
+                acc = F.ext_double(acc)
+            acc = F.ext_add_niels(acc, tbl[(k >> (4 * d)) & 15])
+        assert F.affine_of(acc) == M.pmul(P, k)
+        # continue with mixed additions of affine-niels points (fixed-base stage)
+        tot = M.pmul(P, k)
+        for w in range(6):
+            Qp = M.pmul(M.GEN, rnd.randrange(1, M.R_ORDER))
+            u, v = Qp
+            an = {"vpu": F.to_mont_int((v + u) % F.Q), "vmu": F.to_mont_int((v - u) % F.Q),
+                  "t2d": F.to_mont_int(2 * M.D * u * v % F.Q)}
+            acc = F.ext_add_aniels(acc, an)
+            tot = M.padd(tot, Qp)
+        assert F.affine_of(acc) == tot
+        ru, rv = F.to_mont_int(tot[0]), F.to_mont_int(tot[1])
+        assert F.equal(acc["u"], F.mul(ru, acc["z"])) and F.equal(acc["v"], F.mul(rv, acc["z"]))
+
+
+def test_identity_and_torsion_through_the_formulas():
+    ident = F.ext_identity()
+    d = F.ext_double(ident)
+    assert F.affine_of(d) == (0, 1)
+    o2 = F.ext_from_affine(F.to_mont_int(0), F.to_mont_int(F.Q - 1))
+    assert F.affine_of(F.ext_double(o2)) == (0, 1)
+    s = F.ext_add_niels(o2, F.ext_to_niels(o2))
+    assert F.affine_of(s) == (0, 1)
+    s = F.ext_add_niels(ident, F.ext_to_niels(ident))
+    assert F.affine_of(s) == (0, 1)
