@@ -97,7 +97,7 @@ def main():
         E.challenge_single_dev(batch["R"], batch["m"], c, valid)
         if events is not None:
             events[1].record()
-        E.verify_core_dev(batch["u"], c, valid, batch["PK"], batch["R"], ok)
+        E.verify_core_dev(batch["u"], c, valid, batch["PK"], batch["R"], ok, ws)
         if events is not None:
             events[2].record()
         if world > 1:

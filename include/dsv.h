@@ -90,7 +90,7 @@ int dsv_verify_vargen_dev(const void *u, const void *R_uv, const void *PK_uv, co
  * (which = 0) or G' (which = 1); c and valid as produced by dsv_challenge_*_dev */
 int dsv_verify_core_dev(const void *u, const void *c, const void *valid, const void *PK_uv,
                         const void *R_uv, int which, int accumulate, size_t n, void *ok,
-                        void *stream);
+                        void *workspace, void *stream);
 
 /* ---- challenge hash only (c = trunc250(Poseidon(R.., m))), 32 B LE per item ---- */
 int dsv_challenge_single(const uint8_t *R_uv, const uint8_t *m, size_t n, uint8_t *c);

@@ -196,21 +196,74 @@ DSV_DEV Ext fixed_base_accumulate(Ext acc, const u32 (&s)[8], const u32* __restr
   return acc;
 }
 
-constexpr int kVarDigits = 63;  // 4-bit windows over 252 bits
+// ---- per-lane window table of a variable base, in global memory, LANE-MAJOR ---------------
+// Signed 4-bit digits d in [-8, 8): entries |d| * P for |d| = 0..8, each stored as extended niels
+// (v+u, v-u, z, 2d*t) plus the negated 2d*t, 5 x 9 words = 180 B; 1620 B per lane, contiguous.
+// A lookup is therefore 4 x 36 contiguous bytes of ONE entry (sign handled by WHICH fields are
+// read: -P swaps v+u / v-u and takes the negated t), instead of 36 dwords scattered over 36
+// different 256-B rows as a compiler-scratch array would give (r01 v1: 64.7 GB FETCH_SIZE per
+// 2^20 batch, profiles/r01/v1_pmc_summary.json).  The slot belongs to (workgroup, lane), so the
+// verify kernels run a fixed grid with a grid-stride loop.
+constexpr int kVarEntries = 9;
+constexpr int kVarEntryWords = 5 * NL;
+constexpr int kVarLaneWords = kVarEntries * kVarEntryWords;  // 405 words = 1620 B
+constexpr unsigned kMaxVerifyGrid = 1024;                     // 4 workgroups per CU
 
-DSV_DEV void build_var_table(Niels (&tbl)[16], const Fe& pu, const Fe& pv) {
+DSV_DEV void store_fe_words(u32* p, const Fe& a) {
+#pragma unroll
+  for (int i = 0; i < NL; i++) p[i] = a.l[i];
+}
+DSV_DEV Fe load_fe_words(const u32* p) {
+  Fe r;
+#pragma unroll
+  for (int i = 0; i < NL; i++) r.l[i] = p[i];
+  return r;
+}
+DSV_DEV void store_var_entry(u32* lane_tbl, int e, const Niels& n) {
+  u32* p = lane_tbl + e * kVarEntryWords;
+  store_fe_words(p, n.vpu);
+  store_fe_words(p + NL, n.vmu);
+  store_fe_words(p + 2 * NL, n.z);
+  store_fe_words(p + 3 * NL, n.t2d);
+  store_fe_words(p + 4 * NL, fe_neg2(n.t2d));
+}
+DSV_DEV Niels load_var_entry(const u32* lane_tbl, int d) {
+  const bool neg = d < 0;
+  const int mag = neg ? -d : d;
+  const u32* p = lane_tbl + mag * kVarEntryWords;
+  Niels n;
+  n.vpu = load_fe_words(p + (neg ? NL : 0));
+  n.vmu = load_fe_words(p + (neg ? 0 : NL));
+  n.z = load_fe_words(p + 2 * NL);
+  n.t2d = load_fe_words(p + (neg ? 4 * NL : 3 * NL));
+  return n;
+}
+DSV_DEV void build_var_table(u32* lane_tbl, const Fe& pu, const Fe& pv) {
   Ext p = ext_from_affine(pu, pv);
   Niels n1 = ext_to_niels(p);
-  tbl[0] = niels_identity();
-  tbl[1] = n1;
+  store_var_entry(lane_tbl, 0, niels_identity());
+  store_var_entry(lane_tbl, 1, n1);
   Ext cur = p;
 #pragma unroll 1
-  for (int i = 2; i < 16; i++) {
+  for (int i = 2; i < kVarEntries; i++) {
     cur = ext_add_niels(cur, n1);
-    tbl[i] = ext_to_niels(cur);
+    store_var_entry(lane_tbl, i, ext_to_niels(cur));
   }
 }
-DSV_DEV u32 digit4(const u32 (&s)[8], int k) { return (s[k >> 3] >> (4 * (k & 7))) & 0xf; }
+// signed recoding: y = s + 0x8888..8; digit k of s is nibble k of y minus 8, in [-8, 7].
+// Exact for s < 2^252 (nibble 63 of y is then 8 or 9, i.e. digit 63 is 0 or 1).
+DSV_DEV void recode_signed4(u32 (&y)[8], const u32 (&s)[8]) {
+  u32 carry = 0;
+#pragma unroll
+  for (int i = 0; i < 8; i++) {
+    u64 t = (u64)s[i] + 0x88888888u + carry;
+    y[i] = (u32)t;
+    carry = (u32)(t >> 32);
+  }
+}
+DSV_DEV int sdigit4(const u32 (&y)[8], int k) {
+  return (int)((y[k >> 3] >> (4 * (k & 7))) & 0xf) - 8;
+}
 
 // acc = 16 * acc: three doublings that skip the (t1, t2) outputs nobody reads, then a full one
 DSV_DEV Ext ext_mul16(const Ext& p) {
@@ -224,25 +277,33 @@ DSV_DEV Ext ext_mul16(const Ext& p) {
   return ext_double(q);
 }
 
-// c * P, 4-bit fixed windows (MSB first): acc = 16*acc + T[digit]
-DSV_DEV Ext var_base_mul(const u32 (&s)[8], const Niels (&tbl)[16]) {
-  Ext acc = ext_identity();
+// s * P, signed 4-bit fixed windows, MSB first: acc = 16*acc + T[digit].  TOP = index of the
+// highest possibly non-zero digit (62 for a 250-bit challenge, 63 for a 252-bit Fr scalar); the
+// first window is a plain addition onto the identity (no doublings of the identity).
+template <int TOP>
+DSV_DEV Ext var_base_mul(const u32 (&s)[8], const u32* lane_tbl) {
+  u32 y[8];
+  recode_signed4(y, s);
+  Ext acc = ext_add_niels(ext_identity(), load_var_entry(lane_tbl, sdigit4(y, TOP)));
 #pragma unroll 1
-  for (int k = kVarDigits - 1; k >= 0; k--) {
+  for (int k = TOP - 1; k >= 0; k--) {
     acc = ext_mul16(acc);
-    acc = ext_add_niels(acc, tbl[digit4(s, k)]);
+    acc = ext_add_niels(acc, load_var_entry(lane_tbl, sdigit4(y, k)));
   }
   return acc;
 }
-// a*P + b*Q with one shared doubling chain (Straus)
-DSV_DEV Ext var_base_mul2(const u32 (&a)[8], const Niels (&tp)[16], const u32 (&b)[8],
-                          const Niels (&tq)[16]) {
-  Ext acc = ext_identity();
+// a*P + b*Q with one shared doubling chain (Straus); a < 2^252, b < 2^252
+DSV_DEV Ext var_base_mul2(const u32 (&a)[8], const u32* tp, const u32 (&b)[8], const u32* tq) {
+  u32 ya[8], yb[8];
+  recode_signed4(ya, a);
+  recode_signed4(yb, b);
+  Ext acc = ext_add_niels(ext_identity(), load_var_entry(tp, sdigit4(ya, 63)));
+  acc = ext_add_niels(acc, load_var_entry(tq, sdigit4(yb, 63)));
 #pragma unroll 1
-  for (int k = kVarDigits - 1; k >= 0; k--) {
+  for (int k = 62; k >= 0; k--) {
     acc = ext_mul16(acc);
-    acc = ext_add_niels(acc, tp[digit4(a, k)]);
-    acc = ext_add_niels(acc, tq[digit4(b, k)]);
+    acc = ext_add_niels(acc, load_var_entry(tp, sdigit4(ya, k)));
+    acc = ext_add_niels(acc, load_var_entry(tq, sdigit4(yb, k)));
   }
   return acc;
 }
@@ -252,77 +313,85 @@ DSV_DEV Ext var_base_mul2(const u32 (&a)[8], const Niels (&tp)[16], const u32 (&
 // ------------------------------------------------------------------------------------------
 // ok[i] = ok_in & [ u*Gen + c*PK == R ]   with Gen given by its fixed-base table.
 // ACCUM = false: first pass, ok_in = valid[i];  ACCUM = true: ok_in = ok[i] (double scheme).
-// Order of work is chosen for register pressure: PK -> table (scratch) -> c*PK -> += u*Gen ->
-// compare with R; each input is loaded right before its only use.
+// Order of work is chosen for register pressure: PK -> window table (global workspace) -> c*PK
+// -> += u*Gen -> compare with R; each input is loaded right before its only use.
 template <bool ACCUM>
 __global__ void __launch_bounds__(256, DSV_WAVES_VERIFY)
 k_verify_fixed(const uint8_t* __restrict__ u, const uint8_t* __restrict__ c,
                const uint8_t* __restrict__ PK_uv, const uint8_t* __restrict__ R_uv,
                const u32* __restrict__ table, const uint8_t* __restrict__ valid, size_t n,
-               uint8_t* __restrict__ ok) {
-  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  bool good = ACCUM ? (ok[i] != 0) : (valid[i] != 0);
-  Niels tbl[16];
-  {
-    Fe pku, pkv;
-    good &= load_fq(pku, PK_uv, 2 * i);
-    good &= load_fq(pkv, PK_uv, 2 * i + 1);
-    build_var_table(tbl, pku, pkv);
+               uint8_t* __restrict__ ok, u32* __restrict__ var_tables) {
+  u32* lane_tbl = var_tables + ((size_t)blockIdx.x * 256 + threadIdx.x) * kVarLaneWords;
+#pragma unroll 1
+  for (size_t base = (size_t)blockIdx.x * 256; base < n; base += (size_t)gridDim.x * 256) {
+    const size_t i = base + threadIdx.x;
+    if (i >= n) continue;
+    bool good = ACCUM ? (ok[i] != 0) : (valid[i] != 0);
+    {
+      Fe pku, pkv;
+      good &= load_fq(pku, PK_uv, 2 * i);
+      good &= load_fq(pkv, PK_uv, 2 * i + 1);
+      build_var_table(lane_tbl, pku, pkv);
+    }
+    Ext acc;
+    {
+      u32 cs[8];
+      load_words8(cs, c, i);
+      acc = var_base_mul<62>(cs, lane_tbl);
+    }
+    {
+      u32 us[8];
+      load_words8(us, u, i);
+      good &= words_lt(us, kR32);
+      acc = fixed_base_accumulate(acc, us, table);
+    }
+    Fe ru, rv;
+    good &= load_fq(ru, R_uv, 2 * i);
+    good &= load_fq(rv, R_uv, 2 * i + 1);
+    bool eq = ext_eq_affine(acc, ru, rv);
+    ok[i] = (good & eq) ? 1 : 0;
   }
-  Ext acc;
-  {
-    u32 cs[8];
-    load_words8(cs, c, i);
-    acc = var_base_mul(cs, tbl);
-  }
-  {
-    u32 us[8];
-    load_words8(us, u, i);
-    good &= words_lt(us, kR32);
-    acc = fixed_base_accumulate(acc, us, table);
-  }
-  Fe ru, rv;
-  good &= load_fq(ru, R_uv, 2 * i);
-  good &= load_fq(rv, R_uv, 2 * i + 1);
-  bool eq = ext_eq_affine(acc, ru, rv);
-  ok[i] = (good & eq) ? 1 : 0;
 }
 
 __global__ void __launch_bounds__(256, DSV_WAVES_VERIFY)
 k_verify_var(const uint8_t* __restrict__ u, const uint8_t* __restrict__ c,
              const uint8_t* __restrict__ PK_uv, const uint8_t* __restrict__ Gen_uv,
              const uint8_t* __restrict__ R_uv, const uint8_t* __restrict__ valid, size_t n,
-             uint8_t* __restrict__ ok) {
-  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  bool good = valid[i] != 0;
-  Niels tp[16], tq[16];
-  {
-    Fe gu, gv;
-    good &= load_fq(gu, Gen_uv, 2 * i);
-    good &= load_fq(gv, Gen_uv, 2 * i + 1);
-    build_var_table(tp, gu, gv);
+             uint8_t* __restrict__ ok, u32* __restrict__ var_tables) {
+  u32* tp = var_tables + ((size_t)blockIdx.x * 256 + threadIdx.x) * (2 * kVarLaneWords);
+  u32* tq = tp + kVarLaneWords;
+#pragma unroll 1
+  for (size_t base = (size_t)blockIdx.x * 256; base < n; base += (size_t)gridDim.x * 256) {
+    const size_t i = base + threadIdx.x;
+    if (i >= n) continue;
+    bool good = valid[i] != 0;
+    {
+      Fe gu, gv;
+      good &= load_fq(gu, Gen_uv, 2 * i);
+      good &= load_fq(gv, Gen_uv, 2 * i + 1);
+      build_var_table(tp, gu, gv);
+    }
+    {
+      Fe pku, pkv;
+      good &= load_fq(pku, PK_uv, 2 * i);
+      good &= load_fq(pkv, PK_uv, 2 * i + 1);
+      build_var_table(tq, pku, pkv);
+    }
+    Ext acc;
+    {
+      u32 us[8], cs[8];
+      load_words8(us, u, i);
+      load_words8(cs, c, i);
+      good &= words_lt(us, kR32);
+      if (!words_lt(us, kR32)) us[7] &= 0x0fffffffu;  // keep the recoding in range; verdict is 0 anyway
+      acc = var_base_mul2(us, tp, cs, tq);
+    }
+    Fe ru, rv;
+    good &= load_fq(ru, R_uv, 2 * i);
+    good &= load_fq(rv, R_uv, 2 * i + 1);
+    bool eq = ext_eq_affine(acc, ru, rv);
+    ok[i] = (good & eq) ? 1 : 0;
   }
-  {
-    Fe pku, pkv;
-    good &= load_fq(pku, PK_uv, 2 * i);
-    good &= load_fq(pkv, PK_uv, 2 * i + 1);
-    build_var_table(tq, pku, pkv);
-  }
-  Ext acc;
-  {
-    u32 us[8], cs[8];
-    load_words8(us, u, i);
-    load_words8(cs, c, i);
-    good &= words_lt(us, kR32);
-    acc = var_base_mul2(us, tp, cs, tq);
-  }
-  Fe ru, rv;
-  good &= load_fq(ru, R_uv, 2 * i);
-  good &= load_fq(rv, R_uv, 2 * i + 1);
-  bool eq = ext_eq_affine(acc, ru, rv);
-  ok[i] = (good & eq) ? 1 : 0;
 }
 
 // (u, v, z) -> affine (u/z, v/z), canonical bytes; flags z == 0 / non-canonical as invalid
@@ -371,20 +440,24 @@ k_fixed_base_points(const uint8_t* __restrict__ scalar, const u32* __restrict__ 
 // out = scalar * P for a per-item base P (var-generator scheme: secret.rs:442, public.rs:337-344)
 __global__ void __launch_bounds__(256, DSV_WAVES_VERIFY)
 k_var_base_points(const uint8_t* __restrict__ scalar, const uint8_t* __restrict__ P_uv, size_t n,
-                  uint8_t* __restrict__ out_uv) {
-  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  Niels tbl[16];
-  {
-    Fe pu, pv;
-    load_fq(pu, P_uv, 2 * i);
-    load_fq(pv, P_uv, 2 * i + 1);
-    build_var_table(tbl, pu, pv);
+                  uint8_t* __restrict__ out_uv, u32* __restrict__ var_tables) {
+  u32* lane_tbl = var_tables + ((size_t)blockIdx.x * 256 + threadIdx.x) * kVarLaneWords;
+#pragma unroll 1
+  for (size_t base = (size_t)blockIdx.x * 256; base < n; base += (size_t)gridDim.x * 256) {
+    const size_t i = base + threadIdx.x;
+    if (i >= n) continue;
+    {
+      Fe pu, pv;
+      load_fq(pu, P_uv, 2 * i);
+      load_fq(pv, P_uv, 2 * i + 1);
+      build_var_table(lane_tbl, pu, pv);
+    }
+    u32 s[8];
+    load_words8(s, scalar, i);
+    s[7] &= 0x0fffffffu;  // Fr scalars are < 2^252; keeps the signed recoding in range
+    Ext acc = var_base_mul<63>(s, lane_tbl);
+    store_affine(out_uv, i, acc);
   }
-  u32 s[8];
-  load_words8(s, scalar, i);
-  Ext acc = var_base_mul(s, tbl);
-  store_affine(out_uv, i, acc);
 }
 // u = r - c * sk  in Fr  (secret.rs:165)
 __global__ void __launch_bounds__(256)
@@ -485,14 +558,24 @@ int check_n(size_t n) {
 }
 
 // workspace layout for the *_dev verify entry points: c[n][32] | valid[n]
+// + the per-lane window tables of the verify kernels (fixed grid, see kMaxVerifyGrid)
 struct Workspace {
   uint8_t* c;
   uint8_t* valid;
+  u32* tables;
 };
+unsigned verify_grid(size_t n) {
+  unsigned g = grid_for(n);
+  return g < kMaxVerifyGrid ? g : kMaxVerifyGrid;
+}
+size_t var_table_bytes(size_t n, int tables_per_lane) {
+  return (size_t)verify_grid(n) * 256 * kVarLaneWords * 4 * (size_t)tables_per_lane;
+}
 Workspace carve(void* ws, size_t n) {
   Workspace w;
   w.c = static_cast<uint8_t*>(ws);
   w.valid = w.c + align_up(n * 32, 256);
+  w.tables = reinterpret_cast<u32*>(w.valid + align_up(n, 256));
   return w;
 }
 
@@ -553,7 +636,9 @@ int dsv_shutdown(void) {
   return DSV_OK;
 }
 
-size_t dsv_workspace_bytes(size_t n) { return align_up(n * 32, 256) + align_up(n, 256) + 256; }
+size_t dsv_workspace_bytes(size_t n) {
+  return align_up(n * 32, 256) + align_up(n, 256) + var_table_bytes(n, 2) + 256;
+}
 
 // ---- device-pointer entry points --------------------------------------------------------
 int dsv_challenge_single_dev(const void* R_uv, const void* m, size_t n, void* c, void* valid,
@@ -592,9 +677,9 @@ int dsv_verify_single_dev(const void* u, const void* R_uv, const void* PK_uv, co
   hipStream_t s = (hipStream_t)stream;
   hipLaunchKernelGGL(k_challenge<false>, dim3(grid_for(n)), dim3(256), 0, s, (const uint8_t*)R_uv,
                      (const uint8_t*)nullptr, (const uint8_t*)m, n, w.c, w.valid);
-  hipLaunchKernelGGL(k_verify_fixed<false>, dim3(grid_for(n)), dim3(256), 0, s, (const uint8_t*)u,
+  hipLaunchKernelGGL(k_verify_fixed<false>, dim3(verify_grid(n)), dim3(256), 0, s, (const uint8_t*)u,
                      (const uint8_t*)w.c, (const uint8_t*)PK_uv, (const uint8_t*)R_uv,
-                     (const u32*)g_ctx.table[0], (const uint8_t*)w.valid, n, (uint8_t*)ok);
+                     (const u32*)g_ctx.table[0], (const uint8_t*)w.valid, n, (uint8_t*)ok, w.tables);
   HIP_TRY(hipGetLastError());
   return DSV_OK;
 }
@@ -603,21 +688,22 @@ int dsv_verify_single_dev(const void* u, const void* R_uv, const void* PK_uv, co
 // kernel separately, and re-use one challenge for several key pairs
 int dsv_verify_core_dev(const void* u, const void* c, const void* valid, const void* PK_uv,
                         const void* R_uv, int which, int accumulate, size_t n, void* ok,
-                        void* stream) {
+                        void* workspace, void* stream) {
   if (int r = check_ready()) return r;
   if (int r = check_n(n)) return r;
   if (n == 0) return DSV_OK;
-  if (!u || !c || !valid || !PK_uv || !R_uv || !ok || which < 0 || which > 1)
+  if (!u || !c || !valid || !PK_uv || !R_uv || !ok || !workspace || which < 0 || which > 1)
     return fail(DSV_ERR_INVALID_ARGUMENT, "bad argument");
   hipStream_t s = (hipStream_t)stream;
+  Workspace w = carve(workspace, n);
   if (accumulate)
-    hipLaunchKernelGGL(k_verify_fixed<true>, dim3(grid_for(n)), dim3(256), 0, s, (const uint8_t*)u,
+    hipLaunchKernelGGL(k_verify_fixed<true>, dim3(verify_grid(n)), dim3(256), 0, s, (const uint8_t*)u,
                        (const uint8_t*)c, (const uint8_t*)PK_uv, (const uint8_t*)R_uv,
-                       (const u32*)g_ctx.table[which], (const uint8_t*)valid, n, (uint8_t*)ok);
+                       (const u32*)g_ctx.table[which], (const uint8_t*)valid, n, (uint8_t*)ok, w.tables);
   else
-    hipLaunchKernelGGL(k_verify_fixed<false>, dim3(grid_for(n)), dim3(256), 0, s, (const uint8_t*)u,
+    hipLaunchKernelGGL(k_verify_fixed<false>, dim3(verify_grid(n)), dim3(256), 0, s, (const uint8_t*)u,
                        (const uint8_t*)c, (const uint8_t*)PK_uv, (const uint8_t*)R_uv,
-                       (const u32*)g_ctx.table[which], (const uint8_t*)valid, n, (uint8_t*)ok);
+                       (const u32*)g_ctx.table[which], (const uint8_t*)valid, n, (uint8_t*)ok, w.tables);
   HIP_TRY(hipGetLastError());
   return DSV_OK;
 }
@@ -634,12 +720,12 @@ int dsv_verify_double_dev(const void* u, const void* R_uv, const void* Rp_uv, co
   hipStream_t s = (hipStream_t)stream;
   hipLaunchKernelGGL(k_challenge<true>, dim3(grid_for(n)), dim3(256), 0, s, (const uint8_t*)R_uv,
                      (const uint8_t*)Rp_uv, (const uint8_t*)m, n, w.c, w.valid);
-  hipLaunchKernelGGL(k_verify_fixed<false>, dim3(grid_for(n)), dim3(256), 0, s, (const uint8_t*)u,
+  hipLaunchKernelGGL(k_verify_fixed<false>, dim3(verify_grid(n)), dim3(256), 0, s, (const uint8_t*)u,
                      (const uint8_t*)w.c, (const uint8_t*)PK_uv, (const uint8_t*)R_uv,
-                     (const u32*)g_ctx.table[0], (const uint8_t*)w.valid, n, (uint8_t*)ok);
-  hipLaunchKernelGGL(k_verify_fixed<true>, dim3(grid_for(n)), dim3(256), 0, s, (const uint8_t*)u,
+                     (const u32*)g_ctx.table[0], (const uint8_t*)w.valid, n, (uint8_t*)ok, w.tables);
+  hipLaunchKernelGGL(k_verify_fixed<true>, dim3(verify_grid(n)), dim3(256), 0, s, (const uint8_t*)u,
                      (const uint8_t*)w.c, (const uint8_t*)PKp_uv, (const uint8_t*)Rp_uv,
-                     (const u32*)g_ctx.table[1], (const uint8_t*)w.valid, n, (uint8_t*)ok);
+                     (const u32*)g_ctx.table[1], (const uint8_t*)w.valid, n, (uint8_t*)ok, w.tables);
   HIP_TRY(hipGetLastError());
   return DSV_OK;
 }
@@ -655,9 +741,9 @@ int dsv_verify_vargen_dev(const void* u, const void* R_uv, const void* PK_uv, co
   hipStream_t s = (hipStream_t)stream;
   hipLaunchKernelGGL(k_challenge<false>, dim3(grid_for(n)), dim3(256), 0, s, (const uint8_t*)R_uv,
                      (const uint8_t*)nullptr, (const uint8_t*)m, n, w.c, w.valid);
-  hipLaunchKernelGGL(k_verify_var, dim3(grid_for(n)), dim3(256), 0, s, (const uint8_t*)u,
+  hipLaunchKernelGGL(k_verify_var, dim3(verify_grid(n)), dim3(256), 0, s, (const uint8_t*)u,
                      (const uint8_t*)w.c, (const uint8_t*)PK_uv, (const uint8_t*)Gen_uv,
-                     (const uint8_t*)R_uv, (const uint8_t*)w.valid, n, (uint8_t*)ok);
+                     (const uint8_t*)R_uv, (const uint8_t*)w.valid, n, (uint8_t*)ok, w.tables);
   HIP_TRY(hipGetLastError());
   return DSV_OK;
 }
@@ -882,14 +968,17 @@ int dsv_public_keys(const uint8_t* sk, int which, const uint8_t* gen_uv, size_t 
   if (!sk || !PK_uv || which < 0 || which > 1) return fail(DSV_ERR_INVALID_ARGUMENT, "bad argument");
   std::lock_guard<std::mutex> lk(g_ctx.mu);
   HIP_TRY(hipSetDevice(g_ctx.device));
-  if (int r = ensure_stage(align_up(n * 32, 256) + 2 * align_up(n * 64, 256))) return r;
+  if (int r = ensure_stage(align_up(n * 32, 256) + 2 * align_up(n * 64, 256) +
+                           var_table_bytes(n, 1) + 256))
+    return r;
   Stager st(g_ctx.stage);
-  uint8_t *dsk = st.take(n * 32), *dg = st.take(n * 64), *dpk = st.take(n * 64);
+  uint8_t *dsk = st.take(n * 32), *dg = st.take(n * 64), *dpk = st.take(n * 64),
+          *dtab = st.take(var_table_bytes(n, 1));
   H2D(dsk, sk, n * 32);
   if (gen_uv) {
     H2D(dg, gen_uv, n * 64);
-    hipLaunchKernelGGL(k_var_base_points, dim3(grid_for(n)), dim3(256), 0, 0, (const uint8_t*)dsk,
-                       (const uint8_t*)dg, n, dpk);
+    hipLaunchKernelGGL(k_var_base_points, dim3(verify_grid(n)), dim3(256), 0, 0, (const uint8_t*)dsk,
+                       (const uint8_t*)dg, n, dpk, reinterpret_cast<u32*>(dtab));
     HIP_TRY(hipGetLastError());
   } else {
     if (int r = dsv_public_keys_dev(dsk, which, n, dpk, nullptr)) return r;
@@ -949,16 +1038,19 @@ int dsv_sign_vargen(const uint8_t* sk, const uint8_t* Gen_uv, const uint8_t* m, 
   if (!sk || !Gen_uv || !m || !r || !u || !R_uv) return fail(DSV_ERR_INVALID_ARGUMENT, "null pointer");
   std::lock_guard<std::mutex> lk(g_ctx.mu);
   HIP_TRY(hipSetDevice(g_ctx.device));
-  if (int rc = ensure_stage(4 * align_up(n * 32, 256) + 2 * align_up(n * 64, 256))) return rc;
+  if (int rc = ensure_stage(4 * align_up(n * 32, 256) + 2 * align_up(n * 64, 256) +
+                            var_table_bytes(n, 1) + 256))
+    return rc;
   Stager st(g_ctx.stage);
   uint8_t *dsk = st.take(n * 32), *dm = st.take(n * 32), *dr = st.take(n * 32),
-          *du = st.take(n * 32), *dG = st.take(n * 64), *dR = st.take(n * 64);
+          *du = st.take(n * 32), *dG = st.take(n * 64), *dR = st.take(n * 64),
+          *dtab = st.take(var_table_bytes(n, 1));
   H2D(dsk, sk, n * 32);
   H2D(dm, m, n * 32);
   H2D(dr, r, n * 32);
   H2D(dG, Gen_uv, n * 64);
-  hipLaunchKernelGGL(k_var_base_points, dim3(grid_for(n)), dim3(256), 0, 0, (const uint8_t*)dr,
-                     (const uint8_t*)dG, n, dR);
+  hipLaunchKernelGGL(k_var_base_points, dim3(verify_grid(n)), dim3(256), 0, 0, (const uint8_t*)dr,
+                     (const uint8_t*)dG, n, dR, reinterpret_cast<u32*>(dtab));
   hipLaunchKernelGGL(k_challenge<false>, dim3(grid_for(n)), dim3(256), 0, 0, (const uint8_t*)dR,
                      (const uint8_t*)nullptr, (const uint8_t*)dm, n, du, (uint8_t*)nullptr);
   hipLaunchKernelGGL(k_sign_finish, dim3(grid_for(n)), dim3(256), 0, 0, (const uint8_t*)dr,

@@ -216,12 +216,12 @@ def verify_vargen_dev(u, R, PK, Gen, m, ok, workspace, stream=None):
         ctypes.c_void_p(ok.data_ptr()), ctypes.c_void_p(workspace.data_ptr()), _stream_ptr(stream)))
 
 
-def verify_core_dev(u, c, valid, PK, R, ok, which=0, accumulate=False, stream=None):
+def verify_core_dev(u, c, valid, PK, R, ok, workspace, which=0, accumulate=False, stream=None):
     n = u.shape[0]
     _lib.check(_lib.load().dsv_verify_core_dev(
         _tp(u, 32), _tp(c, 32), ctypes.c_void_p(valid.data_ptr()), _tp(PK, 64), _tp(R, 64),
         ctypes.c_int(which), ctypes.c_int(1 if accumulate else 0), ctypes.c_size_t(n),
-        ctypes.c_void_p(ok.data_ptr()), _stream_ptr(stream)))
+        ctypes.c_void_p(ok.data_ptr()), ctypes.c_void_p(workspace.data_ptr()), _stream_ptr(stream)))
 
 
 def challenge_double_dev(R, Rp, m, c, valid=None, stream=None):
