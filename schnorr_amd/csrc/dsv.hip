@@ -606,6 +606,12 @@ int dsv_init(int device) {
   HIP_TRY(hipSetDevice(device));
   HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(c_hades_rc), DSV_HADES_RC_HOST, sizeof(DSV_HADES_RC_HOST)));
   HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(c_hades_mds), DSV_HADES_MDS_HOST, sizeof(DSV_HADES_MDS_HOST)));
+  HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(c_hades_pre_mds), DSV_HADES_PRE_MDS_HOST,
+                            sizeof(DSV_HADES_PRE_MDS_HOST)));
+  HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(c_hades_kappa0), DSV_HADES_KAPPA0_HOST,
+                            sizeof(DSV_HADES_KAPPA0_HOST)));
+  HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(c_hades_sparse), DSV_HADES_SPARSE_HOST,
+                            sizeof(DSV_HADES_SPARSE_HOST)));
   for (int g = 0; g < 2; g++) {
     HIP_TRY(hipMalloc(&g_ctx.table[g], kTableBytes));
     const int total = kFixedWindows * kFixedEntries;

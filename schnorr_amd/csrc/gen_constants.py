@@ -73,6 +73,59 @@ def mds():
     return [[pow(i + j + WIDTH, -1, Q) for j in range(WIDTH)] for i in range(WIDTH)]
 
 
+def _matmul(A, B):
+    return [[sum(A[i][k] * B[k][j] for k in range(len(B))) % Q for j in range(len(B[0]))]
+            for i in range(len(A))]
+
+
+def _inv(A):
+    n = len(A)
+    A = [row[:] + [1 if i == j else 0 for j in range(n)] for i, row in enumerate(A)]
+    for c in range(n):
+        p = next(r for r in range(c, n) if A[r][c] % Q)
+        A[c], A[p] = A[p], A[c]
+        iv = pow(A[c][c], -1, Q)
+        A[c] = [x * iv % Q for x in A[c]]
+        for r in range(n):
+            if r != c and A[r][c]:
+                f = A[r][c]
+                A[r] = [(x - f * y) % Q for x, y in zip(A[r], A[c])]
+    return [row[n:] for row in A]
+
+
+def sparse_partial_rounds(rc, m):
+    """Equivalent form of the 59 partial rounds (S-box on the LAST word, constants added to all
+    words, dense MDS) in which every round multiplies by a SPARSE matrix.
+
+    With the state split as (y, z) = (words 0..3, word 4) and M_eff = [[A, b], [c^T, d]]:
+        M_eff = M'' * M',   M' = diag(A, 1),   M'' = [[I, b], [c^T A^-1, d]]
+    M' commutes with the partial S-box layer, so it is pushed into the previous round's matrix
+    (T_i below); the recursion runs from the last partial round to the first and leaves one dense
+    "pre" matrix T_0 * M that replaces M in the last of the first four full rounds.
+      w_{i+1} = M''_i * S(w_i + T_i k_i),   w_i = T_i x_i,   T_59 = I.
+    Returns (pre, kappa[60][5], b[59][4], c2[59][4], d[59]); kappa[59] = 0.
+    """
+    ident = [[1 if i == j else 0 for j in range(WIDTH)] for i in range(WIDTH)]
+    T = [None] * (PARTIAL + 1)
+    T[PARTIAL] = ident
+    bs, cs, ds = [None] * PARTIAL, [None] * PARTIAL, [None] * PARTIAL
+    for i in range(PARTIAL - 1, -1, -1):
+        me = _matmul(T[i + 1], m)
+        A = [row[:4] for row in me[:4]]
+        Ai = _inv(A)
+        bs[i] = [me[r][4] for r in range(4)]
+        cs[i] = [sum(me[4][k] * Ai[k][j] for k in range(4)) % Q for j in range(4)]
+        ds[i] = me[4][4]
+        T[i] = [A[r] + [0] for r in range(4)] + [[0, 0, 0, 0, 1]]
+    pre = _matmul(T[0], m)
+    kappa = []
+    for i in range(PARTIAL):
+        k = rc[(FULL // 2) * WIDTH + i * WIDTH:(FULL // 2) * WIDTH + (i + 1) * WIDTH]
+        kappa.append([sum(T[i][r][j] * k[j] for j in range(WIDTH)) % Q for r in range(WIDTH)])
+    kappa.append([0] * WIDTH)
+    return pre, kappa, bs, cs, ds
+
+
 def arr(v):
     return "{" + ", ".join("0x%08xu" % x for x in v) + "}"
 
@@ -121,6 +174,24 @@ def main():
         w("static const uint32_t DSV_HADES_MDS_HOST[%d][9] = {\n" % (WIDTH * WIDTH))
         for row in m:
             for x in row:
+                w("  %s,\n" % arr(mont(x)))
+        w("};\n")
+        pre, kappa, bs, cs, ds = sparse_partial_rounds(rc, m)
+        w("// sparse form of the partial rounds (see sparse_partial_rounds in the generator)\n")
+        w("static const uint32_t DSV_HADES_PRE_MDS_HOST[%d][9] = {\n" % (WIDTH * WIDTH))
+        for row in pre:
+            for x in row:
+                w("  %s,\n" % arr(mont(x)))
+        w("};\n")
+        w("static const uint32_t DSV_HADES_KAPPA0_HOST[%d][9] = {\n" % WIDTH)
+        for x in kappa[0]:
+            w("  %s,\n" % arr(mont(x)))
+        w("};\n")
+        w("// per partial round i: b[4], c''[4], d, kappa_{i+1}[5]\n")
+        w("#define DSV_HADES_SPARSE_STRIDE 14\n")
+        w("static const uint32_t DSV_HADES_SPARSE_HOST[%d][9] = {\n" % (PARTIAL * 14))
+        for i in range(PARTIAL):
+            for x in bs[i] + cs[i] + [ds[i]] + kappa[i + 1]:
                 w("  %s,\n" % arr(mont(x)))
         w("};\n")
     print("wrote", path)

@@ -18,6 +18,10 @@ namespace dsv {
 
 __constant__ u32 c_hades_rc[(DSV_HADES_FULL + DSV_HADES_PARTIAL) * DSV_HADES_WIDTH][NL];
 __constant__ u32 c_hades_mds[DSV_HADES_WIDTH * DSV_HADES_WIDTH][NL];
+// sparse form of the 59 partial rounds (schnorr_amd/csrc/gen_constants.py: sparse_partial_rounds)
+__constant__ u32 c_hades_pre_mds[DSV_HADES_WIDTH * DSV_HADES_WIDTH][NL];
+__constant__ u32 c_hades_kappa0[DSV_HADES_WIDTH][NL];
+__constant__ u32 c_hades_sparse[DSV_HADES_PARTIAL * DSV_HADES_SPARSE_STRIDE][NL];
 
 DSV_DEV Fe fe_load_const(const u32* p) {
   Fe r;
@@ -26,21 +30,21 @@ DSV_DEV Fe fe_load_const(const u32* p) {
   return r;
 }
 
-// x^5.  x limbs < 2^30, x < 3q  ->  N
+// x^5.  x limbs < 2^30, x < 5q  ->  N
 DSV_DEV Fe hades_sbox(const Fe& x) {
   Fe x2 = fe_sqr(x);
   Fe x4 = fe_sqr(x2);
   return fe_mul(x4, x);
 }
 
-// state' = MDS * state, one output word per iteration; state words: limbs < 2^30, < 3q
-DSV_DEV void hades_mds(Fe (&s)[5]) {
-  Fe out[5];
+// state' = MDS * state, one output word per iteration; state words: limbs < 2^29 + 8
+DSV_DEV void hades_mds(Fe (&s)[5], const u32 (*mat)[NL]) {
+  Fe out[5] = {fe_zero(), fe_zero(), fe_zero(), fe_zero(), fe_zero()};
 #pragma unroll 1
   for (int k = 0; k < 5; k++) {
     Fe m[5];
 #pragma unroll
-    for (int j = 0; j < 5; j++) m[j] = fe_load_const(c_hades_mds[k * 5 + j]);
+    for (int j = 0; j < 5; j++) m[j] = fe_load_const(mat[k * 5 + j]);
     Fe r = fe_dot5(s, m);
     // rotate `out` so that after 5 iterations out[k] holds row k (no dynamic register index)
     out[0] = out[1];
@@ -53,29 +57,59 @@ DSV_DEV void hades_mds(Fe (&s)[5]) {
   for (int k = 0; k < 5; k++) s[k] = out[k];
 }
 
-DSV_DEV void hades_permute(Fe (&s)[5]) {
-  int ci = 0;
-#pragma unroll 1
-  for (int round = 0; round < DSV_HADES_FULL + DSV_HADES_PARTIAL; round++) {
-    const bool full = round < DSV_HADES_FULL / 2 || round >= DSV_HADES_FULL / 2 + DSV_HADES_PARTIAL;
+// one full round: add constants, x^5 on every word, dense matrix
+DSV_DEV void hades_full_round(Fe (&s)[5], const u32 (*rc)[NL], const u32 (*mat)[NL]) {
 #pragma unroll
-    for (int k = 0; k < 5; k++) s[k] = fe_add(s[k], fe_load_const(c_hades_rc[ci + k]));
-    ci += 5;
-    if (full) {
-      // S-box on words 0..3 through one inlined copy: apply to s[0], rotate left, 4 times,
-      // then rotate once more so every word is back in place with s[4] still pending.
+  for (int k = 0; k < 5; k++) s[k] = fe_add(s[k], fe_load_const(rc[k]));
+  // S-box through one inlined copy: apply to s[0], rotate, 5 times
 #pragma unroll 1
-      for (int k = 0; k < 4; k++) {
-        Fe t = hades_sbox(s[0]);
-        s[0] = s[1];
-        s[1] = s[2];
-        s[2] = s[3];
-        s[3] = t;
-      }
-    }
-    s[4] = hades_sbox(s[4]);  // partial rounds: last word only
-    hades_mds(s);
+  for (int k = 0; k < 5; k++) {
+    Fe t = hades_sbox(s[0]);
+    s[0] = s[1];
+    s[1] = s[2];
+    s[2] = s[3];
+    s[3] = s[4];
+    s[4] = t;
   }
+  hades_mds(s, mat);
+}
+
+// The permutation.  The 59 partial rounds run in their sparse-matrix form: per round one S-box,
+// one 5-term dot product (new last word) and four multiply-accumulates (words 0..3), i.e.
+// 3 + 1 + 4 reductions instead of 3 + 5 dot products of the dense form.  Words 0..3 are never
+// reduced inside a round (w += kappa + b*z grows by ~2q per round), so they are brought back
+// below 2q by a multiplication with Montgomery-one every 20 rounds and after the last one
+// (value < 45q, far below the 2^261 ~ 70q the representation holds).
+DSV_DEV void hades_permute(Fe (&s)[5]) {
+  constexpr int HALF = DSV_HADES_FULL / 2;
+#pragma unroll 1
+  for (int r = 0; r < HALF; r++)
+    hades_full_round(s, c_hades_rc + 5 * r, r == HALF - 1 ? c_hades_pre_mds : c_hades_mds);
+#pragma unroll
+  for (int k = 0; k < 4; k++) s[k] = fe_carry(fe_add(s[k], fe_load_const(c_hades_kappa0[k])));
+  s[4] = fe_add(s[4], fe_load_const(c_hades_kappa0[4]));
+#pragma unroll 1
+  for (int i = 0; i < DSV_HADES_PARTIAL; i++) {
+    const u32(*k)[NL] = c_hades_sparse + i * DSV_HADES_SPARSE_STRIDE;  // b[4] c[4] d kappa[5]
+    s[4] = hades_sbox(s[4]);
+    Fe row[5];
+#pragma unroll
+    for (int j = 0; j < 5; j++) row[j] = fe_load_const(k[4 + j]);
+    Fe z = fe_dot5(s, row);
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      Fe p = fe_mul(fe_load_const(k[j]), s[4]);
+      s[j] = fe_carry(fe_add(fe_add(s[j], p), fe_load_const(k[9 + j])));
+    }
+    s[4] = fe_add(z, fe_load_const(k[13]));
+    if (i % 20 == 19 || i == DSV_HADES_PARTIAL - 1) {
+#pragma unroll
+      for (int j = 0; j < 4; j++) s[j] = fe_mul(s[j], fe_one());
+    }
+  }
+#pragma unroll 1
+  for (int r = 0; r < HALF; r++)
+    hades_full_round(s, c_hades_rc + 5 * (HALF + DSV_HADES_PARTIAL + r), c_hades_mds);
 }
 
 // sponge::hash over 3 inputs: state = [0, a, b, c, 1] -> one permutation -> state[1]

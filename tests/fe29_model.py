@@ -233,3 +233,61 @@ def ext_to_niels(p):
 def affine_of(p):
     zi = pow(val(from_mont(p["z"])), -1, Q)
     return (val(from_mont(p["u"])) * zi % Q, val(from_mont(p["v"])) * zi % Q)
+
+
+# ---- Hades (hades29.h), with the generated device constants ---------------------------------
+def _load_table(name):
+    text = open(_HDR).read()
+    m = re.search(r"%s\[[^\]]*\]\[9\] = \{(.*?)\n\};" % name, text, flags=re.S)
+    rows = re.findall(r"\{([^}]*)\}", m.group(1))
+    return [[int(x.strip().rstrip("u"), 16) for x in r.split(",")] for r in rows]
+
+
+_H = {}
+
+
+def _hc():
+    if not _H:
+        _H["rc"] = _load_table("DSV_HADES_RC_HOST")
+        _H["mds"] = _load_table("DSV_HADES_MDS_HOST")
+        _H["pre"] = _load_table("DSV_HADES_PRE_MDS_HOST")
+        _H["k0"] = _load_table("DSV_HADES_KAPPA0_HOST")
+        _H["sp"] = _load_table("DSV_HADES_SPARSE_HOST")
+    return _H
+
+
+def sbox(x):
+    x2 = sqr(x)
+    x4 = sqr(x2)
+    return mul(x4, x)
+
+
+def hades_full_round(s, rc, mat):
+    s = [add(s[k], rc[k]) for k in range(5)]
+    s = [sbox(x) for x in s]
+    return [dot(s, [mat[k * 5 + j] for j in range(5)]) for k in range(5)]
+
+
+def hades_permute(s):
+    h = _hc()
+    s = list(s)
+    for r in range(4):
+        s = hades_full_round(s, h["rc"][5 * r:5 * r + 5], h["pre"] if r == 3 else h["mds"])
+    for k in range(4):
+        s[k] = carry(add(s[k], h["k0"][k]))
+    s[4] = add(s[4], h["k0"][4])
+    for i in range(59):
+        k = h["sp"][14 * i:14 * i + 14]
+        s[4] = sbox(s[4])
+        z = dot(s, k[4:9])
+        for j in range(4):
+            p = mul(k[j], s[4])
+            s[j] = carry(add(add(s[j], p), k[9 + j]))
+            assert val(s[j]) < (1 << 260)
+        s[4] = add(z, k[13])
+        if i % 20 == 19 or i == 58:
+            for j in range(4):
+                s[j] = mul(s[j], ONE)
+    for r in range(4):
+        s = hades_full_round(s, h["rc"][5 * (4 + 59 + r):5 * (4 + 59 + r) + 5], h["mds"])
+    return s

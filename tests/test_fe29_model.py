@@ -82,3 +82,14 @@ def test_identity_and_torsion_through_the_formulas():
     assert F.affine_of(s) == (0, 1)
     s = F.ext_add_niels(ident, F.ext_to_niels(ident))
     assert F.affine_of(s) == (0, 1)
+
+
+def test_sparse_hades_permutation_matches_naive_model_and_keeps_bounds():
+    """hades29.h's sparse-partial-round permutation (limb-exact model, generated constants)
+    against the naive dense permutation of tests/pymodel.py, incl. extreme states."""
+    states = [[rnd.randrange(F.Q) for _ in range(5)] for _ in range(3)]
+    states += [[0] * 5, [F.Q - 1] * 5, [0, 1, 2, 3, 4]]
+    for st in states:
+        got = F.hades_permute([F.to_mont_int(x) for x in st])
+        assert [F.val(F.from_mont(x)) for x in got] == M.hades_permute(st)
+    assert F.stats["max_col"] < (1 << 64)
