@@ -6,14 +6,14 @@
 
 One "step" = one pass of the verify hot path over one batch of 2^20 synthetic single signatures
 per GPU (BASELINE.json configs[1]), inputs already resident in HBM: k_challenge (Poseidon) then
-k_verify_fixed (u*G + c*PK == R).  Batches are generated on the GPU by the engine's own sign
+k_verify_fixed_half ((b*u)*G + a*PK - b*R == O, halfgcd.h).  Batches are generated on the GPU by the engine's own sign
 kernels and every 16th item is corrupted, so the expected verdict vector is non-trivial; it is
 checked after the timed region (and a sample is re-verified by the CPU oracle at N = 1).
 
 N > 1: one process per GPU, each rank verifies its own 2^20-item shard (weak scaling) and the
 verdict bytes are all-gathered over RCCL inside the timed region.
 
-Prints ONE JSON line on rank 0.  `roofline` is for the dominant kernel (k_verify_fixed), whose
+Prints ONE JSON line on rank 0.  `roofline` is for the dominant kernel (k_verify_fixed_half), whose
 bound is VALU issue — see DESIGN.md §4 for the instruction model; HBM figures ride along.
 """
 import argparse
@@ -25,23 +25,28 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-# ---- work model of k_verify_fixed: VALU lane-instructions per verdict --------
-FE_MUL, FE_SQR = 225, 189            # fe29.h: 153 / 117 MADs + carry & normalise ops
-CHEAP = 9                            # one limb-wise add
-SUB = 18 + 26                        # biased subtract + parallel carry pass
-DOUBLE_UVZ = 4 * FE_SQR + 3 * FE_MUL + 3 * CHEAP + 3 * SUB
-ADD_NIELS = 8 * FE_MUL + 4 * CHEAP + 26 + 3 * SUB
-ADD_ANIELS = 7 * FE_MUL + 4 * CHEAP + 26 + 3 * SUB
-TO_NIELS = 2 * FE_MUL + CHEAP + 26 + SUB
-VERIFY_FIXED_INSTR = (
-    4 * FE_MUL                                     # PK, R to Montgomery form
-    + 14 * (ADD_NIELS + TO_NIELS) + TO_NIELS       # 16-entry window table of PK
-    + 63 * (4 * DOUBLE_UVZ + ADD_NIELS)            # c*PK: 252 doublings + 63 additions
-    + 32 * ADD_ANIELS                              # += u*G from the 8-bit-window table
-    + 2 * FE_MUL + 2 * 150                         # projective compare
+# ---- work model of the dominant kernel k_verify_fixed_half --------------------
+# VALU lane-instructions per verdict, from the instruction counts hipcc emits for each field
+# operation (tools: `hipcc -S` of fe29.h; checked against rocprof SQ_INSTS_VALU in profiles/).
+FE_MUL, FE_SQR = 211, 181            # 153 / 117 v_mad_u64_u32 + carry & normalise ops
+ADD, SUB, CARRY = 9, 45, 26          # limb-wise add; biased subtract + carry pass; carry pass
+DOUBLE = 4 * FE_SQR + 3 * FE_MUL + 3 * ADD + 3 * SUB
+ADD_NIELS = 8 * FE_MUL + 4 * ADD + CARRY + 3 * SUB
+ADD_ANIELS = 7 * FE_MUL + 4 * ADD + CARRY + 3 * SUB
+TO_NIELS = 2 * FE_MUL + ADD + CARRY + 2 * SUB          # incl. the negated 2d*t of a table entry
+TABLE9 = 7 * ADD_NIELS + 8 * TO_NIELS                  # |d|*P, d = 1..8
+WINDOWS = 34                                           # mean over waves of max lane length / 4
+HALF_GCD = 45000                                       # measured (shift-subtract Euclid, divergent)
+VERIFY_INSTR = (
+    4 * FE_MUL                                         # PK, R to Montgomery form
+    + 2 * TABLE9                                       # window tables of PK and R
+    + HALF_GCD + 2 * 8 * 90                            # (a, b) and b*u mod r
+    + WINDOWS * (4 * DOUBLE + 2 * ADD_NIELS)           # a*PK -/+ b*R, shared doublings
+    + 32 * ADD_ANIELS                                  # += (b*u)*G from the 8-bit-window table
+    + 400                                              # identity test
 )
 ALGO_BYTES_SINGLE = 193                            # 192 B in + 1 B out
-CORE_BYTES = 32 + 32 + 1 + 64 + 64 + 1             # what k_verify_fixed itself moves per item
+CORE_BYTES = 32 + 32 + 1 + 64 + 64 + 1             # what the kernel itself moves per item
 VALU_CYCLES_PER_INSTR = 4.05                       # measured: profiles/r01_valu_rates.txt
 N_CU, SIMD_PER_CU, CLOCK_HZ = 256, 4, 2.4e9
 VALU_PEAK_LANE_INSTR = N_CU * SIMD_PER_CU * CLOCK_HZ / VALU_CYCLES_PER_INSTR * 64
@@ -163,17 +168,17 @@ def main():
 
     if rank == 0:
         core_s = core_ms * 1e-3
-        lane_instr = VERIFY_FIXED_INSTR * n
+        lane_instr = VERIFY_INSTR * n
         achieved = lane_instr / core_s
         out["roofline"] = {
-            "kernel": "k_verify_fixed",
+            "kernel": "k_verify_fixed_half",
             "bound": "valu",
             "achieved": achieved / 1e12,
             "peak": VALU_PEAK_LANE_INSTR / 1e12,
             "unit": "T lane-instr/s",
             "frac": achieved / VALU_PEAK_LANE_INSTR,
             "traffic": None,
-            "model": {"valu_lane_instr_per_verdict": VERIFY_FIXED_INSTR,
+            "model": {"valu_lane_instr_per_verdict": VERIFY_INSTR,
                       "cycles_per_wave_instr": VALU_CYCLES_PER_INSTR,
                       "kernel_ms": core_ms, "hash_kernel_ms": hash_ms},
             "hbm": {"bound": "hbm", "achieved": CORE_BYTES * n / core_s / 1e9,

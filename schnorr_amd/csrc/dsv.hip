@@ -30,6 +30,7 @@
 #include "fe29.h"
 #include "fr.h"
 #include "hades29.h"
+#include "halfgcd.h"
 #include "jubjub29.h"
 
 namespace dsv {
@@ -353,6 +354,77 @@ k_verify_fixed(const uint8_t* __restrict__ u, const uint8_t* __restrict__ c,
   }
 }
 
+// Same verdict, ~half the doublings (halfgcd.h): with (a, b), a = b*c (mod 8r), b odd,
+//   u*G + c*PK == R   <=>   (b*u mod r)*G + a*PK - b*R == O.
+// Two per-lane window tables (PK and R), one Straus chain of ~34 windows whose length is the
+// lane's own max(bitlen a, bitlen b) (lanes of a wave simply leave the loop at different times).
+template <bool ACCUM>
+__global__ void __launch_bounds__(256, DSV_WAVES_VERIFY)
+k_verify_fixed_half(const uint8_t* __restrict__ u, const uint8_t* __restrict__ c,
+                    const uint8_t* __restrict__ PK_uv, const uint8_t* __restrict__ R_uv,
+                    const u32* __restrict__ table, const uint8_t* __restrict__ valid, size_t n,
+                    uint8_t* __restrict__ ok, u32* __restrict__ var_tables) {
+  u32* tpk = var_tables + ((size_t)blockIdx.x * 256 + threadIdx.x) * (2 * kVarLaneWords);
+  u32* tr = tpk + kVarLaneWords;
+#pragma unroll 1
+  for (size_t base = (size_t)blockIdx.x * 256; base < n; base += (size_t)gridDim.x * 256) {
+    const size_t i = base + threadIdx.x;
+    if (i >= n) continue;
+    bool good = ACCUM ? (ok[i] != 0) : (valid[i] != 0);
+    {
+      Fe pku, pkv;
+      good &= load_fq(pku, PK_uv, 2 * i);
+      good &= load_fq(pkv, PK_uv, 2 * i + 1);
+      build_var_table(tpk, pku, pkv);
+    }
+    {
+      Fe ru, rv;
+      good &= load_fq(ru, R_uv, 2 * i);
+      good &= load_fq(rv, R_uv, 2 * i + 1);
+      build_var_table(tr, ru, rv);
+    }
+    u32 ya[8], yb[8], w[8];
+    bool b_neg;
+    int top;
+    {
+      u32 cs[8], a[8], b[8];
+      load_words8(cs, c, i);
+      half_scalars(a, b, b_neg, cs);
+      const int la = bitlen8(a), lb = bitlen8(b);
+      top = ((la > lb ? la : lb) + 3) >> 2;
+      recode_signed4(ya, a);
+      recode_signed4(yb, b);
+      u32 us[8];
+      load_words8(us, u, i);
+      const bool u_ok = words_lt(us, kR32);
+      good &= u_ok;
+      if (!u_ok) us[7] &= 0x0fffffffu;  // keep fr_mul's inputs below r-ish; verdict is 0 anyway
+      fr_mul(w, b, us);                 // |b| * u mod r
+      if (b_neg) {                      // (b*u) mod r with b < 0
+        const u32 zero[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        u32 t[8];
+        fr_sub(t, zero, w);
+#pragma unroll
+        for (int k = 0; k < 8; k++) w[k] = t[k];
+      }
+    }
+    // T = a*PK + (b_neg ? +|b| : -|b|) * R  (+ w*G below)
+    const int rsign = b_neg ? 1 : -1;
+    Ext acc = ext_add_niels(ext_identity(), load_var_entry(tpk, sdigit4(ya, top)));
+    acc = ext_add_niels(acc, load_var_entry(tr, rsign * sdigit4(yb, top)));
+#pragma unroll 1
+    for (int k = top - 1; k >= 0; k--) {
+      acc = ext_mul16(acc);
+      acc = ext_add_niels(acc, load_var_entry(tpk, sdigit4(ya, k)));
+      acc = ext_add_niels(acc, load_var_entry(tr, rsign * sdigit4(yb, k)));
+    }
+    acc = fixed_base_accumulate(acc, w, table);
+    // T == O  <=>  u == 0 and v == z
+    const bool eq = fe_is_zero_canon(fe_canon(acc.u)) & fe_equal(acc.v, acc.z);
+    ok[i] = (good & eq) ? 1 : 0;
+  }
+}
+
 __global__ void __launch_bounds__(256, DSV_WAVES_VERIFY)
 k_verify_var(const uint8_t* __restrict__ u, const uint8_t* __restrict__ c,
              const uint8_t* __restrict__ PK_uv, const uint8_t* __restrict__ Gen_uv,
@@ -523,6 +595,7 @@ int fail(int code, const char* fmt, ...) {
 
 struct Context {
   int device = -1;
+  bool half_scalars = true;  // DSV_VERIFY_ALGO=classic selects the 250-bit chain instead
   u32* table[2] = {nullptr, nullptr};  // fixed-base tables for G, G'
   // staging for the host-pointer entry points (grown on demand, guarded by mu)
   std::mutex mu;
@@ -579,6 +652,23 @@ Workspace carve(void* ws, size_t n) {
   return w;
 }
 
+// the dominant kernel, in either formulation (same verdicts; see halfgcd.h)
+void launch_verify_fixed(bool accumulate, const void* u, const void* c, const void* PK_uv,
+                         const void* R_uv, int which, const void* valid, size_t n, void* ok,
+                         u32* tables, hipStream_t s) {
+  const dim3 grid(verify_grid(n)), block(256);
+#define DSV_LAUNCH(K)                                                                          \
+  hipLaunchKernelGGL(K, grid, block, 0, s, (const uint8_t*)u, (const uint8_t*)c,               \
+                     (const uint8_t*)PK_uv, (const uint8_t*)R_uv, (const u32*)g_ctx.table[which], \
+                     (const uint8_t*)valid, n, (uint8_t*)ok, tables)
+  if (g_ctx.half_scalars) {
+    if (accumulate) DSV_LAUNCH(k_verify_fixed_half<true>); else DSV_LAUNCH(k_verify_fixed_half<false>);
+  } else {
+    if (accumulate) DSV_LAUNCH(k_verify_fixed<true>); else DSV_LAUNCH(k_verify_fixed<false>);
+  }
+#undef DSV_LAUNCH
+}
+
 }  // namespace
 
 extern "C" {
@@ -621,6 +711,8 @@ int dsv_init(int device) {
   }
   HIP_TRY(hipDeviceSynchronize());
   g_ctx.device = device;
+  const char* algo = getenv("DSV_VERIFY_ALGO");
+  g_ctx.half_scalars = !(algo && strcmp(algo, "classic") == 0);
   g_ready.store(true, std::memory_order_release);
   return DSV_OK;
 }
@@ -683,9 +775,7 @@ int dsv_verify_single_dev(const void* u, const void* R_uv, const void* PK_uv, co
   hipStream_t s = (hipStream_t)stream;
   hipLaunchKernelGGL(k_challenge<false>, dim3(grid_for(n)), dim3(256), 0, s, (const uint8_t*)R_uv,
                      (const uint8_t*)nullptr, (const uint8_t*)m, n, w.c, w.valid);
-  hipLaunchKernelGGL(k_verify_fixed<false>, dim3(verify_grid(n)), dim3(256), 0, s, (const uint8_t*)u,
-                     (const uint8_t*)w.c, (const uint8_t*)PK_uv, (const uint8_t*)R_uv,
-                     (const u32*)g_ctx.table[0], (const uint8_t*)w.valid, n, (uint8_t*)ok, w.tables);
+  launch_verify_fixed(false, u, w.c, PK_uv, R_uv, 0, w.valid, n, ok, w.tables, s);
   HIP_TRY(hipGetLastError());
   return DSV_OK;
 }
@@ -702,14 +792,7 @@ int dsv_verify_core_dev(const void* u, const void* c, const void* valid, const v
     return fail(DSV_ERR_INVALID_ARGUMENT, "bad argument");
   hipStream_t s = (hipStream_t)stream;
   Workspace w = carve(workspace, n);
-  if (accumulate)
-    hipLaunchKernelGGL(k_verify_fixed<true>, dim3(verify_grid(n)), dim3(256), 0, s, (const uint8_t*)u,
-                       (const uint8_t*)c, (const uint8_t*)PK_uv, (const uint8_t*)R_uv,
-                       (const u32*)g_ctx.table[which], (const uint8_t*)valid, n, (uint8_t*)ok, w.tables);
-  else
-    hipLaunchKernelGGL(k_verify_fixed<false>, dim3(verify_grid(n)), dim3(256), 0, s, (const uint8_t*)u,
-                       (const uint8_t*)c, (const uint8_t*)PK_uv, (const uint8_t*)R_uv,
-                       (const u32*)g_ctx.table[which], (const uint8_t*)valid, n, (uint8_t*)ok, w.tables);
+  launch_verify_fixed(accumulate != 0, u, c, PK_uv, R_uv, which, valid, n, ok, w.tables, s);
   HIP_TRY(hipGetLastError());
   return DSV_OK;
 }
@@ -726,12 +809,8 @@ int dsv_verify_double_dev(const void* u, const void* R_uv, const void* Rp_uv, co
   hipStream_t s = (hipStream_t)stream;
   hipLaunchKernelGGL(k_challenge<true>, dim3(grid_for(n)), dim3(256), 0, s, (const uint8_t*)R_uv,
                      (const uint8_t*)Rp_uv, (const uint8_t*)m, n, w.c, w.valid);
-  hipLaunchKernelGGL(k_verify_fixed<false>, dim3(verify_grid(n)), dim3(256), 0, s, (const uint8_t*)u,
-                     (const uint8_t*)w.c, (const uint8_t*)PK_uv, (const uint8_t*)R_uv,
-                     (const u32*)g_ctx.table[0], (const uint8_t*)w.valid, n, (uint8_t*)ok, w.tables);
-  hipLaunchKernelGGL(k_verify_fixed<true>, dim3(verify_grid(n)), dim3(256), 0, s, (const uint8_t*)u,
-                     (const uint8_t*)w.c, (const uint8_t*)PKp_uv, (const uint8_t*)Rp_uv,
-                     (const u32*)g_ctx.table[1], (const uint8_t*)w.valid, n, (uint8_t*)ok, w.tables);
+  launch_verify_fixed(false, u, w.c, PK_uv, R_uv, 0, w.valid, n, ok, w.tables, s);
+  launch_verify_fixed(true, u, w.c, PKp_uv, Rp_uv, 1, w.valid, n, ok, w.tables, s);
   HIP_TRY(hipGetLastError());
   return DSV_OK;
 }

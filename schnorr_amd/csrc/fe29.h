@@ -75,13 +75,17 @@ DSV_DEV Fe fe_one() { return fe_const(kOne); }
 // ---- Montgomery reduction of 17 column sums c[0..16] (c[17] scratch), R = 2^261 ----------
 // q = 1 (mod 2^29)  =>  -q^-1 = -1 (mod 2^29): the quotient digit is just the negated low limb,
 // and digit * q[0] only contributes the carry that clears that limb.
+// Callers pre-bias columns 0..8 by +M29 (the first MAD of each of those columns starts from the
+// constant instead of 0, which costs nothing): with s' = s + M29 the quotient digit is
+// m = -s mod 2^29 = ~s' & M29 and the carry (s + m) / 2^29 is simply s' >> 29 — two 64-bit and
+// two 32-bit instructions per row instead of three and two.
 DSV_DEV Fe fe_reduce_cols(u64 (&c)[18]) {
   u64 k = 0;
 #pragma unroll
   for (int i = 0; i < NL; i++) {
     u64 s = c[i] + k;
-    u32 m = (0u - (u32)s) & M29;
-    k = (s + m) >> 29;
+    u32 m = (~(u32)s) & M29;
+    k = s >> 29;
 #pragma unroll
     for (int j = 1; j < NL; j++) c[i + j] += (u64)m * kQ29[j];
   }
@@ -100,7 +104,7 @@ DSV_DEV Fe fe_mul(const Fe& a, const Fe& b) {
   u64 c[18];
 #pragma unroll
   for (int k = 0; k < 17; k++) {
-    u64 s = 0;
+    u64 s = (k < NL) ? (u64)M29 : 0;
 #pragma unroll
     for (int i = 0; i < NL; i++) {
       const int j = k - i;
@@ -120,7 +124,7 @@ DSV_DEV Fe fe_sqr(const Fe& a) {
   u64 c[18];
 #pragma unroll
   for (int k = 0; k < 17; k++) {
-    u64 s = 0;
+    u64 s = (k < NL) ? (u64)M29 : 0;
 #pragma unroll
     for (int i = 0; i < NL; i++) {
       const int j = k - i;
@@ -138,7 +142,7 @@ DSV_DEV Fe fe_dot5(const Fe (&a)[5], const Fe (&b)[5]) {
   u64 c[18];
 #pragma unroll
   for (int k = 0; k < 17; k++) {
-    u64 s = 0;
+    u64 s = (k < NL) ? (u64)M29 : 0;
 #pragma unroll
     for (int t = 0; t < 5; t++) {
 #pragma unroll

@@ -47,15 +47,16 @@ def to_mont_int(x):
 
 
 def reduce_cols(c):
+    """columns 0..8 arrive pre-biased by +M29 (see fe29.h)"""
     k = 0
     c = list(c) + [0]
     for i in range(NL):
+        c[i] += M29
         s = c[i] + k
         assert s < U64
-        m = (-s) & M29
-        t = s + m
-        assert t < U64 and t & M29 == 0
-        k = t >> LB
+        m = (~s) & M29
+        assert (s - M29 + m) & M29 == 0 and (s - M29 + m) >> LB == s >> LB
+        k = s >> LB
         for j in range(1, NL):
             c[i + j] += m * Q29[j]
             assert c[i + j] < U64, "column overflow in reduction"

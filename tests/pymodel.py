@@ -162,3 +162,34 @@ def from_le(b):
 
 def point_bytes(p):
     return le32(p[0]) + le32(p[1])
+
+
+# ---- half-size scalars (schnorr_amd/csrc/halfgcd.h), integer model -------------------------
+def half_scalars(c):
+    """(a, b_mag, b_neg) with a = b*c (mod 8r), b odd; same step sequence as the device code."""
+    N = 8 * R_ORDER
+    A, B, tA, tB, neg = N, c, 0, 1, False
+    while B >= (1 << 128):
+        if A >= B:
+            k = A.bit_length() - B.bit_length()
+            if (B << k) > A:
+                k -= 1
+            A -= B << k
+            tA += tB << k
+        else:
+            A, B, tA, tB = B, A, tB, tA
+            neg = not neg
+    if tB & 1:
+        return B, tB, neg
+    return A, tA, not neg
+
+
+def verify_single_half(u, R, PK, m):
+    """(b*u mod r)*G + a*PK - b*R == O  — must equal verify_single on every on-curve input."""
+    c = challenge(R, m)
+    a, b, bn = half_scalars(c)
+    sb = -b if bn else b
+    w = (sb * u) % R_ORDER
+    t = padd(pmul(GEN, w), pmul(PK, a))
+    t = padd(t, pmul(R, b) if bn else pmul(pneg(R), b))
+    return t == IDENTITY

@@ -241,3 +241,31 @@ def test_full_size_double_batch(engine):
     sub = {k: b[k][idx].cpu().numpy() for k in ("u", "R", "Rp", "PK", "PKp", "m")}
     want = O.verify_double(sub["u"], sub["R"], sub["Rp"], sub["PK"], sub["PKp"], sub["m"], nthreads=8)
     assert np.array_equal(want, ok[idx].cpu().numpy())
+
+
+def test_order8_torsion_components_valid_and_invalid(engine):
+    """Keys and nonce points carrying an order-8 component: the signature is valid exactly when the
+    torsion parts cancel (c*k1 = k2 mod 8).  Both GPU formulations (classic 250-bit chain and the
+    half-size-scalar form, halfgcd.h) must reproduce the reference equation's verdicts."""
+    import test_halfgcd as TH
+    t8 = TH.order8_point()
+    rnd = TH.rnd
+    rows = {"u": [], "R": [], "PK": [], "m": []}
+    want = []
+    while sum(want) < 3 or len(want) < 48:
+        sk, m, rr = rnd.randrange(1, M.R_ORDER), rnd.randrange(M.Q), rnd.randrange(1, M.R_ORDER)
+        k1 = rnd.randrange(1, 8)
+        pk = M.padd(M.pmul(M.GEN, sk), M.pmul(t8, k1))
+        for k2 in range(8):
+            R = M.padd(M.pmul(M.GEN, rr), M.pmul(t8, k2))
+            c = M.challenge(R, m)
+            rows["u"].append(np.frombuffer(M.le32((rr - c * sk) % M.R_ORDER), np.uint8))
+            rows["R"].append(np.frombuffer(M.point_bytes(R), np.uint8))
+            rows["PK"].append(np.frombuffer(M.point_bytes(pk), np.uint8))
+            rows["m"].append(np.frombuffer(M.le32(m), np.uint8))
+            want.append(int((c * k1 - k2) % 8 == 0))
+    a = {k: np.stack(v) for k, v in rows.items()}
+    cpu = O.verify_single(a["u"], a["R"], a["PK"], a["m"], nthreads=8)
+    assert list(cpu) == want
+    got = engine.verify_single(a["u"], a["R"], a["PK"], a["m"])
+    assert list(got) == want

@@ -1,0 +1,75 @@
+"""The half-size-scalar reformulation of the verification equation (halfgcd.h) is EXACT: same
+verdict as the reference equation for every on-curve input, including points with a small-order
+component.  Integer model only (CPU); the GPU kernels are checked against the oracle in
+tests/test_gpu_parity.py."""
+import random
+
+import pymodel as M
+
+rnd = random.Random(2024)
+N = 8 * M.R_ORDER
+
+
+def _sqrt(n, p=M.Q):
+    q, s = p - 1, 0
+    while q % 2 == 0:
+        q //= 2
+        s += 1
+    z = 2
+    while pow(z, (p - 1) // 2, p) != p - 1:
+        z += 1
+    m, c, t, r = s, pow(z, q, p), pow(n, q, p), pow(n, (q + 1) // 2, p)
+    while t != 1:
+        i, tt = 0, t
+        while tt != 1:
+            tt = tt * tt % p
+            i += 1
+        b = pow(c, 1 << (m - i - 1), p)
+        m, c, t, r = i, b * b % p, t * b * b % p, r * b % p
+    return r
+
+
+def order8_point():
+    while True:
+        v = rnd.randrange(M.Q)
+        u2 = (v * v - 1) * pow(1 + M.D * v * v, -1, M.Q) % M.Q
+        if pow(u2, (M.Q - 1) // 2, M.Q) != 1:
+            continue
+        p = (_sqrt(u2), v)
+        assert M.on_curve(p)
+        t = M.pmul(p, M.R_ORDER)
+        if M.pmul(t, 4) != M.IDENTITY:
+            return t
+
+
+def test_half_scalars_congruence_parity_and_size():
+    sizes = []
+    for c in [0, 1, 2, (1 << 128) - 1, 1 << 128, (1 << 128) + 1, (1 << 250) - 1, 1 << 249,
+              (1 << 200) + 1, N >> 6, (N >> 5) - 1] + \
+             [rnd.getrandbits(250) for _ in range(3000)]:
+        a, b, bn = M.half_scalars(c)
+        sb = -b if bn else b
+        assert (a - sb * c) % N == 0
+        assert b & 1 and 0 < b < (1 << 160) and 0 <= a < (1 << 250)
+        sizes.append(max(a.bit_length(), b.bit_length()))
+    sizes.sort()
+    assert sizes[len(sizes) // 2] <= 130 and sizes[int(0.99 * len(sizes))] <= 137
+
+
+def test_half_scalar_check_is_exact_with_torsion():
+    t8 = order8_point()
+    valid = 0
+    for _ in range(12):
+        sk, m, rr = rnd.randrange(1, M.R_ORDER), rnd.randrange(M.Q), rnd.randrange(1, M.R_ORDER)
+        k1 = rnd.randrange(8)
+        pk = M.padd(M.pmul(M.GEN, sk), M.pmul(t8, k1))      # key with a small-order component
+        for k2 in range(8):
+            R = M.padd(M.pmul(M.GEN, rr), M.pmul(t8, k2))   # nonce point with one too
+            c = M.challenge(R, m)
+            u = (rr - c * sk) % M.R_ORDER
+            want = M.verify_single(u, R, pk, m)
+            assert M.verify_single_half(u, R, pk, m) == want
+            assert want == ((c * k1 - k2) % 8 == 0)          # valid iff the torsion parts cancel
+            valid += want
+            assert not M.verify_single_half((u + 1) % M.R_ORDER, R, pk, m)
+    assert valid >= 3  # each (k1, k2) pair is valid with probability 1/8
