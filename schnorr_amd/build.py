@@ -14,7 +14,6 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libdsv.so")
 SOURCES = ["dsv.hip"]
-HEADERS = ["fe29.h", "jubjub29.h", "hades29.h", "fr.h", "dsv_constants.h", "gen_constants.py"]
 ARCH = "gfx950"
 
 
@@ -22,7 +21,7 @@ def _stale():
     if not os.path.exists(LIB):
         return True
     t = os.path.getmtime(LIB)
-    deps = [os.path.join(CSRC, f) for f in SOURCES + HEADERS]
+    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)]  # every source, header, generator
     deps.append(os.path.join(os.path.dirname(HERE), "include", "dsv.h"))
     return any(os.path.exists(d) and os.path.getmtime(d) > t for d in deps)
 

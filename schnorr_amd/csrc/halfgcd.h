@@ -18,9 +18,8 @@
 // (mean 128.2, 99th percentile 134 over random c): the variable-base part of a verification
 // becomes a two-base Straus chain of ~34 signed 4-bit windows instead of 63.
 //
-// The Euclid steps are done by shift-and-subtract (no division instruction): ~180 flat iterations
-// per lane, ~15k VALU instructions, 2-3 % of a verification.  Lanes diverge in iteration count
-// only; every lane exits after at most kHalfGcdMaxIter iterations.
+// Lanes diverge in iteration count only; every lane exits after at most kHalfGcdMaxIter
+// iterations (the pair it holds then is still a valid one, just longer).
 #pragma once
 #include "fe29.h"
 
@@ -29,7 +28,7 @@ namespace dsv {
 // 8 * r  (255 bits)
 __device__ constexpr u32 kN8R[8] = {0xb7b965b8u, 0x84b872f6u, 0x66408416u, 0x3341049eu,
                                     0x09a1d805u, 0x3339d808u, 0x299d7d48u, 0x73eda753u};
-constexpr int kHalfGcdMaxIter = 640;  // > 2 * 255 shift-subtract steps + swaps
+constexpr int kHalfGcdMaxIter = 512;
 
 DSV_DEV int bitlen8(const u32 (&x)[8]) {
   int len = 0;
@@ -49,78 +48,25 @@ DSV_DEV bool sub8(u32 (&d)[8], const u32 (&a)[8], const u32 (&b)[8]) {
   }
   return borrow != 0;
 }
-// r = x << k, 0 <= k <= 31 (bits shifted out of word 7 are dropped; callers keep them zero)
-DSV_DEV void shl8(u32 (&r)[8], const u32 (&x)[8], int k) {
-  r[0] = x[0] << k;
-#pragma unroll
-  for (int i = 1; i < 8; i++) r[i] = __funnelshift_l(x[i - 1], x[i], k);
-}
-// t += x << k  over 5 words (160 bits), 0 <= k <= 31
-DSV_DEV void addshl5(u32 (&t)[5], const u32 (&x)[5], int k) {
-  u32 s[5];
-  s[0] = x[0] << k;
-#pragma unroll
-  for (int i = 1; i < 5; i++) s[i] = __funnelshift_l(x[i - 1], x[i], k);
-  u32 carry = 0;
-#pragma unroll
-  for (int i = 0; i < 5; i++) {
-    u64 v = (u64)t[i] + s[i] + carry;
-    t[i] = (u32)v;
-    carry = (u32)(v >> 32);
-  }
-}
-// word-granular left shifts for the rare step whose quotient has more than 31 bits
-DSV_DEV void shl_words8(u32 (&x)[8], int ws) {
-  if (ws & 4) {
-#pragma unroll
-    for (int i = 7; i >= 0; i--) x[i] = i >= 4 ? x[i - 4] : 0u;
-  }
-  if (ws & 2) {
-#pragma unroll
-    for (int i = 7; i >= 0; i--) x[i] = i >= 2 ? x[i - 2] : 0u;
-  }
-  if (ws & 1) {
-#pragma unroll
-    for (int i = 7; i >= 0; i--) x[i] = i >= 1 ? x[i - 1] : 0u;
-  }
-}
-DSV_DEV void shl_words5(u32 (&x)[5], int ws) {
-  if (ws & 4) {
-    x[4] = x[0];
-    x[3] = x[2] = x[1] = x[0] = 0u;
-  }
-  if (ws & 2) {
-#pragma unroll
-    for (int i = 4; i >= 0; i--) x[i] = i >= 2 ? x[i - 2] : 0u;
-  }
-  if (ws & 1) {
-#pragma unroll
-    for (int i = 4; i >= 0; i--) x[i] = i >= 1 ? x[i - 1] : 0u;
-  }
-}
-// general forms: r = x << k (0 <= k < 256), t += x << k
-DSV_DEV void shl8_any(u32 (&r)[8], const u32 (&x)[8], int k) {
-  shl8(r, x, k & 31);
-  shl_words8(r, k >> 5);
-}
-DSV_DEV void addshl5_any(u32 (&t)[5], const u32 (&x)[5], int k) {
-  u32 s[5];
-  s[0] = x[0] << (k & 31);
-#pragma unroll
-  for (int i = 1; i < 5; i++) s[i] = __funnelshift_l(x[i - 1], x[i], k & 31);
-  shl_words5(s, k >> 5);
-  u32 carry = 0;
-#pragma unroll
-  for (int i = 0; i < 5; i++) {
-    u64 v = (u64)t[i] + s[i] + carry;
-    t[i] = (u32)v;
-    carry = (u32)(v >> 32);
-  }
-}
 DSV_DEV bool below_2_128(const u32 (&x)[8]) { return (x[4] | x[5] | x[6] | x[7]) == 0; }
 
+// value of an 8-word integer as a double (relative error < 2^-51: plenty for a quotient estimate)
+DSV_DEV double to_double8(const u32 (&x)[8]) {
+  double d = (double)x[7];
+#pragma unroll
+  for (int i = 6; i >= 0; i--) d = __builtin_fma(d, 4294967296.0, (double)x[i]);
+  return d;
+}
+
 // out: a (magnitude, 8 words), b (magnitude, 8 words, only 5 can be non-zero), b_neg.
-// a = (b_neg ? -b : b) * c  (mod 8r),  b odd.   c < 8r (any 8-word value below 8r).
+// a = (b_neg ? -b : b) * c  (mod 8r),  b odd.   c < 2^250.
+//
+// Euclid on (8r, c) with quotient ESTIMATES: each iteration makes A >= B by a conditional swap,
+// takes qe = floor(A/B * (1 - 2^-30)) from double-precision images of A and B (qe <= true
+// quotient, clamped to [1, 2^31)), and does A -= qe*B, tA += qe*tB.  A swap happens exactly when
+// A has become the true remainder, so the (remainder, cofactor) pairs at swap time are those of
+// the exact algorithm (tests/pymodel.py: half_scalars) whatever the estimates were; an
+// under-estimate only costs an extra iteration.  ~80 iterations of ~130 instructions.
 DSV_DEV void half_scalars(u32 (&a)[8], u32 (&b)[8], bool& b_neg, const u32 (&c)[8]) {
   u32 A[8], B[8], tA[5] = {0, 0, 0, 0, 0}, tB[5] = {1, 0, 0, 0, 0};
 #pragma unroll
@@ -134,52 +80,44 @@ DSV_DEV void half_scalars(u32 (&a)[8], u32 (&b)[8], bool& b_neg, const u32 (&c)[
   for (int it = 0; it < kHalfGcdMaxIter && !done; it++) {
     u32 D[8];
     const bool lt = sub8(D, A, B);
-    if (!lt) {
-      // one shift-subtract step of the division A / B:  A -= B << k,  tA += tB << k
-      int k = bitlen8(A) - bitlen8(B);
-      if (k > 31) {
-        // quotient with more than 31 bits (probability ~2^-31 per step for hash-derived c):
-        // same step, general shifter
-        u32 Bs[8];
-        shl8_any(Bs, B, k);
-        if (sub8(D, A, Bs)) {
-          k -= 1;
-          shl8_any(Bs, B, k);
-          sub8(D, A, Bs);
-        }
+    // conditional swap: (A, tA) <-> (B, tB); cofactor signs alternate
 #pragma unroll
-        for (int i = 0; i < 8; i++) A[i] = D[i];
-        addshl5_any(tA, tB, k);
-      } else {
-        if (k > 0) {
-          u32 Bs[8];
-          shl8(Bs, B, k);
-          if (sub8(D, A, Bs)) {  // overshoot: B << k > A, so k >= 1 and B << (k-1) <= A
-            k -= 1;
-            shl8(Bs, B, k);
-            sub8(D, A, Bs);
-          }
-        }
+    for (int i = 0; i < 8; i++) {
+      const u32 x = A[i], y = B[i];
+      A[i] = lt ? y : x;
+      B[i] = lt ? x : y;
+    }
 #pragma unroll
-        for (int i = 0; i < 8; i++) A[i] = D[i];
-        addshl5(tA, tB, k);
-      }
-    } else {
-      // remainder found: (A, tA) <-> (B, tB), cofactor signs alternate
+    for (int i = 0; i < 5; i++) {
+      const u32 x = tA[i], y = tB[i];
+      tA[i] = lt ? y : x;
+      tB[i] = lt ? x : y;
+    }
+    neg = neg != lt;
+    done = lt && below_2_128(B);
+    if (!done) {
+      // A >= B >= 2^128 here.  qe in [1, 2^31), qe <= floor(A / B)
+      const double qd = to_double8(A) / to_double8(B) * (1.0 - 0x1p-30);
+      u32 qe = qd >= 2147483647.0 ? 2147483647u : (u32)qd;
+      qe = qe < 1u ? 1u : qe;
+      // A -= qe * B
+      u32 mc = 0, borrow = 0;
 #pragma unroll
       for (int i = 0; i < 8; i++) {
-        u32 x = A[i];
-        A[i] = B[i];
-        B[i] = x;
+        const u64 p = (u64)qe * B[i] + mc;
+        mc = (u32)(p >> 32);
+        const u64 d = (u64)A[i] - (u32)p - borrow;
+        A[i] = (u32)d;
+        borrow = (u32)(d >> 63);
       }
+      // tA += qe * tB
+      u32 carry = 0;
 #pragma unroll
       for (int i = 0; i < 5; i++) {
-        u32 x = tA[i];
-        tA[i] = tB[i];
-        tB[i] = x;
+        const u64 p = (u64)qe * tB[i] + tA[i] + carry;
+        tA[i] = (u32)p;
+        carry = (u32)(p >> 32);
       }
-      neg = !neg;
-      done = below_2_128(B);
     }
   }
   const bool use_b = (tB[0] & 1) != 0;  // else the previous pair, whose cofactor is then odd
