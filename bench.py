@@ -36,7 +36,7 @@ ADD_ANIELS = 7 * FE_MUL + 4 * ADD + CARRY + 3 * SUB
 TO_NIELS = 2 * FE_MUL + ADD + CARRY + 2 * SUB          # incl. the negated 2d*t of a table entry
 TABLE9 = 7 * ADD_NIELS + 8 * TO_NIELS                  # |d|*P, d = 1..8
 WINDOWS = 34                                           # mean over waves of max lane length / 4
-HALF_GCD = 45000                                       # measured (shift-subtract Euclid, divergent)
+HALF_GCD = 13000                                       # ~90 iterations x ~140 instructions
 VERIFY_INSTR = (
     4 * FE_MUL                                         # PK, R to Montgomery form
     + 2 * TABLE9                                       # window tables of PK and R
@@ -51,6 +51,20 @@ VALU_CYCLES_PER_INSTR = 4.05                       # measured: profiles/r01_valu
 N_CU, SIMD_PER_CU, CLOCK_HZ = 256, 4, 2.4e9
 VALU_PEAK_LANE_INSTR = N_CU * SIMD_PER_CU * CLOCK_HZ / VALU_CYCLES_PER_INSTR * 64
 HBM_PEAK_GBS = 8000.0
+
+
+def _pmc_traffic(n):
+    """HBM bytes per launch of the dominant kernel from the last committed rocprofv3 PMC pass
+    (profiles/pmc_latest.json; FETCH_SIZE + WRITE_SIZE, KB -> bytes, scaled to this batch).
+    Counters cannot be read from inside the timed process, so this is the recorded figure, not a
+    live one; null when no profile is committed.  (gfx950 under-reports FETCH_SIZE by up to 2x
+    for wide coalesced reads; these are 16-B-per-lane scattered reads, uncalibrated.)"""
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_latest.json")) as f:
+            p = json.load(f)
+        return (p["FETCH_SIZE_KB"] + p["WRITE_SIZE_KB"]) * 1024.0 * n / p["batch"]
+    except Exception:
+        return None
 
 
 def main():
@@ -177,7 +191,7 @@ def main():
             "peak": VALU_PEAK_LANE_INSTR / 1e12,
             "unit": "T lane-instr/s",
             "frac": achieved / VALU_PEAK_LANE_INSTR,
-            "traffic": None,
+            "traffic": _pmc_traffic(n),
             "model": {"valu_lane_instr_per_verdict": VERIFY_INSTR,
                       "cycles_per_wave_instr": VALU_CYCLES_PER_INSTR,
                       "kernel_ms": core_ms, "hash_kernel_ms": hash_ms},

@@ -1,0 +1,308 @@
+// dusk_schnorr.hpp — host-side mirror (C++17, header-only) of the dusk-schnorr 0.18 key /
+// signature surface for the native verification path, on top of the C ABI in dsv.h.
+//
+// The reference is a Rust crate; this image has no Rust toolchain, so the compiled-language host
+// layer is C++ with the reference's names, argument meaning and error behaviour:
+//
+//   SecretKey::random / sign / sign_double          /root/reference/src/keys/secret.rs:79-86, 150-168, 217-240
+//   SecretKeyVarGen::{new, random, sign}            /root/reference/src/keys/secret.rs:352-376, 433-451
+//   PublicKey::from(&sk) / verify                   /root/reference/src/keys/public.rs:61-67, 121-130
+//   PublicKeyDouble::from(&sk) / verify             /root/reference/src/keys/public.rs:222-244, 265-272
+//   PublicKeyVarGen::from(&sk) / verify             /root/reference/src/keys/public.rs:337-344, 401-415
+//   Signature{u, R}, SignatureDouble{u, R, R_prime}, SignatureVarGen{u, R}
+//                                                   /root/reference/src/signatures.rs:58-73, 180-203, 337-353
+//   verify_batch / verify_batch_double / verify_batch_var_gen : the new batch entry points
+//
+// `verify` is infallible and returns bool exactly like the reference; a failure of the engine
+// itself (no GPU, HIP error) is not a verdict and is thrown as std::runtime_error.
+// All arithmetic happens on the GPU (libdsv.so); the only host arithmetic here is the 512-bit
+// reduction of `random()` (ff::Field::random = from_bytes_wide of 64 random bytes).
+// Points are held in affine form (u, v) — what `JubJubExtended::to_hash_inputs()` yields.
+#pragma once
+#include <array>
+#include <cstdint>
+#include <cstring>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "dsv.h"
+
+namespace dusk_schnorr {
+
+namespace detail {
+inline void check(int rc, const char* what) {
+  if (rc != DSV_OK)
+    throw std::runtime_error(std::string(what) + ": dsv error " + std::to_string(rc) + ": " +
+                             dsv_last_error());
+}
+inline void ensure_init() {
+  static const bool once = (check(dsv_init(0), "dsv_init"), true);
+  (void)once;
+}
+// x mod m for a 512-bit little-endian x and a 256-bit little-endian modulus (shift-subtract)
+inline std::array<uint8_t, 32> mod_wide(const uint8_t x[64], const uint8_t m[32]) {
+  uint64_t r[5] = {0, 0, 0, 0, 0}, mod[4];
+  std::memcpy(mod, m, 32);
+  for (int bit = 511; bit >= 0; bit--) {
+    for (int i = 4; i > 0; i--) r[i] = (r[i] << 1) | (r[i - 1] >> 63);
+    r[0] = (r[0] << 1) | ((x[bit >> 3] >> (bit & 7)) & 1);
+    // if r >= mod: r -= mod
+    uint64_t d[5];
+    unsigned __int128 borrow = 0;
+    for (int i = 0; i < 5; i++) {
+      unsigned __int128 t = (unsigned __int128)r[i] - (i < 4 ? mod[i] : 0) - (uint64_t)borrow;
+      d[i] = (uint64_t)t;
+      borrow = (t >> 64) & 1;
+    }
+    if (!borrow) std::memcpy(r, d, sizeof d);
+  }
+  std::array<uint8_t, 32> out;
+  std::memcpy(out.data(), r, 32);
+  return out;
+}
+inline constexpr uint8_t kFrModulus[32] = {
+    0xb7, 0x2c, 0xf7, 0xd6, 0x5e, 0x0e, 0x97, 0xd0, 0x82, 0x10, 0xc8, 0xcc, 0x93, 0x20, 0x68, 0xa6,
+    0x00, 0x3b, 0x34, 0x01, 0x01, 0x3b, 0x67, 0x06, 0xa9, 0xaf, 0x33, 0x65, 0xea, 0xb4, 0x7d, 0x0e};
+inline constexpr uint8_t kFqModulus[32] = {
+    0x01, 0x00, 0x00, 0x00, 0xff, 0xff, 0xff, 0xff, 0xfe, 0x5b, 0xfe, 0xff, 0x02, 0xa4, 0xbd, 0x53,
+    0x05, 0xd8, 0xa1, 0x09, 0x08, 0xd8, 0x39, 0x33, 0x48, 0x7d, 0x9d, 0x29, 0x53, 0xa7, 0xed, 0x73};
+}  // namespace detail
+
+template <const uint8_t* MOD>
+struct Scalar32 {
+  std::array<uint8_t, 32> bytes{};  // canonical little-endian, as `to_bytes()`
+  static Scalar32 from_u64(uint64_t x) {
+    Scalar32 s;
+    std::memcpy(s.bytes.data(), &x, 8);
+    return s;
+  }
+  static Scalar32 from_bytes_wide(const uint8_t wide[64]) {
+    Scalar32 s;
+    s.bytes = detail::mod_wide(wide, MOD);
+    return s;
+  }
+  // `Field::random`: 64 bytes from the rng, reduced.  Rng: void operator()(uint8_t*, size_t)
+  template <class Rng>
+  static Scalar32 random(Rng& rng) {
+    uint8_t wide[64];
+    rng(wide, 64);
+    return from_bytes_wide(wide);
+  }
+  const std::array<uint8_t, 32>& to_bytes() const { return bytes; }
+  bool operator==(const Scalar32& o) const { return bytes == o.bytes; }
+};
+using BlsScalar = Scalar32<detail::kFqModulus>;
+using JubJubScalar = Scalar32<detail::kFrModulus>;
+
+struct JubJubAffine {  // (u, v), canonical LE — the pair to_hash_inputs() returns
+  std::array<uint8_t, 64> uv{};
+  bool operator==(const JubJubAffine& o) const { return uv == o.uv; }
+};
+
+struct Signature {
+  JubJubScalar u_;
+  JubJubAffine R_;
+  const JubJubScalar& u() const { return u_; }
+  const JubJubAffine& R() const { return R_; }
+  bool operator==(const Signature& o) const { return u_ == o.u_ && R_ == o.R_; }
+};
+struct SignatureDouble {
+  JubJubScalar u_;
+  JubJubAffine R_, R_prime_;
+  const JubJubScalar& u() const { return u_; }
+  const JubJubAffine& R() const { return R_; }
+  const JubJubAffine& R_prime() const { return R_prime_; }
+};
+struct SignatureVarGen {
+  JubJubScalar u_;
+  JubJubAffine R_;
+  const JubJubScalar& u() const { return u_; }
+  const JubJubAffine& R() const { return R_; }
+};
+
+struct SecretKey {
+  JubJubScalar sk;
+  template <class Rng>
+  static SecretKey random(Rng& rng) { return SecretKey{JubJubScalar::random(rng)}; }
+  // sign: r <- rng; R = r*G; c = H(R, m); u = r - c*sk
+  template <class Rng>
+  Signature sign(Rng& rng, const BlsScalar& message) const {
+    detail::ensure_init();
+    const JubJubScalar r = JubJubScalar::random(rng);
+    Signature s;
+    detail::check(dsv_sign_single(sk.bytes.data(), message.bytes.data(), r.bytes.data(), 1,
+                                  s.u_.bytes.data(), s.R_.uv.data()), "dsv_sign_single");
+    return s;
+  }
+  template <class Rng>
+  SignatureDouble sign_double(Rng& rng, const BlsScalar& message) const {
+    detail::ensure_init();
+    const JubJubScalar r = JubJubScalar::random(rng);
+    SignatureDouble s;
+    detail::check(dsv_sign_double(sk.bytes.data(), message.bytes.data(), r.bytes.data(), 1,
+                                  s.u_.bytes.data(), s.R_.uv.data(), s.R_prime_.uv.data()),
+                  "dsv_sign_double");
+    return s;
+  }
+};
+
+struct PublicKey {
+  JubJubAffine pk;
+  static PublicKey from(const SecretKey& sk) {
+    detail::ensure_init();
+    PublicKey p;
+    detail::check(dsv_public_keys(sk.sk.bytes.data(), 0, nullptr, 1, p.pk.uv.data()),
+                  "dsv_public_keys");
+    return p;
+  }
+  const JubJubAffine& as_ref() const { return pk; }
+  // u*G + c*PK == R  with c = H(R || m)
+  bool verify(const Signature& sig, const BlsScalar& message) const {
+    detail::ensure_init();
+    uint8_t ok = 0;
+    detail::check(dsv_verify_single(sig.u_.bytes.data(), sig.R_.uv.data(), pk.uv.data(),
+                                    message.bytes.data(), 1, &ok), "dsv_verify_single");
+    return ok == 1;
+  }
+  bool operator==(const PublicKey& o) const { return pk == o.pk; }
+};
+
+struct PublicKeyDouble {
+  JubJubAffine pk_, pk_prime_;
+  static PublicKeyDouble from(const SecretKey& sk) {
+    detail::ensure_init();
+    PublicKeyDouble p;
+    detail::check(dsv_public_keys(sk.sk.bytes.data(), 0, nullptr, 1, p.pk_.uv.data()), "pk");
+    detail::check(dsv_public_keys(sk.sk.bytes.data(), 1, nullptr, 1, p.pk_prime_.uv.data()), "pk'");
+    return p;
+  }
+  const JubJubAffine& pk() const { return pk_; }
+  const JubJubAffine& pk_prime() const { return pk_prime_; }
+  bool verify(const SignatureDouble& sig, const BlsScalar& message) const {
+    detail::ensure_init();
+    uint8_t ok = 0;
+    detail::check(dsv_verify_double(sig.u_.bytes.data(), sig.R_.uv.data(), sig.R_prime_.uv.data(),
+                                    pk_.uv.data(), pk_prime_.uv.data(), message.bytes.data(), 1,
+                                    &ok), "dsv_verify_double");
+    return ok == 1;
+  }
+};
+
+struct SecretKeyVarGen {
+  JubJubScalar sk;
+  JubJubAffine generator_;
+  static SecretKeyVarGen make(const JubJubScalar& sk, const JubJubAffine& generator) {
+    return SecretKeyVarGen{sk, generator};
+  }
+  // random: sk, then a generator scalar g; generator = g * G   (secret.rs:367-376)
+  template <class Rng>
+  static SecretKeyVarGen random(Rng& rng) {
+    detail::ensure_init();
+    SecretKeyVarGen k;
+    k.sk = JubJubScalar::random(rng);
+    const JubJubScalar g = JubJubScalar::random(rng);
+    detail::check(dsv_public_keys(g.bytes.data(), 0, nullptr, 1, k.generator_.uv.data()), "gen");
+    return k;
+  }
+  const JubJubAffine& generator() const { return generator_; }
+  template <class Rng>
+  SignatureVarGen sign(Rng& rng, const BlsScalar& message) const {
+    detail::ensure_init();
+    const JubJubScalar r = JubJubScalar::random(rng);
+    SignatureVarGen s;
+    detail::check(dsv_sign_vargen(sk.bytes.data(), generator_.uv.data(), message.bytes.data(),
+                                  r.bytes.data(), 1, s.u_.bytes.data(), s.R_.uv.data()),
+                  "dsv_sign_vargen");
+    return s;
+  }
+};
+
+struct PublicKeyVarGen {
+  JubJubAffine pk_, generator_;
+  static PublicKeyVarGen from(const SecretKeyVarGen& sk) {
+    detail::ensure_init();
+    PublicKeyVarGen p;
+    p.generator_ = sk.generator_;
+    detail::check(dsv_public_keys(sk.sk.bytes.data(), 0, sk.generator_.uv.data(), 1,
+                                  p.pk_.uv.data()), "dsv_public_keys(gen)");
+    return p;
+  }
+  const JubJubAffine& public_key() const { return pk_; }
+  const JubJubAffine& generator() const { return generator_; }
+  bool verify(const SignatureVarGen& sig, const BlsScalar& message) const {
+    detail::ensure_init();
+    uint8_t ok = 0;
+    detail::check(dsv_verify_vargen(sig.u_.bytes.data(), sig.R_.uv.data(), pk_.uv.data(),
+                                    generator_.uv.data(), message.bytes.data(), 1, &ok),
+                  "dsv_verify_vargen");
+    return ok == 1;
+  }
+};
+
+// ---- the new batch entry points (north_star): out[i] == pks[i].verify(sigs[i], msgs[i]) --------
+inline std::vector<bool> verify_batch(const std::vector<Signature>& sigs,
+                                      const std::vector<PublicKey>& pks,
+                                      const std::vector<BlsScalar>& msgs) {
+  if (sigs.size() != pks.size() || sigs.size() != msgs.size())
+    throw std::invalid_argument("verify_batch: slice lengths differ");
+  detail::ensure_init();
+  const size_t n = sigs.size();
+  std::vector<uint8_t> u(32 * n), r(64 * n), pk(64 * n), m(32 * n), ok(n);
+  for (size_t i = 0; i < n; i++) {
+    std::memcpy(&u[32 * i], sigs[i].u_.bytes.data(), 32);
+    std::memcpy(&r[64 * i], sigs[i].R_.uv.data(), 64);
+    std::memcpy(&pk[64 * i], pks[i].pk.uv.data(), 64);
+    std::memcpy(&m[32 * i], msgs[i].bytes.data(), 32);
+  }
+  detail::check(dsv_verify_single(u.data(), r.data(), pk.data(), m.data(), n, ok.data()),
+                "dsv_verify_single");
+  std::vector<bool> out(n);
+  for (size_t i = 0; i < n; i++) out[i] = ok[i] == 1;
+  return out;
+}
+inline std::vector<bool> verify_batch_double(const std::vector<SignatureDouble>& sigs,
+                                             const std::vector<PublicKeyDouble>& pks,
+                                             const std::vector<BlsScalar>& msgs) {
+  if (sigs.size() != pks.size() || sigs.size() != msgs.size())
+    throw std::invalid_argument("verify_batch_double: slice lengths differ");
+  detail::ensure_init();
+  const size_t n = sigs.size();
+  std::vector<uint8_t> u(32 * n), r(64 * n), rp(64 * n), pk(64 * n), pkp(64 * n), m(32 * n), ok(n);
+  for (size_t i = 0; i < n; i++) {
+    std::memcpy(&u[32 * i], sigs[i].u_.bytes.data(), 32);
+    std::memcpy(&r[64 * i], sigs[i].R_.uv.data(), 64);
+    std::memcpy(&rp[64 * i], sigs[i].R_prime_.uv.data(), 64);
+    std::memcpy(&pk[64 * i], pks[i].pk_.uv.data(), 64);
+    std::memcpy(&pkp[64 * i], pks[i].pk_prime_.uv.data(), 64);
+    std::memcpy(&m[32 * i], msgs[i].bytes.data(), 32);
+  }
+  detail::check(dsv_verify_double(u.data(), r.data(), rp.data(), pk.data(), pkp.data(), m.data(),
+                                  n, ok.data()), "dsv_verify_double");
+  std::vector<bool> out(n);
+  for (size_t i = 0; i < n; i++) out[i] = ok[i] == 1;
+  return out;
+}
+inline std::vector<bool> verify_batch_var_gen(const std::vector<SignatureVarGen>& sigs,
+                                              const std::vector<PublicKeyVarGen>& pks,
+                                              const std::vector<BlsScalar>& msgs) {
+  if (sigs.size() != pks.size() || sigs.size() != msgs.size())
+    throw std::invalid_argument("verify_batch_var_gen: slice lengths differ");
+  detail::ensure_init();
+  const size_t n = sigs.size();
+  std::vector<uint8_t> u(32 * n), r(64 * n), pk(64 * n), g(64 * n), m(32 * n), ok(n);
+  for (size_t i = 0; i < n; i++) {
+    std::memcpy(&u[32 * i], sigs[i].u_.bytes.data(), 32);
+    std::memcpy(&r[64 * i], sigs[i].R_.uv.data(), 64);
+    std::memcpy(&pk[64 * i], pks[i].pk_.uv.data(), 64);
+    std::memcpy(&g[64 * i], pks[i].generator_.uv.data(), 64);
+    std::memcpy(&m[32 * i], msgs[i].bytes.data(), 32);
+  }
+  detail::check(dsv_verify_vargen(u.data(), r.data(), pk.data(), g.data(), m.data(), n, ok.data()),
+                "dsv_verify_vargen");
+  std::vector<bool> out(n);
+  for (size_t i = 0; i < n; i++) out[i] = ok[i] == 1;
+  return out;
+}
+
+}  // namespace dusk_schnorr

@@ -1,0 +1,126 @@
+// C++ counterpart of the reference's native tests, through include/dusk_schnorr.hpp -> libdsv.so:
+//   /root/reference/tests/schnorr.rs:14-40              sign_verify, test_wrong_keys
+//   /root/reference/tests/schnorr_double.rs:14-41       same for SignatureDouble
+//   /root/reference/tests/schnorr_var_generator.rs:14-40 same for SignatureVarGen
+// plus the new verify_batch entry points.  Exit code 0 = all passed.
+#include <cstdio>
+#include <cstdlib>
+
+#include "dusk_schnorr.hpp"
+
+using namespace dusk_schnorr;
+
+// deterministic test RNG (splitmix64); the reference uses StdRng::seed_from_u64(2321)
+struct Rng {
+  uint64_t s;
+  explicit Rng(uint64_t seed) : s(seed) {}
+  uint64_t next() {
+    uint64_t z = (s += 0x9e3779b97f4a7c15ULL);
+    z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ULL;
+    z = (z ^ (z >> 27)) * 0x94d049bb133111ebULL;
+    return z ^ (z >> 31);
+  }
+  void operator()(uint8_t* out, size_t n) {
+    for (size_t i = 0; i < n; i++) out[i] = (uint8_t)(next() >> 32);
+  }
+};
+
+#define CHECK(cond)                                                        \
+  do {                                                                     \
+    if (!(cond)) {                                                         \
+      std::fprintf(stderr, "FAILED %s:%d: %s\n", __FILE__, __LINE__, #cond); \
+      std::exit(1);                                                        \
+    }                                                                      \
+  } while (0)
+
+static void sign_verify() {
+  Rng rng(2321);
+  SecretKey sk = SecretKey::random(rng);
+  BlsScalar message = BlsScalar::random(rng);
+  PublicKey pk = PublicKey::from(sk);
+  Signature sig = sk.sign(rng, message);
+  CHECK(pk.verify(sig, message));
+}
+static void test_wrong_keys() {
+  Rng rng(2321);
+  SecretKey sk = SecretKey::random(rng);
+  BlsScalar message = BlsScalar::random(rng);
+  Signature sig = sk.sign(rng, message);
+  SecretKey wrong_sk = SecretKey::random(rng);
+  PublicKey pk = PublicKey::from(wrong_sk);
+  CHECK(!pk.verify(sig, message));
+}
+static void sign_verify_double() {
+  Rng rng(2321);
+  SecretKey sk = SecretKey::random(rng);
+  BlsScalar message = BlsScalar::random(rng);
+  PublicKeyDouble pk = PublicKeyDouble::from(sk);
+  SignatureDouble sig = sk.sign_double(rng, message);
+  CHECK(pk.verify(sig, message));
+  SecretKey wrong_sk = SecretKey::random(rng);
+  CHECK(!PublicKeyDouble::from(wrong_sk).verify(sig, message));
+}
+static void sign_verify_var_gen() {
+  Rng rng(2321);
+  SecretKeyVarGen sk = SecretKeyVarGen::random(rng);
+  BlsScalar message = BlsScalar::random(rng);
+  PublicKeyVarGen pk = PublicKeyVarGen::from(sk);
+  SignatureVarGen sig = sk.sign(rng, message);
+  CHECK(pk.verify(sig, message));
+  SecretKeyVarGen wrong_sk = SecretKeyVarGen::random(rng);
+  CHECK(!PublicKeyVarGen::from(wrong_sk).verify(sig, message));
+}
+static void batch() {
+  Rng rng(77);
+  const size_t n = 100;
+  std::vector<Signature> sigs;
+  std::vector<PublicKey> pks;
+  std::vector<BlsScalar> msgs;
+  for (size_t i = 0; i < n; i++) {
+    SecretKey sk = SecretKey::random(rng);
+    BlsScalar m = BlsScalar::random(rng);
+    sigs.push_back(sk.sign(rng, m));
+    pks.push_back(PublicKey::from(sk));
+    msgs.push_back(m);
+  }
+  pks[3] = pks[4];                     // wrong key
+  msgs[10].bytes[0] ^= 1;              // wrong message
+  sigs[20].u_.bytes[5] ^= 0x40;        // corrupted u
+  std::vector<bool> ok = verify_batch(sigs, pks, msgs);
+  CHECK(ok.size() == n);
+  for (size_t i = 0; i < n; i++) {
+    const bool want = !(i == 3 || i == 10 || i == 20);
+    CHECK(ok[i] == want);
+    CHECK(pks[i].verify(sigs[i], msgs[i]) == want);
+  }
+  bool threw = false;
+  try {
+    msgs.pop_back();
+    verify_batch(sigs, pks, msgs);
+  } catch (const std::invalid_argument&) {
+    threw = true;
+  }
+  CHECK(threw);
+  CHECK(verify_batch({}, {}, {}).empty());
+}
+static void random_is_reduced() {
+  uint8_t wide[64];
+  for (int i = 0; i < 64; i++) wide[i] = 0xff;
+  JubJubScalar s = JubJubScalar::from_bytes_wide(wide);
+  // (2^512 - 1) mod r, computed with Python integers
+  static const uint8_t want[32] = {0x30, 0x77, 0xe5, 0x95, 0xa4, 0x9a, 0x71, 0x67, 0x26, 0xfc, 0xe3,
+                                   0x9c, 0xf0, 0xce, 0xb0, 0x51, 0xa5, 0xe9, 0x26, 0xc0, 0xfa, 0xb7,
+                                   0xda, 0x69, 0x88, 0x76, 0x12, 0x8d, 0x7b, 0x54, 0xf6, 0x04};
+  CHECK(std::memcmp(s.bytes.data(), want, 32) == 0);
+}
+
+int main() {
+  random_is_reduced();
+  sign_verify();
+  test_wrong_keys();
+  sign_verify_double();
+  sign_verify_var_gen();
+  batch();
+  std::printf("ok: %s\n", dsv_version());
+  return 0;
+}
