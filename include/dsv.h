@@ -120,6 +120,31 @@ int dsv_sign_double_dev(const void *sk, const void *m, const void *r, size_t n, 
                         void *R_uv, void *Rp_uv, void *stream);
 int dsv_public_keys_dev(const void *sk, int which, size_t n, void *PK_uv, void *stream);
 
+/* ---- wire formats (the reference's Serializable impls) ------------------------------------
+ * compressed point = JubJubAffine::to_bytes(): canonical v with bit 255 = lowest bit of u.
+ * dsv_decompress_points: JubJubAffine::from_bytes for n points; ok[i] = 0 where the reference
+ * would return Err (v >= q, or no square root).  The _dev form reads one 32-byte record every
+ * in_stride bytes (16-byte aligned) and, with accumulate != 0, ANDs into ok[] instead of
+ * overwriting it. */
+int dsv_decompress_points(const uint8_t *in32, size_t n, uint8_t *out_uv, uint8_t *ok);
+int dsv_decompress_points_dev(const void *in, size_t in_stride, size_t n, void *out_uv, void *ok,
+                              int accumulate, void *stream);
+/* verify straight from serialized values (host buffers, array-of-records as the Rust
+ * `to_bytes()` produce them):
+ *   single : Signature (64 B = u || compressed R)            PublicKey (32 B)
+ *            /root/reference/src/signatures.rs:106-123, src/keys/public.rs:87-101
+ *   double : SignatureDouble (96 B = u || R || R')           PublicKeyDouble (64 B = pk || pk')
+ *            /root/reference/src/signatures.rs:245-270, src/keys/public.rs:282-299
+ *   vargen : SignatureVarGen (64 B)                          PublicKeyVarGen (64 B = pk || generator)
+ *            /root/reference/src/signatures.rs:387-404, src/keys/public.rs:347-372
+ * ok[i] = 1 iff every from_bytes would succeed AND verify() would return true. */
+int dsv_verify_single_wire(const uint8_t *sig64, const uint8_t *pk32, const uint8_t *m, size_t n,
+                           uint8_t *ok);
+int dsv_verify_double_wire(const uint8_t *sig96, const uint8_t *pk64, const uint8_t *m, size_t n,
+                           uint8_t *ok);
+int dsv_verify_vargen_wire(const uint8_t *sig64, const uint8_t *pk64, const uint8_t *m, size_t n,
+                           uint8_t *ok);
+
 /* ---- introspection for tests: copy one fixed-base table entry (affine niels v+u, v-u, 2duv
  * as canonical LE, 96 B) for generator `which` (0 = G, 1 = G'), window w (8-bit), digit d ---- */
 int dsv_debug_table_entry(int which, int window, int digit, uint8_t out96[96]);

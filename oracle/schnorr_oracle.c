@@ -828,6 +828,67 @@ int oracle_fixed_base_entry(int which_gen, int window_bits, int window, uint32_t
   return 0;
 }
 
+/* ---- wire formats: Serializable::from_bytes then verify ---------------------------------
+ * signatures.rs:117-122 (u = JubJubScalar::from_slice, R = JubJubAffine::from_slice),
+ * keys/public.rs:94-100 */
+int oracle_decompress(const uint8_t *in32, size_t n, uint8_t *out_uv, uint8_t *ok) {
+  ensure_init();
+  for (size_t i = 0; i < n; i++) {
+    oext_t p;
+    ok[i] = (uint8_t)ojub_decompress(&p, in32 + 32 * i);
+    if (ok[i]) store_point(out_uv + 64 * i, &p); else memset(out_uv + 64 * i, 0, 64);
+  }
+  return 0;
+}
+int oracle_verify_single_wire(const uint8_t *sig64, const uint8_t *pk32, const uint8_t *m, size_t n,
+                              uint8_t *ok) {
+  ensure_init();
+  for (size_t i = 0; i < n; i++) {
+    oext_t R, pk;
+    ofq_t mm;
+    ofr_t us;
+    int good = ofr_from_bytes(&us, sig64 + 64 * i);
+    good &= ojub_decompress(&R, sig64 + 64 * i + 32);
+    good &= ojub_decompress(&pk, pk32 + 32 * i);
+    good &= ofq_from_bytes(&mm, m + 32 * i);
+    ok[i] = (uint8_t)(good ? verify_one(&pk, sig64 + 64 * i, &R, &mm) : 0);
+  }
+  return 0;
+}
+int oracle_verify_double_wire(const uint8_t *sig96, const uint8_t *pk64, const uint8_t *m, size_t n,
+                              uint8_t *ok) {
+  ensure_init();
+  for (size_t i = 0; i < n; i++) {
+    oext_t R, Rp, pk, pkp;
+    ofq_t mm;
+    ofr_t us;
+    int good = ofr_from_bytes(&us, sig96 + 96 * i);
+    good &= ojub_decompress(&R, sig96 + 96 * i + 32);
+    good &= ojub_decompress(&Rp, sig96 + 96 * i + 64);
+    good &= ojub_decompress(&pk, pk64 + 64 * i);
+    good &= ojub_decompress(&pkp, pk64 + 64 * i + 32);
+    good &= ofq_from_bytes(&mm, m + 32 * i);
+    ok[i] = (uint8_t)(good ? verify_one_double(&pk, &pkp, sig96 + 96 * i, &R, &Rp, &mm) : 0);
+  }
+  return 0;
+}
+int oracle_verify_vargen_wire(const uint8_t *sig64, const uint8_t *pk64, const uint8_t *m, size_t n,
+                              uint8_t *ok) {
+  ensure_init();
+  for (size_t i = 0; i < n; i++) {
+    oext_t R, pk, gen;
+    ofq_t mm;
+    ofr_t us;
+    int good = ofr_from_bytes(&us, sig64 + 64 * i);
+    good &= ojub_decompress(&R, sig64 + 64 * i + 32);
+    good &= ojub_decompress(&pk, pk64 + 64 * i);
+    good &= ojub_decompress(&gen, pk64 + 64 * i + 32);
+    good &= ofq_from_bytes(&mm, m + 32 * i);
+    ok[i] = (uint8_t)(good ? verify_one_vargen(&pk, &gen, sig64 + 64 * i, &R, &mm) : 0);
+  }
+  return 0;
+}
+
 const char *oracle_banner(void) {
   return "schnorr_oracle: CPU restatement of dusk-schnorr 0.18 verify/sign — TEST "
          "INFRASTRUCTURE, PARITY UNPINNED (no reference golden vectors exist; Hades "

@@ -136,6 +136,15 @@ int oracle_scalar_mul(const uint8_t *scalar, const uint8_t *P_uv, size_t n, uint
 int oracle_fixed_base_entry(int which_gen, int window_bits, int window, uint32_t digit,
                             uint8_t out96[96]);
 
+/* wire formats: from_bytes (scalar canonicity + point decompression) then verify */
+int oracle_decompress(const uint8_t *in32, size_t n, uint8_t *out_uv, uint8_t *ok);
+int oracle_verify_single_wire(const uint8_t *sig64, const uint8_t *pk32, const uint8_t *m, size_t n,
+                              uint8_t *ok);
+int oracle_verify_double_wire(const uint8_t *sig96, const uint8_t *pk64, const uint8_t *m, size_t n,
+                              uint8_t *ok);
+int oracle_verify_vargen_wire(const uint8_t *sig64, const uint8_t *pk64, const uint8_t *m, size_t n,
+                              uint8_t *ok);
+
 const char *oracle_banner(void);
 
 #ifdef __cplusplus

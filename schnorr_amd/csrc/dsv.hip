@@ -31,6 +31,7 @@
 #include "fr.h"
 #include "hades29.h"
 #include "halfgcd.h"
+#include "decode29.h"
 #include "jubjub29.h"
 
 namespace dsv {
@@ -544,6 +545,55 @@ k_sign_finish(const uint8_t* __restrict__ r, const uint8_t* c,  // c may alias u
   fr_mul(t, cs, ks);
   fr_sub(u, rs, t);
   store_words8(u_out, i, u);
+}
+
+// ------------------------------------------------------------------------------------------
+// wire formats: point decompression (JubJubAffine::from_bytes) and field gathering
+// ------------------------------------------------------------------------------------------
+// in: one 32-byte compressed point per item at in + i*in_stride (16-byte aligned);
+// out_uv: affine u || v canonical; ok[i] = (accumulate ? ok[i] : 1) & decodable
+__global__ void __launch_bounds__(256, DSV_WAVES_HASH)
+k_decompress(const uint8_t* __restrict__ in, size_t in_stride, size_t n,
+             uint8_t* __restrict__ out_uv, uint8_t* __restrict__ ok, int accumulate) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  u32 w[8];
+  {
+    const uint4* p = reinterpret_cast<const uint4*>(in + i * in_stride);
+    uint4 a = p[0], b = p[1];
+    w[0] = a.x; w[1] = a.y; w[2] = a.z; w[3] = a.w;
+    w[4] = b.x; w[5] = b.y; w[6] = b.z; w[7] = b.w;
+  }
+  const u32 sign = w[7] >> 31;
+  w[7] &= 0x7fffffffu;
+  bool good = words_lt(w, kQ32);
+  const Fe v = fe_to_mont(fe_from_words_plain(w));
+  const Fe v2 = fe_sqr(v);
+  const Fe num = fe_sub2(v2, fe_one());                          // v^2 - 1
+  const Fe den = fe_add(fe_mul(v2, fe_const(kD)), fe_one());     // 1 + d v^2  (never 0: -1/d is a non-square)
+  const Fe u2 = fe_mul(num, fe_invert(den));
+  Fe u;
+  good &= fe_sqrt(u, u2);
+  u32 uw[8];
+  fe_to_words_plain(uw, fe_from_mont(u));
+  if ((uw[0] & 1u) != sign) {                                    // take the other root
+    u = fe_neg2(u);
+    fe_to_words_plain(uw, fe_from_mont(u));
+  }
+  store_words8(out_uv, 2 * i, uw);
+  store_words8(out_uv, 2 * i + 1, w);
+  if (accumulate) good &= ok[i] != 0;
+  ok[i] = good ? 1 : 0;
+}
+// out[i] = 32 bytes at in + i*stride   (AoS wire records -> SoA scalar array)
+__global__ void k_gather32(const uint8_t* __restrict__ in, size_t stride, size_t n,
+                           uint8_t* __restrict__ out) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint4* p = reinterpret_cast<const uint4*>(in + i * stride);
+  uint4* o = reinterpret_cast<uint4*>(out + i * 32);
+  o[0] = p[0];
+  o[1] = p[1];
 }
 
 __global__ void __launch_bounds__(256)
@@ -1145,6 +1195,101 @@ int dsv_sign_vargen(const uint8_t* sk, const uint8_t* Gen_uv, const uint8_t* m, 
   D2H(R_uv, dR, n * 64);
   HIP_TRY(hipStreamSynchronize(0));
   return DSV_OK;
+}
+
+// ---- wire formats ---------------------------------------------------------------------------
+int dsv_decompress_points_dev(const void* in, size_t in_stride, size_t n, void* out_uv, void* ok,
+                              int accumulate, void* stream) {
+  if (int r = check_ready()) return r;
+  if (int r = check_n(n)) return r;
+  if (n == 0) return DSV_OK;
+  if (!in || !out_uv || !ok || in_stride < 32 || (in_stride & 15) || ((uintptr_t)in & 15))
+    return fail(DSV_ERR_INVALID_ARGUMENT, "bad pointer / stride (need 16-byte alignment)");
+  hipLaunchKernelGGL(k_decompress, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream,
+                     (const uint8_t*)in, in_stride, n, (uint8_t*)out_uv, (uint8_t*)ok, accumulate);
+  HIP_TRY(hipGetLastError());
+  return DSV_OK;
+}
+int dsv_decompress_points(const uint8_t* in32, size_t n, uint8_t* out_uv, uint8_t* ok) {
+  if (int r = check_ready()) return r;
+  if (int r = check_n(n)) return r;
+  if (n == 0) return DSV_OK;
+  if (!in32 || !out_uv || !ok) return fail(DSV_ERR_INVALID_ARGUMENT, "null pointer");
+  std::lock_guard<std::mutex> lk(g_ctx.mu);
+  HIP_TRY(hipSetDevice(g_ctx.device));
+  if (int r = ensure_stage(align_up(n * 32, 256) + align_up(n * 64, 256) + align_up(n, 256))) return r;
+  Stager st(g_ctx.stage);
+  uint8_t *din = st.take(n * 32), *dout = st.take(n * 64), *dok = st.take(n);
+  H2D(din, in32, n * 32);
+  if (int r = dsv_decompress_points_dev(din, 32, n, dout, dok, 0, nullptr)) return r;
+  D2H(out_uv, dout, n * 64);
+  D2H(ok, dok, n);
+  HIP_TRY(hipStreamSynchronize(0));
+  return DSV_OK;
+}
+
+namespace {
+// shared body of the *_wire entry points.  sig: n records of sig_bytes = 32 (u) + 32*n_sig_points;
+// pk: n records of 32*n_pk_points compressed points.  kind: 0 single, 1 double, 2 vargen.
+int verify_wire(int kind, const uint8_t* sig, const uint8_t* pk, const uint8_t* m, size_t n,
+                uint8_t* ok) {
+  const size_t sig_bytes = kind == 1 ? 96 : 64, pk_bytes = kind == 0 ? 32 : 64;
+  std::lock_guard<std::mutex> lk(g_ctx.mu);
+  HIP_TRY(hipSetDevice(g_ctx.device));
+  size_t need = align_up(n * sig_bytes, 256) + align_up(n * pk_bytes, 256) + 2 * align_up(n * 32, 256) +
+                4 * align_up(n * 64, 256) + 2 * align_up(n, 256) + dsv_workspace_bytes(n);
+  if (int r = ensure_stage(need)) return r;
+  Stager st(g_ctx.stage);
+  uint8_t *dsig = st.take(n * sig_bytes), *dpk = st.take(n * pk_bytes), *dm = st.take(n * 32),
+          *du = st.take(n * 32), *dR = st.take(n * 64), *dRp = st.take(n * 64),
+          *dP0 = st.take(n * 64), *dP1 = st.take(n * 64), *dvalid = st.take(n), *dok = st.take(n),
+          *ws = st.take(dsv_workspace_bytes(n));
+  H2D(dsig, sig, n * sig_bytes);
+  H2D(dpk, pk, n * pk_bytes);
+  H2D(dm, m, n * 32);
+  hipLaunchKernelGGL(k_gather32, dim3(grid_for(n)), dim3(256), 0, 0, (const uint8_t*)dsig, sig_bytes, n, du);
+  if (int r = dsv_decompress_points_dev(dsig + 32, sig_bytes, n, dR, dvalid, 0, nullptr)) return r;
+  if (kind == 1)
+    if (int r = dsv_decompress_points_dev(dsig + 64, sig_bytes, n, dRp, dvalid, 1, nullptr)) return r;
+  if (int r = dsv_decompress_points_dev(dpk, pk_bytes, n, dP0, dvalid, 1, nullptr)) return r;
+  if (kind != 0)
+    if (int r = dsv_decompress_points_dev(dpk + 32, pk_bytes, n, dP1, dvalid, 1, nullptr)) return r;
+  int rc;
+  if (kind == 0) rc = dsv_verify_single_dev(du, dR, dP0, dm, n, dok, ws, nullptr);
+  else if (kind == 1) rc = dsv_verify_double_dev(du, dR, dRp, dP0, dP1, dm, n, dok, ws, nullptr);
+  else rc = dsv_verify_vargen_dev(du, dR, dP0, dP1, dm, n, dok, ws, nullptr);
+  if (rc) return rc;
+  hipLaunchKernelGGL(k_and_bytes, dim3(grid_for(n)), dim3(256), 0, 0, dok, (const uint8_t*)dvalid, n);
+  HIP_TRY(hipGetLastError());
+  D2H(ok, dok, n);
+  HIP_TRY(hipStreamSynchronize(0));
+  return DSV_OK;
+}
+}  // namespace
+
+int dsv_verify_single_wire(const uint8_t* sig64, const uint8_t* pk32, const uint8_t* m, size_t n,
+                           uint8_t* ok) {
+  if (int r = check_ready()) return r;
+  if (int r = check_n(n)) return r;
+  if (n == 0) return DSV_OK;
+  if (!sig64 || !pk32 || !m || !ok) return fail(DSV_ERR_INVALID_ARGUMENT, "null pointer");
+  return verify_wire(0, sig64, pk32, m, n, ok);
+}
+int dsv_verify_double_wire(const uint8_t* sig96, const uint8_t* pk64, const uint8_t* m, size_t n,
+                           uint8_t* ok) {
+  if (int r = check_ready()) return r;
+  if (int r = check_n(n)) return r;
+  if (n == 0) return DSV_OK;
+  if (!sig96 || !pk64 || !m || !ok) return fail(DSV_ERR_INVALID_ARGUMENT, "null pointer");
+  return verify_wire(1, sig96, pk64, m, n, ok);
+}
+int dsv_verify_vargen_wire(const uint8_t* sig64, const uint8_t* pk64, const uint8_t* m, size_t n,
+                           uint8_t* ok) {
+  if (int r = check_ready()) return r;
+  if (int r = check_n(n)) return r;
+  if (n == 0) return DSV_OK;
+  if (!sig64 || !pk64 || !m || !ok) return fail(DSV_ERR_INVALID_ARGUMENT, "null pointer");
+  return verify_wire(2, sig64, pk64, m, n, ok);
 }
 
 int dsv_debug_table_entry(int which, int window, int digit, uint8_t out96[96]) {

@@ -167,6 +167,13 @@ def main():
         w("#define DSV_GEN_U %s\n#define DSV_GEN_V %s\n" % (arr(mont(GEN[0])), arr(mont(GEN[1]))))
         w("#define DSV_GENN_U %s\n#define DSV_GENN_V %s\n"
           % (arr(mont(GEN_NUMS[0])), arr(mont(GEN_NUMS[1]))))
+        # square roots (point decompression): q - 1 = 2^32 * t, c = 7^t is a primitive 2^32-th root
+        t_odd = (Q - 1) >> 32
+        assert pow(7, (Q - 1) // 2, Q) == Q - 1
+        e = (t_odd - 1) // 2
+        w("#define DSV_SQRT_E_WORDS %s\n" % ("{" + ", ".join("0x%08xu" % ((e >> (32 * i)) & 0xFFFFFFFF) for i in range(7)) + "}"))
+        w("#define DSV_SQRT_E_BITS %d\n" % e.bit_length())
+        w("#define DSV_ROOT_OF_UNITY %s\n" % arr(mont(pow(7, t_odd, Q))))
         w("static const uint32_t DSV_HADES_RC_HOST[%d][9] = {\n" % len(rc))
         for c in rc:
             w("  %s,\n" % arr(mont(c)))

@@ -155,6 +155,48 @@ def public_keys(sk, which=0, Gen=None):
     return PK
 
 
+def decompress_points(comp):
+    """JubJubAffine::from_bytes over [n, 32] compressed points -> ([n, 64] affine, ok[n])."""
+    comp = _arr(comp, 32)
+    n = comp.shape[0]
+    out = np.zeros((n, 64), dtype=np.uint8)
+    ok = np.zeros(n, dtype=np.uint8)
+    _lib.check(_lib.load().dsv_decompress_points(_p(comp), ctypes.c_size_t(n), _p(out), _p(ok)))
+    return out, ok
+
+
+def compress_points(uv):
+    """JubJubAffine::to_bytes: v with bit 255 = lowest bit of u (pure byte shuffling)."""
+    uv = _arr(uv, 64)
+    out = uv[:, 32:].copy()
+    out[:, 31] |= (uv[:, 0] & 1) << 7
+    return out
+
+
+def verify_single_wire(sig64, pk32, m):
+    sig, pk, m = _arr(sig64, 64), _arr(pk32, 32), _arr(m, 32)
+    n = _same_n(sig, pk, m)
+    ok = np.zeros(n, dtype=np.uint8)
+    _lib.check(_lib.load().dsv_verify_single_wire(_p(sig), _p(pk), _p(m), ctypes.c_size_t(n), _p(ok)))
+    return ok
+
+
+def verify_double_wire(sig96, pk64, m):
+    sig, pk, m = _arr(sig96, 96), _arr(pk64, 64), _arr(m, 32)
+    n = _same_n(sig, pk, m)
+    ok = np.zeros(n, dtype=np.uint8)
+    _lib.check(_lib.load().dsv_verify_double_wire(_p(sig), _p(pk), _p(m), ctypes.c_size_t(n), _p(ok)))
+    return ok
+
+
+def verify_vargen_wire(sig64, pk64, m):
+    sig, pk, m = _arr(sig64, 64), _arr(pk64, 64), _arr(m, 32)
+    n = _same_n(sig, pk, m)
+    ok = np.zeros(n, dtype=np.uint8)
+    _lib.check(_lib.load().dsv_verify_vargen_wire(_p(sig), _p(pk), _p(m), ctypes.c_size_t(n), _p(ok)))
+    return ok
+
+
 def debug_table_entry(which, window, digit):
     out = np.zeros(96, dtype=np.uint8)
     _lib.check(_lib.load().dsv_debug_table_entry(ctypes.c_int(which), ctypes.c_int(window),

@@ -35,6 +35,8 @@ def lib():
             "oracle_verify_single_ext", "oracle_challenge_single", "oracle_challenge_double",
             "oracle_keygen_sign_single", "oracle_keygen_sign_double",
             "oracle_keygen_sign_vargen", "oracle_scalar_mul", "oracle_fixed_base_entry",
+            "oracle_decompress", "oracle_verify_single_wire", "oracle_verify_double_wire",
+            "oracle_verify_vargen_wire",
         ):
             getattr(L, name).restype = ctypes.c_int
         _lib = L
@@ -153,4 +155,41 @@ def fixed_base_entry(which_gen, window_bits, window, digit):
     out = np.zeros(96, dtype=np.uint8)
     lib().oracle_fixed_base_entry(ctypes.c_int(which_gen), ctypes.c_int(window_bits),
                                   ctypes.c_int(window), ctypes.c_uint32(digit), _p(out))
+    return out
+
+
+def decompress(comp):
+    comp = _u8(comp)
+    n = comp.shape[0]
+    out = np.zeros((n, 64), dtype=np.uint8)
+    ok = np.zeros(n, dtype=np.uint8)
+    lib().oracle_decompress(_p(comp), ctypes.c_size_t(n), _p(out), _p(ok))
+    return out, ok
+
+
+def _wire(fn, sig, pk, m):
+    sig, pk, m = _u8(sig), _u8(pk), _u8(m)
+    n = m.shape[0]
+    ok = np.zeros(n, dtype=np.uint8)
+    getattr(lib(), fn)(_p(sig), _p(pk), _p(m), ctypes.c_size_t(n), _p(ok))
+    return ok
+
+
+def verify_single_wire(sig64, pk32, m):
+    return _wire("oracle_verify_single_wire", sig64, pk32, m)
+
+
+def verify_double_wire(sig96, pk64, m):
+    return _wire("oracle_verify_double_wire", sig96, pk64, m)
+
+
+def verify_vargen_wire(sig64, pk64, m):
+    return _wire("oracle_verify_vargen_wire", sig64, pk64, m)
+
+
+def compress(uv):
+    """JubJubAffine::to_bytes of affine points [n, 64] -> [n, 32]"""
+    uv = _u8(uv)
+    out = uv[:, 32:].copy()
+    out[:, 31] |= (uv[:, 0] & 1) << 7
     return out

@@ -269,3 +269,55 @@ def test_order8_torsion_components_valid_and_invalid(engine):
     assert list(cpu) == want
     got = engine.verify_single(a["u"], a["R"], a["PK"], a["m"])
     assert list(got) == want
+
+
+def test_wire_formats_decompress_and_verify(engine):
+    """Serializable round trip (tests/schnorr.rs:42-51 shape) and verify-from-bytes, GPU vs oracle:
+    valid encodings, wrong sign bit, non-canonical v, v with no square root, non-canonical u."""
+    n = 96
+    d = O.keygen_sign_double(n, 2321, nthreads=8)
+    comp = O.compress(d["PK"])
+    uv, ok = engine.decompress_points(comp)
+    assert ok.all() and np.array_equal(uv, d["PK"])
+    assert np.array_equal(engine.compress_points(uv), comp)
+    # corrupt encodings
+    bad = comp.copy()
+    bad[0, 31] ^= 0x80                      # other root: still a point, different u
+    bad[1] = 0xFF                           # v >= q
+    bad[2] = np.frombuffer(M.le32(2), np.uint8)  # some small v: may or may not be on the curve
+    for k in range(3, 40):
+        bad[k, 0] ^= (k * 7) & 0xFF or 1    # random-ish v: about half have no square root
+    o_uv, o_ok = O.decompress(bad)
+    g_uv, g_ok = engine.decompress_points(bad)
+    assert np.array_equal(g_ok, o_ok) and 0 < int(o_ok[:40].sum()) < 40
+    assert np.array_equal(g_uv[o_ok == 1], o_uv[o_ok == 1])
+    # verify from serialized values
+    ds = O.keygen_sign_single(n, 2321, nthreads=8)
+    sig = np.concatenate([ds["u"], O.compress(ds["R"])], axis=1)
+    pk = O.compress(ds["PK"])
+    assert engine.verify_single_wire(sig, pk, ds["m"]).all()
+    sig2, pk2, m2 = sig.copy(), pk.copy(), ds["m"].copy()
+    sig2[0, 32 + 31] ^= 0x80                # R with the other sign
+    pk2[1] = pk2[2]
+    sig2[3, :32] = np.frombuffer(M.le32(M.from_le(sig2[3, :32]) + M.R_ORDER), np.uint8)  # u + r
+    pk2[4] = bad[1]
+    sig2[5, 32:] = bad[2]
+    m2[6, 0] ^= 1
+    want = O.verify_single_wire(sig2, pk2, m2)
+    got = engine.verify_single_wire(sig2, pk2, m2)
+    assert np.array_equal(got, want)
+    assert list(want[:7]) == [0, 0, 1, 0, 0, 0, 0] and want[7:].all()
+    # double / vargen records
+    sigd = np.concatenate([d["u"], O.compress(d["R"]), O.compress(d["Rp"])], axis=1)
+    pkd = np.concatenate([O.compress(d["PK"]), O.compress(d["PKp"])], axis=1)
+    assert engine.verify_double_wire(sigd, pkd, d["m"]).all()
+    pkd[9, 32:] = pkd[10, 32:]
+    assert np.array_equal(engine.verify_double_wire(sigd, pkd, d["m"]),
+                          O.verify_double_wire(sigd, pkd, d["m"]))
+    dv = O.keygen_sign_vargen(32, 5, nthreads=8)
+    sigv = np.concatenate([dv["u"], O.compress(dv["R"])], axis=1)
+    pkv = np.concatenate([O.compress(dv["PK"]), O.compress(dv["Gen"])], axis=1)
+    assert engine.verify_vargen_wire(sigv, pkv, dv["m"]).all()
+    pkv[3, 32:] = pkv[4, 32:]
+    assert np.array_equal(engine.verify_vargen_wire(sigv, pkv, dv["m"]),
+                          O.verify_vargen_wire(sigv, pkv, dv["m"]))
