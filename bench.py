@@ -87,19 +87,26 @@ def main():
             raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP engine has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    dev = "cuda:%d" % local_rank
+    # rehearsal knobs (one-GPU boxes): DSV_BENCH_DEVICE pins every rank to one GPU and
+    # DSV_BENCH_BACKEND=gloo replaces RCCL, so the N > 1 code path can be exercised without N GPUs
+    dev_index = int(os.environ.get("DSV_BENCH_DEVICE", local_rank))
+    backend = os.environ.get("DSV_BENCH_BACKEND", "nccl")
+    torch.cuda.set_device(dev_index)
+    dev = "cuda:%d" % dev_index
 
     dist = None
     if world > 1:
         import torch.distributed as dist
 
-        dist.init_process_group("nccl", device_id=torch.device(dev))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device(dev))
+        else:
+            dist.init_process_group(backend)
 
     from schnorr_amd import engine as E
     from schnorr_amd import workload as W
 
-    E.init(local_rank)
+    E.init(dev_index)
     n = 1 << args.log2_batch
     batch = W.gen_single(n, seed=2321 + rank, device=dev)
     ok = torch.zeros(n, dtype=torch.uint8, device=dev)
