@@ -752,6 +752,8 @@ int dsv_init(int device) {
                             sizeof(DSV_HADES_KAPPA0_HOST)));
   HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(c_hades_sparse), DSV_HADES_SPARSE_HOST,
                             sizeof(DSV_HADES_SPARSE_HOST)));
+  HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(c_hades_kfinal), DSV_HADES_KFINAL_HOST,
+                            sizeof(DSV_HADES_KFINAL_HOST)));
   for (int g = 0; g < 2; g++) {
     HIP_TRY(hipMalloc(&g_ctx.table[g], kTableBytes));
     const int total = kFixedWindows * kFixedEntries;

@@ -194,12 +194,23 @@ def main():
         for x in kappa[0]:
             w("  %s,\n" % arr(mont(x)))
         w("};\n")
-        w("// per partial round i: b[4], c''[4], d, kappa_{i+1}[5]\n")
-        w("#define DSV_HADES_SPARSE_STRIDE 14\n")
-        w("static const uint32_t DSV_HADES_SPARSE_HOST[%d][9] = {\n" % (PARTIAL * 14))
+        # constants of words 0..3 are never added inside the loop: K_i = running sum of their
+        # kappas; its contribution c_i . K_i to the last word is folded into that word's constant
+        K = list(kappa[0][:4])
+        kap4 = []
         for i in range(PARTIAL):
-            for x in bs[i] + cs[i] + [ds[i]] + kappa[i + 1]:
+            kap4.append((kappa[i + 1][4] + sum(cs[i][j] * K[j] for j in range(4))) % Q)
+            K = [(K[j] + kappa[i + 1][j]) % Q for j in range(4)]
+        w("// per partial round i: b[4], c''[4], d, kappa4'_i\n")
+        w("#define DSV_HADES_SPARSE_STRIDE 10\n")
+        w("static const uint32_t DSV_HADES_SPARSE_HOST[%d][9] = {\n" % (PARTIAL * 10))
+        for i in range(PARTIAL):
+            for x in bs[i] + cs[i] + [ds[i]] + [kap4[i]]:
                 w("  %s,\n" % arr(mont(x)))
+        w("};\n")
+        w("static const uint32_t DSV_HADES_KFINAL_HOST[%d][9] = {\n" % (WIDTH - 1))
+        for x in K:
+            w("  %s,\n" % arr(mont(x)))
         w("};\n")
     print("wrote", path)
 

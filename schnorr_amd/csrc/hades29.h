@@ -21,6 +21,7 @@ __constant__ u32 c_hades_mds[DSV_HADES_WIDTH * DSV_HADES_WIDTH][NL];
 // sparse form of the 59 partial rounds (schnorr_amd/csrc/gen_constants.py: sparse_partial_rounds)
 __constant__ u32 c_hades_pre_mds[DSV_HADES_WIDTH * DSV_HADES_WIDTH][NL];
 __constant__ u32 c_hades_kappa0[DSV_HADES_WIDTH][NL];
+__constant__ u32 c_hades_kfinal[DSV_HADES_WIDTH - 1][NL];
 __constant__ u32 c_hades_sparse[DSV_HADES_PARTIAL * DSV_HADES_SPARSE_STRIDE][NL];
 
 DSV_DEV Fe fe_load_const(const u32* p) {
@@ -77,36 +78,35 @@ DSV_DEV void hades_full_round(Fe (&s)[5], const u32 (*rc)[NL], const u32 (*mat)[
 // The permutation.  The 59 partial rounds run in their sparse-matrix form: per round one S-box,
 // one 5-term dot product (new last word) and four multiply-accumulates (words 0..3), i.e.
 // 3 + 1 + 4 reductions instead of 3 + 5 dot products of the dense form.  Words 0..3 are never
-// reduced inside a round (w += kappa + b*z grows by ~2q per round), so they are brought back
-// below 2q by a multiplication with Montgomery-one every 20 rounds and after the last one
-// (value < 45q, far below the 2^261 ~ 70q the representation holds).
+// reduced inside a round (w += b*z grows by ~1.1q per round), so they are brought back below 2q by
+// a multiplication with Montgomery-one after round 30 and after the last one (value < 35q, far
+// below the 2^261 ~ 70q the representation holds).
 DSV_DEV void hades_permute(Fe (&s)[5]) {
   constexpr int HALF = DSV_HADES_FULL / 2;
 #pragma unroll 1
   for (int r = 0; r < HALF; r++)
     hades_full_round(s, c_hades_rc + 5 * r, r == HALF - 1 ? c_hades_pre_mds : c_hades_mds);
-#pragma unroll
-  for (int k = 0; k < 4; k++) s[k] = fe_carry(fe_add(s[k], fe_load_const(c_hades_kappa0[k])));
+  // words 0..3 carry NO round constants inside the loop: their running sum K_i is folded into the
+  // constant of the last word (kappa4'_i = kappa4_{i+1} + c_i . K_i) and added back once at the end
   s[4] = fe_add(s[4], fe_load_const(c_hades_kappa0[4]));
 #pragma unroll 1
   for (int i = 0; i < DSV_HADES_PARTIAL; i++) {
-    const u32(*k)[NL] = c_hades_sparse + i * DSV_HADES_SPARSE_STRIDE;  // b[4] c[4] d kappa[5]
+    const u32(*k)[NL] = c_hades_sparse + i * DSV_HADES_SPARSE_STRIDE;  // b[4] c[4] d kappa4'
     s[4] = hades_sbox(s[4]);
     Fe row[5];
 #pragma unroll
     for (int j = 0; j < 5; j++) row[j] = fe_load_const(k[4 + j]);
     Fe z = fe_dot5(s, row);
 #pragma unroll
-    for (int j = 0; j < 4; j++) {
-      Fe p = fe_mul(fe_load_const(k[j]), s[4]);
-      s[j] = fe_carry(fe_add(fe_add(s[j], p), fe_load_const(k[9 + j])));
-    }
-    s[4] = fe_add(z, fe_load_const(k[13]));
-    if (i % 20 == 19 || i == DSV_HADES_PARTIAL - 1) {
+    for (int j = 0; j < 4; j++) s[j] = fe_carry(fe_add(s[j], fe_mul(fe_load_const(k[j]), s[4])));
+    s[4] = fe_add(z, fe_load_const(k[9]));
+    if (i == 29 || i == DSV_HADES_PARTIAL - 1) {
 #pragma unroll
       for (int j = 0; j < 4; j++) s[j] = fe_mul(s[j], fe_one());
     }
   }
+#pragma unroll
+  for (int j = 0; j < 4; j++) s[j] = fe_carry(fe_add(s[j], fe_load_const(c_hades_kfinal[j])));
 #pragma unroll 1
   for (int r = 0; r < HALF; r++)
     hades_full_round(s, c_hades_rc + 5 * (HALF + DSV_HADES_PARTIAL + r), c_hades_mds);

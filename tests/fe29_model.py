@@ -254,6 +254,7 @@ def _hc():
         _H["pre"] = _load_table("DSV_HADES_PRE_MDS_HOST")
         _H["k0"] = _load_table("DSV_HADES_KAPPA0_HOST")
         _H["sp"] = _load_table("DSV_HADES_SPARSE_HOST")
+        _H["kf"] = _load_table("DSV_HADES_KFINAL_HOST")
     return _H
 
 
@@ -274,21 +275,20 @@ def hades_permute(s):
     s = list(s)
     for r in range(4):
         s = hades_full_round(s, h["rc"][5 * r:5 * r + 5], h["pre"] if r == 3 else h["mds"])
-    for k in range(4):
-        s[k] = carry(add(s[k], h["k0"][k]))
     s[4] = add(s[4], h["k0"][4])
     for i in range(59):
-        k = h["sp"][14 * i:14 * i + 14]
+        k = h["sp"][10 * i:10 * i + 10]
         s[4] = sbox(s[4])
         z = dot(s, k[4:9])
         for j in range(4):
-            p = mul(k[j], s[4])
-            s[j] = carry(add(add(s[j], p), k[9 + j]))
+            s[j] = carry(add(s[j], mul(k[j], s[4])))
             assert val(s[j]) < (1 << 260)
-        s[4] = add(z, k[13])
-        if i % 20 == 19 or i == 58:
+        s[4] = add(z, k[9])
+        if i == 29 or i == 58:
             for j in range(4):
                 s[j] = mul(s[j], ONE)
+    for j in range(4):
+        s[j] = carry(add(s[j], h["kf"][j]))
     for r in range(4):
         s = hades_full_round(s, h["rc"][5 * (4 + 59 + r):5 * (4 + 59 + r) + 5], h["mds"])
     return s
