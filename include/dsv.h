@@ -148,6 +148,7 @@ int dsv_verify_vargen_wire(const uint8_t *sig64, const uint8_t *pk64, const uint
 /* ---- introspection for tests: copy one fixed-base table entry (affine niels v+u, v-u, 2duv
  * as canonical LE, 96 B) for generator `which` (0 = G, 1 = G'), window w (8-bit), digit d ---- */
 int dsv_debug_table_entry(int which, int window, int digit, uint8_t out96[96]);
+int dsv_fixed_window_bits(void); /* width of the (signed) fixed-base windows; digit <= 2^(bits-1) */
 /* ---- introspection: field-multiplier self test on the device: out = a*b mod q (canonical) */
 int dsv_debug_fq_mul(const uint8_t *a, const uint8_t *b, size_t n, uint8_t *out);
 

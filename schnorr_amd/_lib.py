@@ -4,7 +4,7 @@ import ctypes
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libdsv.so")
+LIB_PATH = os.environ.get("DSV_LIB_PATH") or os.path.join(HERE, "libdsv.so")  # override: A/B builds
 
 # every extern "C" symbol include/dsv.h declares
 SYMBOLS = [
@@ -16,7 +16,7 @@ SYMBOLS = [
     "dsv_sign_vargen", "dsv_public_keys", "dsv_sign_single_dev", "dsv_sign_double_dev",
     "dsv_public_keys_dev", "dsv_decompress_points", "dsv_decompress_points_dev",
     "dsv_verify_single_wire", "dsv_verify_double_wire", "dsv_verify_vargen_wire",
-    "dsv_debug_table_entry", "dsv_debug_fq_mul",
+    "dsv_debug_table_entry", "dsv_fixed_window_bits", "dsv_debug_fq_mul",
 ]
 
 

@@ -45,10 +45,17 @@ namespace dsv {
 #ifndef DSV_WAVES_HASH
 #define DSV_WAVES_HASH 2
 #endif
-constexpr int kFixedWindows = 32;           // 8-bit windows over a 256-bit scalar
-constexpr int kFixedEntries = 256;
-constexpr int kEntryWords = 28;             // 27 used (3 x 9 limbs) + 1 pad: 7 x 16 B
+// fixed-base tables: SIGNED windows of DSV_FIXED_BITS bits over a scalar < 2^252
+#ifndef DSV_FIXED_BITS
+#define DSV_FIXED_BITS 11
+#endif
+constexpr int kFixedBits = DSV_FIXED_BITS;
+constexpr int kFixedWindows = (253 + kFixedBits - 1) / kFixedBits;  // +1 bit: recoding carry
+constexpr int kFixedHalf = 1 << (kFixedBits - 1);
+constexpr int kFixedEntries = kFixedHalf + 1;                       // |digit| = 0 .. 2^(bits-1)
+constexpr int kEntryWords = 4 * NL;  // v+u, v-u, 2d*uv, -(2d*uv): 144 B, 16-byte aligned
 constexpr size_t kTableBytes = (size_t)kFixedWindows * kFixedEntries * kEntryWords * 4;
+static_assert(kFixedWindows * kFixedBits <= 288 && kFixedBits >= 4 && kFixedBits <= 16, "window");
 
 DSV_DEV void load_words8(u32 (&w)[8], const uint8_t* base, size_t idx) {
   const uint4* p = reinterpret_cast<const uint4*>(base + idx * 32);
@@ -75,20 +82,18 @@ DSV_DEV void store_fq(uint8_t* base, size_t idx, const Fe& mont) {
   store_words8(base, idx, w);
 }
 
-DSV_DEV ANiels load_aniels(const u32* __restrict__ table, int window, u32 digit) {
-  const uint4* p = reinterpret_cast<const uint4*>(table + ((size_t)window * kFixedEntries + digit) * kEntryWords);
-  u32 w[kEntryWords];
-#pragma unroll
-  for (int i = 0; i < kEntryWords / 4; i++) {
-    uint4 v = p[i];
-    w[4 * i] = v.x; w[4 * i + 1] = v.y; w[4 * i + 2] = v.z; w[4 * i + 3] = v.w;
-  }
+// entry for signed digit d of `window`: -P swaps (v+u, v-u) and takes the stored negated 2d*uv —
+// the sign costs address arithmetic only
+DSV_DEV ANiels load_aniels(const u32* __restrict__ table, int window, int d) {
+  const bool neg = d < 0;
+  const u32 mag = (u32)(neg ? -d : d);
+  const u32* p = table + ((size_t)window * kFixedEntries + mag) * kEntryWords;
   ANiels n;
 #pragma unroll
   for (int i = 0; i < NL; i++) {
-    n.vpu.l[i] = w[i];
-    n.vmu.l[i] = w[NL + i];
-    n.t2d.l[i] = w[2 * NL + i];
+    n.vpu.l[i] = p[(neg ? NL : 0) + i];
+    n.vmu.l[i] = p[(neg ? 0 : NL) + i];
+    n.t2d.l[i] = p[(neg ? 3 * NL : 2 * NL) + i];
   }
   return n;
 }
@@ -135,22 +140,33 @@ __global__ void __launch_bounds__(64) k_build_fixed_table(u32* __restrict__ tabl
   const u32 gu[NL] = DSV_GEN_U, gv[NL] = DSV_GEN_V, nu[NL] = DSV_GENN_U, nv[NL] = DSV_GENN_V;
   Ext g = which == 0 ? ext_from_affine(fe_const(gu), fe_const(gv))
                      : ext_from_affine(fe_const(nu), fe_const(nv));
+  // scalar = d << (bits * w), d <= 2^(bits-1) <= 2^15: at most two words
   u32 s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  s[w >> 2] = (u32)d << (8 * (w & 3));
+  // (entries whose scalar would not fit 256 bits are never looked up: a digit there is 0 or 1
+  //  and 1 << pos < 2^253)
+  const int pos = kFixedBits * w, wi = pos >> 5, sh = pos & 31;
+  const u64 v = (u64)(u32)d << sh;
+#pragma unroll
+  for (int i = 0; i < 8; i++) {
+    if (i == wi) s[i] = (u32)v;
+    if (i == wi + 1) s[i] = (u32)(v >> 32);
+  }
   Ext p = ext_mul_words(g, s);
   Fe zi = fe_invert(p.z);
-  Fe u = fe_mul(p.u, zi), v = fe_mul(p.v, zi);
-  Fe vpu = fe_canon(fe_add(v, u));
-  Fe vmu = fe_canon(fe_sub2(v, u));
-  Fe t2d = fe_canon(fe_mul(fe_mul(u, v), fe_const(kD2)));
+  Fe u = fe_mul(p.u, zi), v2 = fe_mul(p.v, zi);
+  Fe vpu = fe_canon(fe_add(v2, u));
+  Fe vmu = fe_canon(fe_sub2(v2, u));
+  Fe t2d = fe_mul(fe_mul(u, v2), fe_const(kD2));
+  Fe nt2d = fe_canon(fe_neg2(t2d));
+  t2d = fe_canon(t2d);
   u32* e = table + (size_t)idx * kEntryWords;
 #pragma unroll
   for (int i = 0; i < NL; i++) {
     e[i] = vpu.l[i];
     e[NL + i] = vmu.l[i];
     e[2 * NL + i] = t2d.l[i];
+    e[3 * NL + i] = nt2d.l[i];
   }
-  e[27] = 0;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -189,10 +205,33 @@ k_challenge(const uint8_t* __restrict__ R_uv, const uint8_t* __restrict__ Rp_uv,
 // accumulator is passed in so that u*G + c*PK needs no separate final addition (and no second
 // live point: register pressure, not arithmetic, is what limits occupancy here).
 DSV_DEV Ext fixed_base_accumulate(Ext acc, const u32 (&s)[8], const u32* __restrict__ table) {
+  // signed recoding: add 2^(bits-1) to every window; digit = window value - 2^(bits-1).
+  // s < 2^252, so the top window cannot overflow.  Windows are consumed LSB first (the order of
+  // the additions is irrelevant) by shifting the recoded scalar down, which needs no
+  // dynamically indexed register.
+  u32 y[9];  // 288 bits: room for the windows that reach past bit 255
+  {
+    u32 carry = 0;
+#pragma unroll
+    for (int i = 0; i < 9; i++) {
+      u32 bias = 0;
+#pragma unroll
+      for (int k = 0; k < kFixedWindows; k++) {
+        const int pos = kFixedBits * k + kFixedBits - 1;  // bit of 2^(bits-1) in window k
+        if ((pos >> 5) == i) bias |= 1u << (pos & 31);
+      }
+      const u64 t = (u64)(i < 8 ? s[i] : 0u) + bias + carry;
+      y[i] = (u32)t;
+      carry = (u32)(t >> 32);
+    }
+  }
 #pragma unroll 1
   for (int w = 0; w < kFixedWindows; w++) {
-    u32 digit = (s[w >> 2] >> (8 * (w & 3))) & 0xff;
-    ANiels e = load_aniels(table, w, digit);
+    const int d = (int)(y[0] & ((1u << kFixedBits) - 1)) - kFixedHalf;
+#pragma unroll
+    for (int i = 0; i < 8; i++) y[i] = __funnelshift_r(y[i], y[i + 1], kFixedBits);
+    y[8] >>= kFixedBits;
+    ANiels e = load_aniels(table, w, d);
     acc = ext_add_aniels(acc, e);
   }
   return acc;
@@ -1326,6 +1365,8 @@ int dsv_debug_table_entry(int which, int window, int digit, uint8_t out96[96]) {
   }
   return DSV_OK;
 }
+
+int dsv_fixed_window_bits(void) { return kFixedBits; }
 
 int dsv_debug_fq_mul(const uint8_t* a, const uint8_t* b, size_t n, uint8_t* out) {
   if (int r = check_ready()) return r;

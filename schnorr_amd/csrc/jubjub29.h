@@ -3,7 +3,8 @@
 // Formulas are the extended-coordinate ones dusk-jubjub's operators implement (SURVEY.md
 // Appendix A.3), i.e. what `GENERATOR_EXTENDED * u`, `pk * c`, `+` and `==` evaluate at
 // /root/reference/src/keys/public.rs:127-129, :236-243, :411-414:
-//   double : 4S + 3M     add (extended niels) : 8M     add (affine niels, z = 1) : 7M
+//   double : 3S + 4M (2uv as a product: one subtraction + carry pass fewer than 4S + 3M)
+//   add (extended niels) : 8M     add (affine niels, z = 1) : 7M
 // They are complete on the whole curve (a = -1 is a square, d is not), so identity, small-order
 // and repeated points need no special case — same as the reference.
 //
@@ -54,18 +55,17 @@ DSV_DEV Niels niels_identity() {
 }
 
 // in : u, v, z  N (< 1.5q)            (t1, t2 unused)
-// out: u, v, z  N;  t1 < 5.2q (carried limbs), t2 < 2.1q (limbs < 2^30)
+// out: u, v, z  N;  t1 < 2.1q, t2 < 2.1q (both limbs < 2^30)
 DSV_DEV Ext ext_double(const Ext& p) {
   Fe uu = fe_sqr(p.u);                      // < 1.04
   Fe vv = fe_sqr(p.v);                      // < 1.04
   Fe zz2 = fe_dbl(fe_sqr(p.z));             // < 2.1, limbs < 2^30
-  Fe uv2 = fe_sqr(fe_add(p.u, p.v));        // (3q)^2 -> < 1.13
+  Fe cu = fe_dbl(fe_mul(p.u, p.v));         // 2uv = (u+v)^2 - u^2 - v^2 without the subtraction; < 2.1
   Fe vpu = fe_add(vv, uu);                  // < 2.1, limbs < 2^30
   Fe vmu = fe_sub2(vv, uu);                 // < 3.1
-  Fe cu = fe_sub4(uv2, vpu);                // < 5.2
   Fe ct = fe_sub4(zz2, vmu);                // < 6.1
   Ext r;
-  r.u = fe_mul(cu, ct);                     // 5.2*6.1*0.01414+1 = 1.45
+  r.u = fe_mul(cu, ct);                     // 2.1*6.1*0.01414+1 = 1.2
   r.v = fe_mul(vpu, vmu);                   // < 1.1
   r.z = fe_mul(vmu, ct);                    // < 1.3
   r.t1 = cu;
@@ -78,10 +78,9 @@ DSV_DEV void ext_double_uvz(Fe& u, Fe& v, Fe& z) {
   Fe uu = fe_sqr(u);
   Fe vv = fe_sqr(v);
   Fe zz2 = fe_dbl(fe_sqr(z));
-  Fe uv2 = fe_sqr(fe_add(u, v));
+  Fe cu = fe_dbl(fe_mul(u, v));
   Fe vpu = fe_add(vv, uu);
   Fe vmu = fe_sub2(vv, uu);
-  Fe cu = fe_sub4(uv2, vpu);
   Fe ct = fe_sub4(zz2, vmu);
   u = fe_mul(cu, ct);
   v = fe_mul(vpu, vmu);

@@ -204,6 +204,10 @@ def debug_table_entry(which, window, digit):
     return out
 
 
+def fixed_window_bits():
+    return int(_lib.load().dsv_fixed_window_bits())
+
+
 def debug_fq_mul(a, b):
     a, b = _arr(a, 32), _arr(b, 32)
     n = _same_n(a, b)

@@ -194,10 +194,9 @@ def ext_from_affine(u, v):
 def ext_double(p):
     uu, vv = sqr(p["u"]), sqr(p["v"])
     zz2 = dbl(sqr(p["z"]))
-    uv2 = sqr(add(p["u"], p["v"]))
+    cu = dbl(mul(p["u"], p["v"]))
     vpu = add(vv, uu)
     vmu = sub(vv, uu, 2)
-    cu = sub(uv2, vpu, 4)
     ct = sub(zz2, vmu, 4)
     return {"u": mul(cu, ct), "v": mul(vpu, vmu), "z": mul(vmu, ct), "t1": cu, "t2": vpu}
 

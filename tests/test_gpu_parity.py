@@ -32,10 +32,14 @@ def test_fq_mul_matches_python_integers(engine):
 
 def test_fixed_base_table_entries_match_oracle(engine):
     rinv = pow(1 << 261, -1, M.Q)
-    for which, window, digit in [(0, 0, 0), (0, 0, 1), (0, 0, 255), (0, 1, 1), (0, 17, 200),
-                                 (0, 31, 15), (1, 0, 1), (1, 5, 77), (1, 31, 1), (1, 30, 255)]:
+    bits = engine.fixed_window_bits()
+    windows = (253 + bits - 1) // bits
+    half = 1 << (bits - 1)
+    for which, window, digit in [(0, 0, 0), (0, 0, 1), (0, 0, half), (0, 1, 1), (0, windows // 2, 200),
+                                 (0, windows - 1, 3), (1, 0, 1), (1, 5, 77), (1, windows - 1, 1),
+                                 (1, windows - 2, half - 1)]:
         got = engine.debug_table_entry(which, window, digit)
-        want = O.fixed_base_entry(which, 8, window, digit)
+        want = O.fixed_base_entry(which, bits, window, digit)
         for f in range(3):
             g = M.from_le(got[32 * f:32 * f + 32]) * rinv % M.Q
             assert g == M.from_le(want[32 * f:32 * f + 32]), (which, window, digit, f)
