@@ -30,7 +30,7 @@ sys.path.insert(0, ROOT)
 # operation (tools: `hipcc -S` of fe29.h; checked against rocprof SQ_INSTS_VALU in profiles/).
 FE_MUL, FE_SQR = 211, 181            # 153 / 117 v_mad_u64_u32 + carry & normalise ops
 ADD, SUB, CARRY = 9, 45, 26          # limb-wise add; biased subtract + carry pass; carry pass
-DOUBLE = 4 * FE_SQR + 3 * FE_MUL + 3 * ADD + 3 * SUB
+DOUBLE = 3 * FE_SQR + 4 * FE_MUL + 3 * ADD + 2 * SUB    # uu, vv, zz; 2uv, and the 3 outputs
 ADD_NIELS = 8 * FE_MUL + 4 * ADD + CARRY + 3 * SUB
 ADD_ANIELS = 7 * FE_MUL + 4 * ADD + CARRY + 3 * SUB
 TO_NIELS = 2 * FE_MUL + ADD + CARRY + 2 * SUB          # incl. the negated 2d*t of a table entry
@@ -42,7 +42,7 @@ VERIFY_INSTR = (
     + 2 * TABLE9                                       # window tables of PK and R
     + HALF_GCD + 2 * 8 * 90                            # (a, b) and b*u mod r
     + WINDOWS * (4 * DOUBLE + 2 * ADD_NIELS)           # a*PK -/+ b*R, shared doublings
-    + 32 * ADD_ANIELS                                  # += (b*u)*G from the 8-bit-window table
+    + 23 * (ADD_ANIELS + 12)                           # += (b*u)*G, signed 11-bit windows
     + 400                                              # identity test
 )
 ALGO_BYTES_SINGLE = 193                            # 192 B in + 1 B out
@@ -228,6 +228,23 @@ def main():
                          "workload": "2^%d double-signature batch (BASELINE configs[2])"
                                      % args.log2_batch}
         del bd, okd
+        # var-generator scheme (BASELINE configs[3]: 2^18), both bases variable
+        nv = min(n, 1 << 18)
+        bv = W.gen_vargen(nv, seed=777, device=dev)
+        okv = torch.zeros(nv, dtype=torch.uint8, device=dev)
+        E.verify_vargen_dev(bv["u"], bv["R"], bv["PK"], bv["Gen"], bv["m"], okv, ws)
+        torch.cuda.synchronize()
+        tv0 = time.perf_counter()
+        for _ in range(reps):
+            E.verify_vargen_dev(bv["u"], bv["R"], bv["PK"], bv["Gen"], bv["m"], okv, ws)
+        torch.cuda.synchronize()
+        tvv = time.perf_counter() - tv0
+        if int((okv != bv["expected"]).sum().item()):
+            raise SystemExit("var-generator verdicts differ from the expected pattern")
+        out["vargen"] = {"value": nv * reps / tvv, "unit": "verifies/s",
+                         "workload": "2^%d var-generator batch (BASELINE configs[3])"
+                                     % (nv.bit_length() - 1)}
+        del bv, okv
 
     # ---- CPU baseline: the oracle (port of the reference algorithm) on the host cores
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

@@ -80,3 +80,29 @@ def gen_double(n, seed, device="cuda:0", tamper=True):
     else:
         batch["expected"] = torch.ones(n, dtype=torch.uint8, device=device)
     return batch
+
+
+def gen_vargen(n, seed, device="cuda:0", tamper=True):
+    """Var-generator scheme (benches/signature_var_generator.rs:50-63 shape): sk, generator scalar
+    g, message, nonce; Gen = g*G, PK = sk*Gen, R = r*Gen.  Generated through the host entry points
+    (the variable-base sign/derive kernels have no device-pointer form), then moved to HBM."""
+    gen = torch.Generator(device=device)
+    gen.manual_seed(seed)
+    sk = _rand_scalars(n, 0x07, gen, device).cpu().numpy()
+    g = _rand_scalars(n, 0x07, gen, device).cpu().numpy()
+    r = _rand_scalars(n, 0x07, gen, device).cpu().numpy()
+    m = _rand_scalars(n, 0x3F, gen, device).cpu().numpy()
+    Gen = E.public_keys(g, 0)
+    PK = E.public_keys(sk, 0, Gen)
+    u, R = E.sign_vargen(sk, Gen, m, r)
+    to = lambda a: torch.from_numpy(a).to(device).contiguous()
+    batch = {"u": to(u), "R": to(R), "PK": to(PK), "Gen": to(Gen), "m": to(m)}
+    if tamper:
+        expected = _tamper(batch, n)
+        idx = torch.arange(8, n, TAMPER_PERIOD, device=device)
+        batch["Gen"][idx] = batch["Gen"][(idx + 1) % n]      # wrong generator
+        expected[idx] = 0
+        batch["expected"] = expected
+    else:
+        batch["expected"] = torch.ones(n, dtype=torch.uint8, device=device)
+    return batch

@@ -325,3 +325,40 @@ def test_wire_formats_decompress_and_verify(engine):
     pkv[3, 32:] = pkv[4, 32:]
     assert np.array_equal(engine.verify_vargen_wire(sigv, pkv, dv["m"]),
                           O.verify_vargen_wire(sigv, pkv, dv["m"]))
+
+
+def test_vargen_config_size_batch(engine):
+    """BASELINE.json configs[3]: 2^18 var-generator signatures through the HBM-resident path."""
+    import torch
+    from schnorr_amd import workload as W
+    n = 1 << 18
+    b = W.gen_vargen(n, seed=31)
+    ok = torch.zeros(n, dtype=torch.uint8, device="cuda:0")
+    ws = torch.empty(engine.workspace_bytes(n), dtype=torch.uint8, device="cuda:0")
+    engine.verify_vargen_dev(b["u"], b["R"], b["PK"], b["Gen"], b["m"], ok, ws)
+    torch.cuda.synchronize()
+    assert torch.equal(ok, b["expected"])
+    idx = torch.arange(0, n, 1021, device="cuda:0")[:128]
+    sub = {k: b[k][idx].cpu().numpy() for k in ("u", "R", "PK", "Gen", "m")}
+    want = O.verify_vargen(sub["u"], sub["R"], sub["PK"], sub["Gen"], sub["m"], nthreads=8)
+    assert np.array_equal(want, ok[idx].cpu().numpy())
+
+
+def test_mixed_batch_split_and_reassemble(engine):
+    """BASELINE.json configs[4] shape at small scale: even index single, odd index double;
+    split by kind, verify each kind with its kernel, scatter verdicts back to original order."""
+    from schnorr_amd import distributed as D
+    n = 128
+    ds = O.keygen_sign_single(n // 2, 1, nthreads=8)
+    dd = O.keygen_sign_double(n // 2, 2, nthreads=8)
+    H.tamper(ds, period=5)
+    H.tamper(dd, period=7)
+    kinds = np.arange(n) % 2
+    si, di = D.split_mixed(kinds)
+    verdict = np.zeros(n, np.uint8)
+    verdict[si] = engine.verify_single(ds["u"], ds["R"], ds["PK"], ds["m"])
+    verdict[di] = engine.verify_double(dd["u"], dd["R"], dd["Rp"], dd["PK"], dd["PKp"], dd["m"])
+    want = np.zeros(n, np.uint8)
+    want[si] = O.verify_single(ds["u"], ds["R"], ds["PK"], ds["m"], nthreads=8)
+    want[di] = O.verify_double(dd["u"], dd["R"], dd["Rp"], dd["PK"], dd["PKp"], dd["m"], nthreads=8)
+    assert np.array_equal(verdict, want) and 0 < want.sum() < n
