@@ -430,10 +430,14 @@ k_verify_fixed_half(const uint8_t* __restrict__ u, const uint8_t* __restrict__ c
       u32 cs[8], a[8], b[8];
       load_words8(cs, c, i);
       half_scalars(a, b, b_neg, cs);
-      const int la = bitlen8(a), lb = bitlen8(b);
-      top = ((la > lb ? la : lb) + 3) >> 2;
       recode_signed4(ya, a);
       recode_signed4(yb, b);
+      // index of the highest non-zero signed digit of either scalar (a zero digit is nibble 8)
+      u32 nz[8];
+#pragma unroll
+      for (int k = 0; k < 8; k++) nz[k] = (ya[k] ^ 0x88888888u) | (yb[k] ^ 0x88888888u);
+      const int nzbits = bitlen8(nz);
+      top = nzbits > 0 ? (nzbits - 1) >> 2 : 0;
       u32 us[8];
       load_words8(us, u, i);
       const bool u_ok = words_lt(us, kR32);

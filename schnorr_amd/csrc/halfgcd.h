@@ -14,9 +14,9 @@
 //
 // (a, b) comes from the extended Euclidean algorithm on (8r, c): remainders r_i = t_i*c (mod 8r);
 // stop at the first r_i < 2^128, where |t_i| < 2^127.  Consecutive cofactors are coprime, so if
-// t_i is even, t_{i-1} is odd and (r_{i-1}, t_{i-1}) is used instead.  Sizes are ~128 bits
-// (mean 128.2, 99th percentile 134 over random c): the variable-base part of a verification
-// becomes a two-base Straus chain of ~34 signed 4-bit windows instead of 63.
+// t_i is even, t_{i-1} is odd and a balanced combination (r_{i-1} - k r_i, t_{i-1} + k t_i) is
+// used instead.  Sizes are ~128 bits: the variable-base part of a verification becomes a two-base
+// Straus chain of ~33 signed 4-bit windows instead of 63.
 //
 // Lanes diverge in iteration count only; every lane exits after at most kHalfGcdMaxIter
 // iterations (the pair it holds then is still a valid one, just longer).
@@ -120,12 +120,70 @@ DSV_DEV void half_scalars(u32 (&a)[8], u32 (&b)[8], bool& b_neg, const u32 (&c)[
       }
     }
   }
-  const bool use_b = (tB[0] & 1) != 0;  // else the previous pair, whose cofactor is then odd
+  const bool use_b = (tB[0] & 1) != 0;
+  if (use_b) {
 #pragma unroll
-  for (int i = 0; i < 8; i++) a[i] = use_b ? B[i] : A[i];
+    for (int i = 0; i < 8; i++) a[i] = B[i];
 #pragma unroll
-  for (int i = 0; i < 8; i++) b[i] = i < 5 ? (use_b ? tB[i] : tA[i]) : 0u;
-  b_neg = use_b ? neg : !neg;
+    for (int i = 0; i < 8; i++) b[i] = i < 5 ? tB[i] : 0u;
+    b_neg = neg;
+    return;
+  }
+  // tB is even, so tA (coprime to it) is odd, and so is tA + k*tB for every k: all the vectors
+  // (A - k*B, tA + k*tB), 0 <= k <= A/B, qualify.  Take k near (A - tA) / (B + tB), where the two
+  // components balance, instead of k = 0 (whose first component can be many bits longer): the
+  // longest lane of a wave sets the length of the Straus chain for all 64.
+  u32 bestA[8], bestT[5];
+#pragma unroll
+  for (int i = 0; i < 8; i++) bestA[i] = A[i];
+#pragma unroll
+  for (int i = 0; i < 5; i++) bestT[i] = tA[i];
+  u32 tA8[8], tB8[8];
+#pragma unroll
+  for (int i = 0; i < 8; i++) {
+    tA8[i] = i < 5 ? tA[i] : 0u;
+    tB8[i] = i < 5 ? tB[i] : 0u;
+  }
+  int best = bitlen8(A);  // >= 129 > bitlen(tA)
+  const double kd = (to_double8(A) - to_double8(tA8)) / (to_double8(B) + to_double8(tB8));
+  if (kd >= 1.0 && kd < 2147483000.0) {
+    const u32 k0 = (u32)kd;
+#pragma unroll 1
+    for (u32 kk = k0; kk <= k0 + 1; kk++) {
+      u32 ca[8], ct[8];
+      u32 mc = 0, borrow = 0;
+#pragma unroll
+      for (int i = 0; i < 8; i++) {
+        const u64 p = (u64)kk * B[i] + mc;
+        mc = (u32)(p >> 32);
+        const u64 d = (u64)A[i] - (u32)p - borrow;
+        ca[i] = (u32)d;
+        borrow = (u32)(d >> 63);
+      }
+      u32 carry = 0;
+#pragma unroll
+      for (int i = 0; i < 8; i++) {
+        const u64 p = (u64)kk * tB8[i] + tA8[i] + carry;
+        ct[i] = (u32)p;
+        carry = (u32)(p >> 32);
+      }
+      const bool valid = borrow == 0 && mc == 0 && (ct[5] | ct[6] | ct[7]) == 0;
+      const int la = bitlen8(ca), lt = bitlen8(ct);
+      const int size = la > lt ? la : lt;
+      if (valid && size < best) {
+        best = size;
+#pragma unroll
+        for (int i = 0; i < 8; i++) bestA[i] = ca[i];
+#pragma unroll
+        for (int i = 0; i < 5; i++) bestT[i] = ct[i];
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 8; i++) a[i] = bestA[i];
+#pragma unroll
+  for (int i = 0; i < 8; i++) b[i] = i < 5 ? bestT[i] : 0u;
+  b_neg = !neg;  // sign of t_{i-1}; adding multiples of t_i (opposite sign, subtracted) keeps it
 }
 
 }  // namespace dsv

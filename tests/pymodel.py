@@ -181,7 +181,15 @@ def half_scalars(c):
             neg = not neg
     if tB & 1:
         return B, tB, neg
-    return A, tA, not neg
+    # tB even => tA odd, and so is tA + k*tB: pick k where the two components balance
+    best = (A, tA)
+    k0 = max(0, (A - tA) // (B + tB))
+    for kk in (k0, k0 + 1):
+        a, b = A - kk * B, tA + kk * tB
+        if 1 <= k0 < 2147483000 and a >= 0 and b < (1 << 160) and \
+                max(a.bit_length(), b.bit_length()) < max(best[0].bit_length(), best[1].bit_length()):
+            best = (a, b)
+    return best[0], best[1], not neg
 
 
 def verify_single_half(u, R, PK, m):
