@@ -35,7 +35,7 @@ ADD_NIELS = 8 * FE_MUL + 4 * ADD + CARRY + 3 * SUB
 ADD_ANIELS = 7 * FE_MUL + 4 * ADD + CARRY + 3 * SUB
 TO_NIELS = 2 * FE_MUL + ADD + CARRY + 2 * SUB          # incl. the negated 2d*t of a table entry
 TABLE9 = 7 * ADD_NIELS + 8 * TO_NIELS                  # |d|*P, d = 1..8
-WINDOWS = 34                                           # mean over waves of max lane length / 4
+WINDOWS = 33                                           # mean over waves of the longest lane's digits
 HALF_GCD = 13000                                       # ~90 iterations x ~140 instructions
 VERIFY_INSTR = (
     4 * FE_MUL                                         # PK, R to Montgomery form
