@@ -362,3 +362,32 @@ def test_mixed_batch_split_and_reassemble(engine):
     want[si] = O.verify_single(ds["u"], ds["R"], ds["PK"], ds["m"], nthreads=8)
     want[di] = O.verify_double(dd["u"], dd["R"], dd["Rp"], dd["PK"], dd["PKp"], dd["m"], nthreads=8)
     assert np.array_equal(verdict, want) and 0 < want.sum() < n
+
+
+def test_randomized_parity_sweep(engine):
+    """8192 items: valid signatures, every tamper class at a dense period, special scalars
+    (u = 0, u = r-1, m = 0, m = q-1), keys/nonces replaced by unrelated curve points — GPU
+    verdicts (both formulations share this path) against the oracle, bit for bit."""
+    n = 8192
+    d = O.keygen_sign_single(n, 424242, nthreads=16)
+    H.tamper(d, period=3)
+    le = lambda x: np.frombuffer(M.le32(x), np.uint8)
+    d["u"][1] = 0
+    d["u"][4] = le(M.R_ORDER - 1)
+    d["m"][7] = 0
+    d["m"][10] = le(M.Q - 1)
+    d["m"][13] = le(M.Q)                     # non-canonical message
+    d["R"][16] = d["PK"][17]                 # unrelated on-curve points
+    d["PK"][19] = d["R"][20]
+    d["PK"][22] = np.frombuffer(M.point_bytes(M.GEN), np.uint8)
+    d["R"][25] = np.frombuffer(M.point_bytes(M.GEN_NUMS), np.uint8)
+    want = O.verify_single(d["u"], d["R"], d["PK"], d["m"], nthreads=16)
+    got = engine.verify_single(d["u"], d["R"], d["PK"], d["m"])
+    assert np.array_equal(got, want)
+    assert 0.3 * n < want.sum() < 0.7 * n
+    # same batch as double signatures of the same keys
+    dd = O.keygen_sign_double(2048, 99, nthreads=16)
+    H.tamper(dd, period=3)
+    want = O.verify_double(dd["u"], dd["R"], dd["Rp"], dd["PK"], dd["PKp"], dd["m"], nthreads=16)
+    got = engine.verify_double(dd["u"], dd["R"], dd["Rp"], dd["PK"], dd["PKp"], dd["m"])
+    assert np.array_equal(got, want)
