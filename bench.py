@@ -169,7 +169,7 @@ def main():
     total = n * world
     value = total * args.steps / dt
     out = {
-        "metric": "schnorr_single_verifies_per_sec",
+        "metric": "Schnorr verifies/sec (single) at batch=2^%d" % args.log2_batch,
         "value": value,
         "unit": "verifies/s",
         "n_gpus": world,

@@ -1,0 +1,40 @@
+//! Dumps golden vectors from the REAL dusk-schnorr 0.18 so the repository's restatement of the
+//! hash (Hades constants, sponge padding, 250-bit truncation) can be pinned — the one thing
+//! nothing in the reference tree pins.  Run on a machine with cargo + crates.io:
+//!     cargo run --bin golden_gen > ../../tests/golden/reference_vectors.txt
+//! and compare with tests/golden/vectors.json (same field names).
+use dusk_bls12_381::BlsScalar;
+use dusk_bytes::Serializable;
+use dusk_schnorr::{PublicKey, SecretKey};
+use ff::Field;
+use rand::{rngs::StdRng, SeedableRng};
+
+fn hex(b: &[u8]) -> String {
+    b.iter().map(|x| format!("{x:02x}")).collect()
+}
+
+fn main() {
+    // (a) raw sponge: compare with vectors.json["hash"][1]["sponge"] (big-endian hex there)
+    let h = dusk_poseidon::sponge::hash(&[BlsScalar::from(1u64), BlsScalar::from(2u64),
+                                          BlsScalar::from(3u64)]);
+    println!("sponge_hash_1_2_3_le {}", hex(&h.to_bytes()));
+    let t = dusk_poseidon::sponge::truncated::hash(&[BlsScalar::from(1u64), BlsScalar::from(2u64),
+                                                     BlsScalar::from(3u64)]);
+    println!("truncated_hash_1_2_3_le {}", hex(&t.to_bytes()));
+    // (b) signatures under the reference's own test seed (tests/schnorr.rs:16)
+    let mut rng = StdRng::seed_from_u64(2321);
+    for i in 0..8 {
+        let sk = SecretKey::random(&mut rng);
+        let m = BlsScalar::random(&mut rng);
+        let sig = sk.sign(&mut rng, m);
+        let pk = PublicKey::from(&sk);
+        let [ru, rv] = sig.R().to_hash_inputs();
+        let [pu, pv] = pk.as_ref().to_hash_inputs();
+        println!(
+            "sig {i} sk {} m {} u {} R {}{} PK {}{} sig_bytes {} pk_bytes {} verdict {}",
+            hex(&sk.to_bytes()), hex(&m.to_bytes()), hex(&sig.u().to_bytes()),
+            hex(&ru.to_bytes()), hex(&rv.to_bytes()), hex(&pu.to_bytes()), hex(&pv.to_bytes()),
+            hex(&sig.to_bytes()), hex(&pk.to_bytes()), pk.verify(&sig, m)
+        );
+    }
+}
