@@ -614,9 +614,9 @@ k_decompress(const uint8_t* __restrict__ in, size_t in_stride, size_t n,
   const Fe v2 = fe_sqr(v);
   const Fe num = fe_sub2(v2, fe_one());                          // v^2 - 1
   const Fe den = fe_add(fe_mul(v2, fe_const(kD)), fe_one());     // 1 + d v^2  (never 0: -1/d is a non-square)
-  const Fe u2 = fe_mul(num, fe_invert(den));
-  Fe u;
-  good &= fe_sqrt(u, u2);
+  // u = n * (n d)^(-1/2); accept iff u^2 d == n  (rejects non-squares; n == 0 gives u == 0)
+  Fe u = fe_mul(num, fe_inv_sqrt(fe_mul(num, den)));
+  good &= fe_equal(fe_mul(fe_sqr(u), den), num);
   u32 uw[8];
   fe_to_words_plain(uw, fe_from_mont(u));
   if ((uw[0] & 1u) != sign) {                                    // take the other root
@@ -797,6 +797,8 @@ int dsv_init(int device) {
                             sizeof(DSV_HADES_SPARSE_HOST)));
   HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(c_hades_kfinal), DSV_HADES_KFINAL_HOST,
                             sizeof(DSV_HADES_KFINAL_HOST)));
+  HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(c_root_powers), DSV_ROOT_POWERS_HOST,
+                            sizeof(DSV_ROOT_POWERS_HOST)));
   for (int g = 0; g < 2; g++) {
     HIP_TRY(hipMalloc(&g_ctx.table[g], kTableBytes));
     const int total = kFixedWindows * kFixedEntries;

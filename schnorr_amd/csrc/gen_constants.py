@@ -174,6 +174,13 @@ def main():
         w("#define DSV_SQRT_E_WORDS %s\n" % ("{" + ", ".join("0x%08xu" % ((e >> (32 * i)) & 0xFFFFFFFF) for i in range(7)) + "}"))
         w("#define DSV_SQRT_E_BITS %d\n" % e.bit_length())
         w("#define DSV_ROOT_OF_UNITY %s\n" % arr(mont(pow(7, t_odd, Q))))
+        # c^(2^j), j = 0..32 (the last one is 1): Tonelli-Shanks multipliers by table lookup
+        root = pow(7, t_odd, Q)
+        w("static const uint32_t DSV_ROOT_POWERS_HOST[33][9] = {\n")
+        for j in range(33):
+            w("  %s,\n" % arr(mont(pow(root, 1 << j, Q))))
+        w("};\n")
+        assert pow(root, 1 << 31, Q) == Q - 1 and pow(root, 1 << 32, Q) == 1
         w("static const uint32_t DSV_HADES_RC_HOST[%d][9] = {\n" % len(rc))
         for c in rc:
             w("  %s,\n" % arr(mont(c)))

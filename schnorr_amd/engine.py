@@ -284,6 +284,15 @@ def challenge_single_dev(R, m, c, valid=None, stream=None):
         ctypes.c_void_p(valid.data_ptr() if valid is not None else 0), _stream_ptr(stream)))
 
 
+def decompress_points_dev(comp, out_uv, ok, in_stride=32, accumulate=False, stream=None):
+    """comp: uint8 CUDA tensor holding one 32-byte record every in_stride bytes."""
+    n = out_uv.shape[0]
+    _lib.check(_lib.load().dsv_decompress_points_dev(
+        ctypes.c_void_p(comp.data_ptr()), ctypes.c_size_t(in_stride), ctypes.c_size_t(n),
+        _tp(out_uv, 64), ctypes.c_void_p(ok.data_ptr()), ctypes.c_int(1 if accumulate else 0),
+        _stream_ptr(stream)))
+
+
 def sign_single_dev(sk, m, r, u, R, stream=None):
     n = sk.shape[0]
     _lib.check(_lib.load().dsv_sign_single_dev(
