@@ -248,7 +248,9 @@ DSV_DEV Ext fixed_base_accumulate(Ext acc, const u32 (&s)[8], const u32* __restr
 constexpr int kVarEntries = 9;
 constexpr int kVarEntryWords = 5 * NL;
 constexpr int kVarLaneWords = kVarEntries * kVarEntryWords;  // 405 words = 1620 B
-constexpr unsigned kMaxVerifyGrid = 1024;                     // 4 workgroups per CU
+constexpr int kVerifyBlock = 64;        // ONE wave per workgroup: a finished wave's slot is refilled at
+                                        // once instead of waiting for its three workgroup mates
+constexpr unsigned kMaxVerifyGrid = 4096;                     // 16 single-wave workgroups per CU
 
 DSV_DEV void store_fe_words(u32* p, const Fe& a) {
 #pragma unroll
@@ -357,14 +359,15 @@ DSV_DEV Ext var_base_mul2(const u32 (&a)[8], const u32* tp, const u32 (&b)[8], c
 // Order of work is chosen for register pressure: PK -> window table (global workspace) -> c*PK
 // -> += u*Gen -> compare with R; each input is loaded right before its only use.
 template <bool ACCUM>
-__global__ void __launch_bounds__(256, DSV_WAVES_VERIFY)
+__global__ void __launch_bounds__(kVerifyBlock, DSV_WAVES_VERIFY)
 k_verify_fixed(const uint8_t* __restrict__ u, const uint8_t* __restrict__ c,
                const uint8_t* __restrict__ PK_uv, const uint8_t* __restrict__ R_uv,
                const u32* __restrict__ table, const uint8_t* __restrict__ valid, size_t n,
                uint8_t* __restrict__ ok, u32* __restrict__ var_tables) {
-  u32* lane_tbl = var_tables + ((size_t)blockIdx.x * 256 + threadIdx.x) * kVarLaneWords;
+  u32* lane_tbl = var_tables + ((size_t)blockIdx.x * kVerifyBlock + threadIdx.x) * kVarLaneWords;
 #pragma unroll 1
-  for (size_t base = (size_t)blockIdx.x * 256; base < n; base += (size_t)gridDim.x * 256) {
+  for (size_t base = (size_t)blockIdx.x * kVerifyBlock; base < n;
+       base += (size_t)gridDim.x * kVerifyBlock) {
     const size_t i = base + threadIdx.x;
     if (i >= n) continue;
     bool good = ACCUM ? (ok[i] != 0) : (valid[i] != 0);
@@ -399,15 +402,16 @@ k_verify_fixed(const uint8_t* __restrict__ u, const uint8_t* __restrict__ c,
 // Two per-lane window tables (PK and R), one Straus chain of ~34 windows whose length is the
 // lane's own max(bitlen a, bitlen b) (lanes of a wave simply leave the loop at different times).
 template <bool ACCUM>
-__global__ void __launch_bounds__(256, DSV_WAVES_VERIFY)
+__global__ void __launch_bounds__(kVerifyBlock, DSV_WAVES_VERIFY)
 k_verify_fixed_half(const uint8_t* __restrict__ u, const uint8_t* __restrict__ c,
                     const uint8_t* __restrict__ PK_uv, const uint8_t* __restrict__ R_uv,
                     const u32* __restrict__ table, const uint8_t* __restrict__ valid, size_t n,
                     uint8_t* __restrict__ ok, u32* __restrict__ var_tables) {
-  u32* tpk = var_tables + ((size_t)blockIdx.x * 256 + threadIdx.x) * (2 * kVarLaneWords);
+  u32* tpk = var_tables + ((size_t)blockIdx.x * kVerifyBlock + threadIdx.x) * (2 * kVarLaneWords);
   u32* tr = tpk + kVarLaneWords;
 #pragma unroll 1
-  for (size_t base = (size_t)blockIdx.x * 256; base < n; base += (size_t)gridDim.x * 256) {
+  for (size_t base = (size_t)blockIdx.x * kVerifyBlock; base < n;
+       base += (size_t)gridDim.x * kVerifyBlock) {
     const size_t i = base + threadIdx.x;
     if (i >= n) continue;
     bool good = ACCUM ? (ok[i] != 0) : (valid[i] != 0);
@@ -469,15 +473,16 @@ k_verify_fixed_half(const uint8_t* __restrict__ u, const uint8_t* __restrict__ c
   }
 }
 
-__global__ void __launch_bounds__(256, DSV_WAVES_VERIFY)
+__global__ void __launch_bounds__(kVerifyBlock, DSV_WAVES_VERIFY)
 k_verify_var(const uint8_t* __restrict__ u, const uint8_t* __restrict__ c,
              const uint8_t* __restrict__ PK_uv, const uint8_t* __restrict__ Gen_uv,
              const uint8_t* __restrict__ R_uv, const uint8_t* __restrict__ valid, size_t n,
              uint8_t* __restrict__ ok, u32* __restrict__ var_tables) {
-  u32* tp = var_tables + ((size_t)blockIdx.x * 256 + threadIdx.x) * (2 * kVarLaneWords);
+  u32* tp = var_tables + ((size_t)blockIdx.x * kVerifyBlock + threadIdx.x) * (2 * kVarLaneWords);
   u32* tq = tp + kVarLaneWords;
 #pragma unroll 1
-  for (size_t base = (size_t)blockIdx.x * 256; base < n; base += (size_t)gridDim.x * 256) {
+  for (size_t base = (size_t)blockIdx.x * kVerifyBlock; base < n;
+       base += (size_t)gridDim.x * kVerifyBlock) {
     const size_t i = base + threadIdx.x;
     if (i >= n) continue;
     bool good = valid[i] != 0;
@@ -554,12 +559,13 @@ k_fixed_base_points(const uint8_t* __restrict__ scalar, const u32* __restrict__ 
   store_affine(out_uv, i, acc);
 }
 // out = scalar * P for a per-item base P (var-generator scheme: secret.rs:442, public.rs:337-344)
-__global__ void __launch_bounds__(256, DSV_WAVES_VERIFY)
+__global__ void __launch_bounds__(kVerifyBlock, DSV_WAVES_VERIFY)
 k_var_base_points(const uint8_t* __restrict__ scalar, const uint8_t* __restrict__ P_uv, size_t n,
                   uint8_t* __restrict__ out_uv, u32* __restrict__ var_tables) {
-  u32* lane_tbl = var_tables + ((size_t)blockIdx.x * 256 + threadIdx.x) * kVarLaneWords;
+  u32* lane_tbl = var_tables + ((size_t)blockIdx.x * kVerifyBlock + threadIdx.x) * kVarLaneWords;
 #pragma unroll 1
-  for (size_t base = (size_t)blockIdx.x * 256; base < n; base += (size_t)gridDim.x * 256) {
+  for (size_t base = (size_t)blockIdx.x * kVerifyBlock; base < n;
+       base += (size_t)gridDim.x * kVerifyBlock) {
     const size_t i = base + threadIdx.x;
     if (i >= n) continue;
     {
@@ -731,11 +737,11 @@ struct Workspace {
   u32* tables;
 };
 unsigned verify_grid(size_t n) {
-  unsigned g = grid_for(n);
+  unsigned g = grid_for(n, kVerifyBlock);
   return g < kMaxVerifyGrid ? g : kMaxVerifyGrid;
 }
 size_t var_table_bytes(size_t n, int tables_per_lane) {
-  return (size_t)verify_grid(n) * 256 * kVarLaneWords * 4 * (size_t)tables_per_lane;
+  return (size_t)verify_grid(n) * kVerifyBlock * kVarLaneWords * 4 * (size_t)tables_per_lane;
 }
 Workspace carve(void* ws, size_t n) {
   Workspace w;
@@ -749,7 +755,7 @@ Workspace carve(void* ws, size_t n) {
 void launch_verify_fixed(bool accumulate, const void* u, const void* c, const void* PK_uv,
                          const void* R_uv, int which, const void* valid, size_t n, void* ok,
                          u32* tables, hipStream_t s) {
-  const dim3 grid(verify_grid(n)), block(256);
+  const dim3 grid(verify_grid(n)), block(kVerifyBlock);
 #define DSV_LAUNCH(K)                                                                          \
   hipLaunchKernelGGL(K, grid, block, 0, s, (const uint8_t*)u, (const uint8_t*)c,               \
                      (const uint8_t*)PK_uv, (const uint8_t*)R_uv, (const u32*)g_ctx.table[which], \
@@ -923,7 +929,7 @@ int dsv_verify_vargen_dev(const void* u, const void* R_uv, const void* PK_uv, co
   hipStream_t s = (hipStream_t)stream;
   hipLaunchKernelGGL(k_challenge<false>, dim3(grid_for(n)), dim3(256), 0, s, (const uint8_t*)R_uv,
                      (const uint8_t*)nullptr, (const uint8_t*)m, n, w.c, w.valid);
-  hipLaunchKernelGGL(k_verify_var, dim3(verify_grid(n)), dim3(256), 0, s, (const uint8_t*)u,
+  hipLaunchKernelGGL(k_verify_var, dim3(verify_grid(n)), dim3(kVerifyBlock), 0, s, (const uint8_t*)u,
                      (const uint8_t*)w.c, (const uint8_t*)PK_uv, (const uint8_t*)Gen_uv,
                      (const uint8_t*)R_uv, (const uint8_t*)w.valid, n, (uint8_t*)ok, w.tables);
   HIP_TRY(hipGetLastError());
@@ -1159,7 +1165,7 @@ int dsv_public_keys(const uint8_t* sk, int which, const uint8_t* gen_uv, size_t 
   H2D(dsk, sk, n * 32);
   if (gen_uv) {
     H2D(dg, gen_uv, n * 64);
-    hipLaunchKernelGGL(k_var_base_points, dim3(verify_grid(n)), dim3(256), 0, 0, (const uint8_t*)dsk,
+    hipLaunchKernelGGL(k_var_base_points, dim3(verify_grid(n)), dim3(kVerifyBlock), 0, 0, (const uint8_t*)dsk,
                        (const uint8_t*)dg, n, dpk, reinterpret_cast<u32*>(dtab));
     HIP_TRY(hipGetLastError());
   } else {
@@ -1231,7 +1237,7 @@ int dsv_sign_vargen(const uint8_t* sk, const uint8_t* Gen_uv, const uint8_t* m, 
   H2D(dm, m, n * 32);
   H2D(dr, r, n * 32);
   H2D(dG, Gen_uv, n * 64);
-  hipLaunchKernelGGL(k_var_base_points, dim3(verify_grid(n)), dim3(256), 0, 0, (const uint8_t*)dr,
+  hipLaunchKernelGGL(k_var_base_points, dim3(verify_grid(n)), dim3(kVerifyBlock), 0, 0, (const uint8_t*)dr,
                      (const uint8_t*)dG, n, dR, reinterpret_cast<u32*>(dtab));
   hipLaunchKernelGGL(k_challenge<false>, dim3(grid_for(n)), dim3(256), 0, 0, (const uint8_t*)dR,
                      (const uint8_t*)nullptr, (const uint8_t*)dm, n, du, (uint8_t*)nullptr);
