@@ -278,10 +278,10 @@ def main():
                       "1 thread: %.0f verifies/s on %d items" % (sample, cores, tc, one / t1, one),
         }
         # host-buffer path of the C ABI (PCIe-inclusive), never the headline value
-        hs = min(n, 1 << 18)
+        hs = n
         hu = batch["u"][:hs].cpu().numpy(); hR = batch["R"][:hs].cpu().numpy()
         hPK = batch["PK"][:hs].cpu().numpy(); hm = batch["m"][:hs].cpu().numpy()
-        E.verify_single(hu[:1024], hR[:1024], hPK[:1024], hm[:1024])
+        E.verify_single(hu, hR, hPK, hm)  # warm: staging buffers sized for this batch
         th0 = time.perf_counter()
         E.verify_single(hu, hR, hPK, hm)
         th = time.perf_counter() - th0

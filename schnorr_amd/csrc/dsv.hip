@@ -700,6 +700,11 @@ struct Context {
   std::mutex mu;
   uint8_t* stage = nullptr;
   size_t stage_bytes = 0;
+  // double-buffered pipeline of the host verify entry points: H2D of chunk k+1 overlaps the
+  // kernels of chunk k (two streams, two staging slots)
+  hipStream_t pipe_stream[2] = {nullptr, nullptr};
+  uint8_t* pipe_stage[2] = {nullptr, nullptr};
+  size_t pipe_bytes[2] = {0, 0};
 };
 Context g_ctx;
 std::mutex g_init_mu;
@@ -713,6 +718,17 @@ int ensure_stage(size_t bytes) {
   size_t want = bytes + bytes / 4;
   HIP_TRY(hipMalloc(&g_ctx.stage, want));
   g_ctx.stage_bytes = want;
+  return DSV_OK;
+}
+
+int ensure_pipe_slot(int slot, size_t bytes) {
+  if (!g_ctx.pipe_stream[slot]) HIP_TRY(hipStreamCreateWithFlags(&g_ctx.pipe_stream[slot], hipStreamNonBlocking));
+  if (g_ctx.pipe_bytes[slot] >= bytes) return DSV_OK;
+  if (g_ctx.pipe_stage[slot]) HIP_TRY(hipFree(g_ctx.pipe_stage[slot]));
+  g_ctx.pipe_stage[slot] = nullptr;
+  g_ctx.pipe_bytes[slot] = 0;
+  HIP_TRY(hipMalloc(&g_ctx.pipe_stage[slot], bytes));
+  g_ctx.pipe_bytes[slot] = bytes;
   return DSV_OK;
 }
 
@@ -832,6 +848,13 @@ int dsv_shutdown(void) {
   if (g_ctx.stage) hipFree(g_ctx.stage);
   g_ctx.stage = nullptr;
   g_ctx.stage_bytes = 0;
+  for (int k = 0; k < 2; k++) {
+    if (g_ctx.pipe_stage[k]) hipFree(g_ctx.pipe_stage[k]);
+    if (g_ctx.pipe_stream[k]) hipStreamDestroy(g_ctx.pipe_stream[k]);
+    g_ctx.pipe_stage[k] = nullptr;
+    g_ctx.pipe_stream[k] = nullptr;
+    g_ctx.pipe_bytes[k] = 0;
+  }
   g_ctx.device = -1;
   g_ready.store(false);
   return DSV_OK;
@@ -953,28 +976,64 @@ struct Stager {
 #define H2D(dst, src, bytes) HIP_TRY(hipMemcpyAsync((dst), (src), (bytes), hipMemcpyHostToDevice, 0))
 #define D2H(dst, src, bytes) HIP_TRY(hipMemcpyAsync((dst), (src), (bytes), hipMemcpyDeviceToHost, 0))
 
+extern "C++" {
+namespace {
+// Chunked, double-buffered host path shared by the three verify entry points.
+//   ins[k] = {host array, bytes per item}; launch(dev_ptrs, count, dok, ws, stream) enqueues the
+//   kernels for one chunk.  Chunk c uses slot c & 1: its H2D copies (which block the host while a
+//   pageable buffer is staged) run while the other slot's kernels are still executing.
+struct HostIn {
+  const uint8_t* p;
+  size_t bytes;
+};
+constexpr size_t kPipeChunk = (size_t)1 << 17;  // 2048 waves: one chunk fills every SIMD twice
+
+template <size_t NIN, class Launch>
+int run_pipelined(const HostIn (&ins)[NIN], uint8_t* ok, size_t n, Launch launch) {
+  std::lock_guard<std::mutex> lk(g_ctx.mu);
+  HIP_TRY(hipSetDevice(g_ctx.device));
+  const size_t chunk = n < kPipeChunk ? n : kPipeChunk;
+  size_t need = align_up(chunk, 256) + dsv_workspace_bytes(chunk);
+  for (size_t k = 0; k < NIN; k++) need += align_up(chunk * ins[k].bytes, 256);
+  const int nslots = n > chunk ? 2 : 1;
+  for (int sl = 0; sl < nslots; sl++)
+    if (int r = ensure_pipe_slot(sl, need)) return r;
+  size_t done = 0;
+  for (size_t c = 0; done < n; c++) {
+    const int sl = (int)(c & 1);
+    hipStream_t st = g_ctx.pipe_stream[sl];
+    const size_t cnt = n - done < chunk ? n - done : chunk;
+    if (c >= 2) HIP_TRY(hipStreamSynchronize(st));  // slot free again (its D2H has landed)
+    Stager sg(g_ctx.pipe_stage[sl]);
+    const void* dptr[NIN];
+    for (size_t k = 0; k < NIN; k++) {
+      uint8_t* d = sg.take(chunk * ins[k].bytes);
+      HIP_TRY(hipMemcpyAsync(d, ins[k].p + done * ins[k].bytes, cnt * ins[k].bytes,
+                             hipMemcpyHostToDevice, st));
+      dptr[k] = d;
+    }
+    uint8_t* dok = sg.take(chunk);
+    uint8_t* ws = sg.take(dsv_workspace_bytes(chunk));
+    if (int r = launch(dptr, cnt, dok, ws, st)) return r;
+    HIP_TRY(hipMemcpyAsync(ok + done, dok, cnt, hipMemcpyDeviceToHost, st));
+    done += cnt;
+  }
+  for (int sl = 0; sl < nslots; sl++) HIP_TRY(hipStreamSynchronize(g_ctx.pipe_stream[sl]));
+  return DSV_OK;
+}
+}  // namespace
+}  // extern "C++"
+
 int dsv_verify_single(const uint8_t* u, const uint8_t* R_uv, const uint8_t* PK_uv,
                       const uint8_t* m, size_t n, uint8_t* ok) {
   if (int r = check_ready()) return r;
   if (int r = check_n(n)) return r;
   if (n == 0) return DSV_OK;
   if (!u || !R_uv || !PK_uv || !m || !ok) return fail(DSV_ERR_INVALID_ARGUMENT, "null pointer");
-  std::lock_guard<std::mutex> lk(g_ctx.mu);
-  HIP_TRY(hipSetDevice(g_ctx.device));
-  size_t need = align_up(n * 32, 256) * 2 + align_up(n * 64, 256) * 2 + align_up(n, 256) +
-                dsv_workspace_bytes(n);
-  if (int r = ensure_stage(need)) return r;
-  Stager st(g_ctx.stage);
-  uint8_t *du = st.take(n * 32), *dR = st.take(n * 64), *dPK = st.take(n * 64),
-          *dm = st.take(n * 32), *dok = st.take(n), *ws = st.take(dsv_workspace_bytes(n));
-  H2D(du, u, n * 32);
-  H2D(dR, R_uv, n * 64);
-  H2D(dPK, PK_uv, n * 64);
-  H2D(dm, m, n * 32);
-  if (int r = dsv_verify_single_dev(du, dR, dPK, dm, n, dok, ws, nullptr)) return r;
-  D2H(ok, dok, n);
-  HIP_TRY(hipStreamSynchronize(0));
-  return DSV_OK;
+  const HostIn ins[4] = {{u, 32}, {R_uv, 64}, {PK_uv, 64}, {m, 32}};
+  return run_pipelined(ins, ok, n, [](const void* const* d, size_t cnt, void* dok, void* ws, hipStream_t st) {
+    return dsv_verify_single_dev(d[0], d[1], d[2], d[3], cnt, dok, ws, st);
+  });
 }
 
 int dsv_verify_double(const uint8_t* u, const uint8_t* R_uv, const uint8_t* Rp_uv,
@@ -985,25 +1044,10 @@ int dsv_verify_double(const uint8_t* u, const uint8_t* R_uv, const uint8_t* Rp_u
   if (n == 0) return DSV_OK;
   if (!u || !R_uv || !Rp_uv || !PK_uv || !PKp_uv || !m || !ok)
     return fail(DSV_ERR_INVALID_ARGUMENT, "null pointer");
-  std::lock_guard<std::mutex> lk(g_ctx.mu);
-  HIP_TRY(hipSetDevice(g_ctx.device));
-  size_t need = align_up(n * 32, 256) * 2 + align_up(n * 64, 256) * 4 + align_up(n, 256) +
-                dsv_workspace_bytes(n);
-  if (int r = ensure_stage(need)) return r;
-  Stager st(g_ctx.stage);
-  uint8_t *du = st.take(n * 32), *dR = st.take(n * 64), *dRp = st.take(n * 64),
-          *dPK = st.take(n * 64), *dPKp = st.take(n * 64), *dm = st.take(n * 32),
-          *dok = st.take(n), *ws = st.take(dsv_workspace_bytes(n));
-  H2D(du, u, n * 32);
-  H2D(dR, R_uv, n * 64);
-  H2D(dRp, Rp_uv, n * 64);
-  H2D(dPK, PK_uv, n * 64);
-  H2D(dPKp, PKp_uv, n * 64);
-  H2D(dm, m, n * 32);
-  if (int r = dsv_verify_double_dev(du, dR, dRp, dPK, dPKp, dm, n, dok, ws, nullptr)) return r;
-  D2H(ok, dok, n);
-  HIP_TRY(hipStreamSynchronize(0));
-  return DSV_OK;
+  const HostIn ins[6] = {{u, 32}, {R_uv, 64}, {Rp_uv, 64}, {PK_uv, 64}, {PKp_uv, 64}, {m, 32}};
+  return run_pipelined(ins, ok, n, [](const void* const* d, size_t cnt, void* dok, void* ws, hipStream_t st) {
+    return dsv_verify_double_dev(d[0], d[1], d[2], d[3], d[4], d[5], cnt, dok, ws, st);
+  });
 }
 
 int dsv_verify_vargen(const uint8_t* u, const uint8_t* R_uv, const uint8_t* PK_uv,
@@ -1013,24 +1057,10 @@ int dsv_verify_vargen(const uint8_t* u, const uint8_t* R_uv, const uint8_t* PK_u
   if (n == 0) return DSV_OK;
   if (!u || !R_uv || !PK_uv || !Gen_uv || !m || !ok)
     return fail(DSV_ERR_INVALID_ARGUMENT, "null pointer");
-  std::lock_guard<std::mutex> lk(g_ctx.mu);
-  HIP_TRY(hipSetDevice(g_ctx.device));
-  size_t need = align_up(n * 32, 256) * 2 + align_up(n * 64, 256) * 3 + align_up(n, 256) +
-                dsv_workspace_bytes(n);
-  if (int r = ensure_stage(need)) return r;
-  Stager st(g_ctx.stage);
-  uint8_t *du = st.take(n * 32), *dR = st.take(n * 64), *dPK = st.take(n * 64),
-          *dG = st.take(n * 64), *dm = st.take(n * 32), *dok = st.take(n),
-          *ws = st.take(dsv_workspace_bytes(n));
-  H2D(du, u, n * 32);
-  H2D(dR, R_uv, n * 64);
-  H2D(dPK, PK_uv, n * 64);
-  H2D(dG, Gen_uv, n * 64);
-  H2D(dm, m, n * 32);
-  if (int r = dsv_verify_vargen_dev(du, dR, dPK, dG, dm, n, dok, ws, nullptr)) return r;
-  D2H(ok, dok, n);
-  HIP_TRY(hipStreamSynchronize(0));
-  return DSV_OK;
+  const HostIn ins[5] = {{u, 32}, {R_uv, 64}, {PK_uv, 64}, {Gen_uv, 64}, {m, 32}};
+  return run_pipelined(ins, ok, n, [](const void* const* d, size_t cnt, void* dok, void* ws, hipStream_t st) {
+    return dsv_verify_vargen_dev(d[0], d[1], d[2], d[3], d[4], cnt, dok, ws, st);
+  });
 }
 
 int dsv_verify_single_ext(const uint8_t* u, const uint8_t* R_uvz, const uint8_t* PK_uvz,
