@@ -391,3 +391,20 @@ def test_randomized_parity_sweep(engine):
     want = O.verify_double(dd["u"], dd["R"], dd["Rp"], dd["PK"], dd["PKp"], dd["m"], nthreads=16)
     got = engine.verify_double(dd["u"], dd["R"], dd["Rp"], dd["PK"], dd["PKp"], dd["m"])
     assert np.array_equal(got, want)
+
+
+def test_host_path_multi_chunk_pipeline(engine):
+    """Host entry points with more than one pipeline chunk (2^17 items each), ragged tail:
+    verdicts must equal the HBM-resident path's and the expected tamper pattern."""
+    import torch
+    from schnorr_amd import workload as W
+    n = (1 << 18) + 12345
+    b = W.gen_single(n, seed=5)
+    h = {k: b[k].cpu().numpy() for k in ("u", "R", "PK", "m")}
+    got = engine.verify_single(h["u"], h["R"], h["PK"], h["m"])
+    assert np.array_equal(got, b["expected"].cpu().numpy())
+    nd = (1 << 17) + 777
+    bd = W.gen_double(nd, seed=6)
+    hd = {k: bd[k].cpu().numpy() for k in ("u", "R", "Rp", "PK", "PKp", "m")}
+    got = engine.verify_double(hd["u"], hd["R"], hd["Rp"], hd["PK"], hd["PKp"], hd["m"])
+    assert np.array_equal(got, bd["expected"].cpu().numpy())
