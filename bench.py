@@ -241,6 +241,20 @@ def main():
         tvv = time.perf_counter() - tv0
         if int((okv != bv["expected"]).sum().item()):
             raise SystemExit("var-generator verdicts differ from the expected pattern")
+        # signing (the step in front of verify): R = r*G, c = H(R, m), u = r - c*sk
+        sk_ = torch.randint(0, 256, (n, 32), dtype=torch.uint8, device=dev); sk_[:, 31] &= 0x07
+        r_ = torch.randint(0, 256, (n, 32), dtype=torch.uint8, device=dev); r_[:, 31] &= 0x07
+        su = torch.empty((n, 32), dtype=torch.uint8, device=dev)
+        sR = torch.empty((n, 64), dtype=torch.uint8, device=dev)
+        E.sign_single_dev(sk_, batch["m"], r_, su, sR)
+        torch.cuda.synchronize()
+        ts0 = time.perf_counter()
+        for _ in range(reps):
+            E.sign_single_dev(sk_, batch["m"], r_, su, sR)
+        torch.cuda.synchronize()
+        out["sign"] = {"value": n * reps / (time.perf_counter() - ts0), "unit": "signatures/s",
+                       "workload": "2^%d single signatures, nonces supplied" % args.log2_batch}
+        del sk_, r_, su, sR
         out["vargen"] = {"value": nv * reps / tvv, "unit": "verifies/s",
                          "workload": "2^%d var-generator batch (BASELINE configs[3])"
                                      % (nv.bit_length() - 1)}
@@ -272,10 +286,14 @@ def main():
         t10 = time.perf_counter()
         O.verify_single(hu[:one], hR[:one], hPK[:one], hm[:one], nthreads=1)
         t1 = time.perf_counter() - t10
+        ts = time.perf_counter()
+        O.keygen_sign_single(1024, 0xBEEF, nthreads=1)  # BASELINE configs[0] shape: keygen + sign
+        t_sign = time.perf_counter() - ts
         out["cpu_baseline"] = {
             "value": sample / tc, "unit": "verifies/s", "cores": cores, "kind": "port",
             "sample": "first %d items of the same batch, %d threads, %.1f s wall; "
-                      "1 thread: %.0f verifies/s on %d items" % (sample, cores, tc, one / t1, one),
+                      "1 thread: %.0f verifies/s on %d items; configs[0] shape (1024 x keygen+sign, "
+                      "1 thread): %.0f /s" % (sample, cores, tc, one / t1, one, 1024 / t_sign),
         }
         # host-buffer path of the C ABI (PCIe-inclusive), never the headline value
         hs = n
