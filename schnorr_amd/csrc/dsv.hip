@@ -3,19 +3,24 @@
 // Pipeline per batch (one lane = one signature, 64 signatures per wavefront, no cross-lane
 // traffic, no LDS, no MFMA — integer modular arithmetic on 29-bit limbs, see fe29.h):
 //
-//   k_challenge     c = trunc250(Poseidon(R.u, R.v[, R'.u, R'.v], m))      (~20 % of the work)
-//   k_verify_fixed  ok &= [ u*G + c*PK == R ]                               (~80 %)
-//                   u*G   : 32 mixed additions from an 8-bit-window table of G (or G'),
-//                           896 KiB, built once on the device, L2-resident (4 MiB L2 per XCD)
-//                   c*PK  : 4-bit fixed windows, 16-entry per-lane table in scratch,
-//                           250 doublings + 63 additions
-//   k_verify_var    both bases variable (PublicKeyVarGen): Straus — one doubling chain shared
-//                   by the two 4-bit-window tables
+//   k_challenge          c = trunc250(Poseidon(R.u, R.v[, R'.u, R'.v], m))          (~30 % of the work)
+//   k_verify_fixed_half  ok &= [ u*G + c*PK == R ], evaluated as                      (~70 %)
+//                        (b*u mod r)*G + a*PK - b*R == O  with (a, b) ~ 128 bits, a = b*c mod 8r,
+//                        b odd (halfgcd.h: same verdict on the whole curve group):
+//                          a*PK - b*R : two per-lane signed 4-bit window tables (lane-major in a
+//                                       global workspace), one Straus chain of ~33 windows
+//                          (b*u)*G    : 23 mixed additions from a signed 11-bit-window table of
+//                                       G (or G'), 3.4 MB, built once on the device, L2-resident
+//   k_verify_fixed       the same equation in its classic 250-bit form (DSV_VERIFY_ALGO=classic)
+//   k_verify_var         both bases variable (PublicKeyVarGen): Straus over u and c
+//   k_decompress         wire-format points (JubJubAffine::from_bytes), decode29.h
+//   k_fixed_base_points / k_var_base_points / k_sign_finish : signing and key derivation
 //
-// PublicKeyDouble::verify runs k_challenge<double> then k_verify_fixed twice (G/PK/R and
+// PublicKeyDouble::verify runs k_challenge<double> then the verify kernel twice (G/PK/R and
 // G'/PK'/R'), AND-ing into ok[].  HBM traffic per signature is 193 B (single) / 321 B
-// (double) / 257 B (vargen) in, 1 B out, plus 33 B of c/valid between the two kernels: the
-// path is VALU-bound by four orders of magnitude, not HBM-bound.
+// (double) / 257 B (vargen) in, 1 B out, plus 33 B of c/valid between the two kernels and the
+// window-table workspace: the path is VALU-bound by orders of magnitude, not HBM-bound
+// (DESIGN.md §4).
 #include <hip/hip_runtime.h>
 
 #include <atomic>
