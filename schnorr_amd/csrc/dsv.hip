@@ -820,8 +820,8 @@ int dsv_init(int device) {
                             sizeof(DSV_HADES_PRE_MDS_HOST)));
   HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(c_hades_kappa0), DSV_HADES_KAPPA0_HOST,
                             sizeof(DSV_HADES_KAPPA0_HOST)));
-  HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(c_hades_sparse), DSV_HADES_SPARSE_HOST,
-                            sizeof(DSV_HADES_SPARSE_HOST)));
+  HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(c_hades_blocks), DSV_HADES_BLOCKS_HOST,
+                            sizeof(DSV_HADES_BLOCKS_HOST)));
   HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(c_hades_kfinal), DSV_HADES_KFINAL_HOST,
                             sizeof(DSV_HADES_KFINAL_HOST)));
   HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(c_root_powers), DSV_ROOT_POWERS_HOST,

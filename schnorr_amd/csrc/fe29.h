@@ -157,6 +157,25 @@ DSV_DEV Fe fe_dot5(const Fe (&a)[5], const Fe (&b)[5]) {
   return fe_reduce_cols(c);
 }
 
+// sum_{t<NT} a[t] * k[t] with one reduction; k: wave-uniform constants (scalar loads), limbs < 2^29.
+// The caller's generator proves the 64-bit column bound for the actual constants.
+template <int NT>
+DSV_DEV Fe fe_dot_const(const Fe (&a)[NT], const u32 (*k)[NL]) {
+  u64 c[18];
+#pragma unroll
+  for (int col = 0; col < 17; col++) c[col] = (col < NL) ? (u64)M29 : 0;
+  c[17] = 0;
+#pragma unroll
+  for (int t = 0; t < NT; t++) {
+#pragma unroll
+    for (int i = 0; i < NL; i++) {
+#pragma unroll
+      for (int j = 0; j < NL; j++) c[i + j] += (u64)a[t].l[i] * k[t][j];
+    }
+  }
+  return fe_reduce_cols(c);
+}
+
 DSV_DEV Fe fe_add(const Fe& a, const Fe& b) {
   Fe r;
 #pragma unroll

@@ -208,12 +208,39 @@ def main():
         for i in range(PARTIAL):
             kap4.append((kappa[i + 1][4] + sum(cs[i][j] * K[j] for j in range(4))) % Q)
             K = [(K[j] + kappa[i + 1][j]) % Q for j in range(4)]
-        w("// per partial round i: b[4], c''[4], d, kappa4'_i\n")
-        w("#define DSV_HADES_SPARSE_STRIDE 10\n")
-        w("static const uint32_t DSV_HADES_SPARSE_HOST[%d][9] = {\n" % (PARTIAL * 10))
-        for i in range(PARTIAL):
-            for x in bs[i] + cs[i] + [ds[i]] + [kap4[i]]:
-                w("  %s,\n" % arr(mont(x)))
+        # Blocked form: inside a block of L rounds words 0..3 are NOT updated; their pending
+        # updates b_k * z_k enter the later rounds' dot products through gamma_{m,k} = c_m . b_k
+        # (one reduction per round instead of five), and one (L+1)-term dot product per word
+        # brings the block's updates in at its end:
+        #   row m of a block : [c_m[0..3], gamma_{m,0..m-1}, d_m]  applied to  (s0..s3, z_0..z_m)
+        #   update of word j : [1, b_0[j], .., b_{L-1}[j]]          applied to  (s_j, z_0..z_{L-1})
+        BLOCK = 4
+        blocks = []
+        i0 = 0
+        while i0 < PARTIAL:
+            lb = min(BLOCK, PARTIAL - i0)
+            seq = []
+            for mth in range(lb):
+                i = i0 + mth
+                gam = [sum(cs[i][j] * bs[i0 + k][j] for j in range(4)) % Q for k in range(mth)]
+                row = cs[i] + gam + [ds[i]]
+                # worst-case 64-bit column bound with every state limb at 2^29 + 8
+                for col in range(17):
+                    tot = sum(((1 << 29) + 8) * mont(c)[col - a] for c in row for a in range(9)
+                              if 0 <= col - a < 9)
+                    assert tot + 8 * (1 << 58) + (1 << 37) < (1 << 64), "column overflow"
+                seq += row + [kap4[i]]
+            for j in range(4):
+                seq += [1] + [bs[i0 + k][j] for k in range(lb)]
+            blocks.append(seq)
+            i0 += lb
+        flat = [x for blk in blocks for x in blk]
+        w("// blocked sparse partial rounds (see generator): %d blocks of %d rounds + one of %d\n"
+          % (PARTIAL // BLOCK, BLOCK, PARTIAL % BLOCK))
+        w("#define DSV_HADES_BLOCK %d\n" % BLOCK)
+        w("static const uint32_t DSV_HADES_BLOCKS_HOST[%d][9] = {\n" % len(flat))
+        for x in flat:
+            w("  %s,\n" % arr(mont(x)))
         w("};\n")
         w("static const uint32_t DSV_HADES_KFINAL_HOST[%d][9] = {\n" % (WIDTH - 1))
         for x in K:

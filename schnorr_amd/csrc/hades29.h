@@ -22,7 +22,7 @@ __constant__ u32 c_hades_mds[DSV_HADES_WIDTH * DSV_HADES_WIDTH][NL];
 __constant__ u32 c_hades_pre_mds[DSV_HADES_WIDTH * DSV_HADES_WIDTH][NL];
 __constant__ u32 c_hades_kappa0[DSV_HADES_WIDTH][NL];
 __constant__ u32 c_hades_kfinal[DSV_HADES_WIDTH - 1][NL];
-__constant__ u32 c_hades_sparse[DSV_HADES_PARTIAL * DSV_HADES_SPARSE_STRIDE][NL];
+__constant__ u32 c_hades_blocks[sizeof(DSV_HADES_BLOCKS_HOST) / sizeof(DSV_HADES_BLOCKS_HOST[0])][NL];
 
 DSV_DEV Fe fe_load_const(const u32* p) {
   Fe r;
@@ -75,35 +75,57 @@ DSV_DEV void hades_full_round(Fe (&s)[5], const u32 (*rc)[NL], const u32 (*mat)[
   hades_mds(s, mat);
 }
 
-// The permutation.  The 59 partial rounds run in their sparse-matrix form: per round one S-box,
-// one 5-term dot product (new last word) and four multiply-accumulates (words 0..3), i.e.
-// 3 + 1 + 4 reductions instead of 3 + 5 dot products of the dense form.  Words 0..3 are never
-// reduced inside a round (w += b*z grows by ~1.1q per round), so they are brought back below 2q by
-// a multiplication with Montgomery-one after round 30 and after the last one (value < 35q, far
-// below the 2^261 ~ 70q the representation holds).
+// The permutation.  The 59 partial rounds run in their sparse-matrix form (per round one S-box,
+// one dot product for the new last word, four multiply-accumulates for words 0..3 instead of
+// five dense dot products), and the four multiply-accumulates are deferred block-wise (below).
 DSV_DEV void hades_permute(Fe (&s)[5]) {
   constexpr int HALF = DSV_HADES_FULL / 2;
 #pragma unroll 1
   for (int r = 0; r < HALF; r++)
     hades_full_round(s, c_hades_rc + 5 * r, r == HALF - 1 ? c_hades_pre_mds : c_hades_mds);
   // words 0..3 carry NO round constants inside the loop: their running sum K_i is folded into the
-  // constant of the last word (kappa4'_i = kappa4_{i+1} + c_i . K_i) and added back once at the end
+  // constant of the last word (kappa4'_i = kappa4_{i+1} + c_i . K_i) and added back once at the end.
+  // Rounds run in blocks of 4 (gen_constants.py): inside a block words 0..3 stay untouched and
+  // their pending updates reach the later rounds through extra dot-product terms, so a round is
+  // one S-box + ONE reduction, and each block ends with four 5-term dot products.
   s[4] = fe_add(s[4], fe_load_const(c_hades_kappa0[4]));
+  const u32(*k)[NL] = c_hades_blocks;
 #pragma unroll 1
-  for (int i = 0; i < DSV_HADES_PARTIAL; i++) {
-    const u32(*k)[NL] = c_hades_sparse + i * DSV_HADES_SPARSE_STRIDE;  // b[4] c[4] d kappa4'
-    s[4] = hades_sbox(s[4]);
-    Fe row[5];
-#pragma unroll
-    for (int j = 0; j < 5; j++) row[j] = fe_load_const(k[4 + j]);
-    Fe z = fe_dot5(s, row);
-#pragma unroll
-    for (int j = 0; j < 4; j++) s[j] = fe_carry(fe_add(s[j], fe_mul(fe_load_const(k[j]), s[4])));
-    s[4] = fe_add(z, fe_load_const(k[9]));
-    if (i == 29 || i == DSV_HADES_PARTIAL - 1) {
-#pragma unroll
-      for (int j = 0; j < 4; j++) s[j] = fe_mul(s[j], fe_one());
-    }
+  for (int blk = 0; blk < DSV_HADES_PARTIAL / 4; blk++) {
+    Fe z0 = hades_sbox(s[4]);
+    { const Fe a[5] = {s[0], s[1], s[2], s[3], z0};
+      s[4] = fe_add(fe_dot_const<5>(a, k), fe_load_const(k[5])); }
+    Fe z1 = hades_sbox(s[4]);
+    { const Fe a[6] = {s[0], s[1], s[2], s[3], z0, z1};
+      s[4] = fe_add(fe_dot_const<6>(a, k + 6), fe_load_const(k[12])); }
+    Fe z2 = hades_sbox(s[4]);
+    { const Fe a[7] = {s[0], s[1], s[2], s[3], z0, z1, z2};
+      s[4] = fe_add(fe_dot_const<7>(a, k + 13), fe_load_const(k[20])); }
+    Fe z3 = hades_sbox(s[4]);
+    { const Fe a[8] = {s[0], s[1], s[2], s[3], z0, z1, z2, z3};
+      s[4] = fe_add(fe_dot_const<8>(a, k + 21), fe_load_const(k[29])); }
+    // (written out: a rolled loop here would index s[] dynamically, i.e. through scratch)
+    { const Fe a[5] = {s[0], z0, z1, z2, z3}; s[0] = fe_dot_const<5>(a, k + 30); }
+    { const Fe a[5] = {s[1], z0, z1, z2, z3}; s[1] = fe_dot_const<5>(a, k + 35); }
+    { const Fe a[5] = {s[2], z0, z1, z2, z3}; s[2] = fe_dot_const<5>(a, k + 40); }
+    { const Fe a[5] = {s[3], z0, z1, z2, z3}; s[3] = fe_dot_const<5>(a, k + 45); }
+    k += 50;
+  }
+  {  // last block: 59 = 14 * 4 + 3 rounds
+    static_assert(DSV_HADES_PARTIAL % 4 == 3 && DSV_HADES_BLOCK == 4, "block layout");
+    Fe z0 = hades_sbox(s[4]);
+    { const Fe a[5] = {s[0], s[1], s[2], s[3], z0};
+      s[4] = fe_add(fe_dot_const<5>(a, k), fe_load_const(k[5])); }
+    Fe z1 = hades_sbox(s[4]);
+    { const Fe a[6] = {s[0], s[1], s[2], s[3], z0, z1};
+      s[4] = fe_add(fe_dot_const<6>(a, k + 6), fe_load_const(k[12])); }
+    Fe z2 = hades_sbox(s[4]);
+    { const Fe a[7] = {s[0], s[1], s[2], s[3], z0, z1, z2};
+      s[4] = fe_add(fe_dot_const<7>(a, k + 13), fe_load_const(k[20])); }
+    { const Fe a[4] = {s[0], z0, z1, z2}; s[0] = fe_dot_const<4>(a, k + 21); }
+    { const Fe a[4] = {s[1], z0, z1, z2}; s[1] = fe_dot_const<4>(a, k + 25); }
+    { const Fe a[4] = {s[2], z0, z1, z2}; s[2] = fe_dot_const<4>(a, k + 29); }
+    { const Fe a[4] = {s[3], z0, z1, z2}; s[3] = fe_dot_const<4>(a, k + 33); }
   }
 #pragma unroll
   for (int j = 0; j < 4; j++) s[j] = fe_carry(fe_add(s[j], fe_load_const(c_hades_kfinal[j])));

@@ -252,7 +252,7 @@ def _hc():
         _H["mds"] = _load_table("DSV_HADES_MDS_HOST")
         _H["pre"] = _load_table("DSV_HADES_PRE_MDS_HOST")
         _H["k0"] = _load_table("DSV_HADES_KAPPA0_HOST")
-        _H["sp"] = _load_table("DSV_HADES_SPARSE_HOST")
+        _H["blk"] = _load_table("DSV_HADES_BLOCKS_HOST")
         _H["kf"] = _load_table("DSV_HADES_KFINAL_HOST")
     return _H
 
@@ -275,17 +275,23 @@ def hades_permute(s):
     for r in range(4):
         s = hades_full_round(s, h["rc"][5 * r:5 * r + 5], h["pre"] if r == 3 else h["mds"])
     s[4] = add(s[4], h["k0"][4])
-    for i in range(59):
-        k = h["sp"][10 * i:10 * i + 10]
-        s[4] = sbox(s[4])
-        z = dot(s, k[4:9])
+    k = h["blk"]
+    pos = 0
+    done = 0
+    while done < 59:
+        lb = min(4, 59 - done)
+        z = []
+        for m in range(lb):
+            z.append(sbox(s[4]))
+            a = [s[0], s[1], s[2], s[3]] + z
+            row = k[pos:pos + 5 + m]
+            s[4] = add(dot(a, row), k[pos + 5 + m])
+            pos += 6 + m
         for j in range(4):
-            s[j] = carry(add(s[j], mul(k[j], s[4])))
-            assert val(s[j]) < (1 << 260)
-        s[4] = add(z, k[9])
-        if i == 29 or i == 58:
-            for j in range(4):
-                s[j] = mul(s[j], ONE)
+            s[j] = dot([s[j]] + z, k[pos:pos + lb + 1])
+            pos += lb + 1
+        done += lb
+    assert pos == len(k)
     for j in range(4):
         s[j] = carry(add(s[j], h["kf"][j]))
     for r in range(4):
