@@ -408,3 +408,25 @@ def test_host_path_multi_chunk_pipeline(engine):
     hd = {k: bd[k].cpu().numpy() for k in ("u", "R", "Rp", "PK", "PKp", "m")}
     got = engine.verify_double(hd["u"], hd["R"], hd["Rp"], hd["PK"], hd["PKp"], hd["m"])
     assert np.array_equal(got, bd["expected"].cpu().numpy())
+
+
+def test_predicted_reference_vectors_on_gpu(engine):
+    """The predicted outputs of the real crate for its own test seeds (tests/golden/
+    predicted_reference.json, unverified prediction): signing on the GPU from (sk, m, nonce)
+    reproduces u and R, key derivation reproduces PK, and the serialized records verify."""
+    import json, os
+    import refrng
+    P = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "predicted_reference.json")))
+    unhex = lambda s: np.frombuffer(bytes.fromhex(s), dtype=np.uint8)
+    recs = P["seed_2321"]
+    rng = refrng.StdRng(2321)
+    nonces = []
+    for _ in recs:
+        rng.fill_bytes(128)                       # sk, message
+        w = int.from_bytes(rng.fill_bytes(64), "little") % M.R_ORDER
+        nonces.append(np.frombuffer(M.le32(w), np.uint8))
+    col = lambda k: np.stack([unhex(r[k]) for r in recs])
+    u, R = engine.sign_single(col("sk"), col("m"), np.stack(nonces))
+    assert np.array_equal(u, col("u")) and np.array_equal(R, col("R"))
+    assert np.array_equal(engine.public_keys(col("sk"), 0), col("PK"))
+    assert engine.verify_single_wire(col("sig_bytes"), col("pk_bytes"), col("m")).all()

@@ -187,3 +187,23 @@ def test_oracle_multithreaded_equals_single_thread():
     H.tamper(d, period=5)
     assert np.array_equal(O.verify_single(d["u"], d["R"], d["PK"], d["m"], nthreads=7),
                           O.verify_single(d["u"], d["R"], d["PK"], d["m"], nthreads=1))
+
+
+def test_stdrng_restatement_and_predicted_reference_vectors():
+    """ChaCha core against the RFC 7539 block vector; the predicted reference outputs for the
+    reference's own seeds regenerate byte-identically and verify (self-consistency only — the
+    prediction itself is unverified until golden_gen.rs is run against the real crate)."""
+    import refrng
+    assert refrng.chacha20_rfc7539_selftest()
+    P = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "predicted_reference.json")))
+    sys_path = os.path.join(os.path.dirname(__file__), "golden")
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("make_predicted", os.path.join(sys_path, "make_predicted.py"))
+    mp = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mp)
+    assert mp.run(2321, 8) == P["seed_2321"]
+    for rec in P["seed_2321"] + P["seed_0xbeef"]:
+        assert rec["verdict"] == 1
+        sig = unhex(rec["sig_bytes"]).reshape(1, 64)
+        pk = unhex(rec["pk_bytes"]).reshape(1, 32)
+        assert int(O.verify_single_wire(sig, pk, unhex(rec["m"]).reshape(1, 32))[0]) == 1
