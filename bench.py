@@ -108,7 +108,7 @@ def main():
 
     E.init(dev_index)
     n = 1 << args.log2_batch
-    batch = W.gen_single(n, seed=2321 + rank, device=dev)
+    batch = W.gen_single(n, seed=2321, device=dev, first_item=rank * n)  # one stream, sharded
     ok = torch.zeros(n, dtype=torch.uint8, device=dev)
     ws = torch.empty(E.workspace_bytes(n), dtype=torch.uint8, device=dev)
     c = torch.empty((n, 32), dtype=torch.uint8, device=dev)
@@ -180,7 +180,8 @@ def main():
         "scaling": "weak",
         "vs_baseline": None,
         "dtype": "u32x9 (29-bit limbs, u64 accumulate)",
-        "data": "synthetic: GPU-signed random (sk, m, nonce), every 16th item corrupted",
+        "data": "synthetic: reference harness inputs (StdRng::seed_from_u64(2321): sk, m, nonce per "
+                "item, restated RNG), GPU-signed, every 16th item corrupted",
         "config": {"workload": "2^%d single-signature batch verify per GPU (BASELINE configs[1])"
                                % args.log2_batch,
                    "batch_per_gpu": n, "parallelism": "dp%d" % world,

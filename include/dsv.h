@@ -145,6 +145,15 @@ int dsv_verify_double_wire(const uint8_t *sig96, const uint8_t *pk64, const uint
 int dsv_verify_vargen_wire(const uint8_t *sig64, const uint8_t *pk64, const uint8_t *m, size_t n,
                            uint8_t *ok);
 
+/* ---- the reference harness's input generator (rand 0.8 StdRng::seed_from_u64(seed) = ChaCha12,
+ * draw order per item: sk = JubJubScalar::random, m = BlsScalar::random, nonce r =
+ * JubJubScalar::random; /root/reference/tests/schnorr.rs:16-22, benches/signature.rs:48-60).
+ * Items first_item .. first_item + n - 1 of that stream; 32 B canonical each. */
+int dsv_stdrng_sign_inputs(uint64_t seed, size_t first_item, size_t n, uint8_t *sk, uint8_t *m,
+                           uint8_t *r);
+int dsv_stdrng_sign_inputs_dev(uint64_t seed, size_t first_item, size_t n, void *sk, void *m,
+                               void *r, void *stream);
+
 /* ---- introspection for tests: copy one fixed-base table entry (affine niels v+u, v-u, 2duv
  * as canonical LE, 96 B) for generator `which` (0 = G, 1 = G'), window w (8-bit), digit d ---- */
 int dsv_debug_table_entry(int which, int window, int digit, uint8_t out96[96]);

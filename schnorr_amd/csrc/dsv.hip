@@ -37,6 +37,7 @@
 #include "hades29.h"
 #include "halfgcd.h"
 #include "decode29.h"
+#include "stdrng.h"
 #include "jubjub29.h"
 
 namespace dsv {
@@ -648,6 +649,31 @@ __global__ void k_gather32(const uint8_t* __restrict__ in, size_t stride, size_t
   uint4* o = reinterpret_cast<uint4*>(out + i * 32);
   o[0] = p[0];
   o[1] = p[1];
+}
+
+// ------------------------------------------------------------------------------------------
+// the reference harness's inputs: item i = (sk, message, nonce) from StdRng keystream blocks
+// 3i .. 3i+2 (stdrng.h)
+// ------------------------------------------------------------------------------------------
+struct ChaChaKey {
+  u32 w[8];
+};
+__global__ void __launch_bounds__(256)
+k_stdrng_triples(ChaChaKey key, size_t first_item, size_t n, uint8_t* __restrict__ sk,
+                 uint8_t* __restrict__ m, uint8_t* __restrict__ r) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const u64 blk = 3 * (u64)(first_item + i);
+  u32 ks[16], o[8];
+  chacha12_block(ks, key.w, blk);
+  fr_from_wide(o, ks);
+  store_words8(sk, i, o);
+  chacha12_block(ks, key.w, blk + 1);
+  fq_from_wide(o, ks);
+  store_words8(m, i, o);
+  chacha12_block(ks, key.w, blk + 2);
+  fr_from_wide(o, ks);
+  store_words8(r, i, o);
 }
 
 __global__ void __launch_bounds__(256)
@@ -1378,6 +1404,51 @@ int dsv_verify_vargen_wire(const uint8_t* sig64, const uint8_t* pk64, const uint
   if (n == 0) return DSV_OK;
   if (!sig64 || !pk64 || !m || !ok) return fail(DSV_ERR_INVALID_ARGUMENT, "null pointer");
   return verify_wire(2, sig64, pk64, m, n, ok);
+}
+
+// ---- reference-harness inputs ---------------------------------------------------------------
+namespace {
+// rand_core 0.6 SeedableRng::seed_from_u64: eight PCG32 outputs = the ChaCha key
+ChaChaKey stdrng_key(uint64_t state) {
+  ChaChaKey k;
+  for (int i = 0; i < 8; i++) {
+    state = state * 6364136223846793005ULL + 11634580027462260723ULL;
+    const uint32_t xorshifted = (uint32_t)(((state >> 18) ^ state) >> 27);
+    const uint32_t rot = (uint32_t)(state >> 59);
+    k.w[i] = (xorshifted >> rot) | (xorshifted << ((32 - rot) & 31));
+  }
+  return k;
+}
+}  // namespace
+
+int dsv_stdrng_sign_inputs_dev(uint64_t seed, size_t first_item, size_t n, void* sk, void* m,
+                               void* r, void* stream) {
+  if (int rc = check_ready()) return rc;
+  if (int rc = check_n(n)) return rc;
+  if (n == 0) return DSV_OK;
+  if (!sk || !m || !r) return fail(DSV_ERR_INVALID_ARGUMENT, "null pointer");
+  hipLaunchKernelGGL(k_stdrng_triples, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream,
+                     stdrng_key(seed), first_item, n, (uint8_t*)sk, (uint8_t*)m, (uint8_t*)r);
+  HIP_TRY(hipGetLastError());
+  return DSV_OK;
+}
+int dsv_stdrng_sign_inputs(uint64_t seed, size_t first_item, size_t n, uint8_t* sk, uint8_t* m,
+                           uint8_t* r) {
+  if (int rc = check_ready()) return rc;
+  if (int rc = check_n(n)) return rc;
+  if (n == 0) return DSV_OK;
+  if (!sk || !m || !r) return fail(DSV_ERR_INVALID_ARGUMENT, "null pointer");
+  std::lock_guard<std::mutex> lk(g_ctx.mu);
+  HIP_TRY(hipSetDevice(g_ctx.device));
+  if (int rc = ensure_stage(3 * align_up(n * 32, 256))) return rc;
+  Stager st(g_ctx.stage);
+  uint8_t *dsk = st.take(n * 32), *dm = st.take(n * 32), *dr = st.take(n * 32);
+  if (int rc = dsv_stdrng_sign_inputs_dev(seed, first_item, n, dsk, dm, dr, nullptr)) return rc;
+  D2H(sk, dsk, n * 32);
+  D2H(m, dm, n * 32);
+  D2H(r, dr, n * 32);
+  HIP_TRY(hipStreamSynchronize(0));
+  return DSV_OK;
 }
 
 int dsv_debug_table_entry(int which, int window, int digit, uint8_t out96[96]) {

@@ -197,6 +197,23 @@ def verify_vargen_wire(sig64, pk64, m):
     return ok
 
 
+def stdrng_sign_inputs(seed, n, first_item=0):
+    """(sk, m, nonce) of items first_item.. of the reference harness's StdRng(seed) stream."""
+    sk = np.zeros((n, 32), dtype=np.uint8)
+    m = np.zeros((n, 32), dtype=np.uint8)
+    r = np.zeros((n, 32), dtype=np.uint8)
+    _lib.check(_lib.load().dsv_stdrng_sign_inputs(ctypes.c_uint64(seed), ctypes.c_size_t(first_item),
+                                                  ctypes.c_size_t(n), _p(sk), _p(m), _p(r)))
+    return sk, m, r
+
+
+def stdrng_sign_inputs_dev(seed, sk, m, r, first_item=0, stream=None):
+    n = sk.shape[0]
+    _lib.check(_lib.load().dsv_stdrng_sign_inputs_dev(
+        ctypes.c_uint64(seed), ctypes.c_size_t(first_item), ctypes.c_size_t(n), _tp(sk, 32),
+        _tp(m, 32), _tp(r, 32), _stream_ptr(stream)))
+
+
 def debug_table_entry(which, window, digit):
     out = np.zeros(96, dtype=np.uint8)
     _lib.check(_lib.load().dsv_debug_table_entry(ctypes.c_int(which), ctypes.c_int(window),

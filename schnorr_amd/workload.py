@@ -1,10 +1,10 @@
-"""Synthetic batches generated ON the GPU with the engine's own sign / key-derivation kernels
-(the reference shape: sk, message, nonce -> sig, pk; benches/signature.rs:48-60), then corrupted
-in a known pattern so the expected verdict vector is non-trivial.
-
-Scalars are drawn as 251-bit (sk, nonce) / 254-bit (message) uniform integers: canonical by
-construction (2^251 < r, 2^254 < q).  That is not exactly `Fr::random` (64 bytes mod r) but the
-verification cost does not depend on the distribution.
+"""Synthetic batches generated ON the GPU with the engine's own kernels, in the reference
+harness's shape (tests/schnorr.rs:16-22, benches/signature.rs:48-60): per item sk, message and
+nonce are consecutive draws of `StdRng::seed_from_u64(seed)` (ChaCha12, each `from_bytes_wide` of
+64 bytes — dsv_stdrng_sign_inputs), then sig = sign(sk, m, nonce), pk = sk*G.  Every 16th item is
+corrupted in a known pattern so the expected verdict vector is non-trivial.
+`first_item` selects a slice of the one stream, so N ranks hold consecutive shards of one batch.
+(The var-generator helper still draws 251/254-bit uniform integers with torch's generator.)
 """
 import torch
 
@@ -37,12 +37,16 @@ def _tamper(batch, n):
     return expected
 
 
-def gen_single(n, seed, device="cuda:0", tamper=True):
-    gen = torch.Generator(device=device)
-    gen.manual_seed(seed)
-    sk = _rand_scalars(n, 0x07, gen, device)
-    r = _rand_scalars(n, 0x07, gen, device)
-    m = _rand_scalars(n, 0x3F, gen, device)
+def _harness_inputs(n, seed, first_item, device):
+    sk = torch.empty((n, 32), dtype=torch.uint8, device=device)
+    m = torch.empty((n, 32), dtype=torch.uint8, device=device)
+    r = torch.empty((n, 32), dtype=torch.uint8, device=device)
+    E.stdrng_sign_inputs_dev(seed, sk, m, r, first_item=first_item)
+    return sk, m, r
+
+
+def gen_single(n, seed, device="cuda:0", tamper=True, first_item=0):
+    sk, m, r = _harness_inputs(n, seed, first_item, device)
     u = torch.empty((n, 32), dtype=torch.uint8, device=device)
     R = torch.empty((n, 64), dtype=torch.uint8, device=device)
     PK = torch.empty((n, 64), dtype=torch.uint8, device=device)
@@ -54,12 +58,8 @@ def gen_single(n, seed, device="cuda:0", tamper=True):
     return batch
 
 
-def gen_double(n, seed, device="cuda:0", tamper=True):
-    gen = torch.Generator(device=device)
-    gen.manual_seed(seed)
-    sk = _rand_scalars(n, 0x07, gen, device)
-    r = _rand_scalars(n, 0x07, gen, device)
-    m = _rand_scalars(n, 0x3F, gen, device)
+def gen_double(n, seed, device="cuda:0", tamper=True, first_item=0):
+    sk, m, r = _harness_inputs(n, seed, first_item, device)
     u = torch.empty((n, 32), dtype=torch.uint8, device=device)
     R = torch.empty((n, 64), dtype=torch.uint8, device=device)
     Rp = torch.empty((n, 64), dtype=torch.uint8, device=device)

@@ -430,3 +430,26 @@ def test_predicted_reference_vectors_on_gpu(engine):
     assert np.array_equal(u, col("u")) and np.array_equal(R, col("R"))
     assert np.array_equal(engine.public_keys(col("sk"), 0), col("PK"))
     assert engine.verify_single_wire(col("sig_bytes"), col("pk_bytes"), col("m")).all()
+
+
+def test_stdrng_input_generator_matches_restatement(engine):
+    """dsv_stdrng_sign_inputs (ChaCha12 + from_bytes_wide on the GPU) against tests/refrng.py +
+    Python integers, incl. an offset into the stream, and against the committed predicted
+    reference vectors (sk, m of seed 2321)."""
+    import json, os
+    import refrng
+    for seed, first, n in ((2321, 0, 300), (0xBEEF, 0, 64), (2321, 1000, 130)):
+        sk, m, r = engine.stdrng_sign_inputs(seed, n, first)
+        rng = refrng.StdRng(seed)
+        rng.fill_bytes(192 * first)
+        for i in range(n):
+            a = int.from_bytes(rng.fill_bytes(64), "little") % M.R_ORDER
+            b = int.from_bytes(rng.fill_bytes(64), "little") % M.Q
+            c = int.from_bytes(rng.fill_bytes(64), "little") % M.R_ORDER
+            assert (M.from_le(sk[i]), M.from_le(m[i]), M.from_le(r[i])) == (a, b, c), (seed, i)
+    P = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "predicted_reference.json")))
+    sk, m, r = engine.stdrng_sign_inputs(2321, 8)
+    assert [bytes(x).hex() for x in sk] == [p["sk"] for p in P["seed_2321"]]
+    assert [bytes(x).hex() for x in m] == [p["m"] for p in P["seed_2321"]]
+    u, R = engine.sign_single(sk, m, r)
+    assert [bytes(x).hex() for x in u] == [p["u"] for p in P["seed_2321"]]
