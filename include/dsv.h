@@ -126,6 +126,7 @@ int dsv_public_keys_dev(const void *sk, int which, size_t n, void *PK_uv, void *
  * would return Err (v >= q, or no square root).  The _dev form reads one 32-byte record every
  * in_stride bytes (16-byte aligned) and, with accumulate != 0, ANDs into ok[] instead of
  * overwriting it. */
+int dsv_compress_points(const uint8_t *in_uv, size_t n, uint8_t *out32); /* JubJubAffine::to_bytes */
 int dsv_decompress_points(const uint8_t *in32, size_t n, uint8_t *out_uv, uint8_t *ok);
 int dsv_decompress_points_dev(const void *in, size_t in_stride, size_t n, void *out_uv, void *ok,
                               int accumulate, void *stream);

@@ -14,7 +14,7 @@ SYMBOLS = [
     "dsv_verify_vargen_dev", "dsv_verify_core_dev", "dsv_challenge_single", "dsv_challenge_double",
     "dsv_challenge_single_dev", "dsv_challenge_double_dev", "dsv_sign_single", "dsv_sign_double",
     "dsv_sign_vargen", "dsv_public_keys", "dsv_sign_single_dev", "dsv_sign_double_dev",
-    "dsv_public_keys_dev", "dsv_decompress_points", "dsv_decompress_points_dev",
+    "dsv_public_keys_dev", "dsv_compress_points", "dsv_decompress_points", "dsv_decompress_points_dev",
     "dsv_verify_single_wire", "dsv_verify_double_wire", "dsv_verify_vargen_wire",
     "dsv_stdrng_sign_inputs", "dsv_stdrng_sign_inputs_dev",
     "dsv_debug_table_entry", "dsv_fixed_window_bits", "dsv_debug_fq_mul",

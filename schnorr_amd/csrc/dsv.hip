@@ -1324,6 +1324,19 @@ int dsv_decompress_points_dev(const void* in, size_t in_stride, size_t n, void* 
   HIP_TRY(hipGetLastError());
   return DSV_OK;
 }
+// JubJubAffine::to_bytes: canonical v with bit 255 = lowest bit of canonical u.  Pure byte
+// shuffling on affine input, so it runs on the host.
+int dsv_compress_points(const uint8_t* in_uv, size_t n, uint8_t* out32) {
+  if (int r = check_n(n)) return r;
+  if (n == 0) return DSV_OK;
+  if (!in_uv || !out32) return fail(DSV_ERR_INVALID_ARGUMENT, "null pointer");
+  for (size_t i = 0; i < n; i++) {
+    memcpy(out32 + 32 * i, in_uv + 64 * i + 32, 32);
+    out32[32 * i + 31] |= (uint8_t)((in_uv[64 * i] & 1) << 7);
+  }
+  return DSV_OK;
+}
+
 int dsv_decompress_points(const uint8_t* in32, size_t n, uint8_t* out_uv, uint8_t* ok) {
   if (int r = check_ready()) return r;
   if (int r = check_n(n)) return r;

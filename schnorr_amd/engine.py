@@ -168,8 +168,8 @@ def decompress_points(comp):
 def compress_points(uv):
     """JubJubAffine::to_bytes: v with bit 255 = lowest bit of u (pure byte shuffling)."""
     uv = _arr(uv, 64)
-    out = uv[:, 32:].copy()
-    out[:, 31] |= (uv[:, 0] & 1) << 7
+    out = np.zeros((uv.shape[0], 32), dtype=np.uint8)
+    _lib.check(_lib.load().dsv_compress_points(_p(uv), ctypes.c_size_t(uv.shape[0]), _p(out)))
     return out
 
 
