@@ -9,11 +9,10 @@
 // like the jubjub lineage dusk forked, no further canonicity or subgroup check is applied.)
 //
 // No inversion: u = n * (n d)^(-1/2).  q - 1 = 2^32 * t; Tonelli-Shanks is run on z = n d while
-// tracking the INVERSE square root y (invariant y^2 z = b, b in the 2^32-torsion of Fq*):
-//   y = z^((t-1)/2),  b = z^t;  while b != 1: k = log2(order of b), y *= c^(2^(31-k)),
-//   b *= c^(2^(32-k))          (c = 7^t, powers from a 33-entry constant table)
+// tracking the INVERSE square root y (invariant y^2 z = b, b = g^s in the 2^32-torsion of Fq*,
+// g = 7^t): y = z^((t-1)/2), b = z^t, then s is cancelled in four 8-bit windows (fe_inv_sqrt).
 // z^((t-1)/2) uses fixed 3-bit windows over the constant exponent (digits are wave-uniform).
-// Lanes diverge only in how many squarings the order search needs; every loop is bounded.
+// No lane-dependent control flow at all: every lane runs the same ~350 field operations.
 #pragma once
 #include "fe29.h"
 
@@ -21,7 +20,6 @@ namespace dsv {
 
 __device__ constexpr u32 kSqrtE[7] = DSV_SQRT_E_WORDS;  // (t - 1) / 2, DSV_SQRT_E_BITS bits
 __device__ constexpr u32 kD[NL] = DSV_D;
-__constant__ u32 c_root_powers[33][NL];  // c^(2^j), j = 0..32
 
 // a == 1 (Montgomery one) for a multiplication output (limbs < 2^29, value < 2q)
 DSV_DEV bool fe_is_one(const Fe& a) { return fe_is_zero_canon(fe_canon(fe_sub2(a, fe_one()))); }
@@ -52,34 +50,44 @@ DSV_DEV Fe fe_pow_sqrt_exp(const Fe& z) {
   return acc;
 }
 
+// tables for the windowed discrete log (device global memory, filled at dsv_init)
+struct TsTables {
+  const u32* cancel;      // [4][256][9]: g^(-d 2^(8i-1)) (i = 0: g^(-(d >> 1)))
+  const uint8_t* hash;    // [2^DSV_TS_HASH_BITS]: perfect hash of <h>, h = g^(2^24), to its log
+};
+
+// log_h(w) for w in the order-256 subgroup (anything in [0, 255] otherwise)
+DSV_DEV u32 ts_digit(const Fe& w, const TsTables& t) {
+  const Fe c = fe_canon(w);
+  const u32 idx = (c.l[0] * DSV_TS_HASH_K1 + c.l[1] * DSV_TS_HASH_K2) >> (32 - DSV_TS_HASH_BITS);
+  return t.hash[idx];
+}
+DSV_DEV Fe ts_cancel(const TsTables& t, int window, u32 d) {
+  const u32* p = t.cancel + ((size_t)window * 256 + d) * NL;
+  Fe r;
+#pragma unroll
+  for (int i = 0; i < NL; i++) r.l[i] = p[i];
+  return r;
+}
+
 // y = z^(-1/2) for a non-zero square z (any root); unspecified otherwise — callers validate.
-DSV_DEV Fe fe_inv_sqrt(const Fe& z) {
+// Invariant y^2 z = b with b = g^s in the 2^32-torsion (s even for a square z).  s is read off in
+// four 8-bit digits, least significant first: b^(2^(24-8i)) lies in <h> and equals h^(digit i);
+// each digit is cancelled from b (A^2) and half of it from y (A).  48 + 3 squarings and 7
+// multiplications instead of the ~250 squarings of the bit-by-bit order search.
+DSV_DEV Fe fe_inv_sqrt(const Fe& z, const TsTables& t) {
   Fe y = fe_pow_sqrt_exp(z);
   Fe b = fe_mul(fe_mul(z, y), y);  // z^t
-  int v = 32;
 #pragma unroll 1
-  for (int round = 0; round < 32; round++) {
-    if (fe_is_one(b)) break;
-    int k = 0;
-    Fe bb = b;
+  for (int w = 0; w < 3; w++) {
+    Fe p = b;
 #pragma unroll 1
-    while (k < v - 1) {
-      bb = fe_sqr(bb);
-      k++;
-      if (fe_is_one(bb)) break;
-    }
-    if (!fe_is_one(bb)) break;  // order of b is 2^v or b == 0: z is not a non-zero square
-    Fe cc, c2;
-#pragma unroll
-    for (int i = 0; i < NL; i++) {
-      cc.l[i] = c_root_powers[31 - k][i];
-      c2.l[i] = c_root_powers[32 - k][i];
-    }
-    y = fe_mul(y, cc);
-    b = fe_mul(b, c2);
-    v = k;
+    for (int j = 0; j < 24 - 8 * w; j++) p = fe_sqr(p);
+    const Fe a = ts_cancel(t, w, ts_digit(p, t));
+    y = fe_mul(y, a);
+    b = fe_mul(b, fe_sqr(a));
   }
-  return y;
+  return fe_mul(y, ts_cancel(t, 3, ts_digit(b, t)));
 }
 
 }  // namespace dsv

@@ -609,7 +609,7 @@ k_sign_finish(const uint8_t* __restrict__ r, const uint8_t* c,  // c may alias u
 // out_uv: affine u || v canonical; ok[i] = (accumulate ? ok[i] : 1) & decodable
 __global__ void __launch_bounds__(256, DSV_WAVES_HASH)
 k_decompress(const uint8_t* __restrict__ in, size_t in_stride, size_t n,
-             uint8_t* __restrict__ out_uv, uint8_t* __restrict__ ok, int accumulate) {
+             uint8_t* __restrict__ out_uv, uint8_t* __restrict__ ok, int accumulate, TsTables ts) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   u32 w[8];
@@ -627,7 +627,7 @@ k_decompress(const uint8_t* __restrict__ in, size_t in_stride, size_t n,
   const Fe num = fe_sub2(v2, fe_one());                          // v^2 - 1
   const Fe den = fe_add(fe_mul(v2, fe_const(kD)), fe_one());     // 1 + d v^2  (never 0: -1/d is a non-square)
   // u = n * (n d)^(-1/2); accept iff u^2 d == n  (rejects non-squares; n == 0 gives u == 0)
-  Fe u = fe_mul(num, fe_inv_sqrt(fe_mul(num, den)));
+  Fe u = fe_mul(num, fe_inv_sqrt(fe_mul(num, den), ts));
   good &= fe_equal(fe_mul(fe_sqr(u), den), num);
   u32 uw[8];
   fe_to_words_plain(uw, fe_from_mont(u));
@@ -727,6 +727,8 @@ struct Context {
   int device = -1;
   bool half_scalars = true;  // DSV_VERIFY_ALGO=classic selects the 250-bit chain instead
   u32* table[2] = {nullptr, nullptr};  // fixed-base tables for G, G'
+  u32* ts_cancel = nullptr;            // square-root tables (decode29.h)
+  uint8_t* ts_hash = nullptr;
   // staging for the host-pointer entry points (grown on demand, guarded by mu)
   std::mutex mu;
   uint8_t* stage = nullptr;
@@ -850,8 +852,10 @@ int dsv_init(int device) {
                             sizeof(DSV_HADES_BLOCKS_HOST)));
   HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(c_hades_kfinal), DSV_HADES_KFINAL_HOST,
                             sizeof(DSV_HADES_KFINAL_HOST)));
-  HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(c_root_powers), DSV_ROOT_POWERS_HOST,
-                            sizeof(DSV_ROOT_POWERS_HOST)));
+  HIP_TRY(hipMalloc(&g_ctx.ts_cancel, sizeof(DSV_TS_CANCEL_HOST)));
+  HIP_TRY(hipMemcpy(g_ctx.ts_cancel, DSV_TS_CANCEL_HOST, sizeof(DSV_TS_CANCEL_HOST), hipMemcpyHostToDevice));
+  HIP_TRY(hipMalloc(&g_ctx.ts_hash, sizeof(DSV_TS_HASH_HOST)));
+  HIP_TRY(hipMemcpy(g_ctx.ts_hash, DSV_TS_HASH_HOST, sizeof(DSV_TS_HASH_HOST), hipMemcpyHostToDevice));
   for (int g = 0; g < 2; g++) {
     HIP_TRY(hipMalloc(&g_ctx.table[g], kTableBytes));
     const int total = kFixedWindows * kFixedEntries;
@@ -876,6 +880,10 @@ int dsv_shutdown(void) {
     if (g_ctx.table[g]) hipFree(g_ctx.table[g]);
     g_ctx.table[g] = nullptr;
   }
+  if (g_ctx.ts_cancel) hipFree(g_ctx.ts_cancel);
+  if (g_ctx.ts_hash) hipFree(g_ctx.ts_hash);
+  g_ctx.ts_cancel = nullptr;
+  g_ctx.ts_hash = nullptr;
   if (g_ctx.stage) hipFree(g_ctx.stage);
   g_ctx.stage = nullptr;
   g_ctx.stage_bytes = 0;
@@ -1320,7 +1328,8 @@ int dsv_decompress_points_dev(const void* in, size_t in_stride, size_t n, void* 
   if (!in || !out_uv || !ok || in_stride < 32 || (in_stride & 15) || ((uintptr_t)in & 15))
     return fail(DSV_ERR_INVALID_ARGUMENT, "bad pointer / stride (need 16-byte alignment)");
   hipLaunchKernelGGL(k_decompress, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream,
-                     (const uint8_t*)in, in_stride, n, (uint8_t*)out_uv, (uint8_t*)ok, accumulate);
+                     (const uint8_t*)in, in_stride, n, (uint8_t*)out_uv, (uint8_t*)ok, accumulate,
+                     TsTables{g_ctx.ts_cancel, g_ctx.ts_hash});
   HIP_TRY(hipGetLastError());
   return DSV_OK;
 }

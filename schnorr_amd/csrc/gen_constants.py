@@ -174,13 +174,38 @@ def main():
         w("#define DSV_SQRT_E_WORDS %s\n" % ("{" + ", ".join("0x%08xu" % ((e >> (32 * i)) & 0xFFFFFFFF) for i in range(7)) + "}"))
         w("#define DSV_SQRT_E_BITS %d\n" % e.bit_length())
         w("#define DSV_ROOT_OF_UNITY %s\n" % arr(mont(pow(7, t_odd, Q))))
-        # c^(2^j), j = 0..32 (the last one is 1): Tonelli-Shanks multipliers by table lookup
         root = pow(7, t_odd, Q)
-        w("static const uint32_t DSV_ROOT_POWERS_HOST[33][9] = {\n")
-        for j in range(33):
-            w("  %s,\n" % arr(mont(pow(root, 1 << j, Q))))
-        w("};\n")
         assert pow(root, 1 << 31, Q) == Q - 1 and pow(root, 1 << 32, Q) == 1
+        # Tonelli-Shanks by 8-bit windows (decode29.h): the discrete log of b = z^t to base g = root
+        # is read off in four 8-bit digits; each digit is found by hashing an element of the
+        # order-256 subgroup <h>, h = g^(2^24), into a byte table (perfect hash on the two low limbs
+        # of the canonical Montgomery form), and cancelled with A_i[d] = g^(-d 2^(8i-1)).
+        h = pow(root, 1 << 24, Q)
+        hv = [mont(pow(h, d, Q)) for d in range(256)]
+        import random as _random
+        rnd = _random.Random(20260101)
+        HASH_BITS = 13
+        while True:
+            k1, k2 = rnd.getrandbits(32) | 1, rnd.getrandbits(32) | 1
+            idx = [(((v[0] * k1 + v[1] * k2) & 0xFFFFFFFF) >> (32 - HASH_BITS)) for v in hv]
+            if len(set(idx)) == 256:
+                break
+        table = [0] * (1 << HASH_BITS)
+        for d, i in enumerate(idx):
+            table[i] = d
+        w("#define DSV_TS_HASH_K1 0x%08xu\n#define DSV_TS_HASH_K2 0x%08xu\n#define DSV_TS_HASH_BITS %d\n"
+          % (k1, k2, HASH_BITS))
+        w("static const uint8_t DSV_TS_HASH_HOST[%d] = {\n" % (1 << HASH_BITS))
+        for i in range(0, 1 << HASH_BITS, 32):
+            w("  " + ", ".join(str(x) for x in table[i:i + 32]) + ",\n")
+        w("};\n")
+        ginv = pow(root, -1, Q)
+        w("static const uint32_t DSV_TS_CANCEL_HOST[4 * 256][9] = {\n")
+        for i in range(4):
+            for d in range(256):
+                e = (d >> 1) if i == 0 else d << (8 * i - 1)
+                w("  %s,\n" % arr(mont(pow(ginv, e, Q))))
+        w("};\n")
         w("static const uint32_t DSV_HADES_RC_HOST[%d][9] = {\n" % len(rc))
         for c in rc:
             w("  %s,\n" % arr(mont(c)))
