@@ -24,18 +24,20 @@ __device__ constexpr u32 kD[NL] = DSV_D;
 // a == 1 (Montgomery one) for a multiplication output (limbs < 2^29, value < 2q)
 DSV_DEV bool fe_is_one(const Fe& a) { return fe_is_zero_canon(fe_canon(fe_sub2(a, fe_one()))); }
 
-// z^((t-1)/2)
-DSV_DEV Fe fe_pow_sqrt_exp(const Fe& z) {
+// z^e for a wave-uniform constant exponent of NBITS bits (NBITS % 3 == 0), fixed 3-bit windows:
+// NBITS squarings + at most NBITS/3 + 6 multiplications
+template <int NWORDS, int NBITS>
+DSV_DEV Fe fe_pow_w3(const Fe& z, const u32 (&e)[NWORDS]) {
+  static_assert(NBITS % 3 == 0, "3-bit windows");
   Fe t2 = fe_sqr(z), t3 = fe_mul(t2, z), t4 = fe_sqr(t2), t5 = fe_mul(t4, z), t6 = fe_sqr(t3),
      t7 = fe_mul(t6, z);
-  static_assert(DSV_SQRT_E_BITS % 3 == 0, "3-bit windows");
   Fe acc = fe_one();
 #pragma unroll 1
-  for (int w = DSV_SQRT_E_BITS / 3 - 1; w >= 0; w--) {
+  for (int w = NBITS / 3 - 1; w >= 0; w--) {
     acc = fe_sqr(fe_sqr(fe_sqr(acc)));
     const int pos = 3 * w;
-    u32 lo = kSqrtE[pos >> 5] >> (pos & 31);
-    if ((pos & 31) > 29 && (pos >> 5) + 1 < 7) lo |= kSqrtE[(pos >> 5) + 1] << (32 - (pos & 31));
+    u32 lo = e[pos >> 5] >> (pos & 31);
+    if ((pos & 31) > 29 && (pos >> 5) + 1 < NWORDS) lo |= e[(pos >> 5) + 1] << (32 - (pos & 31));
     switch (lo & 7u) {  // wave-uniform
       case 1: acc = fe_mul(acc, z); break;
       case 2: acc = fe_mul(acc, t2); break;
@@ -48,6 +50,14 @@ DSV_DEV Fe fe_pow_sqrt_exp(const Fe& z) {
     }
   }
   return acc;
+}
+// z^((t-1)/2)
+DSV_DEV Fe fe_pow_sqrt_exp(const Fe& z) { return fe_pow_w3<7, DSV_SQRT_E_BITS>(z, kSqrtE); }
+// z^(q-2) = 1/z  (0 for z = 0)
+DSV_DEV Fe fe_invert(const Fe& z) {
+  // q - 2: the low word of q is 1, so the subtraction borrows from word 1
+  const u32 e[8] = {0xffffffffu, kQ32[1] - 1, kQ32[2], kQ32[3], kQ32[4], kQ32[5], kQ32[6], kQ32[7]};
+  return fe_pow_w3<8, 255>(z, e);
 }
 
 // tables for the windowed discrete log (device global memory, filled at dsv_init)

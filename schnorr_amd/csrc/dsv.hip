@@ -104,19 +104,6 @@ DSV_DEV ANiels load_aniels(const u32* __restrict__ table, int window, int d) {
   return n;
 }
 
-// a^(q-2) (Fermat) — init-time and the *_ext entry points only
-DSV_DEV Fe fe_invert(const Fe& a) {
-  // q - 2: the low word of q is 1, so the subtraction borrows from word 1
-  const u32 e[8] = {0xffffffffu, kQ32[1] - 1, kQ32[2], kQ32[3], kQ32[4], kQ32[5], kQ32[6], kQ32[7]};
-  Fe acc = fe_one();
-#pragma unroll 1
-  for (int bit = 254; bit >= 0; bit--) {
-    acc = fe_sqr(acc);
-    if ((e[bit >> 5] >> (bit & 31)) & 1) acc = fe_mul(acc, a);
-  }
-  return acc;
-}
-
 // generic double-and-add over a 256-bit LE scalar (init-time table construction only)
 DSV_DEV Ext ext_mul_words(const Ext& p, const u32 (&s)[8]) {
   Niels n = ext_to_niels(p);
