@@ -67,6 +67,17 @@ def _pmc_traffic(n):
         return None
 
 
+def _pmc_valu_busy():
+    """VALU issue-slot occupancy of the dominant kernel in the last committed PMC pass:
+    SQ_INSTS_VALU wave-instructions x 4 cycles / (1024 SIMDs x GRBM_GUI_ACTIVE / 8 XCDs)."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_latest.json")) as f:
+            p = json.load(f)
+        return p["SQ_INSTS_VALU"] * 4.0 / (N_CU * SIMD_PER_CU * p["GRBM_GUI_ACTIVE"] / 8.0)
+    except Exception:
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -200,6 +211,7 @@ def main():
             "unit": "T lane-instr/s",
             "frac": achieved / VALU_PEAK_LANE_INSTR,
             "traffic": _pmc_traffic(n),
+            "valu_busy_from_pmc": _pmc_valu_busy(),
             "model": {"valu_lane_instr_per_verdict": VERIFY_INSTR,
                       "cycles_per_wave_instr": VALU_CYCLES_PER_INSTR,
                       "kernel_ms": core_ms, "hash_kernel_ms": hash_ms},
