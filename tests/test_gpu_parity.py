@@ -453,3 +453,45 @@ def test_stdrng_input_generator_matches_restatement(engine):
     assert [bytes(x).hex() for x in m] == [p["m"] for p in P["seed_2321"]]
     u, R = engine.sign_single(sk, m, r)
     assert [bytes(x).hex() for x in u] == [p["u"] for p in P["seed_2321"]]
+
+
+def test_core_kernel_with_crafted_challenges(engine):
+    """The second-stage kernel takes c as an input, so the half-size-scalar machinery can be driven
+    through its corner cases with hand-picked challenges (c below 2^128, powers of two, huge
+    Euclid quotients, even cofactors, maximal 250-bit values): for each c build sk, r, u = r - c*sk,
+    R = r*G, PK = sk*G so that u*G + c*PK == R holds by construction; a second copy with u + 1
+    must fail."""
+    import torch
+    rnd = np.random.default_rng(99)
+    N = 8 * M.R_ORDER
+    cs = [0, 1, 2, 3, (1 << 64) + 1, (1 << 127) - 1, (1 << 128) - 1, 1 << 128, (1 << 128) + 1,
+          (1 << 129) - 1, 1 << 200, (1 << 200) + 1, (1 << 249), (1 << 250) - 1, (1 << 250) - 2,
+          N >> 6, (N >> 5) - 1, (N // 3) >> 4, (N // 7) >> 3, int("5" * 62, 16) >> 2,
+          int("a" * 62, 16) >> 1, (1 << 249) + (1 << 121), ((1 << 125) - 1) << 124]
+    cs += [int.from_bytes(rnd.bytes(32), "little") >> 6 for _ in range(41)]
+    cs = [c % (1 << 250) for c in cs]
+    n = len(cs)
+    le = lambda x: np.frombuffer(M.le32(x), np.uint8)
+    sks = [int.from_bytes(rnd.bytes(40), "little") % M.R_ORDER for _ in range(n)]
+    rs = [int.from_bytes(rnd.bytes(40), "little") % M.R_ORDER for _ in range(n)]
+    G = np.tile(np.frombuffer(M.point_bytes(M.GEN), np.uint8), (n, 1))
+    R = O.scalar_mul(np.stack([le(x) for x in rs]), G)
+    PK = O.scalar_mul(np.stack([le(x) for x in sks]), G)
+    u_good = np.stack([le((r - c * sk) % M.R_ORDER) for r, c, sk in zip(rs, cs, sks)])
+    u_bad = np.stack([le((r - c * sk + 1) % M.R_ORDER) for r, c, sk in zip(rs, cs, sks)])
+    cc = np.stack([le(c) for c in cs])
+    dev = "cuda:0"
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    valid = torch.ones(2 * n, dtype=torch.uint8, device=dev)
+    ok = torch.zeros(2 * n, dtype=torch.uint8, device=dev)
+    ws = torch.empty(engine.workspace_bytes(2 * n), dtype=torch.uint8, device=dev)
+    engine.verify_core_dev(t(np.concatenate([u_good, u_bad])), t(np.concatenate([cc, cc])), valid,
+                           t(np.concatenate([PK, PK])), t(np.concatenate([R, R])), ok, ws)
+    torch.cuda.synchronize()
+    got = ok.cpu().numpy()
+    assert got[:n].all(), np.nonzero(got[:n] == 0)
+    assert not got[n:].any(), np.nonzero(got[n:])
+    # the integer model of the lattice step agrees that every pair is valid
+    for c in cs:
+        a, b, bn = M.half_scalars(c)
+        assert (a - (-b if bn else b) * c) % N == 0 and b & 1
