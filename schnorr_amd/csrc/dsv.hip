@@ -24,11 +24,14 @@
 #include <hip/hip_runtime.h>
 
 #include <atomic>
+#include <condition_variable>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <functional>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/dsv.h"
@@ -710,9 +713,86 @@ int fail(int code, const char* fmt, ...) {
                   __LINE__);                                                                  \
   } while (0)
 
+// Copy threads of the host path: the caller's (pageable) arrays are gathered into pinned staging
+// by several threads at once, so the DMA engine is fed faster than one memcpy stream can.
+class CopyPool {
+ public:
+  ~CopyPool() { stop(); }
+  // fn(t, T) runs on T threads (t = 0 is the caller); returns when all are done
+  void run(int T, const std::function<void(int, int)>& fn) {
+    if (T <= 1) {
+      fn(0, 1);
+      return;
+    }
+    {
+      std::unique_lock<std::mutex> lk(m_);
+      while ((int)th_.size() < T - 1) {
+        const int id = (int)th_.size() + 1;
+        th_.emplace_back([this, id] { loop(id); });
+      }
+      job_ = &fn;
+      job_threads_ = T;
+      pending_ = T - 1;
+      gen_++;
+    }
+    go_.notify_all();
+    fn(0, T);
+    std::unique_lock<std::mutex> lk(m_);
+    done_.wait(lk, [this] { return pending_ == 0; });
+    job_ = nullptr;
+  }
+  void stop() {
+    {
+      std::unique_lock<std::mutex> lk(m_);
+      quit_ = true;
+      gen_++;
+    }
+    go_.notify_all();
+    for (auto& t : th_) t.join();
+    th_.clear();
+    quit_ = false;
+  }
+
+ private:
+  void loop(int id) {
+    uint64_t seen = 0;
+    {
+      std::unique_lock<std::mutex> lk(m_);
+      seen = gen_ - 1;  // started while a job is being posted: take it
+    }
+    for (;;) {
+      const std::function<void(int, int)>* job;
+      int T;
+      {
+        std::unique_lock<std::mutex> lk(m_);
+        go_.wait(lk, [&] { return gen_ != seen; });
+        seen = gen_;
+        if (quit_) return;
+        job = job_;
+        T = job_threads_;
+      }
+      if (job && id < T) {
+        (*job)(id, T);
+        std::unique_lock<std::mutex> lk(m_);
+        if (--pending_ == 0) done_.notify_one();
+      }
+    }
+  }
+  std::vector<std::thread> th_;
+  std::mutex m_;
+  std::condition_variable go_, done_;
+  const std::function<void(int, int)>* job_ = nullptr;
+  int job_threads_ = 0, pending_ = 0;
+  uint64_t gen_ = 0;
+  bool quit_ = false;
+};
+
+constexpr int kPipeSlots = 3;
+
 struct Context {
   int device = -1;
   bool half_scalars = true;  // DSV_VERIFY_ALGO=classic selects the 250-bit chain instead
+  bool split = true;         // DSV_SPLIT=0: one stream, whole batch per launch
   u32* table[2] = {nullptr, nullptr};  // fixed-base tables for G, G'
   u32* ts_cancel = nullptr;            // square-root tables (decode29.h)
   uint8_t* ts_hash = nullptr;
@@ -720,11 +800,17 @@ struct Context {
   std::mutex mu;
   uint8_t* stage = nullptr;
   size_t stage_bytes = 0;
-  // double-buffered pipeline of the host verify entry points: H2D of chunk k+1 overlaps the
-  // kernels of chunk k (two streams, two staging slots)
-  hipStream_t pipe_stream[2] = {nullptr, nullptr};
-  uint8_t* pipe_stage[2] = {nullptr, nullptr};
-  size_t pipe_bytes[2] = {0, 0};
+  // pipeline of the host verify entry points (run_pipelined): kPipeSlots chunks in flight, each
+  // with its own stream, device staging and pinned host staging
+  // two internal streams: a large device-resident batch is cut into sub-batches of kSplitItems
+  // signatures that alternate between them (run_split)
+  hipStream_t split_stream[2] = {nullptr, nullptr};
+  hipStream_t pipe_stream[kPipeSlots] = {};
+  uint8_t* pipe_stage[kPipeSlots] = {};   // device side of a slot
+  size_t pipe_bytes[kPipeSlots] = {};
+  uint8_t* pipe_host[kPipeSlots] = {};    // pinned host side of a slot (inputs, then verdicts)
+  size_t pipe_host_bytes[kPipeSlots] = {};
+  CopyPool copiers;
 };
 Context g_ctx;
 std::mutex g_init_mu;
@@ -741,14 +827,22 @@ int ensure_stage(size_t bytes) {
   return DSV_OK;
 }
 
-int ensure_pipe_slot(int slot, size_t bytes) {
+int ensure_pipe_slot(int slot, size_t dev_bytes, size_t host_bytes) {
   if (!g_ctx.pipe_stream[slot]) HIP_TRY(hipStreamCreateWithFlags(&g_ctx.pipe_stream[slot], hipStreamNonBlocking));
-  if (g_ctx.pipe_bytes[slot] >= bytes) return DSV_OK;
-  if (g_ctx.pipe_stage[slot]) HIP_TRY(hipFree(g_ctx.pipe_stage[slot]));
-  g_ctx.pipe_stage[slot] = nullptr;
-  g_ctx.pipe_bytes[slot] = 0;
-  HIP_TRY(hipMalloc(&g_ctx.pipe_stage[slot], bytes));
-  g_ctx.pipe_bytes[slot] = bytes;
+  if (g_ctx.pipe_bytes[slot] < dev_bytes) {
+    if (g_ctx.pipe_stage[slot]) HIP_TRY(hipFree(g_ctx.pipe_stage[slot]));
+    g_ctx.pipe_stage[slot] = nullptr;
+    g_ctx.pipe_bytes[slot] = 0;
+    HIP_TRY(hipMalloc(&g_ctx.pipe_stage[slot], dev_bytes));
+    g_ctx.pipe_bytes[slot] = dev_bytes;
+  }
+  if (g_ctx.pipe_host_bytes[slot] < host_bytes) {
+    if (g_ctx.pipe_host[slot]) HIP_TRY(hipHostFree(g_ctx.pipe_host[slot]));
+    g_ctx.pipe_host[slot] = nullptr;
+    g_ctx.pipe_host_bytes[slot] = 0;
+    HIP_TRY(hipHostMalloc(&g_ctx.pipe_host[slot], host_bytes, hipHostMallocDefault));
+    g_ctx.pipe_host_bytes[slot] = host_bytes;
+  }
   return DSV_OK;
 }
 
@@ -804,6 +898,60 @@ void launch_verify_fixed(bool accumulate, const void* u, const void* c, const vo
 #undef DSV_LAUNCH
 }
 
+// Sub-batch scheduling of the device-pointer verify entry points.
+// One launch over 2^20 signatures pays a fill and a drain phase per kernel (~0.5 ms + ~0.8 ms of
+// 18 ms, tools/scaling_probe.py) and runs the two waves of every SIMD through the same phase of
+// the same kernel.  Cutting the batch into sub-batches of 2^16 signatures (1024 waves: ONE wave
+// per SIMD) that alternate between two internal streams keeps two different kernels co-resident
+// on every SIMD — hash next to scalar multiplication, table build next to window loop — and
+// leaves no gap between kernels: +8 % on 2^20 (tools/overlap_probe.py).  The caller's stream is
+// forked / joined with events, so the call still behaves as one enqueue on that stream.
+constexpr size_t kSplitItems = (size_t)1 << 16;
+
+struct ForkJoin {
+  hipEvent_t fork = nullptr, join[2] = {nullptr, nullptr};
+};
+ForkJoin& thread_events() {
+  thread_local ForkJoin ev;
+  if (!ev.fork) {
+    hipEventCreateWithFlags(&ev.fork, hipEventDisableTiming);
+    hipEventCreateWithFlags(&ev.join[0], hipEventDisableTiming);
+    hipEventCreateWithFlags(&ev.join[1], hipEventDisableTiming);
+  }
+  return ev;
+}
+// part(offset, count, workspace-for-this-part, stream)
+template <class Part>
+int run_split(size_t n, void* workspace, hipStream_t user, Part part) {
+  Workspace w = carve(workspace, n);
+  if (!g_ctx.split || n < 2 * kSplitItems) {
+    part((size_t)0, n, w, user);
+    HIP_TRY(hipGetLastError());
+    return DSV_OK;
+  }
+  ForkJoin& ev = thread_events();
+  HIP_TRY(hipEventRecord(ev.fork, user));
+  const size_t tbl_words = var_table_bytes(kSplitItems, 2) / 4;  // per internal stream
+  for (int k = 0; k < 2; k++) HIP_TRY(hipStreamWaitEvent(g_ctx.split_stream[k], ev.fork, 0));
+  size_t off = 0;
+  for (size_t p = 0; off < n; p++) {
+    const size_t cnt = n - off < kSplitItems ? n - off : kSplitItems;
+    const int k = (int)(p & 1);
+    Workspace wp;
+    wp.c = w.c + off * 32;
+    wp.valid = w.valid + off;
+    wp.tables = w.tables + (size_t)k * tbl_words;
+    part(off, cnt, wp, g_ctx.split_stream[k]);
+    off += cnt;
+  }
+  HIP_TRY(hipGetLastError());
+  for (int k = 0; k < 2; k++) {
+    HIP_TRY(hipEventRecord(ev.join[k], g_ctx.split_stream[k]));
+    HIP_TRY(hipStreamWaitEvent(user, ev.join[k], 0));
+  }
+  return DSV_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -851,7 +999,11 @@ int dsv_init(int device) {
     HIP_TRY(hipGetLastError());
   }
   HIP_TRY(hipDeviceSynchronize());
+  for (int k = 0; k < 2; k++)
+    HIP_TRY(hipStreamCreateWithFlags(&g_ctx.split_stream[k], hipStreamNonBlocking));
   g_ctx.device = device;
+  const char* split = getenv("DSV_SPLIT");
+  g_ctx.split = !(split && strcmp(split, "0") == 0);
   const char* algo = getenv("DSV_VERIFY_ALGO");
   g_ctx.half_scalars = !(algo && strcmp(algo, "classic") == 0);
   g_ready.store(true, std::memory_order_release);
@@ -875,12 +1027,20 @@ int dsv_shutdown(void) {
   g_ctx.stage = nullptr;
   g_ctx.stage_bytes = 0;
   for (int k = 0; k < 2; k++) {
+    if (g_ctx.split_stream[k]) hipStreamDestroy(g_ctx.split_stream[k]);
+    g_ctx.split_stream[k] = nullptr;
+  }
+  for (int k = 0; k < kPipeSlots; k++) {
     if (g_ctx.pipe_stage[k]) hipFree(g_ctx.pipe_stage[k]);
+    if (g_ctx.pipe_host[k]) hipHostFree(g_ctx.pipe_host[k]);
     if (g_ctx.pipe_stream[k]) hipStreamDestroy(g_ctx.pipe_stream[k]);
     g_ctx.pipe_stage[k] = nullptr;
+    g_ctx.pipe_host[k] = nullptr;
     g_ctx.pipe_stream[k] = nullptr;
     g_ctx.pipe_bytes[k] = 0;
+    g_ctx.pipe_host_bytes[k] = 0;
   }
+  g_ctx.copiers.stop();
   g_ctx.device = -1;
   g_ready.store(false);
   return DSV_OK;
@@ -923,13 +1083,16 @@ int dsv_verify_single_dev(const void* u, const void* R_uv, const void* PK_uv, co
   if (n == 0) return DSV_OK;
   if (!u || !R_uv || !PK_uv || !m || !ok || !workspace)
     return fail(DSV_ERR_INVALID_ARGUMENT, "null pointer");
-  Workspace w = carve(workspace, n);
-  hipStream_t s = (hipStream_t)stream;
-  hipLaunchKernelGGL(k_challenge<false>, dim3(grid_for(n)), dim3(256), 0, s, (const uint8_t*)R_uv,
-                     (const uint8_t*)nullptr, (const uint8_t*)m, n, w.c, w.valid);
-  launch_verify_fixed(false, u, w.c, PK_uv, R_uv, 0, w.valid, n, ok, w.tables, s);
-  HIP_TRY(hipGetLastError());
-  return DSV_OK;
+  const uint8_t *pu = (const uint8_t*)u, *pR = (const uint8_t*)R_uv, *pPK = (const uint8_t*)PK_uv,
+                *pm = (const uint8_t*)m;
+  uint8_t* pok = (uint8_t*)ok;
+  return run_split(n, workspace, (hipStream_t)stream,
+                   [=](size_t off, size_t cnt, const Workspace& w, hipStream_t s) {
+    hipLaunchKernelGGL(k_challenge<false>, dim3(grid_for(cnt)), dim3(256), 0, s, pR + 64 * off,
+                       (const uint8_t*)nullptr, pm + 32 * off, cnt, w.c, w.valid);
+    launch_verify_fixed(false, pu + 32 * off, w.c, pPK + 64 * off, pR + 64 * off, 0, w.valid, cnt,
+                        pok + off, w.tables, s);
+  });
 }
 
 // second stage alone (c and valid already computed): lets callers time / profile the dominant
@@ -957,14 +1120,18 @@ int dsv_verify_double_dev(const void* u, const void* R_uv, const void* Rp_uv, co
   if (n == 0) return DSV_OK;
   if (!u || !R_uv || !Rp_uv || !PK_uv || !PKp_uv || !m || !ok || !workspace)
     return fail(DSV_ERR_INVALID_ARGUMENT, "null pointer");
-  Workspace w = carve(workspace, n);
-  hipStream_t s = (hipStream_t)stream;
-  hipLaunchKernelGGL(k_challenge<true>, dim3(grid_for(n)), dim3(256), 0, s, (const uint8_t*)R_uv,
-                     (const uint8_t*)Rp_uv, (const uint8_t*)m, n, w.c, w.valid);
-  launch_verify_fixed(false, u, w.c, PK_uv, R_uv, 0, w.valid, n, ok, w.tables, s);
-  launch_verify_fixed(true, u, w.c, PKp_uv, Rp_uv, 1, w.valid, n, ok, w.tables, s);
-  HIP_TRY(hipGetLastError());
-  return DSV_OK;
+  const uint8_t *pu = (const uint8_t*)u, *pR = (const uint8_t*)R_uv, *pRp = (const uint8_t*)Rp_uv,
+                *pPK = (const uint8_t*)PK_uv, *pPKp = (const uint8_t*)PKp_uv, *pm = (const uint8_t*)m;
+  uint8_t* pok = (uint8_t*)ok;
+  return run_split(n, workspace, (hipStream_t)stream,
+                   [=](size_t off, size_t cnt, const Workspace& w, hipStream_t s) {
+    hipLaunchKernelGGL(k_challenge<true>, dim3(grid_for(cnt)), dim3(256), 0, s, pR + 64 * off,
+                       pRp + 64 * off, pm + 32 * off, cnt, w.c, w.valid);
+    launch_verify_fixed(false, pu + 32 * off, w.c, pPK + 64 * off, pR + 64 * off, 0, w.valid, cnt,
+                        pok + off, w.tables, s);
+    launch_verify_fixed(true, pu + 32 * off, w.c, pPKp + 64 * off, pRp + 64 * off, 1, w.valid, cnt,
+                        pok + off, w.tables, s);
+  });
 }
 
 int dsv_verify_vargen_dev(const void* u, const void* R_uv, const void* PK_uv, const void* Gen_uv,
@@ -974,15 +1141,17 @@ int dsv_verify_vargen_dev(const void* u, const void* R_uv, const void* PK_uv, co
   if (n == 0) return DSV_OK;
   if (!u || !R_uv || !PK_uv || !Gen_uv || !m || !ok || !workspace)
     return fail(DSV_ERR_INVALID_ARGUMENT, "null pointer");
-  Workspace w = carve(workspace, n);
-  hipStream_t s = (hipStream_t)stream;
-  hipLaunchKernelGGL(k_challenge<false>, dim3(grid_for(n)), dim3(256), 0, s, (const uint8_t*)R_uv,
-                     (const uint8_t*)nullptr, (const uint8_t*)m, n, w.c, w.valid);
-  hipLaunchKernelGGL(k_verify_var, dim3(verify_grid(n)), dim3(kVerifyBlock), 0, s, (const uint8_t*)u,
-                     (const uint8_t*)w.c, (const uint8_t*)PK_uv, (const uint8_t*)Gen_uv,
-                     (const uint8_t*)R_uv, (const uint8_t*)w.valid, n, (uint8_t*)ok, w.tables);
-  HIP_TRY(hipGetLastError());
-  return DSV_OK;
+  const uint8_t *pu = (const uint8_t*)u, *pR = (const uint8_t*)R_uv, *pPK = (const uint8_t*)PK_uv,
+                *pG = (const uint8_t*)Gen_uv, *pm = (const uint8_t*)m;
+  uint8_t* pok = (uint8_t*)ok;
+  return run_split(n, workspace, (hipStream_t)stream,
+                   [=](size_t off, size_t cnt, const Workspace& w, hipStream_t s) {
+    hipLaunchKernelGGL(k_challenge<false>, dim3(grid_for(cnt)), dim3(256), 0, s, pR + 64 * off,
+                       (const uint8_t*)nullptr, pm + 32 * off, cnt, w.c, w.valid);
+    hipLaunchKernelGGL(k_verify_var, dim3(verify_grid(cnt)), dim3(kVerifyBlock), 0, s,
+                       pu + 32 * off, (const uint8_t*)w.c, pPK + 64 * off, pG + 64 * off,
+                       pR + 64 * off, (const uint8_t*)w.valid, cnt, pok + off, w.tables);
+  });
 }
 
 // ---- host-pointer entry points ----------------------------------------------------------
@@ -1004,47 +1173,87 @@ struct Stager {
 
 extern "C++" {
 namespace {
-// Chunked, double-buffered host path shared by the three verify entry points.
+// Chunked host path shared by the three verify entry points.
 //   ins[k] = {host array, bytes per item}; launch(dev_ptrs, count, dok, ws, stream) enqueues the
-//   kernels for one chunk.  Chunk c uses slot c & 1: its H2D copies (which block the host while a
-//   pageable buffer is staged) run while the other slot's kernels are still executing.
+//   kernels for one chunk.  Chunk c uses slot c % kPipeSlots.  Per chunk: the copy threads gather
+//   the caller's arrays (pageable in general) into the slot's pinned staging, ONE asynchronous
+//   DMA moves the block to the device, the kernels run, the verdict bytes come back into the
+//   pinned block; they are handed to the caller when the slot is recycled.  While the GPU works on
+//   chunk c the host is already gathering chunk c + 1, so the slower of (host memcpy, GPU) sets
+//   the rate; a pageable hipMemcpyAsync would serialise staging and DMA on one runtime thread.
 struct HostIn {
   const uint8_t* p;
   size_t bytes;
 };
 constexpr size_t kPipeChunk = (size_t)1 << 17;  // 2048 waves: one chunk fills every SIMD twice
 
+inline int host_copy_threads() {
+  static const int t = [] {
+    const char* e = getenv("DSV_HOST_THREADS");
+    int v = e ? atoi(e) : 4;
+    const int hw = (int)std::thread::hardware_concurrency();
+    if (hw > 0 && v > hw) v = hw;
+    return v < 1 ? 1 : (v > 16 ? 16 : v);
+  }();
+  return t;
+}
+
 template <size_t NIN, class Launch>
 int run_pipelined(const HostIn (&ins)[NIN], uint8_t* ok, size_t n, Launch launch) {
   std::lock_guard<std::mutex> lk(g_ctx.mu);
   HIP_TRY(hipSetDevice(g_ctx.device));
   const size_t chunk = n < kPipeChunk ? n : kPipeChunk;
-  size_t need = align_up(chunk, 256) + dsv_workspace_bytes(chunk);
-  for (size_t k = 0; k < NIN; k++) need += align_up(chunk * ins[k].bytes, 256);
-  const int nslots = n > chunk ? 2 : 1;
+  size_t in_off[NIN + 1];  // offsets inside a slot, the same on both sides
+  in_off[0] = 0;
+  for (size_t k = 0; k < NIN; k++) in_off[k + 1] = in_off[k] + align_up(chunk * ins[k].bytes, 256);
+  const size_t ok_off = in_off[NIN];
+  const size_t host_need = ok_off + align_up(chunk, 256);
+  const size_t dev_need = host_need + dsv_workspace_bytes(chunk);
+  const size_t nchunks = (n + chunk - 1) / chunk;
+  const int nslots = nchunks < (size_t)kPipeSlots ? (int)nchunks : kPipeSlots;
   for (int sl = 0; sl < nslots; sl++)
-    if (int r = ensure_pipe_slot(sl, need)) return r;
+    if (int r = ensure_pipe_slot(sl, dev_need, host_need)) return r;
+  size_t slot_first[kPipeSlots] = {}, slot_cnt[kPipeSlots] = {};  // verdicts parked in a slot
+  auto drain = [&](int sl) -> int {
+    HIP_TRY(hipStreamSynchronize(g_ctx.pipe_stream[sl]));
+    if (slot_cnt[sl]) memcpy(ok + slot_first[sl], g_ctx.pipe_host[sl] + ok_off, slot_cnt[sl]);
+    slot_cnt[sl] = 0;
+    return DSV_OK;
+  };
   size_t done = 0;
   for (size_t c = 0; done < n; c++) {
-    const int sl = (int)(c & 1);
+    const int sl = (int)(c % kPipeSlots);
     hipStream_t st = g_ctx.pipe_stream[sl];
     const size_t cnt = n - done < chunk ? n - done : chunk;
-    if (c >= 2) HIP_TRY(hipStreamSynchronize(st));  // slot free again (its D2H has landed)
-    Stager sg(g_ctx.pipe_stage[sl]);
+    if (int r = drain(sl)) return r;  // slot free again, its verdicts delivered
+    uint8_t* host = g_ctx.pipe_host[sl];
+    uint8_t* dev = g_ctx.pipe_stage[sl];
+    size_t bytes = 0;
+    for (size_t k = 0; k < NIN; k++) bytes += cnt * ins[k].bytes;
+    const int T = bytes >= ((size_t)1 << 20) ? host_copy_threads() : 1;
+    g_ctx.copiers.run(T, [&](int t, int nt) {
+      for (size_t k = 0; k < NIN; k++) {
+        const size_t len = cnt * ins[k].bytes;
+        const size_t lo = len * (size_t)t / (size_t)nt / 64 * 64;
+        const size_t hi = t + 1 == nt ? len : len * (size_t)(t + 1) / (size_t)nt / 64 * 64;
+        memcpy(host + in_off[k] + lo, ins[k].p + done * ins[k].bytes + lo, hi - lo);
+      }
+    });
+    // the input block is contiguous on both sides (pad bytes ride along)
+    HIP_TRY(hipMemcpyAsync(dev, host, in_off[NIN - 1] + cnt * ins[NIN - 1].bytes,
+                           hipMemcpyHostToDevice, st));
     const void* dptr[NIN];
-    for (size_t k = 0; k < NIN; k++) {
-      uint8_t* d = sg.take(chunk * ins[k].bytes);
-      HIP_TRY(hipMemcpyAsync(d, ins[k].p + done * ins[k].bytes, cnt * ins[k].bytes,
-                             hipMemcpyHostToDevice, st));
-      dptr[k] = d;
-    }
-    uint8_t* dok = sg.take(chunk);
-    uint8_t* ws = sg.take(dsv_workspace_bytes(chunk));
+    for (size_t k = 0; k < NIN; k++) dptr[k] = dev + in_off[k];
+    uint8_t* dok = dev + ok_off;
+    uint8_t* ws = dev + host_need;
     if (int r = launch(dptr, cnt, dok, ws, st)) return r;
-    HIP_TRY(hipMemcpyAsync(ok + done, dok, cnt, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(host + ok_off, dok, cnt, hipMemcpyDeviceToHost, st));
+    slot_first[sl] = done;
+    slot_cnt[sl] = cnt;
     done += cnt;
   }
-  for (int sl = 0; sl < nslots; sl++) HIP_TRY(hipStreamSynchronize(g_ctx.pipe_stream[sl]));
+  for (int sl = 0; sl < nslots; sl++)
+    if (int r = drain(sl)) return r;
   return DSV_OK;
 }
 }  // namespace

@@ -495,3 +495,41 @@ def test_core_kernel_with_crafted_challenges(engine):
     for c in cs:
         a, b, bn = M.half_scalars(c)
         assert (a - (-b if bn else b) * c) % N == 0 and b & 1
+
+
+def test_sub_batch_split_boundaries(engine):
+    """The _dev entry points cut batches of >= 2^17 items into 2^16-item parts on two internal
+    streams: ragged totals (tiny last part, exactly-2-part batch) and a non-default caller stream
+    must give the construction-time pattern, and the items either side of every cut must agree
+    with the oracle."""
+    import torch
+    from schnorr_amd import workload as W
+    part = 1 << 16
+    side = torch.cuda.Stream()
+    for n, kind in (((3 * part) + 77, "single"), (2 * part, "single"), ((2 * part) + 1, "double"),
+                    ((2 * part) + 4099, "vargen")):
+        if kind == "single":
+            b = W.gen_single(n, seed=n)
+            keys = ("u", "R", "PK", "m")
+            run, ref = engine.verify_single_dev, O.verify_single
+        elif kind == "double":
+            b = W.gen_double(n, seed=n)
+            keys = ("u", "R", "Rp", "PK", "PKp", "m")
+            run, ref = engine.verify_double_dev, O.verify_double
+        else:
+            b = W.gen_vargen(n, seed=n)
+            keys = ("u", "R", "PK", "Gen", "m")
+            run, ref = engine.verify_vargen_dev, O.verify_vargen
+        ok = torch.full((n,), 7, dtype=torch.uint8, device="cuda:0")
+        ws = torch.empty(engine.workspace_bytes(n), dtype=torch.uint8, device="cuda:0")
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            run(*[b[k] for k in keys], ok, ws)
+            got = ok.clone()          # ordered after the join on the caller's stream
+        side.synchronize()
+        assert torch.equal(got, b["expected"]), (n, kind)
+        cuts = [c for c in range(part, n, part)]
+        idx = torch.tensor(sorted({i for c in cuts for i in range(c - 3, min(n, c + 3))} | {0, n - 1}),
+                           device="cuda:0")
+        sub = [b[k][idx].cpu().numpy() for k in keys]
+        assert np.array_equal(ref(*sub), got[idx].cpu().numpy()), (n, kind)
