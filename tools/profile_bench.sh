@@ -1,12 +1,19 @@
 #!/bin/bash
 # rocprofv3 passes over bench.py (run on the GPU box through gpurun).  Kernel trace + stats in one
 # run, PMC counters in their own runs (never together with sys/hip traces).
+#   trace        : the default command (2^16-item sub-batches on two streams)
+#   trace_nosplit: DSV_SPLIT=0, one launch per kernel per step — the per-launch durations that
+#                  bench.py's roofline.model.kernel_ms / hash_kernel_ms must agree with
+#   pmc_*        : DSV_SPLIT=0 so that one dispatch = one whole 2^20 batch
+# Summarise with tools/summarize_prof.py.
 set -e
 export TMPDIR=/tmp
 OUT=${1:-gpurun_out/prof}
 ARGS="bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-double"
 mkdir -p $OUT
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $ARGS > $OUT/trace.log 2>&1
+export DSV_SPLIT=0
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_nosplit -- python3 $ARGS > $OUT/trace_nosplit.log 2>&1
 rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAVES SQ_INSTS_SALU SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --kernel-trace --output-format csv -d $OUT/pmc_sq -- python3 $ARGS > $OUT/pmc_sq.log 2>&1
 rocprofv3 --pmc SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_WAIT_ANY SQ_IFETCH SQ_INST_LEVEL_VMEM GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT/pmc_sq2 -- python3 $ARGS > $OUT/pmc_sq2.log 2>&1 || true
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -- python3 $ARGS > $OUT/pmc_fetch.log 2>&1

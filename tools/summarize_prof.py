@@ -1,0 +1,88 @@
+#!/usr/bin/env python3
+"""Condense the output of tools/profile_bench.sh into the small files kept under profiles/.
+
+    python tools/summarize_prof.py gpurun_out/prof profiles/r01/v19
+
+writes  <prefix>_kernel_stats.csv          rocprofv3 --stats table of the default command
+        <prefix>_kernel_stats_nosplit.csv  same with DSV_SPLIT=0 (one launch per kernel per step)
+        <prefix>_pmc_summary.json          per kernel: mean counter value per dispatch
+and refreshes profiles/pmc_latest.json (what bench.py's roofline.traffic / valu_busy_from_pmc
+read) from the k_verify_fixed_half rows.
+"""
+import csv
+import glob
+import json
+import os
+import sys
+from collections import defaultdict
+
+ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+
+
+def short(name):
+    name = name.replace("void ", "")
+    return name.split("(")[0]
+
+
+def main():
+    src, prefix = sys.argv[1], sys.argv[2]
+    for sub, suffix in (("trace", ""), ("trace_nosplit", "_nosplit")):
+        hits = glob.glob(os.path.join(src, sub, "**", "*kernel_stats.csv"), recursive=True)
+        if hits:  # keep the engine's kernels and the runtime copies; torch's helper kernels are noise
+            with open(hits[0]) as f, open("%s_kernel_stats%s.csv" % (prefix, suffix), "w") as g:
+                for i, line in enumerate(f):
+                    if i == 0 or "dsv::" in line or "__amd_rocclr" in line:
+                        g.write(line)
+    acc = defaultdict(lambda: defaultdict(list))
+    dur = defaultdict(list)
+    for path in glob.glob(os.path.join(src, "pmc_*", "**", "*counter_collection.csv"), recursive=True):
+        seen = set()
+        with open(path) as f:
+            for row in csv.DictReader(f):
+                k = short(row["Kernel_Name"])
+                if not k.startswith("dsv::"):
+                    continue
+                acc[k][row["Counter_Name"]].append(float(row["Counter_Value"]))
+                key = (path, row["Dispatch_Id"])
+                if key not in seen:
+                    seen.add(key)
+                    dur[k].append(float(row["End_Timestamp"]) - float(row["Start_Timestamp"]))
+    out = {}
+    for k, counters in sorted(acc.items()):
+        out[k] = {c: {"avg_per_launch": sum(v) / len(v), "launches": len(v)}
+                  for c, v in sorted(counters.items())}
+        out[k]["avg_duration_ns_under_pmc"] = sum(dur[k]) / len(dur[k])
+    with open(prefix + "_pmc_summary.json", "w") as f:
+        json.dump(out, f, indent=1)
+    dom = [k for k in out if k.startswith("dsv::k_verify_fixed_half")]
+    if dom:
+        d = out[dom[0]]
+        stats = {}
+        nos = prefix + "_kernel_stats_nosplit.csv"
+        if os.path.exists(nos):
+            with open(nos) as f:
+                for row in csv.DictReader(f):
+                    if "k_verify_fixed_half" in row["Name"]:
+                        stats = row
+        latest = {
+            "source": "tools/profile_bench.sh + tools/summarize_prof.py -> %s_*; DSV_SPLIT=0 passes, "
+                      "per launch over 2^20 signatures" % os.path.relpath(prefix, ROOT),
+            "kernel": dom[0],
+            "batch": 1 << 20,
+        }
+        for c in ("FETCH_SIZE", "WRITE_SIZE"):
+            if c in d:
+                latest[c + "_KB"] = d[c]["avg_per_launch"]
+        for c in ("SQ_INSTS_VALU", "SQ_WAVE_CYCLES", "GRBM_GUI_ACTIVE"):
+            if c in d:
+                latest[c] = d[c]["avg_per_launch"]
+        if stats:
+            latest["avg_duration_ns"] = float(stats["AverageNs"])
+        with open(os.path.join(ROOT, "profiles", "pmc_latest.json"), "w") as f:
+            json.dump(latest, f, indent=1)
+    print(json.dumps({k: {c: v["avg_per_launch"] for c, v in cs.items() if isinstance(v, dict)}
+                      for k, cs in out.items()}, indent=1)[:3000])
+
+
+if __name__ == "__main__":
+    main()
