@@ -26,10 +26,11 @@
  * cannot hold (scalar >= r, coordinate or message >= q) give ok[i] = 0; off-curve
  * coordinates are out of contract (result unspecified, never a fault).
  *
- * Host entry points take HOST pointers, stage through library-owned device buffers and block
- * until the verdicts are in `ok`.  The *_dev entry points take DEVICE pointers (hipMalloc'd,
- * 16-byte aligned) plus a hipStream_t passed as void*, enqueue only, and never synchronise —
- * they are what the bench times with inputs resident in HBM.
+ * Host entry points take HOST pointers (pageable is fine), stage through library-owned pinned
+ * and device buffers in chunks of 2^17 items (DSV_HOST_THREADS copy threads, default 4) and block
+ * until the verdicts are in `ok`; they serialise on one internal lock.  The *_dev entry points
+ * take DEVICE pointers (hipMalloc'd, 16-byte aligned) plus a hipStream_t passed as void*, enqueue
+ * only, and never synchronise — they are what the bench times with inputs resident in HBM.
  *
  * Return value: DSV_OK (0) or a negative dsv_status; dsv_last_error() gives the text for
  * the calling thread.  The library keeps no pointer after a call returns.  Calls on
@@ -76,7 +77,12 @@ int dsv_verify_single_ext(const uint8_t *u, const uint8_t *R_uvz, const uint8_t 
                           const uint8_t *m, size_t n, uint8_t *ok);
 
 /* ---- verify, device buffers (enqueue only) ----
- * workspace: device scratch of dsv_workspace_bytes(n) bytes, 256-byte aligned */
+ * workspace: device scratch of dsv_workspace_bytes(n) bytes, 256-byte aligned, owned by the call
+ * until its work on `stream` has completed (two calls in flight need two workspaces).
+ * Ordering: everything the call enqueues happens after the work already on `stream` and before
+ * anything enqueued on `stream` afterwards.  Batches of >= 2^17 items are cut into 2^16-item
+ * parts that run on two library-owned streams forked from / joined to `stream` by events
+ * (DSV_SPLIT=0 in the environment at dsv_init keeps every launch on `stream` itself). */
 size_t dsv_workspace_bytes(size_t n);
 int dsv_verify_single_dev(const void *u, const void *R_uv, const void *PK_uv, const void *m,
                           size_t n, void *ok, void *workspace, void *stream);
