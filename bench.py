@@ -154,6 +154,10 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    if world > 1:
+        # communicator set-up (RCCL connects lazily on the first collective) is not a step
+        dist.all_gather_into_tensor(gathered, ok)
+    sync_all()
     for _ in range(args.warmup):
         step()
     sync_all()

@@ -533,3 +533,53 @@ def test_sub_batch_split_boundaries(engine):
                            device="cuda:0")
         sub = [b[k][idx].cpu().numpy() for k in keys]
         assert np.array_equal(ref(*sub), got[idx].cpu().numpy()), (n, kind)
+
+
+def test_out_of_contract_inputs_never_fault(engine):
+    """include/dsv.h: off-curve coordinates are out of contract but must never fault, encodings
+    the Rust types cannot hold give 0, and z = 0 in the ext entry (upstream would panic inside
+    to_hash_inputs) gives 0.  In-contract items mixed into the same batch keep their verdicts."""
+    n = 256
+    d = O.keygen_sign_single(n, 4321)
+    want = np.ones(n, np.uint8)
+    rng = np.random.default_rng(8)
+    u, R, PK, m = (d[k].copy() for k in ("u", "R", "PK", "m"))
+    junk = rng.integers(0, 256, size=(n, 64), dtype=np.uint8)
+    junk[:, 31] &= 0x3F
+    junk[:, 63] &= 0x3F                                     # canonical but (almost surely) off-curve
+    R[0::8] = junk[0::8]
+    PK[1::8] = junk[1::8]
+    R[2::8] = 0xFF                                          # coordinates >= q
+    PK[3::8] = 0xFF
+    u[4::8] = 0xFF                                          # scalar >= r
+    m[5::8] = 0xFF                                          # message >= q
+    got = engine.verify_single(u, R, PK, m)
+    assert set(np.unique(got)) <= {0, 1}
+    for k in (2, 3, 4, 5):
+        assert not got[k::8].any()
+    assert got[6::8].all() and got[7::8].all()              # untouched items
+    assert np.array_equal(got[2:8:1], O.verify_single(u, R, PK, m)[2:8:1])
+    # double and var-generator entry points with the same junk
+    dd = O.keygen_sign_double(64, 5)
+    Rp = dd["Rp"].copy()
+    Rp[0::4] = junk[:16]
+    got = engine.verify_double(dd["u"], dd["R"], Rp, dd["PK"], dd["PKp"], dd["m"])
+    assert set(np.unique(got)) <= {0, 1} and got[1::4].all()
+    dv = O.keygen_sign_vargen(64, 6)
+    Gen = dv["Gen"].copy()
+    Gen[0::4] = junk[:16]
+    got = engine.verify_vargen(dv["u"], dv["R"], dv["PK"], Gen, dv["m"])
+    assert set(np.unique(got)) <= {0, 1} and got[1::4].all()
+    # ext entry: z = 0
+    R_uvz = np.zeros((n, 96), np.uint8)
+    PK_uvz = np.zeros((n, 96), np.uint8)
+    R_uvz[:, :64], PK_uvz[:, :64] = d["R"], d["PK"]
+    R_uvz[:, 64] = 1
+    PK_uvz[:, 64] = 1                                       # z = 1
+    R_uvz[0::2, 64] = 0                                     # z = 0 on every other R
+    PK_uvz[1::4, 64] = 0
+    got = engine.verify_single_ext(d["u"], R_uvz, PK_uvz, d["m"])
+    exp = want.copy()
+    exp[0::2] = 0
+    exp[1::4] = 0
+    assert np.array_equal(got, exp)
