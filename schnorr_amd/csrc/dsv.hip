@@ -1174,8 +1174,8 @@ struct Stager {
 extern "C++" {
 namespace {
 // Chunked host path shared by the three verify entry points.
-//   ins[k] = {host array, bytes per item}; launch(dev_ptrs, count, dok, ws, stream) enqueues the
-//   kernels for one chunk.  Chunk c uses slot c % kPipeSlots.  Per chunk: the copy threads gather
+//   ins[k] = {host array, bytes per item}; launch(dev_ptrs, count, dok, ws, extra, stream) enqueues
+//   the kernels for one chunk.  Chunk c uses slot c % kPipeSlots.  Per chunk: the copy threads gather
 //   the caller's arrays (pageable in general) into the slot's pinned staging, ONE asynchronous
 //   DMA moves the block to the device, the kernels run, the verdict bytes come back into the
 //   pinned block; they are handed to the caller when the slot is recycled.  While the GPU works on
@@ -1198,8 +1198,11 @@ inline int host_copy_threads() {
   return t;
 }
 
+//   extra_item_bytes: further device scratch per item that `launch` needs (decoded points of the
+//   wire-format entry points); handed to it as a Stager positioned behind the workspace.
 template <size_t NIN, class Launch>
-int run_pipelined(const HostIn (&ins)[NIN], uint8_t* ok, size_t n, Launch launch) {
+int run_pipelined(const HostIn (&ins)[NIN], uint8_t* ok, size_t n, size_t extra_item_bytes,
+                  Launch launch) {
   std::lock_guard<std::mutex> lk(g_ctx.mu);
   HIP_TRY(hipSetDevice(g_ctx.device));
   const size_t chunk = n < kPipeChunk ? n : kPipeChunk;
@@ -1208,7 +1211,8 @@ int run_pipelined(const HostIn (&ins)[NIN], uint8_t* ok, size_t n, Launch launch
   for (size_t k = 0; k < NIN; k++) in_off[k + 1] = in_off[k] + align_up(chunk * ins[k].bytes, 256);
   const size_t ok_off = in_off[NIN];
   const size_t host_need = ok_off + align_up(chunk, 256);
-  const size_t dev_need = host_need + dsv_workspace_bytes(chunk);
+  const size_t ws_bytes = align_up(dsv_workspace_bytes(chunk), 256);
+  const size_t dev_need = host_need + ws_bytes + chunk * extra_item_bytes + 16 * 256;
   const size_t nchunks = (n + chunk - 1) / chunk;
   const int nslots = nchunks < (size_t)kPipeSlots ? (int)nchunks : kPipeSlots;
   for (int sl = 0; sl < nslots; sl++)
@@ -1246,7 +1250,8 @@ int run_pipelined(const HostIn (&ins)[NIN], uint8_t* ok, size_t n, Launch launch
     for (size_t k = 0; k < NIN; k++) dptr[k] = dev + in_off[k];
     uint8_t* dok = dev + ok_off;
     uint8_t* ws = dev + host_need;
-    if (int r = launch(dptr, cnt, dok, ws, st)) return r;
+    Stager extra(ws + ws_bytes);
+    if (int r = launch(dptr, cnt, dok, ws, extra, st)) return r;
     HIP_TRY(hipMemcpyAsync(host + ok_off, dok, cnt, hipMemcpyDeviceToHost, st));
     slot_first[sl] = done;
     slot_cnt[sl] = cnt;
@@ -1266,7 +1271,7 @@ int dsv_verify_single(const uint8_t* u, const uint8_t* R_uv, const uint8_t* PK_u
   if (n == 0) return DSV_OK;
   if (!u || !R_uv || !PK_uv || !m || !ok) return fail(DSV_ERR_INVALID_ARGUMENT, "null pointer");
   const HostIn ins[4] = {{u, 32}, {R_uv, 64}, {PK_uv, 64}, {m, 32}};
-  return run_pipelined(ins, ok, n, [](const void* const* d, size_t cnt, void* dok, void* ws, hipStream_t st) {
+  return run_pipelined(ins, ok, n, 0, [](const void* const* d, size_t cnt, void* dok, void* ws, Stager&, hipStream_t st) {
     return dsv_verify_single_dev(d[0], d[1], d[2], d[3], cnt, dok, ws, st);
   });
 }
@@ -1280,7 +1285,7 @@ int dsv_verify_double(const uint8_t* u, const uint8_t* R_uv, const uint8_t* Rp_u
   if (!u || !R_uv || !Rp_uv || !PK_uv || !PKp_uv || !m || !ok)
     return fail(DSV_ERR_INVALID_ARGUMENT, "null pointer");
   const HostIn ins[6] = {{u, 32}, {R_uv, 64}, {Rp_uv, 64}, {PK_uv, 64}, {PKp_uv, 64}, {m, 32}};
-  return run_pipelined(ins, ok, n, [](const void* const* d, size_t cnt, void* dok, void* ws, hipStream_t st) {
+  return run_pipelined(ins, ok, n, 0, [](const void* const* d, size_t cnt, void* dok, void* ws, Stager&, hipStream_t st) {
     return dsv_verify_double_dev(d[0], d[1], d[2], d[3], d[4], d[5], cnt, dok, ws, st);
   });
 }
@@ -1293,7 +1298,7 @@ int dsv_verify_vargen(const uint8_t* u, const uint8_t* R_uv, const uint8_t* PK_u
   if (!u || !R_uv || !PK_uv || !Gen_uv || !m || !ok)
     return fail(DSV_ERR_INVALID_ARGUMENT, "null pointer");
   const HostIn ins[5] = {{u, 32}, {R_uv, 64}, {PK_uv, 64}, {Gen_uv, 64}, {m, 32}};
-  return run_pipelined(ins, ok, n, [](const void* const* d, size_t cnt, void* dok, void* ws, hipStream_t st) {
+  return run_pipelined(ins, ok, n, 0, [](const void* const* d, size_t cnt, void* dok, void* ws, Stager&, hipStream_t st) {
     return dsv_verify_vargen_dev(d[0], d[1], d[2], d[3], d[4], cnt, dok, ws, st);
   });
 }
@@ -1304,29 +1309,19 @@ int dsv_verify_single_ext(const uint8_t* u, const uint8_t* R_uvz, const uint8_t*
   if (int r = check_n(n)) return r;
   if (n == 0) return DSV_OK;
   if (!u || !R_uvz || !PK_uvz || !m || !ok) return fail(DSV_ERR_INVALID_ARGUMENT, "null pointer");
-  std::lock_guard<std::mutex> lk(g_ctx.mu);
-  HIP_TRY(hipSetDevice(g_ctx.device));
-  size_t need = align_up(n * 32, 256) * 2 + align_up(n * 96, 256) * 2 + align_up(n * 64, 256) * 2 +
-                align_up(n, 256) * 2 + dsv_workspace_bytes(n);
-  if (int r = ensure_stage(need)) return r;
-  Stager st(g_ctx.stage);
-  uint8_t *du = st.take(n * 32), *dRz = st.take(n * 96), *dPKz = st.take(n * 96),
-          *dR = st.take(n * 64), *dPK = st.take(n * 64), *dm = st.take(n * 32), *dok = st.take(n),
-          *dvalid = st.take(n), *ws = st.take(dsv_workspace_bytes(n));
-  H2D(du, u, n * 32);
-  H2D(dRz, R_uvz, n * 96);
-  H2D(dPKz, PK_uvz, n * 96);
-  H2D(dm, m, n * 32);
-  hipLaunchKernelGGL(k_normalize_uvz, dim3(grid_for(n)), dim3(256), 0, 0, (const uint8_t*)dRz, n,
-                     dR, dvalid, 0);
-  hipLaunchKernelGGL(k_normalize_uvz, dim3(grid_for(n)), dim3(256), 0, 0, (const uint8_t*)dPKz, n,
-                     dPK, dvalid, 1);
-  if (int r = dsv_verify_single_dev(du, dR, dPK, dm, n, dok, ws, nullptr)) return r;
-  hipLaunchKernelGGL(k_and_bytes, dim3(grid_for(n)), dim3(256), 0, 0, dok, (const uint8_t*)dvalid, n);
-  HIP_TRY(hipGetLastError());
-  D2H(ok, dok, n);
-  HIP_TRY(hipStreamSynchronize(0));
-  return DSV_OK;
+  const HostIn ins[4] = {{u, 32}, {R_uvz, 96}, {PK_uvz, 96}, {m, 32}};
+  return run_pipelined(ins, ok, n, 64 + 64 + 1, [](const void* const* d, size_t cnt, void* dok, void* ws, Stager& x, hipStream_t st) {
+    uint8_t *dR = x.take(cnt * 64), *dPK = x.take(cnt * 64), *dvalid = x.take(cnt);
+    hipLaunchKernelGGL(k_normalize_uvz, dim3(grid_for(cnt)), dim3(256), 0, st, (const uint8_t*)d[1], cnt,
+                       dR, dvalid, 0);
+    hipLaunchKernelGGL(k_normalize_uvz, dim3(grid_for(cnt)), dim3(256), 0, st, (const uint8_t*)d[2], cnt,
+                       dPK, dvalid, 1);
+    if (int r = dsv_verify_single_dev(d[0], dR, dPK, d[3], cnt, dok, ws, st)) return r;
+    hipLaunchKernelGGL(k_and_bytes, dim3(grid_for(cnt)), dim3(256), 0, st, (uint8_t*)dok,
+                       (const uint8_t*)dvalid, cnt);
+    HIP_TRY(hipGetLastError());
+    return (int)DSV_OK;
+  });
 }
 
 int dsv_challenge_single(const uint8_t* R_uv, const uint8_t* m, size_t n, uint8_t* c) {
@@ -1566,36 +1561,28 @@ namespace {
 int verify_wire(int kind, const uint8_t* sig, const uint8_t* pk, const uint8_t* m, size_t n,
                 uint8_t* ok) {
   const size_t sig_bytes = kind == 1 ? 96 : 64, pk_bytes = kind == 0 ? 32 : 64;
-  std::lock_guard<std::mutex> lk(g_ctx.mu);
-  HIP_TRY(hipSetDevice(g_ctx.device));
-  size_t need = align_up(n * sig_bytes, 256) + align_up(n * pk_bytes, 256) + 2 * align_up(n * 32, 256) +
-                4 * align_up(n * 64, 256) + 2 * align_up(n, 256) + dsv_workspace_bytes(n);
-  if (int r = ensure_stage(need)) return r;
-  Stager st(g_ctx.stage);
-  uint8_t *dsig = st.take(n * sig_bytes), *dpk = st.take(n * pk_bytes), *dm = st.take(n * 32),
-          *du = st.take(n * 32), *dR = st.take(n * 64), *dRp = st.take(n * 64),
-          *dP0 = st.take(n * 64), *dP1 = st.take(n * 64), *dvalid = st.take(n), *dok = st.take(n),
-          *ws = st.take(dsv_workspace_bytes(n));
-  H2D(dsig, sig, n * sig_bytes);
-  H2D(dpk, pk, n * pk_bytes);
-  H2D(dm, m, n * 32);
-  hipLaunchKernelGGL(k_gather32, dim3(grid_for(n)), dim3(256), 0, 0, (const uint8_t*)dsig, sig_bytes, n, du);
-  if (int r = dsv_decompress_points_dev(dsig + 32, sig_bytes, n, dR, dvalid, 0, nullptr)) return r;
-  if (kind == 1)
-    if (int r = dsv_decompress_points_dev(dsig + 64, sig_bytes, n, dRp, dvalid, 1, nullptr)) return r;
-  if (int r = dsv_decompress_points_dev(dpk, pk_bytes, n, dP0, dvalid, 1, nullptr)) return r;
-  if (kind != 0)
-    if (int r = dsv_decompress_points_dev(dpk + 32, pk_bytes, n, dP1, dvalid, 1, nullptr)) return r;
-  int rc;
-  if (kind == 0) rc = dsv_verify_single_dev(du, dR, dP0, dm, n, dok, ws, nullptr);
-  else if (kind == 1) rc = dsv_verify_double_dev(du, dR, dRp, dP0, dP1, dm, n, dok, ws, nullptr);
-  else rc = dsv_verify_vargen_dev(du, dR, dP0, dP1, dm, n, dok, ws, nullptr);
-  if (rc) return rc;
-  hipLaunchKernelGGL(k_and_bytes, dim3(grid_for(n)), dim3(256), 0, 0, dok, (const uint8_t*)dvalid, n);
-  HIP_TRY(hipGetLastError());
-  D2H(ok, dok, n);
-  HIP_TRY(hipStreamSynchronize(0));
-  return DSV_OK;
+  const HostIn ins[3] = {{sig, sig_bytes}, {pk, pk_bytes}, {m, 32}};
+  return run_pipelined(ins, ok, n, 32 + 4 * 64 + 1, [=](const void* const* d, size_t cnt, void* dok, void* ws, Stager& x, hipStream_t st) {
+    const uint8_t *dsig = (const uint8_t*)d[0], *dpk = (const uint8_t*)d[1];
+    uint8_t *du = x.take(cnt * 32), *dR = x.take(cnt * 64), *dRp = x.take(cnt * 64),
+            *dP0 = x.take(cnt * 64), *dP1 = x.take(cnt * 64), *dvalid = x.take(cnt);
+    hipLaunchKernelGGL(k_gather32, dim3(grid_for(cnt)), dim3(256), 0, st, dsig, sig_bytes, cnt, du);
+    if (int r = dsv_decompress_points_dev(dsig + 32, sig_bytes, cnt, dR, dvalid, 0, st)) return r;
+    if (kind == 1)
+      if (int r = dsv_decompress_points_dev(dsig + 64, sig_bytes, cnt, dRp, dvalid, 1, st)) return r;
+    if (int r = dsv_decompress_points_dev(dpk, pk_bytes, cnt, dP0, dvalid, 1, st)) return r;
+    if (kind != 0)
+      if (int r = dsv_decompress_points_dev(dpk + 32, pk_bytes, cnt, dP1, dvalid, 1, st)) return r;
+    int rc;
+    if (kind == 0) rc = dsv_verify_single_dev(du, dR, dP0, d[2], cnt, dok, ws, st);
+    else if (kind == 1) rc = dsv_verify_double_dev(du, dR, dRp, dP0, dP1, d[2], cnt, dok, ws, st);
+    else rc = dsv_verify_vargen_dev(du, dR, dP0, dP1, d[2], cnt, dok, ws, st);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_and_bytes, dim3(grid_for(cnt)), dim3(256), 0, st, (uint8_t*)dok,
+                       (const uint8_t*)dvalid, cnt);
+    HIP_TRY(hipGetLastError());
+    return (int)DSV_OK;
+  });
 }
 }  // namespace
 

@@ -583,3 +583,39 @@ def test_out_of_contract_inputs_never_fault(engine):
     exp[0::2] = 0
     exp[1::4] = 0
     assert np.array_equal(got, exp)
+
+
+def test_wire_and_ext_entries_multi_chunk(engine):
+    """The serialized-record and projective entry points run through the same chunked host
+    pipeline as dsv_verify_single: more than one 2^17-item chunk plus a ragged tail."""
+    import torch
+    from schnorr_amd import workload as W
+    n = (1 << 17) + 4321
+    b = W.gen_single(n, seed=31337)
+    h = {k: b[k].cpu().numpy() for k in ("u", "R", "PK", "m")}
+    want = b["expected"].cpu().numpy()
+    sig = np.concatenate([h["u"], O.compress(h["R"])], axis=1)
+    pk = O.compress(h["PK"])
+    got = engine.verify_single_wire(sig, pk, h["m"])
+    assert np.array_equal(got, want)
+    # a corrupted record in the second chunk: v >= q cannot be decoded -> 0
+    sig2 = sig.copy()
+    j = (1 << 17) + 5
+    sig2[j, 32:64] = 0xFF
+    got2 = engine.verify_single_wire(sig2, pk, h["m"])
+    want2 = want.copy()
+    want2[j] = 0
+    assert np.array_equal(got2, want2)
+    idx = np.arange(j - 8, j + 8)
+    assert np.array_equal(O.verify_single_wire(sig2[idx], pk[idx], h["m"][idx]), got2[idx])
+    # projective entry: z = 1 everywhere except a stripe with z = 3
+    R_uvz = np.zeros((n, 96), np.uint8)
+    PK_uvz = np.zeros((n, 96), np.uint8)
+    R_uvz[:, :64], PK_uvz[:, :64] = h["R"], h["PK"]
+    R_uvz[:, 64] = 1
+    PK_uvz[:, 64] = 1
+    for i in range(0, n, 9973):
+        uu, vv = H.to_int_point(h["R"][i])
+        R_uvz[i] = np.frombuffer(M.le32(uu * 3 % M.Q) + M.le32(vv * 3 % M.Q) + M.le32(3), np.uint8)
+    got3 = engine.verify_single_ext(h["u"], R_uvz, PK_uvz, h["m"])
+    assert np.array_equal(got3, want)
