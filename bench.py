@@ -348,6 +348,15 @@ def main():
         th = time.perf_counter() - th0
         out["host_path"] = {"value": hs / th, "unit": "verifies/s",
                             "note": "dsv_verify_single on %d host-resident items incl. PCIe staging" % hs}
+        # BASELINE configs[0] size through the same host entry point: latency of a 1024-item call
+        E.verify_single(hu[:1024], hR[:1024], hPK[:1024], hm[:1024])
+        tl0 = time.perf_counter()
+        for _ in range(20):
+            E.verify_single(hu[:1024], hR[:1024], hPK[:1024], hm[:1024])
+        tl = (time.perf_counter() - tl0) / 20
+        out["small_batch"] = {"ms_per_call": tl * 1e3, "value": 1024 / tl, "unit": "verifies/s",
+                              "workload": "1024 single signatures per call, host buffers "
+                                          "(BASELINE configs[0] size)"}
 
     if rank == 0:
         print(json.dumps(out))
