@@ -11,7 +11,9 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 ORACLE_DIR = os.path.join(os.path.dirname(_HERE), "oracle")
-_SO = os.path.join(ORACLE_DIR, "libschnorr_oracle.so")
+# ORACLE_SO: alternative build of the same source (e.g. `make -C oracle asan` + LD_PRELOAD of
+# libasan), never a different implementation
+_SO = os.environ.get("ORACLE_SO") or os.path.join(ORACLE_DIR, "libschnorr_oracle.so")
 
 
 def build(force=False):
