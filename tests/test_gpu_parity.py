@@ -619,3 +619,53 @@ def test_wire_and_ext_entries_multi_chunk(engine):
         R_uvz[i] = np.frombuffer(M.le32(uu * 3 % M.Q) + M.le32(vv * 3 % M.Q) + M.le32(3), np.uint8)
     got3 = engine.verify_single_ext(h["u"], R_uvz, PK_uvz, h["m"])
     assert np.array_equal(got3, want)
+
+
+def test_concurrent_callers_on_their_own_streams(engine):
+    """include/dsv.h: calls on different streams may run concurrently.  Two host threads enqueue
+    split batches (they share the library's two internal streams) and a third uses the host entry
+    point at the same time; every verdict vector must match its construction-time pattern."""
+    import threading
+    import torch
+    from schnorr_amd import workload as W
+    n = (1 << 17) + 321
+    batches = [W.gen_single(n, seed=100 + t) for t in range(2)]
+    hb = W.gen_single(50000, seed=7)
+    host = {k: hb[k].cpu().numpy() for k in ("u", "R", "PK", "m")}
+    host_want = hb["expected"].cpu().numpy()
+    torch.cuda.synchronize()
+    errors = []
+
+    def dev_worker(t):
+        try:
+            b = batches[t]
+            st = torch.cuda.Stream()
+            ws = torch.empty(engine.workspace_bytes(n), dtype=torch.uint8, device="cuda:0")
+            ok = torch.zeros(n, dtype=torch.uint8, device="cuda:0")
+            torch.cuda.synchronize()
+            for _ in range(6):
+                ok.zero_()
+                st.wait_stream(torch.cuda.current_stream())
+                engine.verify_single_dev(b["u"], b["R"], b["PK"], b["m"], ok, ws, stream=st)
+                st.synchronize()
+                if not torch.equal(ok, b["expected"]):
+                    errors.append("device thread %d: wrong verdicts" % t)
+        except Exception as e:  # noqa: BLE001
+            errors.append("device thread %d: %r" % (t, e))
+
+    def host_worker():
+        try:
+            for _ in range(6):
+                got = engine.verify_single(host["u"], host["R"], host["PK"], host["m"])
+                if not np.array_equal(got, host_want):
+                    errors.append("host thread: wrong verdicts")
+        except Exception as e:  # noqa: BLE001
+            errors.append("host thread: %r" % (e,))
+
+    threads = [threading.Thread(target=dev_worker, args=(t,)) for t in range(2)]
+    threads.append(threading.Thread(target=host_worker))
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    assert not errors, errors
