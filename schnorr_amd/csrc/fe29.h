@@ -48,6 +48,7 @@ __device__ constexpr u32 kQ29[NL] = DSV_Q29;
 __device__ constexpr u32 kBias2[NL] = DSV_BIAS2;
 __device__ constexpr u32 kBias4[NL] = DSV_BIAS4;
 __device__ constexpr u32 kBias8[NL] = DSV_BIAS8;
+__device__ constexpr u32 kBias4W[NL] = DSV_BIAS4W;
 __device__ constexpr u32 kQx1[NL] = DSV_Q29_X1;
 __device__ constexpr u32 kQx2[NL] = DSV_Q29_X2;
 __device__ constexpr u32 kQx4[NL] = DSV_Q29_X4;
@@ -198,17 +199,34 @@ DSV_DEV Fe fe_carry(const Fe& a) {
   return r;
 }
 template <int K>
-DSV_DEV Fe fe_sub_bias(const Fe& a, const Fe& b) {
+DSV_DEV Fe fe_sub_bias_raw(const Fe& a, const Fe& b) {
   Fe r;
 #pragma unroll
   for (int i = 0; i < NL; i++) {
     const u32 bias = (K == 2) ? kBias2[i] : (K == 4) ? kBias4[i] : kBias8[i];
     r.l[i] = a.l[i] + (bias - b.l[i]);
   }
-  return fe_carry(r);
+  return r;
+}
+template <int K>
+DSV_DEV Fe fe_sub_bias(const Fe& a, const Fe& b) {
+  return fe_carry(fe_sub_bias_raw<K>(a, b));
 }
 DSV_DEV Fe fe_sub2(const Fe& a, const Fe& b) { return fe_sub_bias<2>(a, b); }
+// a + 2q - b WITHOUT the carry pass: limbs up to a.l + bias2 limb (< 2^31).  Only for results
+// whose every use is a multiplication by an operand with limbs < 2^30 (or fe_sub4w): the column
+// sums of that product still fit 64 bits — proved for the worst case by tests/fe29_bounds.py
+// (the blanket 1.5 * 2^60 per-product contract above is sufficient, not necessary).
+DSV_DEV Fe fe_sub2_raw(const Fe& a, const Fe& b) { return fe_sub_bias_raw<2>(a, b); }
 DSV_DEV Fe fe_sub4(const Fe& a, const Fe& b) { return fe_sub_bias<4>(a, b); }
+// a + 4q - b for an un-carried subtrahend (a fe_sub2_raw result, limbs < 2^31): the bias limbs
+// are lifted to >= 2^31 - 4.  a limbs < 2^30.  One carry pass.
+DSV_DEV Fe fe_sub4w(const Fe& a, const Fe& b) {
+  Fe r;
+#pragma unroll
+  for (int i = 0; i < NL; i++) r.l[i] = a.l[i] + (kBias4W[i] - b.l[i]);
+  return fe_carry(r);
+}
 DSV_DEV Fe fe_sub8(const Fe& a, const Fe& b) { return fe_sub_bias<8>(a, b); }
 DSV_DEV Fe fe_neg2(const Fe& b) { return fe_sub_bias<2>(fe_zero(), b); }
 

@@ -156,6 +156,8 @@ def main():
         w("#define DSV_BIAS2 %s\n" % arr(bias(2, 30)))
         w("#define DSV_BIAS4 %s\n" % arr(bias(4, 30)))
         w("#define DSV_BIAS8 %s\n" % arr(bias(8, 30)))
+        w("// 4q with limbs 0..7 lifted to >= 2^31-4: dominates an un-carried fe_sub2_raw result\n")
+        w("#define DSV_BIAS4W %s\n" % arr(bias(4, 31)))
         w("// canonical multiples of q (fully normalized limbs) for the final reduction\n")
         for k in (1, 2, 4, 8):
             w("#define DSV_Q29_X%d %s\n" % (k, arr(limbs(k * Q))))

@@ -10,8 +10,11 @@
 //
 // Lazy-reduction bookkeeping (bounds in units of q, "N" = output of fe_mul, < 1.5 q,
 // limbs < 2^29): every fe_add result feeds a multiply directly (limbs < 2^30); every
-// subtraction goes through a biased subtract + one carry pass.  The worst case of each
-// formula is annotated inline and re-checked numerically by tests/test_fe29_model.py.
+// subtraction goes through a biased subtract + one carry pass, except the ones marked "raw" whose
+// every consumer is a multiplication by a carried operand (or fe_sub4w, whose bias is lifted to
+// dominate them).  The worst case of each formula is
+// annotated inline, PROVED for all inputs by the interval prover tests/fe29_bounds.py and
+// re-checked numerically by tests/test_fe29_model.py.
 #pragma once
 #include "fe29.h"
 
@@ -62,8 +65,8 @@ DSV_DEV Ext ext_double(const Ext& p) {
   Fe zz2 = fe_dbl(fe_sqr(p.z));             // < 2.1, limbs < 2^30
   Fe cu = fe_dbl(fe_mul(p.u, p.v));         // 2uv = (u+v)^2 - u^2 - v^2 without the subtraction; < 2.1
   Fe vpu = fe_add(vv, uu);                  // < 2.1, limbs < 2^30
-  Fe vmu = fe_sub2(vv, uu);                 // < 3.1
-  Fe ct = fe_sub4(zz2, vmu);                // < 6.1
+  Fe vmu = fe_sub2_raw(vv, uu);             // < 3.1, limbs < 2^31 (partners vpu < 2^30, ct carried)
+  Fe ct = fe_sub4w(zz2, vmu);               // < 6.1, carried
   Ext r;
   r.u = fe_mul(cu, ct);                     // 2.1*6.1*0.01414+1 = 1.2
   r.v = fe_mul(vpu, vmu);                   // < 1.1
@@ -80,8 +83,8 @@ DSV_DEV void ext_double_uvz(Fe& u, Fe& v, Fe& z) {
   Fe zz2 = fe_dbl(fe_sqr(z));
   Fe cu = fe_dbl(fe_mul(u, v));
   Fe vpu = fe_add(vv, uu);
-  Fe vmu = fe_sub2(vv, uu);
-  Fe ct = fe_sub4(zz2, vmu);
+  Fe vmu = fe_sub2_raw(vv, uu);
+  Fe ct = fe_sub4w(zz2, vmu);
   u = fe_mul(cu, ct);
   v = fe_mul(vpu, vmu);
   z = fe_mul(vmu, ct);
@@ -89,7 +92,7 @@ DSV_DEV void ext_double_uvz(Fe& u, Fe& v, Fe& z) {
 
 // shared tail of both additions.  a, b, c < 1.2 (N);  d < 3.0 with limbs < 2^30
 DSV_DEV Ext ext_add_tail(const Fe& a, const Fe& b, const Fe& c, const Fe& d) {
-  Fe cu = fe_sub2(b, a);                    // < 3.2
+  Fe cu = fe_sub2_raw(b, a);                // < 3.2, limbs < 1.5 * 2^30 (partners cz, ct, t2 < 2^30)
   Fe cv = fe_add(b, a);                     // < 2.4, limbs < 2^30
   Fe cz = fe_carry(fe_add(d, c));           // < 4.2, carried
   Fe ct = fe_sub2(d, c);                    // < 5.0
@@ -101,16 +104,17 @@ DSV_DEV Ext ext_add_tail(const Fe& a, const Fe& b, const Fe& c, const Fe& d) {
   r.t2 = cv;
   return r;
 }
-// p: u,v,z N; t1 < 5.2 carried, t2 < 2.4 limbs < 2^30.   n: all N, limbs < 2^29
+// p: u,v,z N; t1 < 3.2 (limbs < 1.5 * 2^30 when it comes from an addition), t2 < 2.4 limbs < 2^30.
+// n: all N / carried, limbs < 2^29 + 3
 DSV_DEV Ext ext_add_niels(const Ext& p, const Niels& n) {
-  Fe a = fe_mul(fe_sub2(p.v, p.u), n.vmu);  // 3.5*1.5 -> < 1.08
+  Fe a = fe_mul(fe_sub2_raw(p.v, p.u), n.vmu);  // 3.5*1.5 -> < 1.08; raw limbs x table limbs < 2^29 + 3
   Fe b = fe_mul(fe_add(p.v, p.u), n.vpu);   // 3.0*1.5 -> < 1.07
   Fe c = fe_mul(fe_mul(p.t1, p.t2), n.t2d); // (5.2*2.4 -> 1.18) * 1.5 -> < 1.03
   Fe d = fe_dbl(fe_mul(p.z, n.z));          // < 2.1, limbs < 2^30
   return ext_add_tail(a, b, c, d);
 }
 DSV_DEV Ext ext_add_aniels(const Ext& p, const ANiels& n) {
-  Fe a = fe_mul(fe_sub2(p.v, p.u), n.vmu);
+  Fe a = fe_mul(fe_sub2_raw(p.v, p.u), n.vmu);
   Fe b = fe_mul(fe_add(p.v, p.u), n.vpu);
   Fe c = fe_mul(fe_mul(p.t1, p.t2), n.t2d);
   Fe d = fe_dbl(p.z);                       // < 3.0, limbs < 2^30

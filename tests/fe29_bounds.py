@@ -1,0 +1,283 @@
+"""Worst-case bound prover for schnorr_amd/csrc/fe29.h + jubjub29.h.  TEST INFRA.
+
+tests/fe29_model.py executes the limb code on concrete values and asserts that nothing overflows
+on THOSE values.  This module is the complement: an abstract interpretation in which a field
+element is (per-limb upper bounds, value upper bound), every limb and value is assumed to be
+anything in [0, bound], and each device operation maps bounds to bounds while asserting that no
+32-bit limb, 64-bit column or biased subtraction can overflow / underflow for ANY input inside
+the bounds.  All operations are monotone in their inputs, so evaluating them at the upper bounds
+gives valid upper bounds of the results.
+
+The point-level functions mirror jubjub29.h line by line.  `prove_group_law()` iterates them from
+the widest inputs the kernels can produce until the bounds stop growing (a fixpoint) — i.e. it
+proves the lazy-reduction bookkeeping of an arbitrarily long double/add chain.
+"""
+import os
+import re
+
+Q = 0x73EDA753299D7D483339D80809A1D80553BDA402FFFE5BFEFFFFFFFF00000001
+NL, LB = 9, 29
+M29 = (1 << LB) - 1
+RBITS = NL * LB
+U32, U64 = 1 << 32, 1 << 64
+
+_HDR = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "schnorr_amd", "csrc",
+                    "dsv_constants.h")
+
+
+def _load(name):
+    text = open(_HDR).read()
+    m = re.search(r"#define %s \{([^}]*)\}" % name, text)
+    return [int(x.strip().rstrip("u"), 16) for x in m.group(1).split(",")]
+
+
+Q29 = _load("DSV_Q29")
+BIAS = {2: _load("DSV_BIAS2"), 4: _load("DSV_BIAS4"), 8: _load("DSV_BIAS8"),
+        "4w": _load("DSV_BIAS4W")}
+BIAS_MULT = {2: 2, 4: 4, 8: 8, "4w": 4}
+for _k, _b in BIAS.items():  # the redundant-limb biases are exact multiples of q
+    assert sum(x << (LB * i) for i, x in enumerate(_b)) == BIAS_MULT[_k] * Q
+
+
+class OverflowError_(AssertionError):
+    pass
+
+
+def _check(cond, msg):
+    if not cond:
+        raise OverflowError_(msg)
+
+
+class B:
+    """Bounds of one field element: l[i] = max of limb i, v = max of the integer value."""
+
+    __slots__ = ("l", "v")
+
+    def __init__(self, limbs, v=None):
+        self.l = list(limbs)
+        full = sum(x << (LB * i) for i, x in enumerate(self.l))
+        self.v = full if v is None else min(v, full)
+        # the top limb can never exceed what the value allows (lower limbs are >= 0)
+        self.l[NL - 1] = min(self.l[NL - 1], self.v >> (LB * (NL - 1)))
+
+    def __repr__(self):
+        return "B(limbs<=%s, v<=%.3f q)" % ([hex(x) for x in self.l], self.v / Q)
+
+
+def join(a, b):
+    return B([max(x, y) for x, y in zip(a.l, b.l)], max(a.v, b.v))
+
+
+def leq(a, b):
+    return all(x <= y for x, y in zip(a.l, b.l)) and a.v <= b.v
+
+
+def const(limbs):
+    return B(limbs)
+
+
+def canonical():
+    """any canonical residue (< q, limbs < 2^29) — table entries, decoded inputs"""
+    return B([M29] * NL, Q - 1)
+
+
+# ---- fe29.h ---------------------------------------------------------------------------------
+def _reduce(cols, vprod):
+    """fe_reduce_cols on column maxima (without the +M29 bias, added here like the device does)"""
+    c = list(cols) + [0]
+    k = 0
+    for i in range(NL):
+        c[i] += M29
+        s = c[i] + k
+        _check(s < U64, "reduction: column %d + carry overflows 64 bits" % i)
+        k = s >> LB
+        for j in range(1, NL):
+            c[i + j] += M29 * Q29[j]
+            _check(c[i + j] < U64, "reduction: column %d overflows 64 bits" % (i + j))
+    out = []
+    for i in range(NL - 1):
+        s = c[NL + i] + k
+        _check(s < U64, "normalisation: column overflows 64 bits")
+        out.append(min(s, M29))
+        k = s >> LB
+    _check(k < U32, "top limb of a product exceeds 32 bits")
+    out.append(k)
+    # value: (a*b + m*q) / 2^261 with m < 2^261
+    v = (vprod + ((1 << RBITS) - 1) * Q) >> RBITS
+    return B(out, v)
+
+
+def mul(a, b):
+    for x in a.l + b.l:
+        _check(x < U32, "multiplier limb exceeds 32 bits")
+    c = [0] * 17
+    for i in range(NL):
+        for j in range(NL):
+            c[i + j] += a.l[i] * b.l[j]
+    for k, x in enumerate(c):
+        _check(x + M29 < U64, "product column %d overflows 64 bits" % k)
+    return _reduce(c, a.v * b.v)
+
+
+def sqr(a):
+    for x in a.l:
+        _check(2 * x < U32, "doubled limb of a squaring exceeds 32 bits")
+    return mul(a, a)
+
+
+def dot(avec, bvec):
+    c = [0] * 17
+    vprod = 0
+    for a, b in zip(avec, bvec):
+        for x in a.l + b.l:
+            _check(x < U32, "multiplier limb exceeds 32 bits")
+        for i in range(NL):
+            for j in range(NL):
+                c[i + j] += a.l[i] * b.l[j]
+        vprod += a.v * b.v
+    for k, x in enumerate(c):
+        _check(x + M29 < U64, "dot-product column %d overflows 64 bits" % k)
+    return _reduce(c, vprod)
+
+
+def add(a, b):
+    r = [x + y for x, y in zip(a.l, b.l)]
+    for x in r:
+        _check(x < U32, "limb-wise add exceeds 32 bits")
+    return B(r, a.v + b.v)
+
+
+def dbl(a):
+    return add(a, a)
+
+
+def carry(a):
+    for x in a.l:
+        _check(x < U32, "carry-pass input exceeds 32 bits")
+    r = [min(a.l[0], M29)]
+    for i in range(1, NL - 1):
+        r.append(min(a.l[i], M29) + (a.l[i - 1] >> LB))
+    r.append(a.l[NL - 1] + (a.l[NL - 2] >> LB))
+    for x in r:
+        _check(x < U32, "carry-pass output exceeds 32 bits")
+    return B(r, a.v)
+
+
+def sub_raw(a, b, k):
+    """a + (bias_k - b) limb-wise, WITHOUT the carry pass"""
+    bias = BIAS[k]
+    r = []
+    for i in range(NL):
+        _check(bias[i] >= b.l[i], "bias%s limb %d (%#x) does not dominate the subtrahend (%#x)"
+               % (k, i, bias[i], b.l[i]))
+        x = a.l[i] + bias[i]
+        _check(x < U32, "biased subtraction exceeds 32 bits")
+        r.append(x)
+    return B(r, a.v + BIAS_MULT[k] * Q)
+
+
+def sub(a, b, k):
+    return carry(sub_raw(a, b, k))
+
+
+def equal_ok(a, b):
+    """fe_equal(a, b): sub8 then canon (value < 16 q, limbs < 2^31 for the ripple)"""
+    d = sub(a, b, 8)
+    for x in d.l:
+        _check(x < (1 << 31), "fe_ripple input limb exceeds 2^31")
+    _check(d.v < 16 * Q, "fe_canon input exceeds 16 q")
+
+
+# ---- jubjub29.h -----------------------------------------------------------------------------
+def ext_double(p):
+    uu, vv = sqr(p["u"]), sqr(p["v"])
+    zz2 = dbl(sqr(p["z"]))
+    cu = dbl(mul(p["u"], p["v"]))
+    vpu = add(vv, uu)
+    vmu = sub_raw(vv, uu, 2)
+    ct = sub(zz2, vmu, "4w")
+    return {"u": mul(cu, ct), "v": mul(vpu, vmu), "z": mul(vmu, ct), "t1": cu, "t2": vpu}
+
+
+def _add_tail(a, b, c, d):
+    cu = sub_raw(b, a, 2)
+    cv = add(b, a)
+    cz = carry(add(d, c))
+    ct = sub(d, c, 2)
+    return {"u": mul(cu, ct), "v": mul(cv, cz), "z": mul(cz, ct), "t1": cu, "t2": cv}
+
+
+def ext_add_niels(p, n):
+    a = mul(sub_raw(p["v"], p["u"], 2), n["vmu"])
+    b = mul(add(p["v"], p["u"]), n["vpu"])
+    c = mul(mul(p["t1"], p["t2"]), n["t2d"])
+    d = dbl(mul(p["z"], n["z"]))
+    return _add_tail(a, b, c, d)
+
+
+def ext_add_aniels(p, n):
+    a = mul(sub_raw(p["v"], p["u"], 2), n["vmu"])
+    b = mul(add(p["v"], p["u"]), n["vpu"])
+    c = mul(mul(p["t1"], p["t2"]), n["t2d"])
+    d = dbl(p["z"])
+    return _add_tail(a, b, c, d)
+
+
+def ext_to_niels(p, d2):
+    return {"vpu": carry(add(p["v"], p["u"])), "vmu": sub(p["v"], p["u"], 2), "z": p["z"],
+            "t2d": mul(mul(p["t1"], p["t2"]), d2)}
+
+
+def table_entry(p, d2):
+    """What load_var_entry can hand to ext_add_niels for an entry built from p: a negated entry
+    swaps vpu/vmu and reads fe_neg2(t2d) (store_var_entry / load_var_entry in dsv.hip), so every
+    role must tolerate either bound."""
+    n = ext_to_niels(p, d2)
+    both = join(n["vpu"], n["vmu"])
+    return {"vpu": both, "vmu": both, "z": n["z"],
+            "t2d": join(n["t2d"], sub(B([0] * NL), n["t2d"], 2))}
+
+
+def widen(b):
+    """round the bounds up to a coarse grid so that the geometric convergence of the value bounds
+    (v -> v*v/R + q) ends in finitely many steps"""
+    g = Q >> 8
+    limbs = list(b.l)
+    limbs[NL - 1] = -(-limbs[NL - 1] // 4096) * 4096
+    return B(limbs, -(-b.v // g) * g)
+
+
+def join_pt(p, q):
+    return {k: join(p[k], q[k]) for k in p}
+
+
+def leq_pt(p, q):
+    return all(leq(p[k], q[k]) for k in p)
+
+
+def prove_group_law(max_rounds=40):
+    """Fixpoint of: accumulator -> {double, add niels (table of a variable base), add affine niels
+    (fixed-base table)}; niels entries -> to_niels of any accumulator the table build produces.
+    Returns the invariant bounds; raises OverflowError_ if any step can overflow."""
+    d2 = canonical()
+    mont_in = mul(canonical(), canonical())          # fe_to_mont of a decoded coordinate
+    acc = {"u": mont_in, "v": mont_in, "z": mont_in, "t1": mont_in, "t2": mont_in}
+    fixed = {"vpu": canonical(), "vmu": canonical(), "t2d": canonical()}
+    niels = table_entry(acc, d2)
+    for rnd in range(max_rounds):
+        nxt = join_pt(acc, ext_double(acc))
+        nxt = join_pt(nxt, ext_add_niels(acc, niels))
+        nxt = join_pt(nxt, ext_add_aniels(acc, fixed))
+        nn = join_pt(niels, table_entry(nxt, d2))
+        if rnd >= 2:
+            nxt = {k: widen(v) for k, v in nxt.items()}
+            nn = {k: widen(v) for k, v in nn.items()}
+        if leq_pt(nxt, acc) and leq_pt(nn, niels):
+            # final comparisons of the kernels: ext_eq_affine and the identity test
+            equal_ok(acc["u"], mul(mont_in, acc["z"]))
+            equal_ok(acc["v"], mul(mont_in, acc["z"]))
+            equal_ok(acc["u"], B([0] * NL))
+            equal_ok(acc["v"], acc["z"])
+            return {"acc": acc, "niels": niels, "rounds": rnd}
+        acc, niels = nxt, nn
+    raise OverflowError_("bounds keep growing: no fixpoint after %d rounds" % max_rounds)

@@ -24,7 +24,9 @@ def _load(name):
 
 
 Q29 = _load("DSV_Q29")
-BIAS = {2: _load("DSV_BIAS2"), 4: _load("DSV_BIAS4"), 8: _load("DSV_BIAS8")}
+BIAS = {2: _load("DSV_BIAS2"), 4: _load("DSV_BIAS4"), 8: _load("DSV_BIAS8"),
+        "4w": _load("DSV_BIAS4W")}
+BIAS_MULT = {2: 2, 4: 4, 8: 8, "4w": 4}
 QX = {1: _load("DSV_Q29_X1"), 2: _load("DSV_Q29_X2"), 4: _load("DSV_Q29_X4"), 8: _load("DSV_Q29_X8")}
 R2 = _load("DSV_R2")
 ONE = _load("DSV_ONE")
@@ -125,7 +127,7 @@ def carry(a):
     return r
 
 
-def sub(a, b, k):
+def sub_raw(a, b, k):
     bias = BIAS[k]
     r = []
     for i in range(NL):
@@ -133,7 +135,11 @@ def sub(a, b, k):
         x = a[i] + (bias[i] - b[i])
         assert x < U32
         r.append(x)
-    return carry(r)
+    return r
+
+
+def sub(a, b, k):
+    return carry(sub_raw(a, b, k))
 
 
 def ripple(a):
@@ -196,13 +202,13 @@ def ext_double(p):
     zz2 = dbl(sqr(p["z"]))
     cu = dbl(mul(p["u"], p["v"]))
     vpu = add(vv, uu)
-    vmu = sub(vv, uu, 2)
-    ct = sub(zz2, vmu, 4)
+    vmu = sub_raw(vv, uu, 2)
+    ct = sub(zz2, vmu, "4w")
     return {"u": mul(cu, ct), "v": mul(vpu, vmu), "z": mul(vmu, ct), "t1": cu, "t2": vpu}
 
 
 def _add_tail(a, b, c, d):
-    cu = sub(b, a, 2)
+    cu = sub_raw(b, a, 2)
     cv = add(b, a)
     cz = carry(add(d, c))
     ct = sub(d, c, 2)
@@ -210,7 +216,7 @@ def _add_tail(a, b, c, d):
 
 
 def ext_add_niels(p, n):
-    a = mul(sub(p["v"], p["u"], 2), n["vmu"])
+    a = mul(sub_raw(p["v"], p["u"], 2), n["vmu"])
     b = mul(add(p["v"], p["u"]), n["vpu"])
     c = mul(mul(p["t1"], p["t2"]), n["t2d"])
     d = dbl(mul(p["z"], n["z"]))
@@ -218,7 +224,7 @@ def ext_add_niels(p, n):
 
 
 def ext_add_aniels(p, n):
-    a = mul(sub(p["v"], p["u"], 2), n["vmu"])
+    a = mul(sub_raw(p["v"], p["u"], 2), n["vmu"])
     b = mul(add(p["v"], p["u"]), n["vpu"])
     c = mul(mul(p["t1"], p["t2"]), n["t2d"])
     d = dbl(p["z"])

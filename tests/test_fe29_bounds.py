@@ -1,0 +1,31 @@
+"""Worst-case (all-inputs) overflow proof of the lazy-reduction bookkeeping in fe29.h /
+jubjub29.h — see tests/fe29_bounds.py.  CPU only."""
+import pytest
+
+import fe29_bounds as FB
+
+
+def test_group_law_bounds_reach_a_fixpoint_without_overflow():
+    inv = FB.prove_group_law()
+    acc = inv["acc"]
+    # what the comments in jubjub29.h promise: multiplication outputs are "N"
+    for k in ("u", "v", "z"):
+        assert all(x <= FB.M29 for x in acc[k].l[:8])
+        assert acc[k].v < 2 * FB.Q
+    assert inv["rounds"] < 10
+
+
+def test_prover_rejects_a_broken_variant():
+    """Sanity of the prover itself: dropping BOTH carry passes of the doubling must be refused."""
+    def bad_double(p):
+        uu, vv = FB.sqr(p["u"]), FB.sqr(p["v"])
+        zz2 = FB.dbl(FB.sqr(p["z"]))
+        cu = FB.dbl(FB.mul(p["u"], p["v"]))
+        vpu = FB.add(vv, uu)
+        vmu = FB.sub_raw(vv, uu, 2)
+        ct = FB.sub_raw(zz2, vmu, 4)
+        return {"u": FB.mul(cu, ct), "v": FB.mul(vpu, vmu), "z": FB.mul(vmu, ct), "t1": cu, "t2": vpu}
+
+    n = FB.mul(FB.canonical(), FB.canonical())
+    with pytest.raises(FB.OverflowError_):
+        bad_double({"u": n, "v": n, "z": n, "t1": n, "t2": n})
