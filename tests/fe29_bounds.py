@@ -281,3 +281,98 @@ def prove_group_law(max_rounds=40):
             return {"acc": acc, "niels": niels, "rounds": rnd}
         acc, niels = nxt, nn
     raise OverflowError_("bounds keep growing: no fixpoint after %d rounds" % max_rounds)
+
+
+# ---- hades29.h ------------------------------------------------------------------------------
+def _load_table(name):
+    text = open(_HDR).read()
+    m = re.search(r"%s\[[^\]]*\]\[9\] = \{(.*?)\n\};" % name, text, flags=re.S)
+    rows = re.findall(r"\{([^}]*)\}", m.group(1))
+    return [B([int(x.strip().rstrip("u"), 16) for x in r.split(",")]) for r in rows]
+
+
+def sbox(x):
+    x2 = sqr(x)
+    x4 = sqr(x2)
+    return mul(x4, x)
+
+
+def hades_full_round(s, rc, mat):
+    s = [add(s[k], rc[k]) for k in range(5)]
+    s = [sbox(x) for x in s]
+    return [dot(s, [mat[k * 5 + j] for j in range(5)]) for k in range(5)]
+
+
+def hades_permute(s):
+    """hades29.h: hades_permute with the ACTUAL constants (exact limbs) and worst-case state"""
+    rc, mds, pre = (_load_table("DSV_HADES_%s_HOST" % n) for n in ("RC", "MDS", "PRE_MDS"))
+    k0, blk, kf = (_load_table("DSV_HADES_%s_HOST" % n) for n in ("KAPPA0", "BLOCKS", "KFINAL"))
+    s = list(s)
+    for r in range(4):
+        s = hades_full_round(s, rc[5 * r:5 * r + 5], pre if r == 3 else mds)
+    s[4] = add(s[4], k0[4])
+    pos = done = 0
+    while done < 59:
+        lb = min(4, 59 - done)
+        z = []
+        for m in range(lb):
+            z.append(sbox(s[4]))
+            a = [s[0], s[1], s[2], s[3]] + z
+            s[4] = add(dot(a, blk[pos:pos + 5 + m]), blk[pos + 5 + m])
+            pos += 6 + m
+        for j in range(4):
+            s[j] = dot([s[j]] + z, blk[pos:pos + lb + 1])
+            pos += lb + 1
+        done += lb
+    assert pos == len(blk)
+    for j in range(4):
+        s[j] = carry(add(s[j], kf[j]))
+    for r in range(4):
+        s = hades_full_round(s, rc[5 * (4 + 59 + r):5 * (4 + 59 + r) + 5], mds)
+    return s
+
+
+def prove_hades():
+    """poseidon_hash3 / poseidon_hash5 on worst-case inputs (fe_to_mont of any canonical word),
+    then the truncation's fe_from_mont (fe_canon needs < 16 q and limbs < 2^31)."""
+    m = mul(canonical(), canonical())
+    zero, one = B([0] * NL), canonical()
+    out3 = hades_permute([zero, m, m, m, one])
+    s = hades_permute([zero, m, m, m, m])
+    s[1] = add(s[1], m)
+    s[2] = add(s[2], one)
+    out5 = hades_permute(s)
+    for o in (out3[1], out5[1]):
+        h = mul(o, B([1] + [0] * (NL - 1)))
+        for x in h.l:
+            _check(x < (1 << 31), "fe_ripple input limb exceeds 2^31")
+        _check(h.v < 16 * Q, "fe_canon input exceeds 16 q")
+    return {"hash3": out3[1], "hash5": out5[1]}
+
+
+# ---- decode29.h / k_decompress (dsv.hip) ------------------------------------------------------
+def canon_ok(a):
+    for x in a.l:
+        _check(x < (1 << 31), "fe_ripple input limb exceeds 2^31")
+    _check(a.v < 16 * Q, "fe_canon input exceeds 16 q")
+
+
+def prove_decompress():
+    """the straight-line field code of JubJub point decompression on worst-case inputs; every
+    power / table product in fe_inv_sqrt and fe_invert is a multiplication of "N" values"""
+    one = canonical()
+    v = mul(canonical(), canonical())
+    v2 = sqr(v)
+    num = sub(v2, one, 2)
+    den = add(mul(v2, canonical()), one)
+    z = mul(num, den)
+    n = mul(z, z)                                   # any product of mul outputs / table entries
+    n = join(n, sqr(n))
+    n = join(n, mul(n, canonical()))
+    canon_ok(n)                                     # ts_digit: fe_canon of a power
+    u = mul(num, n)
+    equal_ok(mul(sqr(u), den), num)
+    canon_ok(mul(u, B([1] + [0] * (NL - 1))))       # fe_from_mont(u)
+    un = sub(B([0] * NL), u, 2)                     # the other root
+    canon_ok(mul(un, B([1] + [0] * (NL - 1))))
+    return {"u": u, "num": num, "den": den}

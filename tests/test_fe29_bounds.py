@@ -29,3 +29,12 @@ def test_prover_rejects_a_broken_variant():
     n = FB.mul(FB.canonical(), FB.canonical())
     with pytest.raises(FB.OverflowError_):
         bad_double({"u": n, "v": n, "z": n, "t1": n, "t2": n})
+
+
+def test_hades_permutation_cannot_overflow_with_the_shipped_constants():
+    out = FB.prove_hades()
+    assert out["hash3"].v < 2 * FB.Q and out["hash5"].v < 2 * FB.Q
+
+
+def test_point_decompression_field_code_cannot_overflow():
+    FB.prove_decompress()
