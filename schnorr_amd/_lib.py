@@ -37,6 +37,16 @@ def load():
         from . import build as _build  # raises if hipcc is absent
 
         _build.build()
+    # One HIP runtime per process: PyTorch-ROCm bundles its own libamdhip64 and libdsv.so is linked
+    # against the system one.  If libdsv (and with it the system runtime) is loaded first, a later
+    # `import torch` + CUDA init in the same process fails with "No HIP GPUs are available"; in the
+    # other order the dynamic loader resolves libdsv's dependency to the copy torch already
+    # mapped.  The device-tensor entry points of this package need torch anyway, so load it first
+    # when it is installed.  (Pure C / Rust callers never see this: they have one runtime.)
+    try:
+        import torch  # noqa: F401
+    except ImportError:  # pragma: no cover
+        pass
     try:
         L = ctypes.CDLL(LIB_PATH)
     except OSError as e:  # pragma: no cover
