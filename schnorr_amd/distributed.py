@@ -59,3 +59,32 @@ def verify_single_sharded(u, R, PK, m, verify_fn, to_tensor, group=None):
     lo, hi = shard_bounds(n, dist.get_rank(group), dist.get_world_size(group))
     local = verify_fn(u[lo:hi], R[lo:hi], PK[lo:hi], m[lo:hi])
     return gather_verdicts(to_tensor(local), n, group)
+
+
+def verify_mixed_sharded(kinds, single, double, verify_single_fn, verify_double_fn, to_tensor,
+                         group=None):
+    """BASELINE.json configs[4] shape: one batch holding single (kind 0) and double (kind 1)
+    signatures in arbitrary interleaving, identical on every rank.
+
+    `single` = (u, R, PK, m), `double` = (u, R, Rp, PK, PKp, m): host arrays holding only the items
+    of that kind, in batch order.  Each kind is sharded evenly on its own (a double costs about
+    twice a single, so every rank gets the same single:double ratio), each rank verifies its two
+    shards, both verdict vectors are all-gathered and scattered back into the original order.
+    Returns the full verdict vector (torch uint8, on the device `to_tensor` puts things on)."""
+    import torch
+    import torch.distributed as dist
+
+    kinds = np.asarray(kinds)
+    idx_s, idx_d = split_mixed(kinds)
+    if single[0].shape[0] != idx_s.size or double[0].shape[0] != idx_d.size:
+        raise ValueError("kind vector and per-kind arrays disagree")
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    parts = []
+    for cols, fn, count in ((single, verify_single_fn, idx_s.size), (double, verify_double_fn, idx_d.size)):
+        lo, hi = shard_bounds(count, rank, world)
+        local = fn(*[c[lo:hi] for c in cols]) if hi > lo else np.zeros(0, np.uint8)
+        parts.append(gather_verdicts(to_tensor(np.ascontiguousarray(local, dtype=np.uint8)), count, group))
+    out = torch.empty(kinds.size, dtype=torch.uint8, device=parts[0].device)
+    out[torch.from_numpy(idx_s).to(out.device)] = parts[0]
+    out[torch.from_numpy(idx_d).to(out.device)] = parts[1]
+    return out

@@ -68,3 +68,45 @@ def test_world_size_2_gloo_gather(n):
         assert p.exitcode == 0
     assert all(ok for _, ok, _ in res), res
     assert res[0][2] == res[1][2] > 0
+
+
+def _mixed_worker(rank, world, port, n, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank),
+                      WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    rng = np.random.default_rng(5)
+    kinds = (rng.integers(0, 3, size=n) == 0).astype(np.uint8)       # ~1/3 double, interleaved
+    ns, nd = int((kinds == 0).sum()), int((kinds == 1).sum())
+    s = O.keygen_sign_single(ns, 11)
+    d = O.keygen_sign_double(nd, 12)
+    H.tamper(s, period=4)
+    d["PKp"][::3] = d["PKp"][1::3][: len(d["PKp"][::3])] if nd > 3 else d["PKp"][::3]
+    single = (s["u"], s["R"], s["PK"], s["m"])
+    double = (d["u"], d["R"], d["Rp"], d["PK"], d["PKp"], d["m"])
+    full = D.verify_mixed_sharded(kinds, single, double,
+                                  verify_single_fn=lambda *a: O.verify_single(*a),
+                                  verify_double_fn=lambda *a: O.verify_double(*a),
+                                  to_tensor=lambda a: torch.from_numpy(a))
+    want = np.zeros(n, np.uint8)
+    want[kinds == 0] = O.verify_single(*single)
+    want[kinds == 1] = O.verify_double(*double)
+    q.put((rank, bool(np.array_equal(full.numpy(), want)), int(full.sum()), int(n - full.sum())))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_world_size_2_gloo_mixed_batch():
+    """BASELINE configs[4] shape at toy size: interleaved single / double signatures, each kind
+    sharded on its own, verdicts gathered and scattered back into batch order."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_mixed_worker, args=(r, 2, port, 61, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(ok for _, ok, _, _ in res), res
+    assert res[0][2] == res[1][2] > 0 and res[0][3] > 0      # both verdicts occur
