@@ -690,3 +690,26 @@ def test_alternative_code_paths_in_subprocesses(engine):
                            cwd=root, env=env, capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, (extra, r.stdout[-2000:], r.stderr[-2000:])
         assert " passed" in r.stdout and "failed" not in r.stdout, (extra, r.stdout[-500:])
+
+
+def test_shutdown_and_reinitialise(engine):
+    """dsv_shutdown releases tables, staging, streams and copy threads; calls then fail loudly;
+    dsv_init builds everything again and verdicts are unchanged.  (Last test of the module.)"""
+    from schnorr_amd import _lib
+    n = 300
+    d = O.keygen_sign_single(n, 99)
+    H.tamper(d, period=7)
+    want = O.verify_single(d["u"], d["R"], d["PK"], d["m"], nthreads=8)
+    assert 0 < want.sum() < n
+    before = engine.verify_single(d["u"], d["R"], d["PK"], d["m"])
+    assert np.array_equal(before, want)
+    engine.shutdown()
+    with pytest.raises(_lib.DsvError):
+        engine.verify_single(d["u"], d["R"], d["PK"], d["m"])
+    engine.init(0)
+    big = (1 << 17) + 5                      # multi-chunk: pinned staging and copy pool again
+    reps = -(-big // n)
+    tile = {k: np.tile(d[k], (reps, 1))[:big] for k in ("u", "R", "PK", "m")}
+    got = engine.verify_single(tile["u"], tile["R"], tile["PK"], tile["m"])
+    assert np.array_equal(got, np.tile(want, reps)[:big])
+    assert np.array_equal(engine.verify_single(d["u"], d["R"], d["PK"], d["m"]), want)
