@@ -692,6 +692,32 @@ def test_alternative_code_paths_in_subprocesses(engine):
         assert " passed" in r.stdout and "failed" not in r.stdout, (extra, r.stdout[-500:])
 
 
+def test_byte_offsets_beyond_2_32(engine):
+    """2^26 + 123 signatures: R / PK arrays of 4 GiB + each, so every byte offset inside the
+    kernels and the sub-batch split passes 2^32 (a 32-bit index anywhere would alias items)."""
+    import torch
+    from schnorr_amd import workload as W
+    n = (1 << 26) + 123
+    b = W.gen_single(n, seed=5)
+    ok = torch.zeros(n, dtype=torch.uint8, device="cuda:0")
+    ws = torch.empty(engine.workspace_bytes(n), dtype=torch.uint8, device="cuda:0")
+    engine.verify_single_dev(b["u"], b["R"], b["PK"], b["m"], ok, ws)
+    torch.cuda.synchronize()
+    assert torch.equal(ok, b["expected"])
+    # spot-check the far end against the oracle (aliasing would reproduce the pattern of the low
+    # items, which is the same pattern — the oracle on the actual bytes is the real check)
+    idx = torch.arange(n - 64, n, device="cuda:0")
+    sub = [b[k][idx].cpu().numpy() for k in ("u", "R", "PK", "m")]
+    assert np.array_equal(O.verify_single(*sub, nthreads=8), ok[idx].cpu().numpy())
+    # and a corruption placed only at the far end must be seen there
+    b["u"][n - 5, 1] ^= 4
+    engine.verify_single_dev(b["u"], b["R"], b["PK"], b["m"], ok, ws)
+    torch.cuda.synchronize()
+    assert int(ok[n - 5]) == 0 and int(ok[n - 6]) == int(b["expected"][n - 6])
+    del b, ok, ws
+    torch.cuda.empty_cache()
+
+
 def test_shutdown_and_reinitialise(engine):
     """dsv_shutdown releases tables, staging, streams and copy threads; calls then fail loudly;
     dsv_init builds everything again and verdicts are unchanged.  (Last test of the module.)"""
