@@ -718,6 +718,51 @@ def test_byte_offsets_beyond_2_32(engine):
     torch.cuda.empty_cache()
 
 
+def test_structured_relations_grid(engine):
+    """Every combination of 'special' keys, nonce points, scalars and messages: PK, R in
+    {O, +-G, +-G', order-2, order-4, P, -P, 2P, a valid R for the item}, u in {0, 1, r-1, the
+    valid response}, m in {0, q-1, random}.  These hit P + (-P), doubling of O, equal table
+    entries and zero digits in the window chains; GPU single / double / var-generator verdicts
+    must equal the oracle's on all of them (and some must come out valid)."""
+    rnd = np.random.default_rng(2718)
+    sqrt_m1 = pow(7, (M.Q - 1) // 4, M.Q)
+    P = M.pmul(M.GEN, 0x1234567_89ABCDEF)
+    specials = [M.IDENTITY, M.GEN, M.pneg(M.GEN), M.GEN_NUMS, M.pneg(M.GEN_NUMS), (0, M.Q - 1),
+                (sqrt_m1, 0), P, M.pneg(P), M.padd(P, P)]
+    rows = {k: [] for k in ("u", "R", "PK", "m")}
+    for m in (0, M.Q - 1, int(rnd.integers(1, 1 << 62)) ** 4 % M.Q):
+        for pk in specials:
+            rr = int(rnd.integers(1, 1 << 62))
+            for R in specials[:7] + [M.pmul(M.GEN, rr)]:
+                for u in (0, 1, M.R_ORDER - 1, rr):    # rr*G + c*O == rr*G: valid when pk = O
+                    rows["u"].append(np.frombuffer(M.le32(u), np.uint8))
+                    rows["R"].append(np.frombuffer(M.point_bytes(R), np.uint8))
+                    rows["PK"].append(np.frombuffer(M.point_bytes(pk), np.uint8))
+                    rows["m"].append(np.frombuffer(M.le32(m), np.uint8))
+    # plus honest signatures under the special keys' discrete logs where they are known
+    for sk in (1, M.R_ORDER - 1, 2, 0x1234567_89ABCDEF):
+        m = int(rnd.integers(1, 1 << 62)) ** 3 % M.Q
+        rr = int(rnd.integers(1, 1 << 62))
+        u, R = M.sign_single(sk, m, rr)
+        rows["u"].append(np.frombuffer(M.le32(u), np.uint8))
+        rows["R"].append(np.frombuffer(M.point_bytes(R), np.uint8))
+        rows["PK"].append(np.frombuffer(M.point_bytes(M.pmul(M.GEN, sk)), np.uint8))
+        rows["m"].append(np.frombuffer(M.le32(m), np.uint8))
+    a = {k: np.stack(v) for k, v in rows.items()}
+    want = O.verify_single(a["u"], a["R"], a["PK"], a["m"], nthreads=8)
+    got = engine.verify_single(a["u"], a["R"], a["PK"], a["m"])
+    assert np.array_equal(got, want)
+    assert want[-4:].all() and 4 <= want.sum() < len(want)
+    # the same grid through the double (R' = R, PK' = PK shifted by one row) and var-generator
+    # (generator = the next row's key) entry points: arbitrary but deterministic pairings
+    Rp, PKp = np.roll(a["R"], 1, axis=0), np.roll(a["PK"], 1, axis=0)
+    assert np.array_equal(engine.verify_double(a["u"], a["R"], Rp, a["PK"], PKp, a["m"]),
+                          O.verify_double(a["u"], a["R"], Rp, a["PK"], PKp, a["m"], nthreads=8))
+    Gen = np.roll(a["PK"], 3, axis=0)
+    assert np.array_equal(engine.verify_vargen(a["u"], a["R"], a["PK"], Gen, a["m"]),
+                          O.verify_vargen(a["u"], a["R"], a["PK"], Gen, a["m"], nthreads=8))
+
+
 def test_shutdown_and_reinitialise(engine):
     """dsv_shutdown releases tables, staging, streams and copy threads; calls then fail loudly;
     dsv_init builds everything again and verdicts are unchanged.  (Last test of the module.)"""
