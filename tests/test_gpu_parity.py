@@ -175,6 +175,34 @@ def test_sign_and_public_keys_match_oracle(engine):
     assert np.array_equal(engine.public_keys(dv["sk"], 0, dv["Gen"]), dv["PK"])
 
 
+def test_sign_edge_scalars(engine):
+    """Signing and key derivation at the ends of the scalar range: sk, nonce in {0, 1, 2, r-1},
+    m in {0, q-1} — identity / generator results, zero digits everywhere or nowhere in the
+    fixed-base windows.  GPU against the Python model, and the signatures verify on both sides."""
+    vals = (0, 1, 2, M.R_ORDER - 1, M.R_ORDER - 2)
+    sk, r, m = [], [], []
+    for a in vals:
+        for b in vals:
+            for mm in (0, M.Q - 1):
+                sk.append(a); r.append(b); m.append(mm)
+    to = lambda xs: np.stack([np.frombuffer(M.le32(x), np.uint8) for x in xs])
+    SK, RR, MM = to(sk), to(r), to(m)
+    u, R = engine.sign_single(SK, MM, RR)
+    PK = engine.public_keys(SK, 0)
+    PKp = engine.public_keys(SK, 1)
+    u2, R2, Rp2 = engine.sign_double(SK, MM, RR)
+    for i in range(len(sk)):
+        uu, Rm = M.sign_single(sk[i], m[i], r[i])
+        assert M.from_le(u[i]) == uu and H.to_int_point(R[i]) == Rm, i
+        assert H.to_int_point(PK[i]) == M.pmul(M.GEN, sk[i]), i
+        assert H.to_int_point(PKp[i]) == M.pmul(M.GEN_NUMS, sk[i]), i
+        ud, Rd, Rpd = M.sign_double(sk[i], m[i], r[i])
+        assert M.from_le(u2[i]) == ud and H.to_int_point(R2[i]) == Rd and H.to_int_point(Rp2[i]) == Rpd, i
+    assert engine.verify_single(u, R, PK, MM).all() and O.verify_single(u, R, PK, MM).all()
+    assert engine.verify_double(u2, R2, Rp2, PK, PKp, MM).all()
+    assert O.verify_double(u2, R2, Rp2, PK, PKp, MM).all()
+
+
 def test_ragged_and_empty_batches(engine):
     d = O.keygen_sign_single(300, 4)
     H.tamper(d, period=7)
