@@ -355,6 +355,34 @@ def test_wire_formats_decompress_and_verify(engine):
                           O.verify_vargen_wire(sigv, pkv, dv["m"]))
 
 
+def test_decompress_special_encodings(engine):
+    """JubJubAffine::from_bytes on the encodings with u = 0 (identity v = 1, order-2 point
+    v = -1) with and without the sign bit ("negative zero": accepted, u stays 0, as in the
+    pre-ZIP-216 jubjub lineage the oracle restates), v = 0 (order-4 points, both signs), the
+    generators, v = q - 1 + 1 (non-canonical) and all-ones."""
+    def enc(v, sign):
+        b = bytearray(M.le32(v))
+        b[31] |= sign << 7
+        return np.frombuffer(bytes(b), np.uint8)
+    rows = [enc(1, 0), enc(1, 1), enc(M.Q - 1, 0), enc(M.Q - 1, 1), enc(0, 0), enc(0, 1),
+            enc(M.GEN[1], M.GEN[0] & 1), enc(M.GEN[1], 1 - (M.GEN[0] & 1)),
+            enc(M.GEN_NUMS[1], M.GEN_NUMS[0] & 1), enc(M.Q, 0), enc((1 << 255) - 1, 1),
+            enc(2, 0), enc(3, 0), enc(4, 1), enc(5, 0)]
+    comp = np.stack(rows)
+    want_uv, want_ok = O.decompress(comp)
+    got_uv, got_ok = engine.decompress_points(comp)
+    assert np.array_equal(got_ok, want_ok)
+    assert np.array_equal(got_uv[want_ok == 1], want_uv[want_ok == 1])
+    assert list(want_ok[:9]) == [1] * 9 and list(want_ok[9:11]) == [0, 0]
+    assert H.to_int_point(got_uv[0]) == (0, 1) and H.to_int_point(got_uv[1]) == (0, 1)
+    assert H.to_int_point(got_uv[6]) == M.GEN and H.to_int_point(got_uv[7]) == M.pneg(M.GEN)
+    for i in np.nonzero(want_ok)[0]:
+        assert M.on_curve(H.to_int_point(got_uv[i]))
+        # and to_bytes o from_bytes is the identity on canonical encodings (not on negative zero)
+        if i not in (1, 3):
+            assert np.array_equal(engine.compress_points(got_uv[i:i + 1])[0], comp[i])
+
+
 def test_vargen_config_size_batch(engine):
     """BASELINE.json configs[3]: 2^18 var-generator signatures through the HBM-resident path."""
     import torch
