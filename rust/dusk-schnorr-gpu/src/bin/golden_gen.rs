@@ -37,4 +37,21 @@ fn main() {
             hex(&sig.to_bytes()), hex(&pk.to_bytes()), pk.verify(&sig, m)
         );
     }
+    // (c) wire-decoding edge semantics: u = 0 with and without the sign bit,
+    // the order-2 point, v = 0 — compare with tests/test_gpu_parity.py::
+    // test_decompress_special_encodings (this build accepts rows 1 and 3, "negative zero")
+    let enc = |v: BlsScalar, sign: u8| {
+        let mut b = v.to_bytes();
+        b[31] |= sign << 7;
+        b
+    };
+    let cases = [enc(BlsScalar::one(), 0), enc(BlsScalar::one(), 1), enc(-BlsScalar::one(), 0),
+                 enc(-BlsScalar::one(), 1), enc(BlsScalar::zero(), 0), enc(BlsScalar::zero(), 1)];
+    for (i, b) in cases.iter().enumerate() {
+        match dusk_jubjub::JubJubAffine::from_bytes(b) {
+            Ok(p) => println!("from_bytes {i} {} ok u {} v {}", hex(b), hex(&p.get_u().to_bytes()),
+                              hex(&p.get_v().to_bytes())),
+            Err(_) => println!("from_bytes {i} {} err", hex(b)),
+        }
+    }
 }
