@@ -37,7 +37,7 @@ def build(force=False, extra_flags=(), verbose=False):
     if not os.path.exists(const_h) or os.path.getmtime(gen) > os.path.getmtime(const_h):
         subprocess.check_call([sys.executable, gen])
     cmd = [hipcc, "--offload-arch=" + ARCH, "-O3", "-std=c++17", "-shared", "-fPIC",
-           "-Wno-unused-value", "-o", LIB] + [os.path.join(CSRC, s) for s in SOURCES]
+           "-Wall", "-Wextra", "-o", LIB] + [os.path.join(CSRC, s) for s in SOURCES]
     cmd += list(extra_flags)
     if verbose:
         print(" ".join(cmd), file=sys.stderr)

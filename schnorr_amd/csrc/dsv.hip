@@ -464,7 +464,7 @@ k_verify_fixed_half(const uint8_t* __restrict__ u, const uint8_t* __restrict__ c
     }
     acc = fixed_base_accumulate(acc, w, table);
     // T == O  <=>  u == 0 and v == z
-    const bool eq = fe_is_zero_canon(fe_canon(acc.u)) & fe_equal(acc.v, acc.z);
+    const bool eq = (int)fe_is_zero_canon(fe_canon(acc.u)) & (int)fe_equal(acc.v, acc.z);
     ok[i] = (good & eq) ? 1 : 0;
   }
 }
@@ -904,21 +904,22 @@ void launch_verify_fixed(bool accumulate, const void* u, const void* c, const vo
 // the same kernel.  Cutting the batch into sub-batches of 2^16 signatures (1024 waves: ONE wave
 // per SIMD) that alternate between two internal streams keeps two different kernels co-resident
 // on every SIMD — hash next to scalar multiplication, table build next to window loop — and
-// leaves no gap between kernels: +8 % on 2^20 (tools/overlap_probe.py).  The caller's stream is
+// leaves no gap between kernels: +6 % on 2^20, same-box A/B (probe: tools/overlap_probe.py).  The caller's stream is
 // forked / joined with events, so the call still behaves as one enqueue on that stream.
 constexpr size_t kSplitItems = (size_t)1 << 16;
 
 struct ForkJoin {
   hipEvent_t fork = nullptr, join[2] = {nullptr, nullptr};
 };
-ForkJoin& thread_events() {
+int thread_events(ForkJoin*& out) {
   thread_local ForkJoin ev;
-  if (!ev.fork) {
-    hipEventCreateWithFlags(&ev.fork, hipEventDisableTiming);
-    hipEventCreateWithFlags(&ev.join[0], hipEventDisableTiming);
-    hipEventCreateWithFlags(&ev.join[1], hipEventDisableTiming);
+  if (!ev.join[1]) {
+    if (!ev.fork) HIP_TRY(hipEventCreateWithFlags(&ev.fork, hipEventDisableTiming));
+    if (!ev.join[0]) HIP_TRY(hipEventCreateWithFlags(&ev.join[0], hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&ev.join[1], hipEventDisableTiming));
   }
-  return ev;
+  out = &ev;
+  return DSV_OK;
 }
 // part(offset, count, workspace-for-this-part, stream)
 template <class Part>
@@ -929,7 +930,9 @@ int run_split(size_t n, void* workspace, hipStream_t user, Part part) {
     HIP_TRY(hipGetLastError());
     return DSV_OK;
   }
-  ForkJoin& ev = thread_events();
+  ForkJoin* evp = nullptr;
+  if (int r = thread_events(evp)) return r;
+  ForkJoin& ev = *evp;
   HIP_TRY(hipEventRecord(ev.fork, user));
   const size_t tbl_words = var_table_bytes(kSplitItems, 2) / 4;  // per internal stream
   for (int k = 0; k < 2; k++) HIP_TRY(hipStreamWaitEvent(g_ctx.split_stream[k], ev.fork, 0));
@@ -1013,27 +1016,28 @@ int dsv_init(int device) {
 int dsv_shutdown(void) {
   std::lock_guard<std::mutex> lk(g_init_mu);
   if (!g_ready.load()) return DSV_OK;
-  hipSetDevice(g_ctx.device);
-  hipDeviceSynchronize();
+  // best effort: nothing useful can be done about a failing release
+  (void)hipSetDevice(g_ctx.device);
+  (void)hipDeviceSynchronize();
   for (int g = 0; g < 2; g++) {
-    if (g_ctx.table[g]) hipFree(g_ctx.table[g]);
+    if (g_ctx.table[g]) (void)hipFree(g_ctx.table[g]);
     g_ctx.table[g] = nullptr;
   }
-  if (g_ctx.ts_cancel) hipFree(g_ctx.ts_cancel);
-  if (g_ctx.ts_hash) hipFree(g_ctx.ts_hash);
+  if (g_ctx.ts_cancel) (void)hipFree(g_ctx.ts_cancel);
+  if (g_ctx.ts_hash) (void)hipFree(g_ctx.ts_hash);
   g_ctx.ts_cancel = nullptr;
   g_ctx.ts_hash = nullptr;
-  if (g_ctx.stage) hipFree(g_ctx.stage);
+  if (g_ctx.stage) (void)hipFree(g_ctx.stage);
   g_ctx.stage = nullptr;
   g_ctx.stage_bytes = 0;
   for (int k = 0; k < 2; k++) {
-    if (g_ctx.split_stream[k]) hipStreamDestroy(g_ctx.split_stream[k]);
+    if (g_ctx.split_stream[k]) (void)hipStreamDestroy(g_ctx.split_stream[k]);
     g_ctx.split_stream[k] = nullptr;
   }
   for (int k = 0; k < kPipeSlots; k++) {
-    if (g_ctx.pipe_stage[k]) hipFree(g_ctx.pipe_stage[k]);
-    if (g_ctx.pipe_host[k]) hipHostFree(g_ctx.pipe_host[k]);
-    if (g_ctx.pipe_stream[k]) hipStreamDestroy(g_ctx.pipe_stream[k]);
+    if (g_ctx.pipe_stage[k]) (void)hipFree(g_ctx.pipe_stage[k]);
+    if (g_ctx.pipe_host[k]) (void)hipHostFree(g_ctx.pipe_host[k]);
+    if (g_ctx.pipe_stream[k]) (void)hipStreamDestroy(g_ctx.pipe_stream[k]);
     g_ctx.pipe_stage[k] = nullptr;
     g_ctx.pipe_host[k] = nullptr;
     g_ctx.pipe_stream[k] = nullptr;
