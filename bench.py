@@ -69,7 +69,7 @@ HBM_PEAK_GBS = 8000.0
 
 
 def _pmc_traffic(n):
-    """HBM bytes per launch of the dominant kernel from the last committed rocprofv3 PMC pass
+    """HBM bytes per step (k_verify_fixed_half + k_challenge) from the last committed rocprofv3 PMC pass
     (profiles/pmc_latest.json; FETCH_SIZE + WRITE_SIZE, KB -> bytes, scaled to this batch).
     Counters cannot be read from inside the timed process, so this is the recorded figure, not a
     live one; null when no profile is committed.  (gfx950 under-reports FETCH_SIZE by up to 2x
@@ -77,7 +77,10 @@ def _pmc_traffic(n):
     try:
         with open(os.path.join(ROOT, "profiles", "pmc_latest.json")) as f:
             p = json.load(f)
-        return (p["FETCH_SIZE_KB"] + p["WRITE_SIZE_KB"]) * 1024.0 * n / p["batch"]
+        kb = p["FETCH_SIZE_KB"] + p["WRITE_SIZE_KB"]
+        h = p.get("k_challenge", {})                       # the hash kernel of the same step
+        kb += h.get("FETCH_SIZE_KB", 0.0) + h.get("WRITE_SIZE_KB", 0.0)
+        return kb * 1024.0 * n / p["batch"]
     except Exception:
         return None
 

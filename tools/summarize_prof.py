@@ -78,6 +78,11 @@ def main():
                 latest[c] = d[c]["avg_per_launch"]
         if stats:
             latest["avg_duration_ns"] = float(stats["AverageNs"])
+        hk = [k for k in out if k.startswith("dsv::k_challenge<false>")]
+        if hk:  # the other kernel of a step (bench.py adds its HBM bytes to roofline.traffic)
+            h = out[hk[0]]
+            latest["k_challenge"] = {c + ("_KB" if c.endswith("_SIZE") else ""): h[c]["avg_per_launch"]
+                                     for c in ("FETCH_SIZE", "WRITE_SIZE", "SQ_INSTS_VALU") if c in h}
         with open(os.path.join(ROOT, "profiles", "pmc_latest.json"), "w") as f:
             json.dump(latest, f, indent=1)
     print(json.dumps({k: {c: v["avg_per_launch"] for c, v in cs.items() if isinstance(v, dict)}
