@@ -11,6 +11,11 @@
 //   PublicKeyVarGen::from(&sk) / verify             /root/reference/src/keys/public.rs:337-344, 401-415
 //   Signature{u, R}, SignatureDouble{u, R, R_prime}, SignatureVarGen{u, R}
 //                                                   /root/reference/src/signatures.rs:58-73, 180-203, 337-353
+//   Serializable: to_bytes / from_bytes of every key and signature type
+//                                                   /root/reference/src/signatures.rs:106-123, 245-270, 387-404
+//                                                   /root/reference/src/keys/public.rs:87-101, 282-299, 347-372
+//                                                   /root/reference/src/keys/secret.rs:89-103, 313-336
+//     (`Result<Self, BytesError>` becomes std::optional: empty = the reference's Err)
 //   verify_batch / verify_batch_double / verify_batch_var_gen : the new batch entry points
 //
 // `verify` is infallible and returns bool exactly like the reference; a failure of the engine
@@ -22,6 +27,7 @@
 #include <array>
 #include <cstdint>
 #include <cstring>
+#include <optional>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -90,6 +96,18 @@ struct Scalar32 {
     return from_bytes_wide(wide);
   }
   const std::array<uint8_t, 32>& to_bytes() const { return bytes; }
+  // Serializable::from_bytes: rejects encodings >= the modulus
+  static std::optional<Scalar32> from_bytes(const uint8_t b[32]) {
+    for (int i = 31; i >= 0; i--) {
+      if (b[i] < MOD[i]) {
+        Scalar32 s;
+        std::memcpy(s.bytes.data(), b, 32);
+        return s;
+      }
+      if (b[i] > MOD[i]) return std::nullopt;
+    }
+    return std::nullopt;  // equal to the modulus
+  }
   bool operator==(const Scalar32& o) const { return bytes == o.bytes; }
 };
 using BlsScalar = Scalar32<detail::kFqModulus>;
@@ -98,33 +116,99 @@ using JubJubScalar = Scalar32<detail::kFrModulus>;
 struct JubJubAffine {  // (u, v), canonical LE — the pair to_hash_inputs() returns
   std::array<uint8_t, 64> uv{};
   bool operator==(const JubJubAffine& o) const { return uv == o.uv; }
+  // compressed form: canonical v, bit 255 = lowest bit of u
+  std::array<uint8_t, 32> to_bytes() const {
+    std::array<uint8_t, 32> out;
+    detail::check(dsv_compress_points(uv.data(), 1, out.data()), "dsv_compress_points");
+    return out;
+  }
+  static std::optional<JubJubAffine> from_bytes(const uint8_t b[32]) {
+    detail::ensure_init();
+    JubJubAffine p;
+    uint8_t ok = 0;
+    detail::check(dsv_decompress_points(b, 1, p.uv.data(), &ok), "dsv_decompress_points");
+    if (!ok) return std::nullopt;
+    return p;
+  }
 };
 
 struct Signature {
+  static constexpr size_t SIZE = 64;  // u || compressed R
   JubJubScalar u_;
   JubJubAffine R_;
   const JubJubScalar& u() const { return u_; }
   const JubJubAffine& R() const { return R_; }
   bool operator==(const Signature& o) const { return u_ == o.u_ && R_ == o.R_; }
+  std::array<uint8_t, SIZE> to_bytes() const {
+    std::array<uint8_t, SIZE> b;
+    std::memcpy(b.data(), u_.bytes.data(), 32);
+    std::memcpy(b.data() + 32, R_.to_bytes().data(), 32);
+    return b;
+  }
+  static std::optional<Signature> from_bytes(const std::array<uint8_t, SIZE>& b) {
+    auto u = JubJubScalar::from_bytes(b.data());
+    auto R = JubJubAffine::from_bytes(b.data() + 32);
+    if (!u || !R) return std::nullopt;
+    return Signature{*u, *R};
+  }
 };
 struct SignatureDouble {
+  static constexpr size_t SIZE = 96;  // u || compressed R || compressed R'
   JubJubScalar u_;
   JubJubAffine R_, R_prime_;
   const JubJubScalar& u() const { return u_; }
   const JubJubAffine& R() const { return R_; }
   const JubJubAffine& R_prime() const { return R_prime_; }
+  bool operator==(const SignatureDouble& o) const {
+    return u_ == o.u_ && R_ == o.R_ && R_prime_ == o.R_prime_;
+  }
+  std::array<uint8_t, SIZE> to_bytes() const {
+    std::array<uint8_t, SIZE> b;
+    std::memcpy(b.data(), u_.bytes.data(), 32);
+    std::memcpy(b.data() + 32, R_.to_bytes().data(), 32);
+    std::memcpy(b.data() + 64, R_prime_.to_bytes().data(), 32);
+    return b;
+  }
+  static std::optional<SignatureDouble> from_bytes(const std::array<uint8_t, SIZE>& b) {
+    auto u = JubJubScalar::from_bytes(b.data());
+    auto R = JubJubAffine::from_bytes(b.data() + 32);
+    auto Rp = JubJubAffine::from_bytes(b.data() + 64);
+    if (!u || !R || !Rp) return std::nullopt;
+    return SignatureDouble{*u, *R, *Rp};
+  }
 };
 struct SignatureVarGen {
+  static constexpr size_t SIZE = 64;
   JubJubScalar u_;
   JubJubAffine R_;
   const JubJubScalar& u() const { return u_; }
   const JubJubAffine& R() const { return R_; }
+  bool operator==(const SignatureVarGen& o) const { return u_ == o.u_ && R_ == o.R_; }
+  std::array<uint8_t, SIZE> to_bytes() const {
+    std::array<uint8_t, SIZE> b;
+    std::memcpy(b.data(), u_.bytes.data(), 32);
+    std::memcpy(b.data() + 32, R_.to_bytes().data(), 32);
+    return b;
+  }
+  static std::optional<SignatureVarGen> from_bytes(const std::array<uint8_t, SIZE>& b) {
+    auto u = JubJubScalar::from_bytes(b.data());
+    auto R = JubJubAffine::from_bytes(b.data() + 32);
+    if (!u || !R) return std::nullopt;
+    return SignatureVarGen{*u, *R};
+  }
 };
 
 struct SecretKey {
   JubJubScalar sk;
   template <class Rng>
   static SecretKey random(Rng& rng) { return SecretKey{JubJubScalar::random(rng)}; }
+  bool operator==(const SecretKey& o) const { return sk == o.sk; }
+  std::array<uint8_t, 32> to_bytes() const { return sk.bytes; }
+  static std::optional<SecretKey> from_bytes(const std::array<uint8_t, 32>& b) {
+    auto s = JubJubScalar::from_bytes(b.data());
+    if (!s) return std::nullopt;
+    return SecretKey{*s};
+  }
   // sign: r <- rng; R = r*G; c = H(R, m); u = r - c*sk
   template <class Rng>
   Signature sign(Rng& rng, const BlsScalar& message) const {
@@ -157,6 +241,14 @@ struct PublicKey {
     return p;
   }
   const JubJubAffine& as_ref() const { return pk; }
+  // public.rs:142 from_raw_unchecked: any coordinates, no validation
+  static PublicKey from_raw_unchecked(const JubJubAffine& p) { return PublicKey{p}; }
+  std::array<uint8_t, 32> to_bytes() const { return pk.to_bytes(); }
+  static std::optional<PublicKey> from_bytes(const std::array<uint8_t, 32>& b) {
+    auto p = JubJubAffine::from_bytes(b.data());
+    if (!p) return std::nullopt;
+    return PublicKey{*p};
+  }
   // u*G + c*PK == R  with c = H(R || m)
   bool verify(const Signature& sig, const BlsScalar& message) const {
     detail::ensure_init();
@@ -179,6 +271,19 @@ struct PublicKeyDouble {
   }
   const JubJubAffine& pk() const { return pk_; }
   const JubJubAffine& pk_prime() const { return pk_prime_; }
+  bool operator==(const PublicKeyDouble& o) const { return pk_ == o.pk_ && pk_prime_ == o.pk_prime_; }
+  std::array<uint8_t, 64> to_bytes() const {  // pk || pk'
+    std::array<uint8_t, 64> b;
+    std::memcpy(b.data(), pk_.to_bytes().data(), 32);
+    std::memcpy(b.data() + 32, pk_prime_.to_bytes().data(), 32);
+    return b;
+  }
+  static std::optional<PublicKeyDouble> from_bytes(const std::array<uint8_t, 64>& b) {
+    auto p = JubJubAffine::from_bytes(b.data());
+    auto pp = JubJubAffine::from_bytes(b.data() + 32);
+    if (!p || !pp) return std::nullopt;
+    return PublicKeyDouble{*p, *pp};
+  }
   bool verify(const SignatureDouble& sig, const BlsScalar& message) const {
     detail::ensure_init();
     uint8_t ok = 0;
@@ -206,6 +311,19 @@ struct SecretKeyVarGen {
     return k;
   }
   const JubJubAffine& generator() const { return generator_; }
+  bool operator==(const SecretKeyVarGen& o) const { return sk == o.sk && generator_ == o.generator_; }
+  std::array<uint8_t, 64> to_bytes() const {  // sk || compressed generator
+    std::array<uint8_t, 64> b;
+    std::memcpy(b.data(), sk.bytes.data(), 32);
+    std::memcpy(b.data() + 32, generator_.to_bytes().data(), 32);
+    return b;
+  }
+  static std::optional<SecretKeyVarGen> from_bytes(const std::array<uint8_t, 64>& b) {
+    auto s = JubJubScalar::from_bytes(b.data());
+    auto g = JubJubAffine::from_bytes(b.data() + 32);
+    if (!s || !g) return std::nullopt;
+    return SecretKeyVarGen{*s, *g};
+  }
   template <class Rng>
   SignatureVarGen sign(Rng& rng, const BlsScalar& message) const {
     detail::ensure_init();
@@ -230,6 +348,19 @@ struct PublicKeyVarGen {
   }
   const JubJubAffine& public_key() const { return pk_; }
   const JubJubAffine& generator() const { return generator_; }
+  bool operator==(const PublicKeyVarGen& o) const { return pk_ == o.pk_ && generator_ == o.generator_; }
+  std::array<uint8_t, 64> to_bytes() const {  // compressed pk || compressed generator
+    std::array<uint8_t, 64> b;
+    std::memcpy(b.data(), pk_.to_bytes().data(), 32);
+    std::memcpy(b.data() + 32, generator_.to_bytes().data(), 32);
+    return b;
+  }
+  static std::optional<PublicKeyVarGen> from_bytes(const std::array<uint8_t, 64>& b) {
+    auto p = JubJubAffine::from_bytes(b.data());
+    auto g = JubJubAffine::from_bytes(b.data() + 32);
+    if (!p || !g) return std::nullopt;
+    return PublicKeyVarGen{*p, *g};
+  }
   bool verify(const SignatureVarGen& sig, const BlsScalar& message) const {
     detail::ensure_init();
     uint8_t ok = 0;

@@ -2,6 +2,8 @@
 //   /root/reference/tests/schnorr.rs:14-40              sign_verify, test_wrong_keys
 //   /root/reference/tests/schnorr_double.rs:14-41       same for SignatureDouble
 //   /root/reference/tests/schnorr_var_generator.rs:14-40 same for SignatureVarGen
+//   to_from_bytes of all three (tests/schnorr.rs:42-51, schnorr_double.rs:43-52,
+//   schnorr_var_generator.rs:43-52) and of the key types, with the Err cases
 // plus the new verify_batch entry points.  Exit code 0 = all passed.
 #include <cstdio>
 #include <cstdlib>
@@ -103,6 +105,49 @@ static void batch() {
   CHECK(threw);
   CHECK(verify_batch({}, {}, {}).empty());
 }
+static void to_from_bytes() {
+  Rng rng(2321);
+  SecretKey sk = SecretKey::random(rng);
+  BlsScalar message = BlsScalar::random(rng);
+  Signature sig = sk.sign(rng, message);
+  CHECK(sig == *Signature::from_bytes(sig.to_bytes()));
+  SignatureDouble sigd = sk.sign_double(rng, message);
+  CHECK(sigd == *SignatureDouble::from_bytes(sigd.to_bytes()));
+  SecretKeyVarGen skv = SecretKeyVarGen::random(rng);
+  SignatureVarGen sigv = skv.sign(rng, message);
+  CHECK(sigv == *SignatureVarGen::from_bytes(sigv.to_bytes()));
+  // keys
+  CHECK(sk == *SecretKey::from_bytes(sk.to_bytes()));
+  PublicKey pk = PublicKey::from(sk);
+  CHECK(pk == *PublicKey::from_bytes(pk.to_bytes()));
+  PublicKeyDouble pkd = PublicKeyDouble::from(sk);
+  CHECK(pkd == *PublicKeyDouble::from_bytes(pkd.to_bytes()));
+  CHECK(skv == *SecretKeyVarGen::from_bytes(skv.to_bytes()));
+  PublicKeyVarGen pkv = PublicKeyVarGen::from(skv);
+  CHECK(pkv == *PublicKeyVarGen::from_bytes(pkv.to_bytes()));
+  // a deserialised signature and key still verify
+  CHECK(PublicKey::from_bytes(pk.to_bytes())->verify(*Signature::from_bytes(sig.to_bytes()), message));
+  // Err cases: scalar >= r, v >= q, v with no square root
+  auto bad = sig.to_bytes();
+  std::memset(bad.data(), 0xff, 32);
+  CHECK(!Signature::from_bytes(bad));
+  bad = sig.to_bytes();
+  std::memset(bad.data() + 32, 0xff, 32);
+  bad[63] = 0x7f;
+  CHECK(!Signature::from_bytes(bad));
+  int rejected = 0;
+  for (uint8_t v = 2; v < 40; v++) {  // about half of all v have no u on the curve
+    std::array<uint8_t, 32> b{};
+    b[0] = v;
+    rejected += !PublicKey::from_bytes(b);
+  }
+  CHECK(rejected > 5 && rejected < 33);
+  std::array<uint8_t, 32> r_bytes;
+  std::memcpy(r_bytes.data(), detail::kFrModulus, 32);
+  CHECK(!SecretKey::from_bytes(r_bytes));  // exactly r
+  r_bytes[0] -= 1;
+  CHECK(SecretKey::from_bytes(r_bytes).has_value());  // r - 1
+}
 static void random_is_reduced() {
   uint8_t wide[64];
   for (int i = 0; i < 64; i++) wide[i] = 0xff;
@@ -115,6 +160,7 @@ static void random_is_reduced() {
 }
 
 int main() {
+  to_from_bytes();
   random_is_reduced();
   sign_verify();
   test_wrong_keys();
