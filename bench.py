@@ -33,9 +33,10 @@ sys.path.insert(0, ROOT)
 # operation (tools: `hipcc -S` of fe29.h; checked against rocprof SQ_INSTS_VALU in profiles/).
 FE_MUL, FE_SQR = 211, 181            # 153 / 117 v_mad_u64_u32 + carry & normalise ops
 ADD, SUB, CARRY = 9, 45, 26          # limb-wise add; biased subtract + carry pass; carry pass
-DOUBLE = 3 * FE_SQR + 4 * FE_MUL + 3 * ADD + 2 * SUB    # uu, vv, zz; 2uv, and the 3 outputs
-ADD_NIELS = 8 * FE_MUL + 4 * ADD + CARRY + 3 * SUB
-ADD_ANIELS = 7 * FE_MUL + 4 * ADD + CARRY + 3 * SUB
+SUB_RAW = SUB - CARRY                # biased subtract whose consumers tolerate un-carried limbs
+DOUBLE = 3 * FE_SQR + 4 * FE_MUL + 3 * ADD + SUB + SUB_RAW    # uu, vv, zz; 2uv, and the 3 outputs
+ADD_NIELS = 8 * FE_MUL + 4 * ADD + CARRY + SUB + 2 * SUB_RAW
+ADD_ANIELS = 7 * FE_MUL + 4 * ADD + CARRY + SUB + 2 * SUB_RAW
 TO_NIELS = 2 * FE_MUL + ADD + CARRY + 2 * SUB          # incl. the negated 2d*t of a table entry
 TABLE9 = 7 * ADD_NIELS + 8 * TO_NIELS                  # |d|*P, d = 1..8
 WINDOWS = 33                                           # mean over waves of the longest lane's digits
