@@ -1,100 +1,143 @@
 #!/usr/bin/env python3
 """bench.py — Schnorr verifies/sec on MI355X (BASELINE.json metric).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--log2-batch B]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--log2-batch B] [--config single|mixed]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-One "step" = one pass of the verify hot path over one batch of 2^20 synthetic single signatures
-per GPU (BASELINE.json configs[1]), inputs already resident in HBM, through the public
-dsv_verify_single_dev: k_challenge (Poseidon) then k_verify_fixed_half ((b*u)*G + a*PK - b*R == O,
-halfgcd.h), which the library cuts into 2^16-item sub-batches on two internal streams.  Batches are generated on the GPU by the engine's own sign
-kernels and every 16th item is corrupted, so the expected verdict vector is non-trivial; it is
-checked after the timed region (and a sample is re-verified by the CPU oracle at N = 1).
+One "step" = one pass of the verify hot path over one batch per GPU, inputs already resident in
+HBM, through the public device-pointer entry points of libdsv.so:
 
-N > 1: one process per GPU, each rank verifies its own 2^20-item shard (weak scaling) and the
-verdict bytes are all-gathered over RCCL inside the timed region.
+  --config single (default; BASELINE.json configs[1]): 2^20 single signatures per GPU through
+      dsv_verify_single_dev = k_challenge (Poseidon) + k_verify_fixed_half
+      ((b*u)*G + a*PK - b*R == O, halfgcd.h), cut by the library into 2^16-item sub-batches on two
+      internal streams.  N > 1: every rank verifies its own shard (weak scaling) and the verdict
+      bytes are all-gathered over RCCL inside the timed region.
+  --config mixed (configs[4]): per GPU 2^20 items, single and double signatures interleaved by
+      index parity in ONE structure of arrays; per step the kind vector is split ON THE DEVICE,
+      each kind is gathered and verified by its own kernels, the two verdict vectors are
+      all-gathered and scattered back into global batch order
+      (schnorr_amd/distributed.py: MixedShardedVerifier).  With N > 1 the default run also reports
+      this configuration as the `mixed` sub-object of its JSON line.
 
-Prints ONE JSON line on rank 0.  `roofline` covers both kernels of the step (each is VALU-issue
-bound, and their sub-batches overlap, so no single launch can be bracketed inside the timed
-region): lane-instructions per step / step time — see DESIGN.md §4 for the instruction model; the
-single-launch durations of each kernel, taken after the timed region, and HBM figures ride along.
+Launch: `python bench.py --gpus N` from a plain shell SPAWNS its N ranks itself (fresh child
+processes, started before this process touches the GPU; LOCAL_RANK -> device, rendezvous on
+127.0.0.1); under torch.distributed.run (RANK / WORLD_SIZE in the environment) it is one rank.
+
+Batches are generated on the GPU by the engine's own sign kernels from the reference harness's
+StdRng streams; every 16th item is corrupted, so the expected verdict vector is non-trivial; it is
+checked after the timed region, and at N = 1 samples are re-verified by the CPU oracle.
+
+Prints ONE JSON line on rank 0.  `roofline` is SURVEY.md §8(d)'s figure for the dominant kernel
+k_verify_fixed_half: v_mad_u64_u32 lane-operations per verdict x verdicts / the kernel's launch
+duration (HIP events, one whole-batch launch on the current stream, right after the timed region),
+against the measured MAD issue peak.  DESIGN.md §4 has the instruction model.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-# ---- work model of the dominant kernel k_verify_fixed_half --------------------
-# VALU lane-instructions per verdict, from the instruction counts hipcc emits for each field
-# operation (tools: `hipcc -S` of fe29.h; checked against rocprof SQ_INSTS_VALU in profiles/).
-FE_MUL, FE_SQR = 211, 181            # 153 / 117 v_mad_u64_u32 + carry & normalise ops
-ADD, SUB, CARRY = 9, 45, 26          # limb-wise add; biased subtract + carry pass; carry pass
-SUB_RAW = SUB - CARRY                # biased subtract whose consumers tolerate un-carried limbs
-DOUBLE = 3 * FE_SQR + 4 * FE_MUL + 3 * ADD + SUB + SUB_RAW    # uu, vv, zz; 2uv, and the 3 outputs
-ADD_NIELS = 8 * FE_MUL + 4 * ADD + CARRY + SUB + 2 * SUB_RAW
-ADD_ANIELS = 7 * FE_MUL + 4 * ADD + CARRY + SUB + 2 * SUB_RAW
-TO_NIELS = 2 * FE_MUL + ADD + CARRY + 2 * SUB          # incl. the negated 2d*t of a table entry
-TABLE9 = 7 * ADD_NIELS + 8 * TO_NIELS                  # |d|*P, d = 1..8
-WINDOWS = 33                                           # mean over waves of the longest lane's digits
-HALF_GCD = 13000                                       # ~90 iterations x ~140 instructions
-VERIFY_INSTR = (
-    4 * FE_MUL                                         # PK, R to Montgomery form
-    + 2 * TABLE9                                       # window tables of PK and R
-    + HALF_GCD + 2 * 8 * 90                            # (a, b) and b*u mod r
-    + WINDOWS * (4 * DOUBLE + 2 * ADD_NIELS)           # a*PK -/+ b*R, shared doublings
-    + 23 * (ADD_ANIELS + 12)                           # += (b*u)*G, signed 11-bit windows
-    + 400                                              # identity test
-)
-# k_challenge (hades29.h): 8 full rounds (5 S-boxes + five 5-term constant dots), 59 partial
-# rounds in blocks of 4 (4 S-boxes, rows of 5..8 terms, four 5-term updates), last block of 3
-SBOX = 2 * FE_SQR + FE_MUL
-DOT = lambda nt: 81 * nt + (FE_MUL - 81)               # nt limb products, one reduction
-HASH_INSTR = (
-    3 * FE_MUL                                         # Ru, Rv, m to Montgomery form
-    + 8 * (5 * SBOX + 5 * DOT(5))
-    + 14 * (4 * SBOX + DOT(5) + DOT(6) + DOT(7) + DOT(8) + 4 * DOT(5))
-    + (3 * SBOX + DOT(5) + DOT(6) + DOT(7) + 4 * DOT(5))
-    + FE_MUL + 150                                     # out of Montgomery form, truncate, store
-)
-ALGO_BYTES_SINGLE = 193                            # 192 B in + 1 B out
-CORE_BYTES = 32 + 32 + 1 + 64 + 64 + 1             # what k_verify_fixed_half moves per item
-HASH_BYTES = 64 + 32 + 32 + 1                      # k_challenge: R, m in; c, valid out
-VALU_CYCLES_PER_INSTR = 4.05                       # measured: profiles/r01_valu_rates.txt
+METRIC = "Schnorr verifies/sec (single + double) at batch=2^20; 1/2/4/8 MI355X"  # BASELINE.json
+
+# ---- work model (tools/isa_hist.py -> profiles/r02/isa_hist.json) ---------------
+# v_mad_u64_u32 and total VALU instructions of one field operation, as hipcc emits them
+MUL_MAD, MUL_ALL = 153, 189            # 81 + 72 MADs; + 36 digit / shift instructions
+SQR_MAD, SQR_ALL = 117, 161            # 45 + 72 MADs; + 8 doublings + 36
+WINDOWS = 33.1                         # mean over waves of the longest lane's window count
+FIXED_ADDS = 23                        # signed 11-bit windows over 253 bits
+
+
+def _verify_counts(chains=1):
+    """(multiplications, squarings) per verdict of k_verify_fixed_half<., chains>"""
+    table = 7 * 8 + 8 * 2                              # |d|P, d = 2..8: 7 additions; 8 to_niels
+    dbl_m, dbl_s, add_m = 4, 3, 8
+    per_chain_m = (4 + 2 * table                       # PK, R to Montgomery form; two tables
+                   + 2 * add_m                         # top window: two additions onto O
+                   + (WINDOWS - 1) * (4 * dbl_m + 2 * add_m)
+                   + FIXED_ADDS * 7)                   # += (b*u)*G, mixed additions
+    per_chain_s = (WINDOWS - 1) * 4 * dbl_s
+    return chains * per_chain_m, chains * per_chain_s
+
+
+def _hash_counts(double):
+    """(multiplications, squarings, dot-product limb products, reductions of dots) of k_challenge"""
+    def perm(first_const, word1_only):
+        sbox = 5 * 8 + 59 - first_const
+        dots5 = 5 * 8 - (4 if word1_only else 0)
+        terms = 5 * dots5 + 14 * (5 + 6 + 7 + 8 + 4 * 5) + (5 + 6 + 7 + 4 * 4)
+        ndots = dots5 + 14 * 8 + 7
+        return sbox, terms, ndots
+    if double:
+        a, b = perm(1, False), perm(0, True)
+        sbox, terms, ndots = a[0] + b[0], a[1] + b[1], a[2] + b[2]
+        conv = 5
+    else:
+        sbox, terms, ndots = perm(2, True)
+        conv = 3
+    return conv + 1 + sbox, 2 * sbox, terms, ndots     # +1: out of Montgomery form
+
+
+def _mads(m, s, dot_terms=0, dot_reds=0):
+    return m * MUL_MAD + s * SQR_MAD + dot_terms * 81 + dot_reds * 72
+
+
+def _valu(m, s, dot_terms=0, dot_reds=0, other=0):
+    # a dot product: 81 MADs per term + one operand-scanning reduction (72 MADs + 58 others)
+    return m * MUL_ALL + s * SQR_ALL + dot_terms * 81 + dot_reds * 130 + other
+
+
+# lane-instructions outside multiplications: limb-wise add / biased subtract / carry passes of the
+# group law, half-gcd (~13 k), recoding, conversions, identity test
+VERIFY_OTHER = 33.1 * (4 * 91 + 2 * 145) + 16 * 145 + 23 * 150 + 13000 + 1500 + 66 * 60
+ALGO_BYTES = {"single": 193, "double": 321, "vargen": 257}
+MAD_CYCLES = 4.12        # v_mad_u64_u32 (SGPR carry-out) per wave64, 2 waves/SIMD: profiles/r02/valu_rates.txt
 N_CU, SIMD_PER_CU, CLOCK_HZ = 256, 4, 2.4e9
-VALU_PEAK_LANE_INSTR = N_CU * SIMD_PER_CU * CLOCK_HZ / VALU_CYCLES_PER_INSTR * 64
+MAD_PEAK = N_CU * SIMD_PER_CU * CLOCK_HZ / MAD_CYCLES * 64      # lane-MADs / s
 HBM_PEAK_GBS = 8000.0
 
 
-def _pmc_traffic(n):
-    """HBM bytes per step (k_verify_fixed_half + k_challenge) from the last committed rocprofv3 PMC pass
-    (profiles/pmc_latest.json; FETCH_SIZE + WRITE_SIZE, KB -> bytes, scaled to this batch).
-    Counters cannot be read from inside the timed process, so this is the recorded figure, not a
-    live one; null when no profile is committed.  (gfx950 under-reports FETCH_SIZE by up to 2x
-    for wide coalesced reads; these are 16-B-per-lane scattered reads, uncalibrated.)"""
+def _pmc():
+    """Last committed rocprofv3 PMC pass (profiles/pmc_latest.json): counters cannot be read from
+    inside the timed process, so traffic / held clock are the RECORDED figures of the same
+    command, not live ones.  (gfx950 under-reports FETCH_SIZE by up to 2x for wide coalesced
+    reads; these are 16-B-per-lane scattered reads, uncalibrated.)"""
     try:
         with open(os.path.join(ROOT, "profiles", "pmc_latest.json")) as f:
-            p = json.load(f)
-        kb = p["FETCH_SIZE_KB"] + p["WRITE_SIZE_KB"]
-        h = p.get("k_challenge", {})                       # the hash kernel of the same step
-        kb += h.get("FETCH_SIZE_KB", 0.0) + h.get("WRITE_SIZE_KB", 0.0)
-        return kb * 1024.0 * n / p["batch"]
+            return json.load(f)
     except Exception:
         return None
 
 
-def _pmc_valu_busy():
-    """VALU issue-slot occupancy of the dominant kernel in the last committed PMC pass:
-    SQ_INSTS_VALU wave-instructions x 4 cycles / (1024 SIMDs x GRBM_GUI_ACTIVE / 8 XCDs)."""
-    try:
-        with open(os.path.join(ROOT, "profiles", "pmc_latest.json")) as f:
-            p = json.load(f)
-        return p["SQ_INSTS_VALU"] * 4.0 / (N_CU * SIMD_PER_CU * p["GRBM_GUI_ACTIVE"] / 8.0)
-    except Exception:
-        return None
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _spawn_ranks(n):
+    """python bench.py --gpus N from a plain shell: start N fresh rank processes (this process has
+    not initialised the GPU and never will), forward rank 0's output, return the worst exit code."""
+    port = _free_port()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), DSV_BENCH_SPAWNED="1")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        out = None if r == 0 else subprocess.DEVNULL
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:],
+                                      env=env, stdout=out))
+    rc = 0
+    for p in procs:
+        rc = max(rc, abs(p.wait()))
+    return rc
 
 
 def main():
@@ -103,9 +146,13 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--log2-batch", type=int, default=20)
+    ap.add_argument("--config", choices=("single", "mixed"), default="single")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-double", action="store_true")
+    ap.add_argument("--no-double", action="store_true", help="skip the secondary figures")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(_spawn_ranks(args.gpus))
 
     import torch
 
@@ -113,8 +160,7 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
+        raise SystemExit("WORLD_SIZE=%d but --gpus %d" % (world, args.gpus))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP engine has no CPU fallback")
     # rehearsal knobs (one-GPU boxes): DSV_BENCH_DEVICE pins every rank to one GPU and
@@ -135,9 +181,83 @@ def main():
 
     from schnorr_amd import engine as E
     from schnorr_amd import workload as W
+    from schnorr_amd.distributed import MixedShardedVerifier
 
     E.init(dev_index)
     n = 1 << args.log2_batch
+
+    def sync_all():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def timed(step, steps, warmup):
+        """W untimed + exactly K timed steps between barrier + synchronize; max over ranks"""
+        sync_all()
+        for _ in range(warmup):
+            step()
+        sync_all()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        sync_all()
+        dt = time.perf_counter() - t0
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        if world > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    # ------------------------------------------------------------------ configs[4]: mixed batch
+    def run_mixed(steps, warmup):
+        mb = W.gen_mixed(n, seed=2321, device=dev, first_item=rank * n)
+        gk = (torch.arange(world * n, device=dev) & 1).to(torch.uint8)   # the global kind vector
+        ver = MixedShardedVerifier(n, mb["n_double"], world, rank, dev)
+        if world > 1:
+            ver(mb, gk)                          # communicator set-up is not a step
+        dtm = timed(lambda: ver(mb, gk), steps, warmup)
+        out_all = ver(mb, gk)
+        torch.cuda.synchronize()
+        mine = out_all[rank * n:(rank + 1) * n]
+        bad = int((mine != mb["expected"]).sum().item())
+        if world > 1:                            # the gathered verdicts of the OTHER ranks
+            exp_all = torch.empty(world * n, dtype=torch.uint8, device=dev)
+            dist.all_gather_into_tensor(exp_all, mb["expected"])
+            bad += int((out_all != exp_all).sum().item())
+        if bad or ver.local_counts() != (n - mb["n_double"], mb["n_double"]):
+            raise SystemExit("rank %d: mixed batch: %d verdicts differ / counts %r"
+                             % (rank, bad, ver.local_counts()))
+        res = {"value": world * n * steps / dtm, "unit": "verifies/s", "ms_per_step": dtm / steps * 1e3,
+               "workload": "2^%d mixed items per GPU (single on even, double on odd positions; "
+                           "BASELINE configs[4] = 2^23 over 8 GPUs), device-side kind split, "
+                           "two all_gathers, scatter back" % args.log2_batch,
+               "n_gpus": world}
+        return res, mb
+
+    base = {
+        "metric": METRIC, "unit": "verifies/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "u32x9 (29-bit limbs, u64 accumulate)",
+        "world_size": world, "backend": ("rccl" if backend == "nccl" else backend) if world > 1 else "none",
+        "rccl_version": ".".join(map(str, torch.cuda.nccl.version())) if world > 1 and backend == "nccl" else None,
+        "launcher": "self-spawned" if os.environ.get("DSV_BENCH_SPAWNED") else
+                    ("torch.distributed.run" if world > 1 else "single process"),
+    }
+
+    if args.config == "mixed":
+        res, _ = run_mixed(args.steps, args.warmup)
+        out = dict(base, value=res["value"], ms_per_step=res["ms_per_step"],
+                   data="synthetic: reference harness inputs (StdRng 2321 / 2322), GPU-signed, every "
+                        "16th item of each kind corrupted",
+                   config={"workload": res["workload"], "batch_per_gpu": n, "parallelism": "dp%d" % world,
+                           "collective": "2 x all_gather of per-kind verdict bytes" if world > 1 else "none"})
+        if rank == 0:
+            print(json.dumps(out))
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
+
+    # ------------------------------------------------------------------ configs[1]: single
     batch = W.gen_single(n, seed=2321, device=dev, first_item=rank * n)  # one stream, sharded
     ok = torch.zeros(n, dtype=torch.uint8, device=dev)
     ws = torch.empty(E.workspace_bytes(n), dtype=torch.uint8, device=dev)
@@ -146,52 +266,31 @@ def main():
     gathered = torch.empty(world * n, dtype=torch.uint8, device=dev) if world > 1 else None
 
     def step():
-        # the public device-pointer entry point: k_challenge + k_verify_fixed_half, cut by the
-        # library into 2^16-signature sub-batches on two internal streams (forked from / joined to
-        # the current stream)
         E.verify_single_dev(batch["u"], batch["R"], batch["PK"], batch["m"], ok, ws)
         if world > 1:
             dist.all_gather_into_tensor(gathered, ok)
 
-    def sync_all():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
     if world > 1:
-        # communicator set-up (RCCL connects lazily on the first collective) is not a step
-        dist.all_gather_into_tensor(gathered, ok)
-    sync_all()
-    for _ in range(args.warmup):
-        step()
-    sync_all()
-    t0 = time.perf_counter()
-    for k in range(args.steps):
-        step()
-    sync_all()
-    dt = time.perf_counter() - t0
+        dist.all_gather_into_tensor(gathered, ok)  # RCCL connects lazily: not a step
+    dt = timed(step, args.steps, args.warmup)
     ok_api = ok.clone()
 
-    t = torch.tensor([dt], dtype=torch.float64, device=dev)
-    if world > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    dt = float(t.item())
+    # ---- per-kernel launch durations: one whole-batch launch each on the current stream,
+    # bracketed by HIP events (outside the timed region: inside it the sub-batches of the two
+    # kernels overlap on the library's internal streams, so no single launch can be bracketed)
+    def event_ms(fn, reps=3):
+        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+               for _ in range(reps)]
+        for a, b in evs:
+            a.record()
+            fn()
+            b.record()
+        torch.cuda.synchronize()
+        return sum(a.elapsed_time(b) for a, b in evs) / reps
 
-    # ---- per-kernel durations for the roofline: the same two kernels over the whole batch, one
-    # launch each on the current stream, bracketed by events (outside the timed region; inside it
-    # the sub-batches of the two kernels overlap, so no single launch can be bracketed)
-    evs = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(3)]
-    for e in evs:
-        e[0].record()
-        E.challenge_single_dev(batch["R"], batch["m"], c, valid)
-        e[1].record()
-        E.verify_core_dev(batch["u"], c, valid, batch["PK"], batch["R"], ok, ws)
-        e[2].record()
-    torch.cuda.synchronize()
-    hash_ms = sum(e[0].elapsed_time(e[1]) for e in evs) / len(evs)
-    core_ms = sum(e[1].elapsed_time(e[2]) for e in evs) / len(evs)
+    hash_ms = event_ms(lambda: E.challenge_single_dev(batch["R"], batch["m"], c, valid))
+    core_ms = event_ms(lambda: E.verify_core_dev(batch["u"], c, valid, batch["PK"], batch["R"], ok, ws))
 
-    # ---- correctness of what was timed
     mism = int((ok != batch["expected"]).sum().item())
     mism_api = int((ok_api != batch["expected"]).sum().item())
     if world > 1:
@@ -201,111 +300,131 @@ def main():
         raise SystemExit("rank %d: %d / %d verdicts differ from the expected pattern"
                          % (rank, mism, mism_api))
 
-    total = n * world
-    value = total * args.steps / dt
-    out = {
-        "metric": "Schnorr verifies/sec (single) at batch=2^%d" % args.log2_batch,
-        "value": value,
-        "unit": "verifies/s",
-        "n_gpus": world,
-        "steps": args.steps,
-        "warmup": args.warmup,
-        "ms_per_step": dt / args.steps * 1e3,
-        "higher_is_better": True,
-        "scaling": "weak",
-        "vs_baseline": None,
-        "dtype": "u32x9 (29-bit limbs, u64 accumulate)",
-        "data": "synthetic: reference harness inputs (StdRng::seed_from_u64(2321): sk, m, nonce per "
-                "item, restated RNG), GPU-signed, every 16th item corrupted",
-        "config": {"workload": "2^%d single-signature batch verify per GPU (BASELINE configs[1])"
-                               % args.log2_batch,
-                   "batch_per_gpu": n, "parallelism": "dp%d" % world,
-                   "collective": "all_gather of verdict bytes" if world > 1 else "none"},
-    }
+    value = n * world * args.steps / dt
+    out = dict(base, value=value, ms_per_step=dt / args.steps * 1e3,
+               data="synthetic: reference harness inputs (StdRng::seed_from_u64(2321): sk, m, nonce "
+                    "per item, restated RNG), GPU-signed, every 16th item corrupted",
+               config={"workload": "2^%d single-signature batch verify per GPU (BASELINE configs[1]); "
+                                   "`value` is this figure, `double` / `vargen` / `mixed` ride along"
+                                   % args.log2_batch,
+                       "batch_per_gpu": n, "parallelism": "dp%d" % world,
+                       "collective": "all_gather of verdict bytes" if world > 1 else "none"})
+
+    kernels = {}
+
+    def kernel_block(name, ms, items, m, s, dt_=0, dr=0, other=0, algo_bytes=None):
+        mads, valu = _mads(m, s, dt_, dr), _valu(m, s, dt_, dr, other)
+        sec = ms * 1e-3
+        blk = {"ms_per_launch": ms, "items": items, "mad_lane_ops_per_item": round(mads),
+               "valu_lane_instr_per_item": round(valu),
+               "mad_frac": mads * items / sec / MAD_PEAK,
+               "valu_issue_frac": valu * items / sec / (MAD_PEAK * MAD_CYCLES / 4.05)}
+        if algo_bytes:
+            blk["algorithmic_GBps"] = algo_bytes * items / sec / 1e9
+        kernels[name] = blk
+        return blk
 
     if rank == 0:
-        # The timed region IS the bracket: the library forks its two internal streams from the
-        # current stream and joins them back, so `dt` covers exactly steps x (k_challenge +
-        # k_verify_fixed_half over n items).  Both kernels are VALU-issue bound; achieved = the
-        # lane-instructions of both per step / the step time of this rank's own launches.
-        step_s = dt / args.steps
-        core_s = core_ms * 1e-3
-        lane_instr = (VERIFY_INSTR + HASH_INSTR) * n
-        achieved = lane_instr / step_s
+        vm, vs = _verify_counts(1)
+        dom = kernel_block("k_verify_fixed_half<false,1>", core_ms, n, vm, vs, other=VERIFY_OTHER,
+                           algo_bytes=ALGO_BYTES["single"])
+        hm, hs, ht, hr = _hash_counts(False)
+        kernel_block("k_challenge<false>", hash_ms, n, hm, hs, ht, hr, other=600)
+        pmc = _pmc()
+        traffic = clock = None
+        if pmc:
+            traffic = (pmc["FETCH_SIZE_KB"] + pmc["WRITE_SIZE_KB"]) * 1024.0 * n / pmc["batch"]
+            clock = pmc.get("clock_held_ghz")
+            if clock is None and "GRBM_GUI_ACTIVE" in pmc and "avg_duration_ns" in pmc:
+                clock = pmc["GRBM_GUI_ACTIVE"] / 8.0 / pmc["avg_duration_ns"]
+        algo = ALGO_BYTES["single"] * n
         out["roofline"] = {
-            "kernel": "k_challenge + k_verify_fixed_half (2^16-item sub-batches, two streams)",
-            "bound": "valu",
-            "achieved": achieved / 1e12,
-            "peak": VALU_PEAK_LANE_INSTR / 1e12,
-            "unit": "T lane-instr/s",
-            "frac": achieved / VALU_PEAK_LANE_INSTR,
-            "traffic": _pmc_traffic(n),
-            "valu_busy_from_pmc": _pmc_valu_busy(),
-            "model": {"valu_lane_instr_per_verdict": {"k_verify_fixed_half": VERIFY_INSTR,
-                                                      "k_challenge": HASH_INSTR},
-                      "cycles_per_wave_instr": VALU_CYCLES_PER_INSTR,
-                      # one full-batch launch of each kernel on one stream, after the timed region
-                      "kernel_ms": core_ms, "hash_kernel_ms": hash_ms,
-                      "verify_kernel_frac_alone": VERIFY_INSTR * n / core_s / VALU_PEAK_LANE_INSTR,
-                      "hash_kernel_frac_alone": HASH_INSTR * n / (hash_ms * 1e-3)
-                                                / VALU_PEAK_LANE_INSTR},
-            "hbm": {"bound": "hbm", "achieved": (CORE_BYTES + HASH_BYTES) * n / step_s / 1e9,
-                    "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": (CORE_BYTES + HASH_BYTES) * n / step_s / 1e9 / HBM_PEAK_GBS,
-                    "algorithmic_bytes_per_verdict": ALGO_BYTES_SINGLE,
-                    "kernel_bytes_per_verdict": CORE_BYTES + HASH_BYTES},
+            "kernel": "k_verify_fixed_half<false,1> (dominant: %.0f %% of a step)"
+                      % (100 * core_ms / (core_ms + hash_ms)),
+            "bound": "valu",       # neither HBM nor MFMA binds: integer MAD issue
+            "achieved": dom["mad_lane_ops_per_item"] * n / (core_ms * 1e-3) / 1e12,
+            "peak": MAD_PEAK / 1e12,
+            "unit": "T lane-MAD/s",
+            "frac": dom["mad_frac"],
+            "mad_frac": dom["mad_frac"],
+            "valu_issue_frac": dom["valu_issue_frac"],
+            "clock_held_ghz": clock,
+            "traffic": traffic,
+            "traffic_ratio": traffic / algo if traffic else None,
+            "step_mad_frac": (_mads(vm, vs) + _mads(hm, hs, ht, hr)) * n / (dt / args.steps) / MAD_PEAK,
+            "model": {"mad_cycles_per_wave_instr": MAD_CYCLES, "windows": WINDOWS,
+                      "mul_sqr_per_verdict": [round(vm), round(vs)], "kernel_ms": core_ms,
+                      "hash_kernel_ms": hash_ms,
+                      "peak_note": "256 CU x 4 SIMD x 64 lanes x 2.4 GHz / 4.12 cycles"},
+            "hbm": {"bound": "hbm", "achieved": algo / (dt / args.steps) / 1e9, "peak": HBM_PEAK_GBS,
+                    "unit": "GB/s", "frac": algo / (dt / args.steps) / 1e9 / HBM_PEAK_GBS,
+                    "algorithmic_bytes_per_verdict": ALGO_BYTES["single"]},
+            "kernels": kernels,
         }
 
-    # ---- secondary figure: double signatures (BASELINE configs[2]), outside the timed region
+    # ---- secondary figures (N = 1): double (configs[2]), var-generator (configs[3]), signing
+    sample_checks = {}
     if not args.no_double and world == 1:
-        nd = n
-        bd = W.gen_double(nd, seed=4242, device=dev)
-        okd = torch.zeros(nd, dtype=torch.uint8, device=dev)
-        E.verify_double_dev(bd["u"], bd["R"], bd["Rp"], bd["PK"], bd["PKp"], bd["m"], okd, ws)
-        torch.cuda.synchronize()
-        td0 = time.perf_counter()
         reps = max(1, args.steps // 2)
-        for _ in range(reps):
-            E.verify_double_dev(bd["u"], bd["R"], bd["Rp"], bd["PK"], bd["PKp"], bd["m"], okd, ws)
-        torch.cuda.synchronize()
-        tdd = time.perf_counter() - td0
+        bd = W.gen_double(n, seed=4242, device=dev)
+        okd = torch.zeros(n, dtype=torch.uint8, device=dev)
+        fd = lambda: E.verify_double_dev(bd["u"], bd["R"], bd["Rp"], bd["PK"], bd["PKp"], bd["m"], okd, ws)
+        tdd = timed(fd, reps, 1)
         if int((okd != bd["expected"]).sum().item()):
             raise SystemExit("double-signature verdicts differ from the expected pattern")
-        out["double"] = {"value": nd * reps / tdd, "unit": "verifies/s",
-                         "workload": "2^%d double-signature batch (BASELINE configs[2])"
-                                     % args.log2_batch}
-        del bd, okd
-        # var-generator scheme (BASELINE configs[3]: 2^18), both bases variable
+        out["double"] = {"value": n * reps / tdd, "unit": "verifies/s",
+                         "workload": "2^%d double-signature batch (BASELINE configs[2]), fused "
+                                     "two-equation kernel" % args.log2_batch}
+        hd_ms = event_ms(lambda: E.challenge_double_dev(bd["R"], bd["Rp"], bd["m"], c, valid))
+        cd_ms = event_ms(lambda: E.verify_core_double_dev(bd["u"], c, valid, bd["PK"], bd["R"],
+                                                          bd["PKp"], bd["Rp"], okd, ws))
+        if int((okd != bd["expected"]).sum().item()):
+            raise SystemExit("fused double kernel: verdicts differ from the expected pattern")
+        vm2, vs2 = _verify_counts(2)
+        kernel_block("k_verify_fixed_half<false,2>", cd_ms, n, vm2, vs2, other=2 * VERIFY_OTHER - 14500,
+                     algo_bytes=ALGO_BYTES["double"])
+        hm2, hs2, ht2, hr2 = _hash_counts(True)
+        kernel_block("k_challenge<true>", hd_ms, n, hm2, hs2, ht2, hr2, other=900)
+        sample_checks["double"] = (bd, okd.clone())
+
         nv = min(n, 1 << 18)
         bv = W.gen_vargen(nv, seed=777, device=dev)
         okv = torch.zeros(nv, dtype=torch.uint8, device=dev)
-        E.verify_vargen_dev(bv["u"], bv["R"], bv["PK"], bv["Gen"], bv["m"], okv, ws)
-        torch.cuda.synchronize()
-        tv0 = time.perf_counter()
-        for _ in range(reps):
-            E.verify_vargen_dev(bv["u"], bv["R"], bv["PK"], bv["Gen"], bv["m"], okv, ws)
-        torch.cuda.synchronize()
-        tvv = time.perf_counter() - tv0
+        fv = lambda: E.verify_vargen_dev(bv["u"], bv["R"], bv["PK"], bv["Gen"], bv["m"], okv, ws)
+        tvv = timed(fv, reps, 1)
         if int((okv != bv["expected"]).sum().item()):
             raise SystemExit("var-generator verdicts differ from the expected pattern")
+        out["vargen"] = {"value": nv * reps / tvv, "unit": "verifies/s",
+                         "workload": "2^%d var-generator batch (BASELINE configs[3]), inputs from "
+                                     "StdRng(777): sk, g, m, nonce per item" % (nv.bit_length() - 1)}
+        var_ms = event_ms(fv)
+        hv_ms = event_ms(lambda: E.challenge_single_dev(bv["R"], bv["m"], c[:nv], valid[:nv]))
+        # Straus over two 252-bit scalars: 2 tables, 63 x (4 doublings + 2 additions), compare
+        vvm = 6 + 2 * (7 * 8 + 8 * 2) + 2 * 8 + 63 * (16 + 16) + 2
+        vvs = 63 * 12
+        kernel_block("k_verify_var (whole call minus k_challenge, 2^%d items)" % (nv.bit_length() - 1),
+                     max(var_ms - hv_ms, 1e-3), nv, vvm, vvs, other=63 * (4 * 91 + 2 * 145) + 6000,
+                     algo_bytes=ALGO_BYTES["vargen"])
+        sample_checks["vargen"] = (bv, okv.clone())
+
         # signing (the step in front of verify): R = r*G, c = H(R, m), u = r - c*sk
         sk_ = torch.randint(0, 256, (n, 32), dtype=torch.uint8, device=dev); sk_[:, 31] &= 0x07
         r_ = torch.randint(0, 256, (n, 32), dtype=torch.uint8, device=dev); r_[:, 31] &= 0x07
         su = torch.empty((n, 32), dtype=torch.uint8, device=dev)
         sR = torch.empty((n, 64), dtype=torch.uint8, device=dev)
-        E.sign_single_dev(sk_, batch["m"], r_, su, sR)
-        torch.cuda.synchronize()
-        ts0 = time.perf_counter()
-        for _ in range(reps):
-            E.sign_single_dev(sk_, batch["m"], r_, su, sR)
-        torch.cuda.synchronize()
-        out["sign"] = {"value": n * reps / (time.perf_counter() - ts0), "unit": "signatures/s",
+        tss = timed(lambda: E.sign_single_dev(sk_, batch["m"], r_, su, sR), reps, 1)
+        out["sign"] = {"value": n * reps / tss, "unit": "signatures/s",
                        "workload": "2^%d single signatures, nonces supplied" % args.log2_batch}
         del sk_, r_, su, sR
-        out["vargen"] = {"value": nv * reps / tvv, "unit": "verifies/s",
-                         "workload": "2^%d var-generator batch (BASELINE configs[3])"
-                                     % (nv.bit_length() - 1)}
-        del bv, okv
+        mres, mb = run_mixed(reps, 1)
+        out["mixed"] = mres
+        sample_checks["mixed"] = (mb, None)
+        if rank == 0:
+            out["roofline"]["kernels"] = kernels
+    elif world > 1 and not args.no_double:
+        # the multi-GPU run also measures configs[4] (2^20 mixed items per GPU), same process group
+        mres, _ = run_mixed(max(1, args.steps // 2), 1)
+        out["mixed"] = mres
 
     # ---- CPU baseline: the oracle (port of the reference algorithm) on the host cores
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -318,10 +437,8 @@ def main():
             cores = os.cpu_count() or 1
         cores = max(1, min(cores, 16))  # the GPU box's CPU share for one GPU
         sample = 4096 * cores
-        hu = batch["u"][:sample].cpu().numpy()
-        hR = batch["R"][:sample].cpu().numpy()
-        hPK = batch["PK"][:sample].cpu().numpy()
-        hm = batch["m"][:sample].cpu().numpy()
+        h = lambda t, k: t[:k].cpu().numpy()
+        hu, hR, hPK, hm = (h(batch[k], sample) for k in ("u", "R", "PK", "m"))
         O.verify_single(hu[:64], hR[:64], hPK[:64], hm[:64])  # warm
         tc0 = time.perf_counter()
         cpu_ok = O.verify_single(hu, hR, hPK, hm, nthreads=cores)
@@ -342,16 +459,42 @@ def main():
                       "1 thread: %.0f verifies/s on %d items; configs[0] shape (1024 x keygen+sign, "
                       "1 thread): %.0f /s" % (sample, cores, tc, one / t1, one, 1024 / t_sign),
         }
+        # oracle samples of the secondary figures (the timed verdicts, not a re-run)
+        k = 2048
+        checked = []
+        if "double" in sample_checks:
+            bd, got = sample_checks["double"]
+            w_ = O.verify_double(*(h(bd[x], k) for x in ("u", "R", "Rp", "PK", "PKp", "m")), nthreads=cores)
+            if (w_ != got[:k].cpu().numpy()).any():
+                raise SystemExit("CPU oracle disagrees with the GPU double verdicts on the sample")
+            checked.append("double")
+        if "vargen" in sample_checks:
+            bv, got = sample_checks["vargen"]
+            w_ = O.verify_vargen(*(h(bv[x], k) for x in ("u", "R", "PK", "Gen", "m")), nthreads=cores)
+            if (w_ != got[:k].cpu().numpy()).any():
+                raise SystemExit("CPU oracle disagrees with the GPU var-generator verdicts on the sample")
+            checked.append("vargen")
+        if "mixed" in sample_checks:
+            mb, _ = sample_checks["mixed"]
+            ks = mb["kinds"][:k].cpu().numpy()
+            exp = mb["expected"][:k].cpu().numpy()
+            cols = {x: h(mb[x], k) for x in ("u", "R", "Rp", "PK", "PKp", "m")}
+            s_, d_ = ks == 0, ks == 1
+            ws_ = O.verify_single(cols["u"][s_], cols["R"][s_], cols["PK"][s_], cols["m"][s_], nthreads=cores)
+            wd_ = O.verify_double(*(cols[x][d_] for x in ("u", "R", "Rp", "PK", "PKp", "m")), nthreads=cores)
+            if (ws_ != exp[s_]).any() or (wd_ != exp[d_]).any():
+                raise SystemExit("CPU oracle disagrees with the mixed batch's expected verdicts")
+            checked.append("mixed")
+        out["cpu_baseline"]["oracle_samples"] = "first %d items of: single (%d), %s" % (
+            k, sample, ", ".join(checked))
         # host-buffer path of the C ABI (PCIe-inclusive), never the headline value
-        hs = n
-        hu = batch["u"][:hs].cpu().numpy(); hR = batch["R"][:hs].cpu().numpy()
-        hPK = batch["PK"][:hs].cpu().numpy(); hm = batch["m"][:hs].cpu().numpy()
+        hu, hR, hPK, hm = (h(batch[x], n) for x in ("u", "R", "PK", "m"))
         E.verify_single(hu, hR, hPK, hm)  # warm: staging buffers sized for this batch
         th0 = time.perf_counter()
         E.verify_single(hu, hR, hPK, hm)
         th = time.perf_counter() - th0
-        out["host_path"] = {"value": hs / th, "unit": "verifies/s",
-                            "note": "dsv_verify_single on %d host-resident items incl. PCIe staging" % hs}
+        out["host_path"] = {"value": n / th, "unit": "verifies/s",
+                            "note": "dsv_verify_single on %d host-resident items incl. PCIe staging" % n}
         # BASELINE configs[0] size through the same host entry point: latency of a 1024-item call
         E.verify_single(hu[:1024], hR[:1024], hPK[:1024], hm[:1024])
         tl0 = time.perf_counter()

@@ -8,9 +8,11 @@
  *   dsv_verify_double   replaces  PublicKeyDouble::verify  /root/reference/src/keys/public.rs:222-244
  *   dsv_verify_vargen   replaces  PublicKeyVarGen::verify  /root/reference/src/keys/public.rs:401-415
  *   dsv_challenge_*     exposes   challenge_hash{,_double} /root/reference/src/signatures.rs:127-134, 275-290
- *   dsv_sign_*          replaces  SecretKey::sign / sign_double / SecretKeyVarGen::sign
+ *   dsv_sign_*          computes what SecretKey::sign / sign_double / SecretKeyVarGen::sign compute
  *                                                          /root/reference/src/keys/secret.rs:150-168, 217-240, 433-451
- *   dsv_public_keys     replaces  PublicKey::from(&SecretKey)  /root/reference/src/keys/public.rs:61-67, 265-272
+ *   dsv_public_keys     computes  PublicKey::from(&SecretKey)  /root/reference/src/keys/public.rs:61-67, 265-272
+ *                       — as INPUT GENERATORS for tests and benchmarks, not as a production
+ *                       signer: see the note at the signing section.
  *
  * Data layout (all entry points): structure-of-arrays, caller-owned, one batch = n items.
  *   scalar  (JubJubScalar u, sk, c; BlsScalar message m) : 32 bytes, canonical little-endian
@@ -21,20 +23,40 @@
  *   ext point (the *_ext entry points)                     : 96 bytes = u || v || z of a
  *                                                           JubJubExtended with arbitrary z != 0
  *   verdict ok[i]                                          : one byte, 1 = verify() true, 0 = false
- * Verdicts are bit-exact with the reference's `verify` for every input its types can hold
- * (any on-curve point incl. identity / small order, any scalar).  Encodings the Rust types
+ * Verdicts are those of the reference's `verify` for every input its types can hold (any
+ * on-curve point incl. identity / small order, any scalar) — bit-exact against this repository's
+ * CPU restatement of the reference algorithm (oracle/); the challenge hash's constants are
+ * recipe-derived and NOT pinned by any upstream vector ("parity unpinned").
+ * Encodings the Rust types
  * cannot hold (scalar >= r, coordinate or message >= q) give ok[i] = 0; off-curve
  * coordinates are out of contract (result unspecified, never a fault).
  *
  * Host entry points take HOST pointers (pageable is fine), stage through library-owned pinned
  * and device buffers in chunks of 2^17 items (DSV_HOST_THREADS copy threads, default 4) and block
- * until the verdicts are in `ok`; they serialise on one internal lock.  The *_dev entry points
- * take DEVICE pointers (hipMalloc'd, 16-byte aligned) plus a hipStream_t passed as void*, enqueue
- * only, and never synchronise — they are what the bench times with inputs resident in HBM.
+ * until the verdicts are in `ok`.  The *_dev entry points take DEVICE pointers (hipMalloc'd,
+ * 16-byte aligned) plus a hipStream_t passed as void*, enqueue only, and never synchronise —
+ * they are what the bench times with inputs resident in HBM.
+ *
+ * Devices and threads.  dsv_init(d) may be called for several devices of one process; each gets
+ * its own context (tables, streams, staging) and nothing is shared between contexts.
+ *   - *_dev entry points run on the device that OWNS their output buffer (the stream must belong
+ *     to the same device); they may be called concurrently from any number of threads, on the
+ *     same or on different streams, and leave the calling thread's current device unchanged.
+ *     Callers on different streams get different internal sub-batch streams (up to 8 per device,
+ *     shared beyond that), so they overlap on the GPU.
+ *   - host entry points run on the calling thread's device: dsv_set_device(d) (thread-local), else
+ *     the first device initialised.  Host calls on ONE device serialise on that device's lock;
+ *     host calls on different devices run in parallel.
+ *   - dsv_verify_*_multi shard one host batch over ALL initialised devices (contiguous shards, one
+ *     host thread per device, no collective).
+ *   - dsv_shutdown[_device] waits for the host call in flight on that device, synchronises the
+ *     device and releases everything; the caller must not have *_dev work of its own still
+ *     enqueued whose workspace it frees, and must not start new calls on that device until a
+ *     later dsv_init.  Calls that arrive after shutdown return DSV_ERR_NOT_INITIALIZED.
  *
  * Return value: DSV_OK (0) or a negative dsv_status; dsv_last_error() gives the text for
- * the calling thread.  The library keeps no pointer after a call returns.  Calls on
- * different streams may run concurrently; dsv_init is idempotent and thread-safe.
+ * the calling thread.  The library keeps no pointer after a call returns.  dsv_init is
+ * idempotent and thread-safe.
  */
 #ifndef DSV_H
 #define DSV_H
@@ -57,8 +79,12 @@ typedef enum {
 #define DSV_MAX_BATCH ((size_t)1 << 28)
 
 /* ---- lifecycle ---- */
-int dsv_init(int device);             /* select GPU, build the fixed-base tables for G and G' */
-int dsv_shutdown(void);
+int dsv_init(int device);             /* create this GPU's context: fixed-base tables for G and G' */
+int dsv_shutdown(void);               /* every initialised device */
+int dsv_shutdown_device(int device);
+int dsv_set_device(int device);       /* device of THIS thread's host entry points (must be initialised) */
+int dsv_get_device(void);             /* ... the current choice; -1 before any dsv_init */
+int dsv_initialized_devices(int *out, int cap); /* returns how many; fills out[0 .. min(cap, count)) */
 const char *dsv_version(void);
 const char *dsv_last_error(void);
 int dsv_device_count(void);
@@ -75,6 +101,15 @@ int dsv_verify_vargen(const uint8_t *u, const uint8_t *R_uv, const uint8_t *PK_u
  * JubJubExtended values (the device does the z inversion of to_hash_inputs) */
 int dsv_verify_single_ext(const uint8_t *u, const uint8_t *R_uvz, const uint8_t *PK_uvz,
                           const uint8_t *m, size_t n, uint8_t *ok);
+
+/* ---- verify, host buffers, sharded over every initialised device (see "Devices and threads") ---- */
+int dsv_verify_single_multi(const uint8_t *u, const uint8_t *R_uv, const uint8_t *PK_uv,
+                            const uint8_t *m, size_t n, uint8_t *ok);
+int dsv_verify_double_multi(const uint8_t *u, const uint8_t *R_uv, const uint8_t *Rp_uv,
+                            const uint8_t *PK_uv, const uint8_t *PKp_uv, const uint8_t *m,
+                            size_t n, uint8_t *ok);
+int dsv_verify_vargen_multi(const uint8_t *u, const uint8_t *R_uv, const uint8_t *PK_uv,
+                            const uint8_t *Gen_uv, const uint8_t *m, size_t n, uint8_t *ok);
 
 /* ---- verify, device buffers (enqueue only) ----
  * workspace: device scratch of dsv_workspace_bytes(n) bytes, 256-byte aligned, owned by the call
@@ -98,6 +133,38 @@ int dsv_verify_core_dev(const void *u, const void *c, const void *valid, const v
                         const void *R_uv, int which, int accumulate, size_t n, void *ok,
                         void *workspace, void *stream);
 
+/* both equations of PublicKeyDouble::verify from a precomputed challenge, ONE launch (what
+ * dsv_verify_double_dev runs after k_challenge): ok[i] = valid[i] & [uG + cPK == R] & [uG' + cPK' == R'] */
+int dsv_verify_core_double_dev(const void *u, const void *c, const void *valid, const void *PK_uv,
+                               const void *R_uv, const void *PKp_uv, const void *Rp_uv, size_t n,
+                               void *ok, void *workspace, void *stream);
+
+/* ---- mixed batches (single and double signatures interleaved), device buffers ----------------
+ * kinds[i] = 0: item i is a Signature / PublicKey pair, 1: a SignatureDouble / PublicKeyDouble
+ * pair; the batch is a structure of arrays over ALL n items (Rp_uv / PKp_uv rows of single items
+ * are ignored).  The library splits the batch by kind ON THE DEVICE (stable compaction of the
+ * index vector + row gathers), runs each kind through its own kernels and scatters the verdicts
+ * back into batch order.  n_double = number of kind-1 items; every other item must be kind 0.  If
+ * the counts do not match the kind vector, or an item has another kind, the affected verdicts
+ * (all of them for a count mismatch) are 0.  kinds must be 16-byte aligned.
+ * workspace: dsv_mixed_workspace_bytes(n) device bytes, 256-byte aligned. */
+size_t dsv_mixed_workspace_bytes(size_t n);
+int dsv_verify_mixed_dev(const void *kinds, const void *u, const void *R_uv, const void *Rp_uv,
+                         const void *PK_uv, const void *PKp_uv, const void *m, size_t n,
+                         size_t n_double, void *ok, void *workspace, void *stream);
+/* the pieces, for callers that shard each kind separately (schnorr_amd/distributed.py):
+ *   split : idx_single[j] / idx_double[j] = batch position (uint32) of the j-th item of that kind,
+ *           at most cap_* entries written; scratch: dsv_split_scratch_bytes(n) device bytes whose
+ *           last two uint32 (at offset dsv_split_scratch_bytes(n) - 256) receive the two counts
+ *   gather: dst row j = src row idx[j], rows of row_bytes (multiple of 16) bytes
+ *   scatter: dst[idx[j]] = src[j] (verdict bytes back into batch order) */
+size_t dsv_split_scratch_bytes(size_t n);
+int dsv_split_kinds_dev(const void *kinds, size_t n, void *idx_single, size_t cap_single,
+                        void *idx_double, size_t cap_double, void *scratch, void *stream);
+int dsv_gather_rows_dev(const void *src, size_t row_bytes, const void *idx, size_t count, void *dst,
+                        void *stream);
+int dsv_scatter_verdicts_dev(const void *src, const void *idx, size_t count, void *dst, void *stream);
+
 /* ---- challenge hash only (c = trunc250(Poseidon(R.., m))), 32 B LE per item ---- */
 int dsv_challenge_single(const uint8_t *R_uv, const uint8_t *m, size_t n, uint8_t *c);
 int dsv_challenge_double(const uint8_t *R_uv, const uint8_t *Rp_uv, const uint8_t *m, size_t n,
@@ -107,10 +174,16 @@ int dsv_challenge_single_dev(const void *R_uv, const void *m, size_t n, void *c,
 int dsv_challenge_double_dev(const void *R_uv, const void *Rp_uv, const void *m, size_t n,
                              void *c, void *valid, void *stream);
 
-/* ---- signing / key derivation (fixed-base only; input generation and the "next" row) ----
+/* ---- signing / key derivation: input generation for tests and benchmarks ("next" row f-1) ----
  * sk, m, r canonical 32 B.  r is the caller-drawn nonce (the reference draws it from its RNG
  * inside sign()).  Outputs: u (32 B), R_uv / Rp_uv (64 B).  gen_uv == NULL means the standard
- * generator G;  for the var-generator scheme pass the per-key generator (variable base). */
+ * generator G;  for the var-generator scheme pass the per-key generator (variable base).
+ * NOT A PRODUCTION SIGNER: unlike dusk-jubjub's constant-time multiplication, these kernels index
+ * global-memory tables with digits of sk and of the nonce (memory addresses depend on secrets).
+ * The host entry points zero their device staging of sk / nonce before returning (and the
+ * library zeroes staging it releases); the *_dev forms work in the caller's buffers only.
+ * A scalar that is not canonical (>= r): host entry points return DSV_ERR_INVALID_ARGUMENT; the
+ * *_dev forms write 0xff..ff (never a valid encoding) to that item's outputs. */
 int dsv_sign_single(const uint8_t *sk, const uint8_t *m, const uint8_t *r, size_t n, uint8_t *u,
                     uint8_t *R_uv);
 int dsv_sign_double(const uint8_t *sk, const uint8_t *m, const uint8_t *r, size_t n, uint8_t *u,
@@ -125,6 +198,11 @@ int dsv_sign_single_dev(const void *sk, const void *m, const void *r, size_t n, 
 int dsv_sign_double_dev(const void *sk, const void *m, const void *r, size_t n, void *u,
                         void *R_uv, void *Rp_uv, void *stream);
 int dsv_public_keys_dev(const void *sk, int which, size_t n, void *PK_uv, void *stream);
+/* variable-base forms (var-generator scheme); workspace: dsv_workspace_bytes(n) device bytes */
+int dsv_public_keys_vargen_dev(const void *sk, const void *Gen_uv, size_t n, void *PK_uv,
+                               void *workspace, void *stream);
+int dsv_sign_vargen_dev(const void *sk, const void *Gen_uv, const void *m, const void *r, size_t n,
+                        void *u, void *R_uv, void *workspace, void *stream);
 
 /* ---- wire formats (the reference's Serializable impls) ------------------------------------
  * compressed point = JubJubAffine::to_bytes(): canonical v with bit 255 = lowest bit of u.
@@ -160,9 +238,15 @@ int dsv_stdrng_sign_inputs(uint64_t seed, size_t first_item, size_t n, uint8_t *
                            uint8_t *r);
 int dsv_stdrng_sign_inputs_dev(uint64_t seed, size_t first_item, size_t n, void *sk, void *m,
                                void *r, void *stream);
+/* var-generator harness: SecretKeyVarGen::random draws sk, then the generator scalar g
+ * (Gen = g*G), then the message, then the nonce — four draws per item
+ * (/root/reference/src/keys/secret.rs:371-373, tests/schnorr_var_generator.rs:16-22) */
+int dsv_stdrng_vargen_inputs_dev(uint64_t seed, size_t first_item, size_t n, void *sk, void *g,
+                                 void *m, void *r, void *stream);
 
 /* ---- introspection for tests: copy one fixed-base table entry (affine niels v+u, v-u, 2duv
- * as canonical LE, 96 B) for generator `which` (0 = G, 1 = G'), window w (8-bit), digit d ---- */
+ * as canonical LE, 96 B) for generator `which` (0 = G, 1 = G'), window w (signed windows of
+ * dsv_fixed_window_bits() bits), digit magnitude d ---- */
 int dsv_debug_table_entry(int which, int window, int digit, uint8_t out96[96]);
 int dsv_fixed_window_bits(void); /* width of the (signed) fixed-base windows; digit <= 2^(bits-1) */
 /* ---- introspection: field-multiplier self test on the device: out = a*b mod q (canonical) */

@@ -18,7 +18,15 @@ SYMBOLS = [
     "dsv_verify_single_wire", "dsv_verify_double_wire", "dsv_verify_vargen_wire",
     "dsv_stdrng_sign_inputs", "dsv_stdrng_sign_inputs_dev",
     "dsv_debug_table_entry", "dsv_fixed_window_bits", "dsv_debug_fq_mul",
+    # r02: several devices per process, fused double kernel, mixed batches, var-generator inputs
+    "dsv_shutdown_device", "dsv_set_device", "dsv_get_device", "dsv_initialized_devices",
+    "dsv_verify_single_multi", "dsv_verify_double_multi", "dsv_verify_vargen_multi",
+    "dsv_verify_core_double_dev", "dsv_mixed_workspace_bytes", "dsv_verify_mixed_dev",
+    "dsv_split_scratch_bytes", "dsv_split_kinds_dev", "dsv_gather_rows_dev",
+    "dsv_scatter_verdicts_dev", "dsv_public_keys_vargen_dev", "dsv_sign_vargen_dev",
+    "dsv_stdrng_vargen_inputs_dev",
 ]
+_SIZE_T_FUNCS = ("dsv_workspace_bytes", "dsv_mixed_workspace_bytes", "dsv_split_scratch_bytes")
 
 
 class DsvError(RuntimeError):
@@ -53,11 +61,12 @@ def load():
         raise DsvError("cannot load the HIP engine %s: %s" % (LIB_PATH, e))
     L.dsv_version.restype = ctypes.c_char_p
     L.dsv_last_error.restype = ctypes.c_char_p
-    L.dsv_workspace_bytes.restype = ctypes.c_size_t
-    L.dsv_workspace_bytes.argtypes = [ctypes.c_size_t]
+    for name in _SIZE_T_FUNCS:
+        getattr(L, name).restype = ctypes.c_size_t
+        getattr(L, name).argtypes = [ctypes.c_size_t]
     for name in SYMBOLS:
         fn = getattr(L, name)  # AttributeError if a declared symbol is not exported
-        if name not in ("dsv_version", "dsv_last_error", "dsv_workspace_bytes"):
+        if name not in ("dsv_version", "dsv_last_error") + _SIZE_T_FUNCS:
             fn.restype = ctypes.c_int
     _lib = L
     return L

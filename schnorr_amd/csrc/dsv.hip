@@ -127,7 +127,8 @@ DSV_DEV Ext ext_mul_words(const Ext& p, const u32 (&s)[8]) {
 }
 
 // ------------------------------------------------------------------------------------------
-// init: fixed-base tables.  table[w][d] = affine niels of (d * 2^(8w)) * Gen, canonical limbs.
+// init: fixed-base tables.  table[w][d] = affine niels of (d * 2^(kFixedBits*w)) * Gen, d = 0 ..
+// 2^(kFixedBits-1), canonical limbs (+ the negated 2d*uv).
 // ------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(64) k_build_fixed_table(u32* __restrict__ table, int which) {
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
@@ -197,9 +198,9 @@ k_challenge(const uint8_t* __restrict__ R_uv, const uint8_t* __restrict__ Rp_uv,
 // ------------------------------------------------------------------------------------------
 // scalar multiplications
 // ------------------------------------------------------------------------------------------
-// acc += u * Gen from the 8-bit-window table: 32 mixed additions, no doubling.  The running
-// accumulator is passed in so that u*G + c*PK needs no separate final addition (and no second
-// live point: register pressure, not arithmetic, is what limits occupancy here).
+// acc += u * Gen from the signed kFixedBits-bit-window table: kFixedWindows (23 for 11 bits) mixed
+// additions, no doubling.  The running accumulator is passed in so that u*G + c*PK needs no
+// separate final addition (and no second live point).
 DSV_DEV Ext fixed_base_accumulate(Ext acc, const u32 (&s)[8], const u32* __restrict__ table) {
   // signed recoding: add 2^(bits-1) to every window; digit = window value - 2^(bits-1).
   // s < 2^252, so the top window cannot overflow.  Windows are consumed LSB first (the order of
@@ -235,18 +236,29 @@ DSV_DEV Ext fixed_base_accumulate(Ext acc, const u32 (&s)[8], const u32* __restr
 
 // ---- per-lane window table of a variable base, in global memory, LANE-MAJOR ---------------
 // Signed 4-bit digits d in [-8, 8): entries |d| * P for |d| = 0..8, each stored as extended niels
-// (v+u, v-u, z, 2d*t) plus the negated 2d*t, 5 x 9 words = 180 B; 1620 B per lane, contiguous.
-// A lookup is therefore 4 x 36 contiguous bytes of ONE entry (sign handled by WHICH fields are
-// read: -P swaps v+u / v-u and takes the negated t), instead of 36 dwords scattered over 36
+// (v+u, v-u, z, 2d*t), 4 x 9 words = 144 B; 1296 B per lane, contiguous.
+// A lookup is therefore 4 x 36 contiguous bytes of ONE entry (-P swaps v+u / v-u by address and
+// negates 2d*t in registers), instead of 36 dwords scattered over 36
 // different 256-B rows as a compiler-scratch array would give (r01 v1: 64.7 GB FETCH_SIZE per
 // 2^20 batch, profiles/r01/v1_pmc_summary.json).  The slot belongs to (workgroup, lane), so the
 // verify kernels run a fixed grid with a grid-stride loop.
+// Entries hold four fields (144 B); a negative digit swaps v+u / v-u by address and negates 2d*t
+// after the load.  -DDSV_VAR_NEG_T2D=1 is the r01 layout, which also STORED the negated 2d*t
+// (180 B): r02 same-box A/B, 2^20 signatures: 65.6 M/s with the stored negation, 66.8 M/s without
+// (profiles/r02/ab_table_traffic.txt) — 20 % less table-write traffic buys more than the 45
+// cheap instructions per lookup cost, on a kernel that runs at its power limit.
+#ifndef DSV_VAR_NEG_T2D
+#define DSV_VAR_NEG_T2D 0
+#endif
 constexpr int kVarEntries = 9;
-constexpr int kVarEntryWords = 5 * NL;
-constexpr int kVarLaneWords = kVarEntries * kVarEntryWords;  // 405 words = 1620 B
+constexpr int kVarEntryWords = (DSV_VAR_NEG_T2D ? 5 : 4) * NL;
+constexpr int kVarLaneWords = kVarEntries * kVarEntryWords;  // 324 words = 1296 B (405 / 1620 with the stored negation)
 constexpr int kVerifyBlock = 64;        // ONE wave per workgroup: a finished wave's slot is refilled at
                                         // once instead of waiting for its three workgroup mates
-constexpr unsigned kMaxVerifyGrid = 4096;                     // 16 single-wave workgroups per CU
+#ifndef DSV_MAX_VERIFY_GRID
+#define DSV_MAX_VERIFY_GRID 4096                              // 16 single-wave workgroups per CU
+#endif
+constexpr unsigned kMaxVerifyGrid = DSV_MAX_VERIFY_GRID;
 
 DSV_DEV void store_fe_words(u32* p, const Fe& a) {
 #pragma unroll
@@ -264,7 +276,7 @@ DSV_DEV void store_var_entry(u32* lane_tbl, int e, const Niels& n) {
   store_fe_words(p + NL, n.vmu);
   store_fe_words(p + 2 * NL, n.z);
   store_fe_words(p + 3 * NL, n.t2d);
-  store_fe_words(p + 4 * NL, fe_neg2(n.t2d));
+  if (DSV_VAR_NEG_T2D) store_fe_words(p + 4 * NL, fe_neg2(n.t2d));
 }
 DSV_DEV Niels load_var_entry(const u32* lane_tbl, int d) {
   const bool neg = d < 0;
@@ -274,7 +286,12 @@ DSV_DEV Niels load_var_entry(const u32* lane_tbl, int d) {
   n.vpu = load_fe_words(p + (neg ? NL : 0));
   n.vmu = load_fe_words(p + (neg ? 0 : NL));
   n.z = load_fe_words(p + 2 * NL);
-  n.t2d = load_fe_words(p + (neg ? 4 * NL : 3 * NL));
+  if (DSV_VAR_NEG_T2D) {
+    n.t2d = load_fe_words(p + (neg ? 4 * NL : 3 * NL));
+  } else {
+    const Fe t = load_fe_words(p + 3 * NL);
+    n.t2d = fe_select(neg, fe_neg2(t), t);
+  }
   return n;
 }
 DSV_DEV void build_var_table(u32* lane_tbl, const Fe& pu, const Fe& pv) {
@@ -397,12 +414,22 @@ k_verify_fixed(const uint8_t* __restrict__ u, const uint8_t* __restrict__ c,
 //   u*G + c*PK == R   <=>   (b*u mod r)*G + a*PK - b*R == O.
 // Two per-lane window tables (PK and R), one Straus chain of ~34 windows whose length is the
 // lane's own max(bitlen a, bitlen b) (lanes of a wave simply leave the loop at different times).
-template <bool ACCUM>
+//
+// NCHAIN = 2 is PublicKeyDouble::verify (/root/reference/src/keys/public.rs:222-244) in ONE
+// launch: both equations share u and c, so (a, b), both recodings and b*u mod r are computed once
+// and the chain runs twice — (G, PK, R) then (G', PK', R') — through the same code (a rolled loop
+// over the two operand sets: the hot loop exists once in the instruction cache) and the same two
+// table slots.  r01 launched the single-equation kernel twice and repeated the shared part.
+struct ChainOperands {
+  const uint8_t* PK_uv;
+  const uint8_t* R_uv;
+  const u32* table;  // fixed-base table of the generator that goes with this (PK, R) pair
+};
+template <bool ACCUM, int NCHAIN>
 __global__ void __launch_bounds__(kVerifyBlock, DSV_WAVES_VERIFY)
 k_verify_fixed_half(const uint8_t* __restrict__ u, const uint8_t* __restrict__ c,
-                    const uint8_t* __restrict__ PK_uv, const uint8_t* __restrict__ R_uv,
-                    const u32* __restrict__ table, const uint8_t* __restrict__ valid, size_t n,
-                    uint8_t* __restrict__ ok, u32* __restrict__ var_tables) {
+                    ChainOperands op0, ChainOperands op1, const uint8_t* __restrict__ valid,
+                    size_t n, uint8_t* __restrict__ ok, u32* __restrict__ var_tables) {
   u32* tpk = var_tables + ((size_t)blockIdx.x * kVerifyBlock + threadIdx.x) * (2 * kVarLaneWords);
   u32* tr = tpk + kVarLaneWords;
 #pragma unroll 1
@@ -411,18 +438,6 @@ k_verify_fixed_half(const uint8_t* __restrict__ u, const uint8_t* __restrict__ c
     const size_t i = base + threadIdx.x;
     if (i >= n) continue;
     bool good = ACCUM ? (ok[i] != 0) : (valid[i] != 0);
-    {
-      Fe pku, pkv;
-      good &= load_fq(pku, PK_uv, 2 * i);
-      good &= load_fq(pkv, PK_uv, 2 * i + 1);
-      build_var_table(tpk, pku, pkv);
-    }
-    {
-      Fe ru, rv;
-      good &= load_fq(ru, R_uv, 2 * i);
-      good &= load_fq(rv, R_uv, 2 * i + 1);
-      build_var_table(tr, ru, rv);
-    }
     u32 ya[8], yb[8], w[8];
     bool b_neg;
     int top;
@@ -452,20 +467,36 @@ k_verify_fixed_half(const uint8_t* __restrict__ u, const uint8_t* __restrict__ c
         for (int k = 0; k < 8; k++) w[k] = t[k];
       }
     }
-    // T = a*PK + (b_neg ? +|b| : -|b|) * R  (+ w*G below)
     const int rsign = b_neg ? 1 : -1;
-    Ext acc = ext_add_niels(ext_identity(), load_var_entry(tpk, sdigit4(ya, top)));
-    acc = ext_add_niels(acc, load_var_entry(tr, rsign * sdigit4(yb, top)));
 #pragma unroll 1
-    for (int k = top - 1; k >= 0; k--) {
-      acc = ext_mul16(acc);
-      acc = ext_add_niels(acc, load_var_entry(tpk, sdigit4(ya, k)));
-      acc = ext_add_niels(acc, load_var_entry(tr, rsign * sdigit4(yb, k)));
+    for (int h = 0; h < NCHAIN; h++) {
+      const ChainOperands op = h ? op1 : op0;
+      {
+        Fe pku, pkv;
+        good &= load_fq(pku, op.PK_uv, 2 * i);
+        good &= load_fq(pkv, op.PK_uv, 2 * i + 1);
+        build_var_table(tpk, pku, pkv);
+      }
+      {
+        Fe ru, rv;
+        good &= load_fq(ru, op.R_uv, 2 * i);
+        good &= load_fq(rv, op.R_uv, 2 * i + 1);
+        build_var_table(tr, ru, rv);
+      }
+      // T = a*PK + (b_neg ? +|b| : -|b|) * R  (+ w*G below)
+      Ext acc = ext_add_niels(ext_identity(), load_var_entry(tpk, sdigit4(ya, top)));
+      acc = ext_add_niels(acc, load_var_entry(tr, rsign * sdigit4(yb, top)));
+#pragma unroll 1
+      for (int k = top - 1; k >= 0; k--) {
+        acc = ext_mul16(acc);
+        acc = ext_add_niels(acc, load_var_entry(tpk, sdigit4(ya, k)));
+        acc = ext_add_niels(acc, load_var_entry(tr, rsign * sdigit4(yb, k)));
+      }
+      acc = fixed_base_accumulate(acc, w, op.table);
+      // T == O  <=>  u == 0 and v == z
+      good &= (bool)((int)fe_is_zero_canon(fe_canon(acc.u)) & (int)fe_equal(acc.v, acc.z));
     }
-    acc = fixed_base_accumulate(acc, w, table);
-    // T == O  <=>  u == 0 and v == z
-    const bool eq = (int)fe_is_zero_canon(fe_canon(acc.u)) & (int)fe_equal(acc.v, acc.z);
-    ok[i] = (good & eq) ? 1 : 0;
+    ok[i] = good ? 1 : 0;
   }
 }
 
@@ -537,6 +568,11 @@ __global__ void k_and_bytes(uint8_t* __restrict__ ok, const uint8_t* __restrict_
 // ------------------------------------------------------------------------------------------
 // signing / key derivation ("next" row of the scope table: the step that precedes verify)
 // ------------------------------------------------------------------------------------------
+// marks an output element as invalid: 0xff..ff is >= q and >= r, every consumer rejects it
+DSV_DEV void store_poison(uint8_t* base, size_t idx) {
+  const u32 w[8] = {~0u, ~0u, ~0u, ~0u, ~0u, ~0u, ~0u, ~0u};
+  store_words8(base, idx, w);
+}
 DSV_DEV void store_affine(uint8_t* out_uv, size_t i, const Ext& p) {
   Fe zi = fe_invert(p.z);
   store_fq(out_uv, 2 * i, fe_mul(p.u, zi));
@@ -551,6 +587,11 @@ k_fixed_base_points(const uint8_t* __restrict__ scalar, const u32* __restrict__ 
   if (i >= n) return;
   u32 s[8];
   load_words8(s, scalar, i);
+  if (!words_lt(s, kR32)) {  // not a JubJubScalar: poison (no canonical point has 0xff.. coordinates)
+    store_poison(out_uv, 2 * i);
+    store_poison(out_uv, 2 * i + 1);
+    return;
+  }
   Ext acc = fixed_base_accumulate(ext_identity(), s, table);
   store_affine(out_uv, i, acc);
 }
@@ -572,9 +613,15 @@ k_var_base_points(const uint8_t* __restrict__ scalar, const uint8_t* __restrict_
     }
     u32 s[8];
     load_words8(s, scalar, i);
-    s[7] &= 0x0fffffffu;  // Fr scalars are < 2^252; keeps the signed recoding in range
+    const bool canonical = words_lt(s, kR32);
+    s[7] &= 0x0fffffffu;  // keeps the signed recoding in range for a non-canonical scalar
     Ext acc = var_base_mul<63>(s, lane_tbl);
-    store_affine(out_uv, i, acc);
+    if (canonical) {
+      store_affine(out_uv, i, acc);
+    } else {
+      store_poison(out_uv, 2 * i);
+      store_poison(out_uv, 2 * i + 1);
+    }
   }
 }
 // u = r - c * sk  in Fr  (secret.rs:165)
@@ -587,6 +634,10 @@ k_sign_finish(const uint8_t* __restrict__ r, const uint8_t* c,  // c may alias u
   load_words8(rs, r, i);
   load_words8(cs, c, i);
   load_words8(ks, sk, i);
+  if (!words_lt(rs, kR32) || !words_lt(ks, kR32)) {  // nonce or key not a JubJubScalar
+    store_poison(u_out, i);
+    return;
+  }
   fr_mul(t, cs, ks);
   fr_sub(u, rs, t);
   store_words8(u_out, i, u);
@@ -666,6 +717,30 @@ k_stdrng_triples(ChaChaKey key, size_t first_item, size_t n, uint8_t* __restrict
   store_words8(r, i, o);
 }
 
+// var-generator harness (tests/schnorr_var_generator.rs:16-22, benches/signature_var_generator.rs:
+// 50-63): SecretKeyVarGen::random draws sk then the generator scalar (src/keys/secret.rs:371-373),
+// then the message, then (inside sign) the nonce: item i = keystream blocks 4i .. 4i+3
+__global__ void __launch_bounds__(256)
+k_stdrng_quads(ChaChaKey key, size_t first_item, size_t n, uint8_t* __restrict__ sk,
+               uint8_t* __restrict__ g, uint8_t* __restrict__ m, uint8_t* __restrict__ r) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const u64 blk = 4 * (u64)(first_item + i);
+  u32 ks[16], o[8];
+  chacha12_block(ks, key.w, blk);
+  fr_from_wide(o, ks);
+  store_words8(sk, i, o);
+  chacha12_block(ks, key.w, blk + 1);
+  fr_from_wide(o, ks);
+  store_words8(g, i, o);
+  chacha12_block(ks, key.w, blk + 2);
+  fq_from_wide(o, ks);
+  store_words8(m, i, o);
+  chacha12_block(ks, key.w, blk + 3);
+  fr_from_wide(o, ks);
+  store_words8(r, i, o);
+}
+
 __global__ void __launch_bounds__(256)
 k_debug_fq_mul(const uint8_t* __restrict__ a, const uint8_t* __restrict__ b, size_t n,
                uint8_t* __restrict__ out) {
@@ -686,10 +761,155 @@ k_debug_fq_mul(const uint8_t* __restrict__ a, const uint8_t* __restrict__ b, siz
   store_words8(out, i, w);
 }
 
+// ------------------------------------------------------------------------------------------
+// mixed batches (BASELINE.json configs[4]): split a batch by kind ON THE DEVICE
+// kinds[i] = 0 (single signature) / 1 (double signature); anything else is an invalid item that
+// lands in neither list (its verdict stays 0).  Stable compaction in three small kernels:
+// per-tile counts, one-block exclusive scan of the tile counts, per-tile write-out.  HBM-bound
+// byte work (n bytes in, 4n bytes out); against the ~600 k VALU instructions per verdict it is
+// noise — written for coalescing, not tuned further.
+// ------------------------------------------------------------------------------------------
+constexpr int kSplitThreads = 256;
+constexpr int kSplitPerThread = 16;                        // one 16-byte load per thread
+constexpr int kSplitTile = kSplitThreads * kSplitPerThread;  // 4096 items per workgroup
+
+// counts of kind 0 and kind 1 among the 16 items of this thread, packed (kind1 << 16 | kind0)
+DSV_DEV u32 split_thread_counts(const uint8_t* __restrict__ kinds, size_t n, size_t first,
+                                uint8_t (&k)[kSplitPerThread]) {
+  u32 cnt = 0;
+  if (first + kSplitPerThread <= n) {
+    const uint4 v = *reinterpret_cast<const uint4*>(kinds + first);
+    const u32 w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int j = 0; j < kSplitPerThread; j++) k[j] = (uint8_t)(w[j >> 2] >> (8 * (j & 3)));
+  } else {
+#pragma unroll
+    for (int j = 0; j < kSplitPerThread; j++) k[j] = first + j < n ? kinds[first + j] : (uint8_t)0xff;
+  }
+#pragma unroll
+  for (int j = 0; j < kSplitPerThread; j++) cnt += (k[j] == 0 ? 1u : 0u) + (k[j] == 1 ? 0x10000u : 0u);
+  return cnt;
+}
+// exclusive scan over the workgroup of one packed counter per thread; returns the block total
+DSV_DEV u32 split_block_scan(u32 v, u32& exclusive) {
+  __shared__ u32 wave_tot[kSplitThreads / 64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  u32 inc = v;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const u32 t = __shfl_up(inc, d, 64);
+    if (lane >= d) inc += t;
+  }
+  if (lane == 63) wave_tot[wave] = inc;
+  __syncthreads();
+  u32 before = 0, total = 0;
+#pragma unroll
+  for (int w2 = 0; w2 < kSplitThreads / 64; w2++) {
+    const u32 t = wave_tot[w2];
+    if (w2 < wave) before += t;
+    total += t;
+  }
+  exclusive = before + inc - v;
+  __syncthreads();
+  return total;
+}
+__global__ void __launch_bounds__(kSplitThreads)
+k_kind_count(const uint8_t* __restrict__ kinds, size_t n, u32* __restrict__ tile_counts) {
+  uint8_t k[kSplitPerThread];
+  const size_t first = ((size_t)blockIdx.x * kSplitThreads + threadIdx.x) * kSplitPerThread;
+  u32 ex;
+  const u32 total = split_block_scan(split_thread_counts(kinds, n, first, k), ex);
+  if (threadIdx.x == 0) {
+    tile_counts[2 * blockIdx.x] = total & 0xffffu;
+    tile_counts[2 * blockIdx.x + 1] = total >> 16;
+  }
+}
+// in place: tile_counts[2t + k] -> number of kind-k items in tiles before t; totals[k] = all of them
+__global__ void __launch_bounds__(1024)
+k_kind_scan(u32* __restrict__ tile_counts, size_t ntiles, u32* __restrict__ totals) {
+  __shared__ u32 part[2][1024];
+  const size_t per = (ntiles + 1023) / 1024;
+  const size_t lo = (size_t)threadIdx.x * per, hi = lo + per < ntiles ? lo + per : ntiles;
+  u32 s0 = 0, s1 = 0;
+  for (size_t t = lo; t < hi; t++) {
+    s0 += tile_counts[2 * t];
+    s1 += tile_counts[2 * t + 1];
+  }
+  part[0][threadIdx.x] = s0;
+  part[1][threadIdx.x] = s1;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    u32 a = 0, b = 0;
+    for (int t = 0; t < 1024; t++) {
+      const u32 x = part[0][t], y = part[1][t];
+      part[0][t] = a;
+      part[1][t] = b;
+      a += x;
+      b += y;
+    }
+    totals[0] = a;
+    totals[1] = b;
+  }
+  __syncthreads();
+  u32 a = part[0][threadIdx.x], b = part[1][threadIdx.x];
+  for (size_t t = lo; t < hi; t++) {
+    const u32 x = tile_counts[2 * t], y = tile_counts[2 * t + 1];
+    tile_counts[2 * t] = a;
+    tile_counts[2 * t + 1] = b;
+    a += x;
+    b += y;
+  }
+}
+// idx_k[j] = batch position of the j-th item of kind k (j < cap_k: a caller that understated a
+// count loses the surplus instead of overrunning its buffer; totals[] tell)
+__global__ void __launch_bounds__(kSplitThreads)
+k_kind_write(const uint8_t* __restrict__ kinds, size_t n, const u32* __restrict__ tile_offsets,
+             u32* __restrict__ idx0, size_t cap0, u32* __restrict__ idx1, size_t cap1) {
+  uint8_t k[kSplitPerThread];
+  const size_t first = ((size_t)blockIdx.x * kSplitThreads + threadIdx.x) * kSplitPerThread;
+  u32 ex;
+  split_block_scan(split_thread_counts(kinds, n, first, k), ex);
+  size_t p0 = (size_t)tile_offsets[2 * blockIdx.x] + (ex & 0xffffu);
+  size_t p1 = (size_t)tile_offsets[2 * blockIdx.x + 1] + (ex >> 16);
+#pragma unroll
+  for (int j = 0; j < kSplitPerThread; j++) {
+    if (k[j] == 0) {
+      if (p0 < cap0) idx0[p0] = (u32)(first + j);
+      p0++;
+    } else if (k[j] == 1) {
+      if (p1 < cap1) idx1[p1] = (u32)(first + j);
+      p1++;
+    }
+  }
+}
+// dst row j = src row idx[j]; rows of row16 * 16 bytes, one thread per 16-byte piece
+__global__ void __launch_bounds__(256)
+k_gather_rows(const uint4* __restrict__ src, u32 row16, const u32* __restrict__ idx, size_t count,
+              uint4* __restrict__ dst) {
+  const size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= count * row16) return;
+  const size_t j = g / row16;
+  const u32 part = (u32)(g - j * row16);
+  dst[g] = src[(size_t)idx[j] * row16 + part];
+}
+__global__ void __launch_bounds__(256)
+k_scatter_bytes(const uint8_t* __restrict__ src, const u32* __restrict__ idx, size_t count,
+                uint8_t* __restrict__ dst) {
+  const size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j < count) dst[idx[j]] = src[j];
+}
+// a mixed call whose declared kind counts disagree with the kind vector has no usable verdicts
+__global__ void __launch_bounds__(256)
+k_mixed_check(const u32* __restrict__ totals, u32 want0, u32 want1, uint8_t* __restrict__ ok, size_t n) {
+  if (totals[0] == want0 && totals[1] == want1) return;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+    ok[i] = 0;
+}
+
 }  // namespace dsv
 
 // ==========================================================================================
-// host side: context + C ABI
+// host side: per-device contexts + C ABI
 // ==========================================================================================
 namespace {
 
@@ -788,23 +1008,42 @@ class CopyPool {
 };
 
 constexpr int kPipeSlots = 3;
+constexpr int kMaxDevices = 16;
+constexpr int kSplitLanes = 8;
 
+// Two internal streams + the events that fork them from / join them to ONE caller stream.  A lane
+// is bound to the caller stream that first used it, so callers on different streams get different
+// internal streams and really run concurrently (r01 had two process-wide streams: every large
+// batch of every caller queued on them).  With more than kSplitLanes distinct caller streams in
+// flight lanes are shared by hashing — still correct (work is ordered by the events), only
+// serialised.
+struct SplitLane {
+  hipStream_t owner = nullptr;
+  bool made = false;
+  hipStream_t stream[2] = {nullptr, nullptr};
+  hipEvent_t fork = nullptr, join[2] = {nullptr, nullptr};
+};
+
+// Everything the library owns on one GPU.  One Context per device ordinal; several devices can be
+// initialised in one process (dsv_init(d) for each) and used concurrently from different host
+// threads: no state is shared between contexts.
 struct Context {
+  std::atomic<bool> ready{false};
   int device = -1;
   bool half_scalars = true;  // DSV_VERIFY_ALGO=classic selects the 250-bit chain instead
   bool split = true;         // DSV_SPLIT=0: one stream, whole batch per launch
   u32* table[2] = {nullptr, nullptr};  // fixed-base tables for G, G'
   u32* ts_cancel = nullptr;            // square-root tables (decode29.h)
   uint8_t* ts_hash = nullptr;
-  // staging for the host-pointer entry points (grown on demand, guarded by mu)
+  // host-pointer entry points of this device serialise here (they share the staging below)
   std::mutex mu;
   uint8_t* stage = nullptr;
   size_t stage_bytes = 0;
+  // sub-batch lanes of the device-pointer entry points (run_split)
+  std::mutex lane_mu;
+  SplitLane lanes[kSplitLanes];
   // pipeline of the host verify entry points (run_pipelined): kPipeSlots chunks in flight, each
   // with its own stream, device staging and pinned host staging
-  // two internal streams: a large device-resident batch is cut into sub-batches of kSplitItems
-  // signatures that alternate between them (run_split)
-  hipStream_t split_stream[2] = {nullptr, nullptr};
   hipStream_t pipe_stream[kPipeSlots] = {};
   uint8_t* pipe_stage[kPipeSlots] = {};   // device side of a slot
   size_t pipe_bytes[kPipeSlots] = {};
@@ -812,36 +1051,64 @@ struct Context {
   size_t pipe_host_bytes[kPipeSlots] = {};
   CopyPool copiers;
 };
-Context g_ctx;
-std::mutex g_init_mu;
-std::atomic<bool> g_ready{false};
+Context g_ctx[kMaxDevices];
+std::mutex g_init_mu;               // dsv_init / dsv_shutdown
+std::atomic<int> g_primary{-1};     // first device initialised: default of the host entry points
+thread_local int t_device = -1;     // dsv_set_device: this thread's choice for host entry points
 
-int ensure_stage(size_t bytes) {
-  if (g_ctx.stage_bytes >= bytes) return DSV_OK;
-  if (g_ctx.stage) HIP_TRY(hipFree(g_ctx.stage));
-  g_ctx.stage = nullptr;
-  g_ctx.stage_bytes = 0;
+// the calling thread's current HIP device is restored on scope exit: the library must not leave a
+// caller's thread on another GPU
+struct DeviceGuard {
+  int prev = -1;
+  bool switched = false;
+  hipError_t err = hipSuccess;
+  explicit DeviceGuard(int device) {
+    err = hipGetDevice(&prev);
+    if (err == hipSuccess && prev != device) {
+      err = hipSetDevice(device);
+      switched = err == hipSuccess;
+    }
+  }
+  ~DeviceGuard() {
+    if (switched) (void)hipSetDevice(prev);
+  }
+};
+#define DSV_ON_DEVICE(ctx)                     \
+  DeviceGuard guard_((ctx).device);            \
+  if (guard_.err != hipSuccess)                \
+  return fail(DSV_ERR_HIP, "cannot select device %d: %s", (ctx).device, hipGetErrorString(guard_.err))
+
+int ensure_stage(Context& ctx, size_t bytes) {
+  if (ctx.stage_bytes >= bytes) return DSV_OK;
+  if (ctx.stage) {
+    // what is released may hold secret keys / nonces of an earlier signing call
+    HIP_TRY(hipMemset(ctx.stage, 0, ctx.stage_bytes));
+    HIP_TRY(hipFree(ctx.stage));
+  }
+  ctx.stage = nullptr;
+  ctx.stage_bytes = 0;
   size_t want = bytes + bytes / 4;
-  HIP_TRY(hipMalloc(&g_ctx.stage, want));
-  g_ctx.stage_bytes = want;
+  HIP_TRY(hipMalloc(&ctx.stage, want));
+  ctx.stage_bytes = want;
   return DSV_OK;
 }
 
-int ensure_pipe_slot(int slot, size_t dev_bytes, size_t host_bytes) {
-  if (!g_ctx.pipe_stream[slot]) HIP_TRY(hipStreamCreateWithFlags(&g_ctx.pipe_stream[slot], hipStreamNonBlocking));
-  if (g_ctx.pipe_bytes[slot] < dev_bytes) {
-    if (g_ctx.pipe_stage[slot]) HIP_TRY(hipFree(g_ctx.pipe_stage[slot]));
-    g_ctx.pipe_stage[slot] = nullptr;
-    g_ctx.pipe_bytes[slot] = 0;
-    HIP_TRY(hipMalloc(&g_ctx.pipe_stage[slot], dev_bytes));
-    g_ctx.pipe_bytes[slot] = dev_bytes;
+int ensure_pipe_slot(Context& ctx, int slot, size_t dev_bytes, size_t host_bytes) {
+  if (!ctx.pipe_stream[slot])
+    HIP_TRY(hipStreamCreateWithFlags(&ctx.pipe_stream[slot], hipStreamNonBlocking));
+  if (ctx.pipe_bytes[slot] < dev_bytes) {
+    if (ctx.pipe_stage[slot]) HIP_TRY(hipFree(ctx.pipe_stage[slot]));
+    ctx.pipe_stage[slot] = nullptr;
+    ctx.pipe_bytes[slot] = 0;
+    HIP_TRY(hipMalloc(&ctx.pipe_stage[slot], dev_bytes));
+    ctx.pipe_bytes[slot] = dev_bytes;
   }
-  if (g_ctx.pipe_host_bytes[slot] < host_bytes) {
-    if (g_ctx.pipe_host[slot]) HIP_TRY(hipHostFree(g_ctx.pipe_host[slot]));
-    g_ctx.pipe_host[slot] = nullptr;
-    g_ctx.pipe_host_bytes[slot] = 0;
-    HIP_TRY(hipHostMalloc(&g_ctx.pipe_host[slot], host_bytes, hipHostMallocDefault));
-    g_ctx.pipe_host_bytes[slot] = host_bytes;
+  if (ctx.pipe_host_bytes[slot] < host_bytes) {
+    if (ctx.pipe_host[slot]) HIP_TRY(hipHostFree(ctx.pipe_host[slot]));
+    ctx.pipe_host[slot] = nullptr;
+    ctx.pipe_host_bytes[slot] = 0;
+    HIP_TRY(hipHostMalloc(&ctx.pipe_host[slot], host_bytes, hipHostMallocDefault));
+    ctx.pipe_host_bytes[slot] = host_bytes;
   }
   return DSV_OK;
 }
@@ -849,13 +1116,36 @@ int ensure_pipe_slot(int slot, size_t dev_bytes, size_t host_bytes) {
 inline unsigned grid_for(size_t n, unsigned block = 256) { return (unsigned)((n + block - 1) / block); }
 inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
-int check_ready() {
-  if (!g_ready.load(std::memory_order_acquire))
-    return fail(DSV_ERR_NOT_INITIALIZED, "dsv_init() has not been called");
-  return DSV_OK;
-}
 int check_n(size_t n) {
   if (n > DSV_MAX_BATCH) return fail(DSV_ERR_TOO_LARGE, "batch of %zu exceeds DSV_MAX_BATCH", n);
+  return DSV_OK;
+}
+// context of the host entry points: this thread's dsv_set_device choice, else the first device
+// that was initialised
+int host_context(Context*& out) {
+  const int d = t_device >= 0 ? t_device : g_primary.load(std::memory_order_acquire);
+  if (d < 0 || d >= kMaxDevices || !g_ctx[d].ready.load(std::memory_order_acquire))
+    return fail(DSV_ERR_NOT_INITIALIZED, d < 0 ? "dsv_init() has not been called"
+                                               : "device %d is not initialised", d);
+  out = &g_ctx[d];
+  return DSV_OK;
+}
+// context of a device-pointer entry point: the device that owns `ptr` (one of the call's buffers)
+int device_context(const void* ptr, Context*& out) {
+  if (g_primary.load(std::memory_order_acquire) < 0)
+    return fail(DSV_ERR_NOT_INITIALIZED, "dsv_init() has not been called");
+  int d = -1;
+  hipPointerAttribute_t attr;
+  if (ptr && hipPointerGetAttributes(&attr, ptr) == hipSuccess &&
+      (attr.type == hipMemoryTypeDevice || attr.type == hipMemoryTypeManaged)) {
+    d = attr.device;
+  } else {
+    (void)hipGetLastError();  // a failed query leaves a sticky "invalid value"
+    if (hipGetDevice(&d) != hipSuccess) d = -1;
+  }
+  if (d < 0 || d >= kMaxDevices || !g_ctx[d].ready.load(std::memory_order_acquire))
+    return fail(DSV_ERR_NOT_INITIALIZED, "device %d (owner of the buffers) is not initialised", d);
+  out = &g_ctx[d];
   return DSV_OK;
 }
 
@@ -881,21 +1171,53 @@ Workspace carve(void* ws, size_t n) {
   return w;
 }
 
+struct Stager {
+  uint8_t* base;
+  size_t off = 0;
+  explicit Stager(uint8_t* b) : base(b) {}
+  uint8_t* take(size_t bytes) {
+    uint8_t* p = base + off;
+    off += align_up(bytes, 256);
+    return p;
+  }
+};
+
 // the dominant kernel, in either formulation (same verdicts; see halfgcd.h)
-void launch_verify_fixed(bool accumulate, const void* u, const void* c, const void* PK_uv,
-                         const void* R_uv, int which, const void* valid, size_t n, void* ok,
-                         u32* tables, hipStream_t s) {
+void launch_verify_fixed(const Context& ctx, bool accumulate, const void* u, const void* c,
+                         const void* PK_uv, const void* R_uv, int which, const void* valid,
+                         size_t n, void* ok, u32* tables, hipStream_t s) {
   const dim3 grid(verify_grid(n)), block(kVerifyBlock);
+  if (ctx.half_scalars) {
+    const ChainOperands op{(const uint8_t*)PK_uv, (const uint8_t*)R_uv, ctx.table[which]};
+    if (accumulate)
+      hipLaunchKernelGGL((k_verify_fixed_half<true, 1>), grid, block, 0, s, (const uint8_t*)u,
+                         (const uint8_t*)c, op, op, (const uint8_t*)valid, n, (uint8_t*)ok, tables);
+    else
+      hipLaunchKernelGGL((k_verify_fixed_half<false, 1>), grid, block, 0, s, (const uint8_t*)u,
+                         (const uint8_t*)c, op, op, (const uint8_t*)valid, n, (uint8_t*)ok, tables);
+    return;
+  }
 #define DSV_LAUNCH(K)                                                                          \
   hipLaunchKernelGGL(K, grid, block, 0, s, (const uint8_t*)u, (const uint8_t*)c,               \
-                     (const uint8_t*)PK_uv, (const uint8_t*)R_uv, (const u32*)g_ctx.table[which], \
+                     (const uint8_t*)PK_uv, (const uint8_t*)R_uv, (const u32*)ctx.table[which], \
                      (const uint8_t*)valid, n, (uint8_t*)ok, tables)
-  if (g_ctx.half_scalars) {
-    if (accumulate) DSV_LAUNCH(k_verify_fixed_half<true>); else DSV_LAUNCH(k_verify_fixed_half<false>);
-  } else {
-    if (accumulate) DSV_LAUNCH(k_verify_fixed<true>); else DSV_LAUNCH(k_verify_fixed<false>);
-  }
+  if (accumulate) DSV_LAUNCH(k_verify_fixed<true>); else DSV_LAUNCH(k_verify_fixed<false>);
 #undef DSV_LAUNCH
+}
+// both equations of a double signature: one fused launch (half-size scalars) or two (classic)
+void launch_verify_fixed_double(const Context& ctx, const void* u, const void* c, const void* PK_uv,
+                                const void* R_uv, const void* PKp_uv, const void* Rp_uv,
+                                const void* valid, size_t n, void* ok, u32* tables, hipStream_t s) {
+  if (ctx.half_scalars) {
+    const ChainOperands op0{(const uint8_t*)PK_uv, (const uint8_t*)R_uv, ctx.table[0]};
+    const ChainOperands op1{(const uint8_t*)PKp_uv, (const uint8_t*)Rp_uv, ctx.table[1]};
+    hipLaunchKernelGGL((k_verify_fixed_half<false, 2>), dim3(verify_grid(n)), dim3(kVerifyBlock), 0,
+                       s, (const uint8_t*)u, (const uint8_t*)c, op0, op1, (const uint8_t*)valid, n,
+                       (uint8_t*)ok, tables);
+    return;
+  }
+  launch_verify_fixed(ctx, false, u, c, PK_uv, R_uv, 0, valid, n, ok, tables, s);
+  launch_verify_fixed(ctx, true, u, c, PKp_uv, Rp_uv, 1, valid, n, ok, tables, s);
 }
 
 // Sub-batch scheduling of the device-pointer verify entry points.
@@ -908,34 +1230,47 @@ void launch_verify_fixed(bool accumulate, const void* u, const void* c, const vo
 // forked / joined with events, so the call still behaves as one enqueue on that stream.
 constexpr size_t kSplitItems = (size_t)1 << 16;
 
-struct ForkJoin {
-  hipEvent_t fork = nullptr, join[2] = {nullptr, nullptr};
-};
-int thread_events(ForkJoin*& out) {
-  thread_local ForkJoin ev;
-  if (!ev.join[1]) {
-    if (!ev.fork) HIP_TRY(hipEventCreateWithFlags(&ev.fork, hipEventDisableTiming));
-    if (!ev.join[0]) HIP_TRY(hipEventCreateWithFlags(&ev.join[0], hipEventDisableTiming));
-    HIP_TRY(hipEventCreateWithFlags(&ev.join[1], hipEventDisableTiming));
+int acquire_lane(Context& ctx, hipStream_t user, SplitLane*& out) {
+  std::lock_guard<std::mutex> lk(ctx.lane_mu);
+  SplitLane* pick = nullptr;
+  for (auto& l : ctx.lanes)
+    if (l.made && l.owner == user) pick = &l;
+  if (!pick)
+    for (auto& l : ctx.lanes)
+      if (!l.made) {
+        pick = &l;
+        break;
+      }
+  if (!pick) pick = &ctx.lanes[((uintptr_t)user >> 6) % kSplitLanes];  // all taken: share one
+  if (!pick->made) {
+    for (int k = 0; k < 2; k++) {
+      HIP_TRY(hipStreamCreateWithFlags(&pick->stream[k], hipStreamNonBlocking));
+      HIP_TRY(hipEventCreateWithFlags(&pick->join[k], hipEventDisableTiming));
+    }
+    HIP_TRY(hipEventCreateWithFlags(&pick->fork, hipEventDisableTiming));
+    pick->owner = user;
+    pick->made = true;
   }
-  out = &ev;
+  out = pick;
   return DSV_OK;
 }
 // part(offset, count, workspace-for-this-part, stream)
 template <class Part>
-int run_split(size_t n, void* workspace, hipStream_t user, Part part) {
+int run_split(Context& ctx, size_t n, void* workspace, hipStream_t user, Part part) {
   Workspace w = carve(workspace, n);
-  if (!g_ctx.split || n < 2 * kSplitItems) {
+  if (!ctx.split || n < 2 * kSplitItems) {
     part((size_t)0, n, w, user);
     HIP_TRY(hipGetLastError());
     return DSV_OK;
   }
-  ForkJoin* evp = nullptr;
-  if (int r = thread_events(evp)) return r;
-  ForkJoin& ev = *evp;
-  HIP_TRY(hipEventRecord(ev.fork, user));
+  SplitLane* lane = nullptr;
+  if (int r = acquire_lane(ctx, user, lane)) return r;
+  // a shared lane's events may be re-recorded by another caller between our record and our
+  // wait; record + wait pairs are therefore issued under the lane lock
+  std::lock_guard<std::mutex> lk(ctx.lane_mu);
+  HIP_TRY(hipEventRecord(lane->fork, user));
   const size_t tbl_words = var_table_bytes(kSplitItems, 2) / 4;  // per internal stream
-  for (int k = 0; k < 2; k++) HIP_TRY(hipStreamWaitEvent(g_ctx.split_stream[k], ev.fork, 0));
+  for (int k = 0; k < 2; k++) HIP_TRY(hipStreamWaitEvent(lane->stream[k], lane->fork, 0));
   size_t off = 0;
   for (size_t p = 0; off < n; p++) {
     const size_t cnt = n - off < kSplitItems ? n - off : kSplitItems;
@@ -944,22 +1279,62 @@ int run_split(size_t n, void* workspace, hipStream_t user, Part part) {
     wp.c = w.c + off * 32;
     wp.valid = w.valid + off;
     wp.tables = w.tables + (size_t)k * tbl_words;
-    part(off, cnt, wp, g_ctx.split_stream[k]);
+    part(off, cnt, wp, lane->stream[k]);
     off += cnt;
   }
   HIP_TRY(hipGetLastError());
   for (int k = 0; k < 2; k++) {
-    HIP_TRY(hipEventRecord(ev.join[k], g_ctx.split_stream[k]));
-    HIP_TRY(hipStreamWaitEvent(user, ev.join[k], 0));
+    HIP_TRY(hipEventRecord(lane->join[k], lane->stream[k]));
+    HIP_TRY(hipStreamWaitEvent(user, lane->join[k], 0));
   }
   return DSV_OK;
+}
+
+void release_context(Context& ctx) {
+  // best effort: nothing useful can be done about a failing release
+  (void)hipSetDevice(ctx.device);
+  (void)hipDeviceSynchronize();
+  for (int g = 0; g < 2; g++) {
+    if (ctx.table[g]) (void)hipFree(ctx.table[g]);
+    ctx.table[g] = nullptr;
+  }
+  if (ctx.ts_cancel) (void)hipFree(ctx.ts_cancel);
+  if (ctx.ts_hash) (void)hipFree(ctx.ts_hash);
+  ctx.ts_cancel = nullptr;
+  ctx.ts_hash = nullptr;
+  if (ctx.stage) {
+    (void)hipMemset(ctx.stage, 0, ctx.stage_bytes);  // may hold secret keys / nonces
+    (void)hipFree(ctx.stage);
+  }
+  ctx.stage = nullptr;
+  ctx.stage_bytes = 0;
+  for (auto& l : ctx.lanes) {
+    if (!l.made) continue;
+    for (int k = 0; k < 2; k++) {
+      (void)hipStreamDestroy(l.stream[k]);
+      (void)hipEventDestroy(l.join[k]);
+    }
+    (void)hipEventDestroy(l.fork);
+    l = SplitLane();
+  }
+  for (int k = 0; k < kPipeSlots; k++) {
+    if (ctx.pipe_stage[k]) (void)hipFree(ctx.pipe_stage[k]);
+    if (ctx.pipe_host[k]) (void)hipHostFree(ctx.pipe_host[k]);
+    if (ctx.pipe_stream[k]) (void)hipStreamDestroy(ctx.pipe_stream[k]);
+    ctx.pipe_stage[k] = nullptr;
+    ctx.pipe_host[k] = nullptr;
+    ctx.pipe_stream[k] = nullptr;
+    ctx.pipe_bytes[k] = 0;
+    ctx.pipe_host_bytes[k] = 0;
+  }
+  ctx.copiers.stop();
 }
 
 }  // namespace
 
 extern "C" {
 
-const char* dsv_version(void) { return "dsv 0.1.0 (gfx950, fe29)"; }
+const char* dsv_version(void) { return "dsv 0.2.0 (gfx950, fe29)"; }
 const char* dsv_last_error(void) { return g_err.c_str(); }
 
 int dsv_device_count(void) {
@@ -970,16 +1345,16 @@ int dsv_device_count(void) {
 
 int dsv_init(int device) {
   std::lock_guard<std::mutex> lk(g_init_mu);
-  if (g_ready.load()) {
-    if (g_ctx.device == device) return DSV_OK;
-    return fail(DSV_ERR_INVALID_ARGUMENT, "already initialised on device %d", g_ctx.device);
-  }
   int count = 0;
   if (hipGetDeviceCount(&count) != hipSuccess || count == 0)
     return fail(DSV_ERR_NO_DEVICE, "no HIP device visible");
-  if (device < 0 || device >= count)
+  if (device < 0 || device >= count || device >= kMaxDevices)
     return fail(DSV_ERR_INVALID_ARGUMENT, "device %d out of range (count %d)", device, count);
-  HIP_TRY(hipSetDevice(device));
+  Context& ctx = g_ctx[device];
+  if (ctx.ready.load()) return DSV_OK;
+  ctx.device = device;
+  DSV_ON_DEVICE(ctx);
+  // __constant__ symbols exist once per device: these copies go to the device just selected
   HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(c_hades_rc), DSV_HADES_RC_HOST, sizeof(DSV_HADES_RC_HOST)));
   HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(c_hades_mds), DSV_HADES_MDS_HOST, sizeof(DSV_HADES_MDS_HOST)));
   HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(c_hades_pre_mds), DSV_HADES_PRE_MDS_HOST,
@@ -990,64 +1365,71 @@ int dsv_init(int device) {
                             sizeof(DSV_HADES_BLOCKS_HOST)));
   HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(c_hades_kfinal), DSV_HADES_KFINAL_HOST,
                             sizeof(DSV_HADES_KFINAL_HOST)));
-  HIP_TRY(hipMalloc(&g_ctx.ts_cancel, sizeof(DSV_TS_CANCEL_HOST)));
-  HIP_TRY(hipMemcpy(g_ctx.ts_cancel, DSV_TS_CANCEL_HOST, sizeof(DSV_TS_CANCEL_HOST), hipMemcpyHostToDevice));
-  HIP_TRY(hipMalloc(&g_ctx.ts_hash, sizeof(DSV_TS_HASH_HOST)));
-  HIP_TRY(hipMemcpy(g_ctx.ts_hash, DSV_TS_HASH_HOST, sizeof(DSV_TS_HASH_HOST), hipMemcpyHostToDevice));
+  HIP_TRY(hipMalloc(&ctx.ts_cancel, sizeof(DSV_TS_CANCEL_HOST)));
+  HIP_TRY(hipMemcpy(ctx.ts_cancel, DSV_TS_CANCEL_HOST, sizeof(DSV_TS_CANCEL_HOST), hipMemcpyHostToDevice));
+  HIP_TRY(hipMalloc(&ctx.ts_hash, sizeof(DSV_TS_HASH_HOST)));
+  HIP_TRY(hipMemcpy(ctx.ts_hash, DSV_TS_HASH_HOST, sizeof(DSV_TS_HASH_HOST), hipMemcpyHostToDevice));
   for (int g = 0; g < 2; g++) {
-    HIP_TRY(hipMalloc(&g_ctx.table[g], kTableBytes));
+    HIP_TRY(hipMalloc(&ctx.table[g], kTableBytes));
     const int total = kFixedWindows * kFixedEntries;
-    hipLaunchKernelGGL(k_build_fixed_table, dim3((total + 63) / 64), dim3(64), 0, 0,
-                       g_ctx.table[g], g);
+    hipLaunchKernelGGL(k_build_fixed_table, dim3((total + 63) / 64), dim3(64), 0, 0, ctx.table[g], g);
     HIP_TRY(hipGetLastError());
   }
   HIP_TRY(hipDeviceSynchronize());
-  for (int k = 0; k < 2; k++)
-    HIP_TRY(hipStreamCreateWithFlags(&g_ctx.split_stream[k], hipStreamNonBlocking));
-  g_ctx.device = device;
   const char* split = getenv("DSV_SPLIT");
-  g_ctx.split = !(split && strcmp(split, "0") == 0);
+  ctx.split = !(split && strcmp(split, "0") == 0);
   const char* algo = getenv("DSV_VERIFY_ALGO");
-  g_ctx.half_scalars = !(algo && strcmp(algo, "classic") == 0);
-  g_ready.store(true, std::memory_order_release);
+  ctx.half_scalars = !(algo && strcmp(algo, "classic") == 0);
+  ctx.ready.store(true, std::memory_order_release);
+  int none = -1;
+  g_primary.compare_exchange_strong(none, device);
   return DSV_OK;
 }
 
-int dsv_shutdown(void) {
+int dsv_shutdown_device(int device) {
   std::lock_guard<std::mutex> lk(g_init_mu);
-  if (!g_ready.load()) return DSV_OK;
-  // best effort: nothing useful can be done about a failing release
-  (void)hipSetDevice(g_ctx.device);
-  (void)hipDeviceSynchronize();
-  for (int g = 0; g < 2; g++) {
-    if (g_ctx.table[g]) (void)hipFree(g_ctx.table[g]);
-    g_ctx.table[g] = nullptr;
+  if (device < 0 || device >= kMaxDevices) return fail(DSV_ERR_INVALID_ARGUMENT, "bad device %d", device);
+  Context& ctx = g_ctx[device];
+  if (!ctx.ready.load()) return DSV_OK;
+  int prev = -1;
+  (void)hipGetDevice(&prev);
+  ctx.ready.store(false);  // new calls are refused from here on
+  {
+    std::lock_guard<std::mutex> hold(ctx.mu);  // a host call in flight finishes first
+    release_context(ctx);
   }
-  if (g_ctx.ts_cancel) (void)hipFree(g_ctx.ts_cancel);
-  if (g_ctx.ts_hash) (void)hipFree(g_ctx.ts_hash);
-  g_ctx.ts_cancel = nullptr;
-  g_ctx.ts_hash = nullptr;
-  if (g_ctx.stage) (void)hipFree(g_ctx.stage);
-  g_ctx.stage = nullptr;
-  g_ctx.stage_bytes = 0;
-  for (int k = 0; k < 2; k++) {
-    if (g_ctx.split_stream[k]) (void)hipStreamDestroy(g_ctx.split_stream[k]);
-    g_ctx.split_stream[k] = nullptr;
+  if (prev >= 0) (void)hipSetDevice(prev);
+  if (g_primary.load() == device) {
+    int next = -1;
+    for (int d = 0; d < kMaxDevices; d++)
+      if (g_ctx[d].ready.load()) {
+        next = d;
+        break;
+      }
+    g_primary.store(next);
   }
-  for (int k = 0; k < kPipeSlots; k++) {
-    if (g_ctx.pipe_stage[k]) (void)hipFree(g_ctx.pipe_stage[k]);
-    if (g_ctx.pipe_host[k]) (void)hipHostFree(g_ctx.pipe_host[k]);
-    if (g_ctx.pipe_stream[k]) (void)hipStreamDestroy(g_ctx.pipe_stream[k]);
-    g_ctx.pipe_stage[k] = nullptr;
-    g_ctx.pipe_host[k] = nullptr;
-    g_ctx.pipe_stream[k] = nullptr;
-    g_ctx.pipe_bytes[k] = 0;
-    g_ctx.pipe_host_bytes[k] = 0;
-  }
-  g_ctx.copiers.stop();
-  g_ctx.device = -1;
-  g_ready.store(false);
   return DSV_OK;
+}
+int dsv_shutdown(void) {
+  for (int d = 0; d < kMaxDevices; d++)
+    if (int r = dsv_shutdown_device(d)) return r;
+  return DSV_OK;
+}
+int dsv_set_device(int device) {
+  if (device < 0 || device >= kMaxDevices || !g_ctx[device].ready.load(std::memory_order_acquire))
+    return fail(DSV_ERR_NOT_INITIALIZED, "device %d is not initialised", device);
+  t_device = device;
+  return DSV_OK;
+}
+int dsv_get_device(void) { return t_device >= 0 ? t_device : g_primary.load(); }
+int dsv_initialized_devices(int* out, int cap) {
+  int n = 0;
+  for (int d = 0; d < kMaxDevices; d++)
+    if (g_ctx[d].ready.load(std::memory_order_acquire)) {
+      if (out && n < cap) out[n] = d;
+      n++;
+    }
+  return n;
 }
 
 size_t dsv_workspace_bytes(size_t n) {
@@ -1055,12 +1437,20 @@ size_t dsv_workspace_bytes(size_t n) {
 }
 
 // ---- device-pointer entry points --------------------------------------------------------
+// The context is the one of the device that owns the output buffer; the calling thread's current
+// device is switched for the duration of the call and restored.
+#define DSV_DEV_PROLOGUE(n, owner_ptr)              \
+  if (int r_ = check_n(n)) return r_;               \
+  if ((n) == 0) return DSV_OK;                      \
+  Context* ctxp_ = nullptr;                         \
+  if (int r_ = device_context(owner_ptr, ctxp_)) return r_; \
+  Context& ctx = *ctxp_;                            \
+  DSV_ON_DEVICE(ctx)
+
 int dsv_challenge_single_dev(const void* R_uv, const void* m, size_t n, void* c, void* valid,
                              void* stream) {
-  if (int r = check_ready()) return r;
-  if (int r = check_n(n)) return r;
-  if (n == 0) return DSV_OK;
-  if (!R_uv || !m || !c) return fail(DSV_ERR_INVALID_ARGUMENT, "null pointer");
+  if (n && (!R_uv || !m || !c)) return fail(DSV_ERR_INVALID_ARGUMENT, "null pointer");
+  DSV_DEV_PROLOGUE(n, c);
   hipLaunchKernelGGL(k_challenge<false>, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream,
                      (const uint8_t*)R_uv, (const uint8_t*)nullptr, (const uint8_t*)m, n,
                      (uint8_t*)c, (uint8_t*)valid);
@@ -1069,10 +1459,8 @@ int dsv_challenge_single_dev(const void* R_uv, const void* m, size_t n, void* c,
 }
 int dsv_challenge_double_dev(const void* R_uv, const void* Rp_uv, const void* m, size_t n, void* c,
                              void* valid, void* stream) {
-  if (int r = check_ready()) return r;
-  if (int r = check_n(n)) return r;
-  if (n == 0) return DSV_OK;
-  if (!R_uv || !Rp_uv || !m || !c) return fail(DSV_ERR_INVALID_ARGUMENT, "null pointer");
+  if (n && (!R_uv || !Rp_uv || !m || !c)) return fail(DSV_ERR_INVALID_ARGUMENT, "null pointer");
+  DSV_DEV_PROLOGUE(n, c);
   hipLaunchKernelGGL(k_challenge<true>, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream,
                      (const uint8_t*)R_uv, (const uint8_t*)Rp_uv, (const uint8_t*)m, n,
                      (uint8_t*)c, (uint8_t*)valid);
@@ -1080,75 +1468,44 @@ int dsv_challenge_double_dev(const void* R_uv, const void* Rp_uv, const void* m,
   return DSV_OK;
 }
 
-int dsv_verify_single_dev(const void* u, const void* R_uv, const void* PK_uv, const void* m,
-                          size_t n, void* ok, void* workspace, void* stream) {
-  if (int r = check_ready()) return r;
-  if (int r = check_n(n)) return r;
-  if (n == 0) return DSV_OK;
-  if (!u || !R_uv || !PK_uv || !m || !ok || !workspace)
-    return fail(DSV_ERR_INVALID_ARGUMENT, "null pointer");
+namespace {
+// bodies shared by the device-pointer entry points and the host pipeline (context resolved)
+int verify_single_on(Context& ctx, const void* u, const void* R_uv, const void* PK_uv, const void* m,
+                     size_t n, void* ok, void* workspace, hipStream_t stream) {
   const uint8_t *pu = (const uint8_t*)u, *pR = (const uint8_t*)R_uv, *pPK = (const uint8_t*)PK_uv,
                 *pm = (const uint8_t*)m;
   uint8_t* pok = (uint8_t*)ok;
-  return run_split(n, workspace, (hipStream_t)stream,
+  Context* cp = &ctx;
+  return run_split(ctx, n, workspace, stream,
                    [=](size_t off, size_t cnt, const Workspace& w, hipStream_t s) {
     hipLaunchKernelGGL(k_challenge<false>, dim3(grid_for(cnt)), dim3(256), 0, s, pR + 64 * off,
                        (const uint8_t*)nullptr, pm + 32 * off, cnt, w.c, w.valid);
-    launch_verify_fixed(false, pu + 32 * off, w.c, pPK + 64 * off, pR + 64 * off, 0, w.valid, cnt,
-                        pok + off, w.tables, s);
+    launch_verify_fixed(*cp, false, pu + 32 * off, w.c, pPK + 64 * off, pR + 64 * off, 0, w.valid,
+                        cnt, pok + off, w.tables, s);
   });
 }
-
-// second stage alone (c and valid already computed): lets callers time / profile the dominant
-// kernel separately, and re-use one challenge for several key pairs
-int dsv_verify_core_dev(const void* u, const void* c, const void* valid, const void* PK_uv,
-                        const void* R_uv, int which, int accumulate, size_t n, void* ok,
-                        void* workspace, void* stream) {
-  if (int r = check_ready()) return r;
-  if (int r = check_n(n)) return r;
-  if (n == 0) return DSV_OK;
-  if (!u || !c || !valid || !PK_uv || !R_uv || !ok || !workspace || which < 0 || which > 1)
-    return fail(DSV_ERR_INVALID_ARGUMENT, "bad argument");
-  hipStream_t s = (hipStream_t)stream;
-  Workspace w = carve(workspace, n);
-  launch_verify_fixed(accumulate != 0, u, c, PK_uv, R_uv, which, valid, n, ok, w.tables, s);
-  HIP_TRY(hipGetLastError());
-  return DSV_OK;
-}
-
-int dsv_verify_double_dev(const void* u, const void* R_uv, const void* Rp_uv, const void* PK_uv,
-                          const void* PKp_uv, const void* m, size_t n, void* ok, void* workspace,
-                          void* stream) {
-  if (int r = check_ready()) return r;
-  if (int r = check_n(n)) return r;
-  if (n == 0) return DSV_OK;
-  if (!u || !R_uv || !Rp_uv || !PK_uv || !PKp_uv || !m || !ok || !workspace)
-    return fail(DSV_ERR_INVALID_ARGUMENT, "null pointer");
+int verify_double_on(Context& ctx, const void* u, const void* R_uv, const void* Rp_uv,
+                     const void* PK_uv, const void* PKp_uv, const void* m, size_t n, void* ok,
+                     void* workspace, hipStream_t stream) {
   const uint8_t *pu = (const uint8_t*)u, *pR = (const uint8_t*)R_uv, *pRp = (const uint8_t*)Rp_uv,
                 *pPK = (const uint8_t*)PK_uv, *pPKp = (const uint8_t*)PKp_uv, *pm = (const uint8_t*)m;
   uint8_t* pok = (uint8_t*)ok;
-  return run_split(n, workspace, (hipStream_t)stream,
+  Context* cp = &ctx;
+  return run_split(ctx, n, workspace, stream,
                    [=](size_t off, size_t cnt, const Workspace& w, hipStream_t s) {
     hipLaunchKernelGGL(k_challenge<true>, dim3(grid_for(cnt)), dim3(256), 0, s, pR + 64 * off,
                        pRp + 64 * off, pm + 32 * off, cnt, w.c, w.valid);
-    launch_verify_fixed(false, pu + 32 * off, w.c, pPK + 64 * off, pR + 64 * off, 0, w.valid, cnt,
-                        pok + off, w.tables, s);
-    launch_verify_fixed(true, pu + 32 * off, w.c, pPKp + 64 * off, pRp + 64 * off, 1, w.valid, cnt,
-                        pok + off, w.tables, s);
+    launch_verify_fixed_double(*cp, pu + 32 * off, w.c, pPK + 64 * off, pR + 64 * off,
+                               pPKp + 64 * off, pRp + 64 * off, w.valid, cnt, pok + off, w.tables, s);
   });
 }
-
-int dsv_verify_vargen_dev(const void* u, const void* R_uv, const void* PK_uv, const void* Gen_uv,
-                          const void* m, size_t n, void* ok, void* workspace, void* stream) {
-  if (int r = check_ready()) return r;
-  if (int r = check_n(n)) return r;
-  if (n == 0) return DSV_OK;
-  if (!u || !R_uv || !PK_uv || !Gen_uv || !m || !ok || !workspace)
-    return fail(DSV_ERR_INVALID_ARGUMENT, "null pointer");
+int verify_vargen_on(Context& ctx, const void* u, const void* R_uv, const void* PK_uv,
+                     const void* Gen_uv, const void* m, size_t n, void* ok, void* workspace,
+                     hipStream_t stream) {
   const uint8_t *pu = (const uint8_t*)u, *pR = (const uint8_t*)R_uv, *pPK = (const uint8_t*)PK_uv,
                 *pG = (const uint8_t*)Gen_uv, *pm = (const uint8_t*)m;
   uint8_t* pok = (uint8_t*)ok;
-  return run_split(n, workspace, (hipStream_t)stream,
+  return run_split(ctx, n, workspace, stream,
                    [=](size_t off, size_t cnt, const Workspace& w, hipStream_t s) {
     hipLaunchKernelGGL(k_challenge<false>, dim3(grid_for(cnt)), dim3(256), 0, s, pR + 64 * off,
                        (const uint8_t*)nullptr, pm + 32 * off, cnt, w.c, w.valid);
@@ -1157,20 +1514,197 @@ int dsv_verify_vargen_dev(const void* u, const void* R_uv, const void* PK_uv, co
                        pR + 64 * off, (const uint8_t*)w.valid, cnt, pok + off, w.tables);
   });
 }
+int decompress_on(Context& ctx, const void* in, size_t in_stride, size_t n, void* out_uv, void* ok,
+                  int accumulate, hipStream_t stream) {
+  if (!in || !out_uv || !ok || in_stride < 32 || (in_stride & 15) || ((uintptr_t)in & 15))
+    return fail(DSV_ERR_INVALID_ARGUMENT, "bad pointer / stride (need 16-byte alignment)");
+  hipLaunchKernelGGL(k_decompress, dim3(grid_for(n)), dim3(256), 0, stream, (const uint8_t*)in,
+                     in_stride, n, (uint8_t*)out_uv, (uint8_t*)ok, accumulate,
+                     TsTables{ctx.ts_cancel, ctx.ts_hash});
+  HIP_TRY(hipGetLastError());
+  return DSV_OK;
+}
+}  // namespace
+
+int dsv_verify_single_dev(const void* u, const void* R_uv, const void* PK_uv, const void* m,
+                          size_t n, void* ok, void* workspace, void* stream) {
+  if (n && (!u || !R_uv || !PK_uv || !m || !ok || !workspace))
+    return fail(DSV_ERR_INVALID_ARGUMENT, "null pointer");
+  DSV_DEV_PROLOGUE(n, ok);
+  return verify_single_on(ctx, u, R_uv, PK_uv, m, n, ok, workspace, (hipStream_t)stream);
+}
+
+// second stage alone (c and valid already computed): lets callers time / profile the dominant
+// kernel separately, and re-use one challenge for several key pairs
+int dsv_verify_core_dev(const void* u, const void* c, const void* valid, const void* PK_uv,
+                        const void* R_uv, int which, int accumulate, size_t n, void* ok,
+                        void* workspace, void* stream) {
+  if (n && (!u || !c || !valid || !PK_uv || !R_uv || !ok || !workspace || which < 0 || which > 1))
+    return fail(DSV_ERR_INVALID_ARGUMENT, "bad argument");
+  DSV_DEV_PROLOGUE(n, ok);
+  Workspace w = carve(workspace, n);
+  launch_verify_fixed(ctx, accumulate != 0, u, c, PK_uv, R_uv, which, valid, n, ok, w.tables,
+                      (hipStream_t)stream);
+  HIP_TRY(hipGetLastError());
+  return DSV_OK;
+}
+// both equations of a double signature from a precomputed challenge, one launch
+int dsv_verify_core_double_dev(const void* u, const void* c, const void* valid, const void* PK_uv,
+                               const void* R_uv, const void* PKp_uv, const void* Rp_uv, size_t n,
+                               void* ok, void* workspace, void* stream) {
+  if (n && (!u || !c || !valid || !PK_uv || !R_uv || !PKp_uv || !Rp_uv || !ok || !workspace))
+    return fail(DSV_ERR_INVALID_ARGUMENT, "bad argument");
+  DSV_DEV_PROLOGUE(n, ok);
+  Workspace w = carve(workspace, n);
+  launch_verify_fixed_double(ctx, u, c, PK_uv, R_uv, PKp_uv, Rp_uv, valid, n, ok, w.tables,
+                             (hipStream_t)stream);
+  HIP_TRY(hipGetLastError());
+  return DSV_OK;
+}
+
+int dsv_verify_double_dev(const void* u, const void* R_uv, const void* Rp_uv, const void* PK_uv,
+                          const void* PKp_uv, const void* m, size_t n, void* ok, void* workspace,
+                          void* stream) {
+  if (n && (!u || !R_uv || !Rp_uv || !PK_uv || !PKp_uv || !m || !ok || !workspace))
+    return fail(DSV_ERR_INVALID_ARGUMENT, "null pointer");
+  DSV_DEV_PROLOGUE(n, ok);
+  return verify_double_on(ctx, u, R_uv, Rp_uv, PK_uv, PKp_uv, m, n, ok, workspace, (hipStream_t)stream);
+}
+
+int dsv_verify_vargen_dev(const void* u, const void* R_uv, const void* PK_uv, const void* Gen_uv,
+                          const void* m, size_t n, void* ok, void* workspace, void* stream) {
+  if (n && (!u || !R_uv || !PK_uv || !Gen_uv || !m || !ok || !workspace))
+    return fail(DSV_ERR_INVALID_ARGUMENT, "null pointer");
+  DSV_DEV_PROLOGUE(n, ok);
+  return verify_vargen_on(ctx, u, R_uv, PK_uv, Gen_uv, m, n, ok, workspace, (hipStream_t)stream);
+}
+
+// ---- mixed batches: device-side split by kind ---------------------------------------------
+namespace {
+struct SplitScratch {
+  u32* tile_counts;
+  u32* totals;
+};
+size_t split_scratch_bytes(size_t n) {
+  const size_t tiles = (n + kSplitTile - 1) / kSplitTile;
+  return align_up(tiles * 8, 256) + 256;
+}
+SplitScratch carve_split(void* p, size_t n) {
+  const size_t tiles = (n + kSplitTile - 1) / kSplitTile;
+  SplitScratch s;
+  s.tile_counts = static_cast<u32*>(p);
+  s.totals = reinterpret_cast<u32*>(static_cast<uint8_t*>(p) + align_up(tiles * 8, 256));
+  return s;
+}
+int split_on(const void* kinds, size_t n, void* idx_single, size_t cap_single, void* idx_double,
+             size_t cap_double, void* scratch, hipStream_t s) {
+  if ((uintptr_t)kinds & 15) return fail(DSV_ERR_INVALID_ARGUMENT, "kinds must be 16-byte aligned");
+  const size_t tiles = (n + kSplitTile - 1) / kSplitTile;
+  SplitScratch sc = carve_split(scratch, n);
+  hipLaunchKernelGGL(k_kind_count, dim3((unsigned)tiles), dim3(kSplitThreads), 0, s,
+                     (const uint8_t*)kinds, n, sc.tile_counts);
+  hipLaunchKernelGGL(k_kind_scan, dim3(1), dim3(1024), 0, s, sc.tile_counts, tiles, sc.totals);
+  hipLaunchKernelGGL(k_kind_write, dim3((unsigned)tiles), dim3(kSplitThreads), 0, s,
+                     (const uint8_t*)kinds, n, (const u32*)sc.tile_counts, (u32*)idx_single,
+                     cap_single, (u32*)idx_double, cap_double);
+  HIP_TRY(hipGetLastError());
+  return DSV_OK;
+}
+int gather_on(const void* src, size_t row_bytes, const void* idx, size_t count, void* dst,
+              hipStream_t s) {
+  if (row_bytes == 0 || (row_bytes & 15) || ((uintptr_t)src & 15) || ((uintptr_t)dst & 15))
+    return fail(DSV_ERR_INVALID_ARGUMENT, "rows must be multiples of 16 bytes, 16-byte aligned");
+  if (count == 0) return DSV_OK;
+  const u32 row16 = (u32)(row_bytes / 16);
+  hipLaunchKernelGGL(k_gather_rows, dim3(grid_for(count * row16)), dim3(256), 0, s,
+                     (const uint4*)src, row16, (const u32*)idx, count, (uint4*)dst);
+  HIP_TRY(hipGetLastError());
+  return DSV_OK;
+}
+}  // namespace
+
+size_t dsv_split_scratch_bytes(size_t n) { return split_scratch_bytes(n); }
+
+int dsv_split_kinds_dev(const void* kinds, size_t n, void* idx_single, size_t cap_single,
+                        void* idx_double, size_t cap_double, void* scratch, void* stream) {
+  if (n && (!kinds || !idx_single || !idx_double || !scratch))
+    return fail(DSV_ERR_INVALID_ARGUMENT, "null pointer");
+  DSV_DEV_PROLOGUE(n, scratch);
+  return split_on(kinds, n, idx_single, cap_single, idx_double, cap_double, scratch, (hipStream_t)stream);
+}
+int dsv_gather_rows_dev(const void* src, size_t row_bytes, const void* idx, size_t count, void* dst,
+                        void* stream) {
+  if (count && (!src || !idx || !dst)) return fail(DSV_ERR_INVALID_ARGUMENT, "null pointer");
+  DSV_DEV_PROLOGUE(count, dst);
+  return gather_on(src, row_bytes, idx, count, dst, (hipStream_t)stream);
+}
+int dsv_scatter_verdicts_dev(const void* src, const void* idx, size_t count, void* dst, void* stream) {
+  if (count && (!src || !idx || !dst)) return fail(DSV_ERR_INVALID_ARGUMENT, "null pointer");
+  DSV_DEV_PROLOGUE(count, dst);
+  hipLaunchKernelGGL(k_scatter_bytes, dim3(grid_for(count)), dim3(256), 0, (hipStream_t)stream,
+                     (const uint8_t*)src, (const u32*)idx, count, (uint8_t*)dst);
+  HIP_TRY(hipGetLastError());
+  return DSV_OK;
+}
+
+size_t dsv_mixed_workspace_bytes(size_t n) {
+  // split scratch | idx_single[n] | idx_double[n] | compacted rows (<= 320 B per item) |
+  // per-kind verdicts | verify workspace
+  return split_scratch_bytes(n) + 2 * align_up(n * 4, 256) + 6 * align_up(n * 64, 256) +
+         2 * align_up(n, 256) + align_up(dsv_workspace_bytes(n), 256) + 256;
+}
+
+// One batch holding single (kind 0) and double (kind 1) signatures in any interleaving, as a
+// structure of arrays over ALL n items (Rp_uv / PKp_uv rows of single items are ignored).
+// n_double = number of kind-1 items (the caller knows its batch); every other item must be kind 0.
+int dsv_verify_mixed_dev(const void* kinds, const void* u, const void* R_uv, const void* Rp_uv,
+                         const void* PK_uv, const void* PKp_uv, const void* m, size_t n,
+                         size_t n_double, void* ok, void* workspace, void* stream) {
+  if (n && (!kinds || !u || !R_uv || !Rp_uv || !PK_uv || !PKp_uv || !m || !ok || !workspace))
+    return fail(DSV_ERR_INVALID_ARGUMENT, "null pointer");
+  if (n_double > n) return fail(DSV_ERR_INVALID_ARGUMENT, "n_double exceeds n");
+  DSV_DEV_PROLOGUE(n, ok);
+  hipStream_t s = (hipStream_t)stream;
+  const size_t ns = n - n_double, nd = n_double;
+  Stager st(static_cast<uint8_t*>(workspace));
+  void* scratch = st.take(split_scratch_bytes(n));
+  u32* idx_s = reinterpret_cast<u32*>(st.take(n * 4));
+  u32* idx_d = reinterpret_cast<u32*>(st.take(n * 4));
+  uint8_t *cu = st.take(n * 32), *cm = st.take(n * 32);   // singles first, doubles behind them
+  uint8_t *cR = st.take(n * 64), *cPK = st.take(n * 64);
+  uint8_t *cRp = st.take(n * 64), *cPKp = st.take(n * 64);  // doubles only
+  uint8_t *oks = st.take(n), *okd = st.take(n);
+  void* vws = st.take(dsv_workspace_bytes(n));
+  HIP_TRY(hipMemsetAsync(ok, 0, n, s));  // items of an invalid kind keep verdict 0
+  if (int r = split_on(kinds, n, idx_s, ns, idx_d, nd, scratch, s)) return r;
+  struct Col { const void* src; size_t bytes; uint8_t* dst; };
+  const Col single_cols[4] = {{u, 32, cu}, {m, 32, cm}, {R_uv, 64, cR}, {PK_uv, 64, cPK}};
+  for (const Col& c : single_cols)
+    if (int r = gather_on(c.src, c.bytes, idx_s, ns, c.dst, s)) return r;
+  const Col double_cols[6] = {{u, 32, cu + ns * 32},      {m, 32, cm + ns * 32},
+                              {R_uv, 64, cR + ns * 64},   {PK_uv, 64, cPK + ns * 64},
+                              {Rp_uv, 64, cRp},           {PKp_uv, 64, cPKp}};
+  for (const Col& c : double_cols)
+    if (int r = gather_on(c.src, c.bytes, idx_d, nd, c.dst, s)) return r;
+  if (ns) {
+    if (int r = verify_single_on(ctx, cu, cR, cPK, cm, ns, oks, vws, s)) return r;
+    hipLaunchKernelGGL(k_scatter_bytes, dim3(grid_for(ns)), dim3(256), 0, s, (const uint8_t*)oks,
+                       (const u32*)idx_s, ns, (uint8_t*)ok);
+  }
+  if (nd) {
+    if (int r = verify_double_on(ctx, cu + ns * 32, cR + ns * 64, cRp, cPK + ns * 64, cPKp,
+                                 cm + ns * 32, nd, okd, vws, s))
+      return r;
+    hipLaunchKernelGGL(k_scatter_bytes, dim3(grid_for(nd)), dim3(256), 0, s, (const uint8_t*)okd,
+                       (const u32*)idx_d, nd, (uint8_t*)ok);
+  }
+  hipLaunchKernelGGL(k_mixed_check, dim3(256), dim3(256), 0, s, (const u32*)carve_split(scratch, n).totals,
+                     (u32)ns, (u32)nd, (uint8_t*)ok, n);
+  HIP_TRY(hipGetLastError());
+  return DSV_OK;
+}
 
 // ---- host-pointer entry points ----------------------------------------------------------
-namespace {
-struct Stager {
-  uint8_t* base;
-  size_t off = 0;
-  explicit Stager(uint8_t* b) : base(b) {}
-  uint8_t* take(size_t bytes) {
-    uint8_t* p = base + off;
-    off += align_up(bytes, 256);
-    return p;
-  }
-};
-}  // namespace
 
 #define H2D(dst, src, bytes) HIP_TRY(hipMemcpyAsync((dst), (src), (bytes), hipMemcpyHostToDevice, 0))
 #define D2H(dst, src, bytes) HIP_TRY(hipMemcpyAsync((dst), (src), (bytes), hipMemcpyDeviceToHost, 0))
@@ -1205,10 +1739,12 @@ inline int host_copy_threads() {
 //   extra_item_bytes: further device scratch per item that `launch` needs (decoded points of the
 //   wire-format entry points); handed to it as a Stager positioned behind the workspace.
 template <size_t NIN, class Launch>
-int run_pipelined(const HostIn (&ins)[NIN], uint8_t* ok, size_t n, size_t extra_item_bytes,
-                  Launch launch) {
-  std::lock_guard<std::mutex> lk(g_ctx.mu);
-  HIP_TRY(hipSetDevice(g_ctx.device));
+int run_pipelined(Context& ctx, const HostIn (&ins)[NIN], uint8_t* ok, size_t n,
+                  size_t extra_item_bytes, Launch launch) {
+  std::lock_guard<std::mutex> lk(ctx.mu);
+  if (!ctx.ready.load(std::memory_order_acquire))
+    return fail(DSV_ERR_NOT_INITIALIZED, "device %d was shut down", ctx.device);
+  DSV_ON_DEVICE(ctx);
   const size_t chunk = n < kPipeChunk ? n : kPipeChunk;
   size_t in_off[NIN + 1];  // offsets inside a slot, the same on both sides
   in_off[0] = 0;
@@ -1220,26 +1756,26 @@ int run_pipelined(const HostIn (&ins)[NIN], uint8_t* ok, size_t n, size_t extra_
   const size_t nchunks = (n + chunk - 1) / chunk;
   const int nslots = nchunks < (size_t)kPipeSlots ? (int)nchunks : kPipeSlots;
   for (int sl = 0; sl < nslots; sl++)
-    if (int r = ensure_pipe_slot(sl, dev_need, host_need)) return r;
+    if (int r = ensure_pipe_slot(ctx, sl, dev_need, host_need)) return r;
   size_t slot_first[kPipeSlots] = {}, slot_cnt[kPipeSlots] = {};  // verdicts parked in a slot
   auto drain = [&](int sl) -> int {
-    HIP_TRY(hipStreamSynchronize(g_ctx.pipe_stream[sl]));
-    if (slot_cnt[sl]) memcpy(ok + slot_first[sl], g_ctx.pipe_host[sl] + ok_off, slot_cnt[sl]);
+    HIP_TRY(hipStreamSynchronize(ctx.pipe_stream[sl]));
+    if (slot_cnt[sl]) memcpy(ok + slot_first[sl], ctx.pipe_host[sl] + ok_off, slot_cnt[sl]);
     slot_cnt[sl] = 0;
     return DSV_OK;
   };
   size_t done = 0;
   for (size_t c = 0; done < n; c++) {
     const int sl = (int)(c % kPipeSlots);
-    hipStream_t st = g_ctx.pipe_stream[sl];
+    hipStream_t st = ctx.pipe_stream[sl];
     const size_t cnt = n - done < chunk ? n - done : chunk;
     if (int r = drain(sl)) return r;  // slot free again, its verdicts delivered
-    uint8_t* host = g_ctx.pipe_host[sl];
-    uint8_t* dev = g_ctx.pipe_stage[sl];
+    uint8_t* host = ctx.pipe_host[sl];
+    uint8_t* dev = ctx.pipe_stage[sl];
     size_t bytes = 0;
     for (size_t k = 0; k < NIN; k++) bytes += cnt * ins[k].bytes;
     const int T = bytes >= ((size_t)1 << 20) ? host_copy_threads() : 1;
-    g_ctx.copiers.run(T, [&](int t, int nt) {
+    ctx.copiers.run(T, [&](int t, int nt) {
       for (size_t k = 0; k < NIN; k++) {
         const size_t len = cnt * ins[k].bytes;
         const size_t lo = len * (size_t)t / (size_t)nt / 64 * 64;
@@ -1268,59 +1804,158 @@ int run_pipelined(const HostIn (&ins)[NIN], uint8_t* ok, size_t n, size_t extra_
 }  // namespace
 }  // extern "C++"
 
-int dsv_verify_single(const uint8_t* u, const uint8_t* R_uv, const uint8_t* PK_uv,
-                      const uint8_t* m, size_t n, uint8_t* ok) {
-  if (int r = check_ready()) return r;
-  if (int r = check_n(n)) return r;
-  if (n == 0) return DSV_OK;
-  if (!u || !R_uv || !PK_uv || !m || !ok) return fail(DSV_ERR_INVALID_ARGUMENT, "null pointer");
+
+#define DSV_HOST_PROLOGUE(n)                                  \
+  if (int r_ = check_n(n)) return r_;                         \
+  if ((n) == 0) return DSV_OK;                                \
+  Context* ctxp_ = nullptr;                                   \
+  if (int r_ = host_context(ctxp_)) return r_;                \
+  Context& ctx = *ctxp_
+// small host calls: one lock, the context's staging buffer, the device's null stream
+#define DSV_HOST_LOCK()                                                                \
+  std::lock_guard<std::mutex> lk(ctx.mu);                                              \
+  if (!ctx.ready.load(std::memory_order_acquire))                                      \
+    return fail(DSV_ERR_NOT_INITIALIZED, "device %d was shut down", ctx.device);       \
+  DSV_ON_DEVICE(ctx)
+
+extern "C++" {
+namespace {
+int verify_single_host(Context& ctx, const uint8_t* u, const uint8_t* R_uv, const uint8_t* PK_uv,
+                       const uint8_t* m, size_t n, uint8_t* ok) {
   const HostIn ins[4] = {{u, 32}, {R_uv, 64}, {PK_uv, 64}, {m, 32}};
-  return run_pipelined(ins, ok, n, 0, [](const void* const* d, size_t cnt, void* dok, void* ws, Stager&, hipStream_t st) {
-    return dsv_verify_single_dev(d[0], d[1], d[2], d[3], cnt, dok, ws, st);
+  Context* cp = &ctx;
+  return run_pipelined(ctx, ins, ok, n, 0, [cp](const void* const* d, size_t cnt, void* dok, void* ws, Stager&, hipStream_t st) {
+    return verify_single_on(*cp, d[0], d[1], d[2], d[3], cnt, dok, ws, st);
+  });
+}
+int verify_double_host(Context& ctx, const uint8_t* u, const uint8_t* R_uv, const uint8_t* Rp_uv,
+                       const uint8_t* PK_uv, const uint8_t* PKp_uv, const uint8_t* m, size_t n,
+                       uint8_t* ok) {
+  const HostIn ins[6] = {{u, 32}, {R_uv, 64}, {Rp_uv, 64}, {PK_uv, 64}, {PKp_uv, 64}, {m, 32}};
+  Context* cp = &ctx;
+  return run_pipelined(ctx, ins, ok, n, 0, [cp](const void* const* d, size_t cnt, void* dok, void* ws, Stager&, hipStream_t st) {
+    return verify_double_on(*cp, d[0], d[1], d[2], d[3], d[4], d[5], cnt, dok, ws, st);
+  });
+}
+int verify_vargen_host(Context& ctx, const uint8_t* u, const uint8_t* R_uv, const uint8_t* PK_uv,
+                       const uint8_t* Gen_uv, const uint8_t* m, size_t n, uint8_t* ok) {
+  const HostIn ins[5] = {{u, 32}, {R_uv, 64}, {PK_uv, 64}, {Gen_uv, 64}, {m, 32}};
+  Context* cp = &ctx;
+  return run_pipelined(ctx, ins, ok, n, 0, [cp](const void* const* d, size_t cnt, void* dok, void* ws, Stager&, hipStream_t st) {
+    return verify_vargen_on(*cp, d[0], d[1], d[2], d[3], d[4], cnt, dok, ws, st);
   });
 }
 
+// One host batch over every initialised device: contiguous shards, one host thread per device
+// (the calling thread takes the first shard), no collective — each context stages, computes and
+// returns its own slice of ok[].  part(ctx, offset, count) -> dsv_status.
+template <class Part>
+int run_multi(size_t n, Part part) {
+  Context* devs[kMaxDevices];
+  int nd = 0;
+  for (int d = 0; d < kMaxDevices; d++)
+    if (g_ctx[d].ready.load(std::memory_order_acquire)) devs[nd++] = &g_ctx[d];
+  if (nd == 0) return fail(DSV_ERR_NOT_INITIALIZED, "dsv_init() has not been called");
+  // DSV_MULTI_SHARDS=k (read per call): at least k shards, wrapping over the devices — lets a
+  // one-GPU box exercise the sharding, the worker threads and their error path (shards of one
+  // device then serialise on that device's lock)
+  if (const char* e = getenv("DSV_MULTI_SHARDS")) {
+    const int want = atoi(e);
+    const int have = nd;
+    while (nd < want && nd < kMaxDevices) {
+      devs[nd] = devs[nd % have];
+      nd++;
+    }
+  }
+  if (nd == 1 || n < (size_t)nd * 1024) return part(*devs[0], (size_t)0, n);
+  int rc[kMaxDevices] = {};
+  std::string msg[kMaxDevices];
+  std::vector<std::thread> th;
+  auto work = [&](int k) {
+    const size_t lo = n * (size_t)k / (size_t)nd, hi = n * (size_t)(k + 1) / (size_t)nd;
+    rc[k] = hi > lo ? part(*devs[k], lo, hi - lo) : (int)DSV_OK;
+    if (rc[k]) msg[k] = g_err;  // the error text lives in the worker's thread-local
+  };
+  for (int k = 1; k < nd; k++) th.emplace_back(work, k);
+  work(0);
+  for (auto& t : th) t.join();
+  for (int k = 0; k < nd; k++)
+    if (rc[k]) return fail(rc[k], "device %d: %s", devs[k]->device, msg[k].c_str());
+  return DSV_OK;
+}
+}  // namespace
+}  // extern "C++"
+
+int dsv_verify_single(const uint8_t* u, const uint8_t* R_uv, const uint8_t* PK_uv,
+                      const uint8_t* m, size_t n, uint8_t* ok) {
+  if (n && (!u || !R_uv || !PK_uv || !m || !ok)) return fail(DSV_ERR_INVALID_ARGUMENT, "null pointer");
+  DSV_HOST_PROLOGUE(n);
+  return verify_single_host(ctx, u, R_uv, PK_uv, m, n, ok);
+}
 int dsv_verify_double(const uint8_t* u, const uint8_t* R_uv, const uint8_t* Rp_uv,
                       const uint8_t* PK_uv, const uint8_t* PKp_uv, const uint8_t* m, size_t n,
                       uint8_t* ok) {
-  if (int r = check_ready()) return r;
+  if (n && (!u || !R_uv || !Rp_uv || !PK_uv || !PKp_uv || !m || !ok))
+    return fail(DSV_ERR_INVALID_ARGUMENT, "null pointer");
+  DSV_HOST_PROLOGUE(n);
+  return verify_double_host(ctx, u, R_uv, Rp_uv, PK_uv, PKp_uv, m, n, ok);
+}
+int dsv_verify_vargen(const uint8_t* u, const uint8_t* R_uv, const uint8_t* PK_uv,
+                      const uint8_t* Gen_uv, const uint8_t* m, size_t n, uint8_t* ok) {
+  if (n && (!u || !R_uv || !PK_uv || !Gen_uv || !m || !ok))
+    return fail(DSV_ERR_INVALID_ARGUMENT, "null pointer");
+  DSV_HOST_PROLOGUE(n);
+  return verify_vargen_host(ctx, u, R_uv, PK_uv, Gen_uv, m, n, ok);
+}
+
+// ---- the same over ALL initialised devices (what a Rust verify_batch on an 8-GPU node calls) ----
+int dsv_verify_single_multi(const uint8_t* u, const uint8_t* R_uv, const uint8_t* PK_uv,
+                            const uint8_t* m, size_t n, uint8_t* ok) {
+  if (int r = check_n(n)) return r;
+  if (n == 0) return DSV_OK;
+  if (!u || !R_uv || !PK_uv || !m || !ok) return fail(DSV_ERR_INVALID_ARGUMENT, "null pointer");
+  return run_multi(n, [=](Context& ctx, size_t off, size_t cnt) {
+    return verify_single_host(ctx, u + 32 * off, R_uv + 64 * off, PK_uv + 64 * off, m + 32 * off, cnt,
+                              ok + off);
+  });
+}
+int dsv_verify_double_multi(const uint8_t* u, const uint8_t* R_uv, const uint8_t* Rp_uv,
+                            const uint8_t* PK_uv, const uint8_t* PKp_uv, const uint8_t* m, size_t n,
+                            uint8_t* ok) {
   if (int r = check_n(n)) return r;
   if (n == 0) return DSV_OK;
   if (!u || !R_uv || !Rp_uv || !PK_uv || !PKp_uv || !m || !ok)
     return fail(DSV_ERR_INVALID_ARGUMENT, "null pointer");
-  const HostIn ins[6] = {{u, 32}, {R_uv, 64}, {Rp_uv, 64}, {PK_uv, 64}, {PKp_uv, 64}, {m, 32}};
-  return run_pipelined(ins, ok, n, 0, [](const void* const* d, size_t cnt, void* dok, void* ws, Stager&, hipStream_t st) {
-    return dsv_verify_double_dev(d[0], d[1], d[2], d[3], d[4], d[5], cnt, dok, ws, st);
+  return run_multi(n, [=](Context& ctx, size_t off, size_t cnt) {
+    return verify_double_host(ctx, u + 32 * off, R_uv + 64 * off, Rp_uv + 64 * off, PK_uv + 64 * off,
+                              PKp_uv + 64 * off, m + 32 * off, cnt, ok + off);
   });
 }
-
-int dsv_verify_vargen(const uint8_t* u, const uint8_t* R_uv, const uint8_t* PK_uv,
-                      const uint8_t* Gen_uv, const uint8_t* m, size_t n, uint8_t* ok) {
-  if (int r = check_ready()) return r;
+int dsv_verify_vargen_multi(const uint8_t* u, const uint8_t* R_uv, const uint8_t* PK_uv,
+                            const uint8_t* Gen_uv, const uint8_t* m, size_t n, uint8_t* ok) {
   if (int r = check_n(n)) return r;
   if (n == 0) return DSV_OK;
   if (!u || !R_uv || !PK_uv || !Gen_uv || !m || !ok)
     return fail(DSV_ERR_INVALID_ARGUMENT, "null pointer");
-  const HostIn ins[5] = {{u, 32}, {R_uv, 64}, {PK_uv, 64}, {Gen_uv, 64}, {m, 32}};
-  return run_pipelined(ins, ok, n, 0, [](const void* const* d, size_t cnt, void* dok, void* ws, Stager&, hipStream_t st) {
-    return dsv_verify_vargen_dev(d[0], d[1], d[2], d[3], d[4], cnt, dok, ws, st);
+  return run_multi(n, [=](Context& ctx, size_t off, size_t cnt) {
+    return verify_vargen_host(ctx, u + 32 * off, R_uv + 64 * off, PK_uv + 64 * off, Gen_uv + 64 * off,
+                              m + 32 * off, cnt, ok + off);
   });
 }
 
 int dsv_verify_single_ext(const uint8_t* u, const uint8_t* R_uvz, const uint8_t* PK_uvz,
                           const uint8_t* m, size_t n, uint8_t* ok) {
-  if (int r = check_ready()) return r;
-  if (int r = check_n(n)) return r;
-  if (n == 0) return DSV_OK;
-  if (!u || !R_uvz || !PK_uvz || !m || !ok) return fail(DSV_ERR_INVALID_ARGUMENT, "null pointer");
+  if (n && (!u || !R_uvz || !PK_uvz || !m || !ok)) return fail(DSV_ERR_INVALID_ARGUMENT, "null pointer");
+  DSV_HOST_PROLOGUE(n);
   const HostIn ins[4] = {{u, 32}, {R_uvz, 96}, {PK_uvz, 96}, {m, 32}};
-  return run_pipelined(ins, ok, n, 64 + 64 + 1, [](const void* const* d, size_t cnt, void* dok, void* ws, Stager& x, hipStream_t st) {
+  Context* cp = &ctx;
+  return run_pipelined(ctx, ins, ok, n, 64 + 64 + 1, [cp](const void* const* d, size_t cnt, void* dok, void* ws, Stager& x, hipStream_t st) {
     uint8_t *dR = x.take(cnt * 64), *dPK = x.take(cnt * 64), *dvalid = x.take(cnt);
     hipLaunchKernelGGL(k_normalize_uvz, dim3(grid_for(cnt)), dim3(256), 0, st, (const uint8_t*)d[1], cnt,
                        dR, dvalid, 0);
     hipLaunchKernelGGL(k_normalize_uvz, dim3(grid_for(cnt)), dim3(256), 0, st, (const uint8_t*)d[2], cnt,
                        dPK, dvalid, 1);
-    if (int r = dsv_verify_single_dev(d[0], dR, dPK, d[3], cnt, dok, ws, st)) return r;
+    if (int r = verify_single_on(*cp, d[0], dR, dPK, d[3], cnt, dok, ws, st)) return r;
     hipLaunchKernelGGL(k_and_bytes, dim3(grid_for(cnt)), dim3(256), 0, st, (uint8_t*)dok,
                        (const uint8_t*)dvalid, cnt);
     HIP_TRY(hipGetLastError());
@@ -1329,64 +1964,131 @@ int dsv_verify_single_ext(const uint8_t* u, const uint8_t* R_uvz, const uint8_t*
 }
 
 int dsv_challenge_single(const uint8_t* R_uv, const uint8_t* m, size_t n, uint8_t* c) {
-  if (int r = check_ready()) return r;
-  if (int r = check_n(n)) return r;
-  if (n == 0) return DSV_OK;
-  if (!R_uv || !m || !c) return fail(DSV_ERR_INVALID_ARGUMENT, "null pointer");
-  std::lock_guard<std::mutex> lk(g_ctx.mu);
-  HIP_TRY(hipSetDevice(g_ctx.device));
-  if (int r = ensure_stage(align_up(n * 64, 256) + 2 * align_up(n * 32, 256))) return r;
-  Stager st(g_ctx.stage);
+  if (n && (!R_uv || !m || !c)) return fail(DSV_ERR_INVALID_ARGUMENT, "null pointer");
+  DSV_HOST_PROLOGUE(n);
+  DSV_HOST_LOCK();
+  if (int r = ensure_stage(ctx, align_up(n * 64, 256) + 2 * align_up(n * 32, 256))) return r;
+  Stager st(ctx.stage);
   uint8_t *dR = st.take(n * 64), *dm = st.take(n * 32), *dc = st.take(n * 32);
   H2D(dR, R_uv, n * 64);
   H2D(dm, m, n * 32);
-  if (int r = dsv_challenge_single_dev(dR, dm, n, dc, nullptr, nullptr)) return r;
+  hipLaunchKernelGGL(k_challenge<false>, dim3(grid_for(n)), dim3(256), 0, 0, (const uint8_t*)dR,
+                     (const uint8_t*)nullptr, (const uint8_t*)dm, n, dc, (uint8_t*)nullptr);
+  HIP_TRY(hipGetLastError());
   D2H(c, dc, n * 32);
   HIP_TRY(hipStreamSynchronize(0));
   return DSV_OK;
 }
 int dsv_challenge_double(const uint8_t* R_uv, const uint8_t* Rp_uv, const uint8_t* m, size_t n,
                          uint8_t* c) {
-  if (int r = check_ready()) return r;
-  if (int r = check_n(n)) return r;
-  if (n == 0) return DSV_OK;
-  if (!R_uv || !Rp_uv || !m || !c) return fail(DSV_ERR_INVALID_ARGUMENT, "null pointer");
-  std::lock_guard<std::mutex> lk(g_ctx.mu);
-  HIP_TRY(hipSetDevice(g_ctx.device));
-  if (int r = ensure_stage(2 * align_up(n * 64, 256) + 2 * align_up(n * 32, 256))) return r;
-  Stager st(g_ctx.stage);
+  if (n && (!R_uv || !Rp_uv || !m || !c)) return fail(DSV_ERR_INVALID_ARGUMENT, "null pointer");
+  DSV_HOST_PROLOGUE(n);
+  DSV_HOST_LOCK();
+  if (int r = ensure_stage(ctx, 2 * align_up(n * 64, 256) + 2 * align_up(n * 32, 256))) return r;
+  Stager st(ctx.stage);
   uint8_t *dR = st.take(n * 64), *dRp = st.take(n * 64), *dm = st.take(n * 32),
           *dc = st.take(n * 32);
   H2D(dR, R_uv, n * 64);
   H2D(dRp, Rp_uv, n * 64);
   H2D(dm, m, n * 32);
-  if (int r = dsv_challenge_double_dev(dR, dRp, dm, n, dc, nullptr, nullptr)) return r;
+  hipLaunchKernelGGL(k_challenge<true>, dim3(grid_for(n)), dim3(256), 0, 0, (const uint8_t*)dR,
+                     (const uint8_t*)dRp, (const uint8_t*)dm, n, dc, (uint8_t*)nullptr);
+  HIP_TRY(hipGetLastError());
   D2H(c, dc, n * 32);
   HIP_TRY(hipStreamSynchronize(0));
   return DSV_OK;
 }
 
-// ---- signing / key derivation -----------------------------------------------------------
+// ---- signing / key derivation: INPUT GENERATION for tests and benchmarks ----------------------
+// NOT a replacement for SecretKey::sign in production: the fixed- and variable-base multiplications
+// index tables in global memory with digits of the secret scalar (addresses depend on secrets;
+// dusk-jubjub's multiplication is constant-time), and secrets pass through library-owned staging.
+// The host entry points scrub that staging before they return; the *_dev ones never own secrets.
+namespace {
+void launch_sign_single(Context& ctx, const void* sk, const void* m, const void* r, size_t n, void* u,
+                        void* R_uv, hipStream_t s) {
+  hipLaunchKernelGGL(k_fixed_base_points, dim3(grid_for(n)), dim3(256), 0, s, (const uint8_t*)r,
+                     (const u32*)ctx.table[0], n, (uint8_t*)R_uv);
+  // scratch use: c is written to u (32 B per item) before k_sign_finish overwrites it in place
+  hipLaunchKernelGGL(k_challenge<false>, dim3(grid_for(n)), dim3(256), 0, s, (const uint8_t*)R_uv,
+                     (const uint8_t*)nullptr, (const uint8_t*)m, n, (uint8_t*)u, (uint8_t*)nullptr);
+  hipLaunchKernelGGL(k_sign_finish, dim3(grid_for(n)), dim3(256), 0, s, (const uint8_t*)r,
+                     (const uint8_t*)u, (const uint8_t*)sk, n, (uint8_t*)u);
+}
+void launch_sign_double(Context& ctx, const void* sk, const void* m, const void* r, size_t n, void* u,
+                        void* R_uv, void* Rp_uv, hipStream_t s) {
+  hipLaunchKernelGGL(k_fixed_base_points, dim3(grid_for(n)), dim3(256), 0, s, (const uint8_t*)r,
+                     (const u32*)ctx.table[0], n, (uint8_t*)R_uv);
+  hipLaunchKernelGGL(k_fixed_base_points, dim3(grid_for(n)), dim3(256), 0, s, (const uint8_t*)r,
+                     (const u32*)ctx.table[1], n, (uint8_t*)Rp_uv);
+  hipLaunchKernelGGL(k_challenge<true>, dim3(grid_for(n)), dim3(256), 0, s, (const uint8_t*)R_uv,
+                     (const uint8_t*)Rp_uv, (const uint8_t*)m, n, (uint8_t*)u, (uint8_t*)nullptr);
+  hipLaunchKernelGGL(k_sign_finish, dim3(grid_for(n)), dim3(256), 0, s, (const uint8_t*)r,
+                     (const uint8_t*)u, (const uint8_t*)sk, n, (uint8_t*)u);
+}
+// host-side check of what the kernels would otherwise poison: scalars must be < r
+int check_canonical_scalars(const uint8_t* s, size_t n, const char* what) {
+  static const uint32_t kR[8] = DSV_R32;
+  for (size_t i = 0; i < n; i++) {
+    uint32_t w[8];
+    memcpy(w, s + 32 * i, 32);
+    bool lt = false;
+    for (int k = 7; k >= 0; k--) {
+      if (w[k] != kR[k]) {
+        lt = w[k] < kR[k];
+        break;
+      }
+    }
+    if (!lt) return fail(DSV_ERR_INVALID_ARGUMENT, "%s[%zu] is not a canonical JubJubScalar (>= r)", what, i);
+  }
+  return DSV_OK;
+}
+}  // namespace
+
 int dsv_public_keys_dev(const void* sk, int which, size_t n, void* PK_uv, void* stream) {
-  if (int r = check_ready()) return r;
-  if (int r = check_n(n)) return r;
-  if (n == 0) return DSV_OK;
-  if (!sk || !PK_uv || which < 0 || which > 1) return fail(DSV_ERR_INVALID_ARGUMENT, "bad argument");
+  if (n && (!sk || !PK_uv || which < 0 || which > 1)) return fail(DSV_ERR_INVALID_ARGUMENT, "bad argument");
+  DSV_DEV_PROLOGUE(n, PK_uv);
   hipLaunchKernelGGL(k_fixed_base_points, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream,
-                     (const uint8_t*)sk, (const u32*)g_ctx.table[which], n, (uint8_t*)PK_uv);
+                     (const uint8_t*)sk, (const u32*)ctx.table[which], n, (uint8_t*)PK_uv);
   HIP_TRY(hipGetLastError());
   return DSV_OK;
 }
-// scratch use: c is written to u (32 B per item) before k_sign_finish overwrites it in place
 int dsv_sign_single_dev(const void* sk, const void* m, const void* r, size_t n, void* u, void* R_uv,
                         void* stream) {
-  if (int rc = check_ready()) return rc;
-  if (int rc = check_n(n)) return rc;
-  if (n == 0) return DSV_OK;
-  if (!sk || !m || !r || !u || !R_uv) return fail(DSV_ERR_INVALID_ARGUMENT, "null pointer");
+  if (n && (!sk || !m || !r || !u || !R_uv)) return fail(DSV_ERR_INVALID_ARGUMENT, "null pointer");
+  DSV_DEV_PROLOGUE(n, u);
+  launch_sign_single(ctx, sk, m, r, n, u, R_uv, (hipStream_t)stream);
+  HIP_TRY(hipGetLastError());
+  return DSV_OK;
+}
+int dsv_sign_double_dev(const void* sk, const void* m, const void* r, size_t n, void* u, void* R_uv,
+                        void* Rp_uv, void* stream) {
+  if (n && (!sk || !m || !r || !u || !R_uv || !Rp_uv)) return fail(DSV_ERR_INVALID_ARGUMENT, "null pointer");
+  DSV_DEV_PROLOGUE(n, u);
+  launch_sign_double(ctx, sk, m, r, n, u, R_uv, Rp_uv, (hipStream_t)stream);
+  HIP_TRY(hipGetLastError());
+  return DSV_OK;
+}
+// variable-base forms (var-generator scheme): PK = sk * Gen; R = r * Gen, c, u.  `workspace`:
+// dsv_workspace_bytes(n) device bytes (the per-lane window tables live there)
+int dsv_public_keys_vargen_dev(const void* sk, const void* Gen_uv, size_t n, void* PK_uv,
+                               void* workspace, void* stream) {
+  if (n && (!sk || !Gen_uv || !PK_uv || !workspace)) return fail(DSV_ERR_INVALID_ARGUMENT, "null pointer");
+  DSV_DEV_PROLOGUE(n, PK_uv);
+  hipLaunchKernelGGL(k_var_base_points, dim3(verify_grid(n)), dim3(kVerifyBlock), 0, (hipStream_t)stream,
+                     (const uint8_t*)sk, (const uint8_t*)Gen_uv, n, (uint8_t*)PK_uv,
+                     reinterpret_cast<u32*>(workspace));
+  HIP_TRY(hipGetLastError());
+  return DSV_OK;
+}
+int dsv_sign_vargen_dev(const void* sk, const void* Gen_uv, const void* m, const void* r, size_t n,
+                        void* u, void* R_uv, void* workspace, void* stream) {
+  if (n && (!sk || !Gen_uv || !m || !r || !u || !R_uv || !workspace))
+    return fail(DSV_ERR_INVALID_ARGUMENT, "null pointer");
+  DSV_DEV_PROLOGUE(n, u);
   hipStream_t s = (hipStream_t)stream;
-  hipLaunchKernelGGL(k_fixed_base_points, dim3(grid_for(n)), dim3(256), 0, s, (const uint8_t*)r,
-                     (const u32*)g_ctx.table[0], n, (uint8_t*)R_uv);
+  hipLaunchKernelGGL(k_var_base_points, dim3(verify_grid(n)), dim3(kVerifyBlock), 0, s, (const uint8_t*)r,
+                     (const uint8_t*)Gen_uv, n, (uint8_t*)R_uv, reinterpret_cast<u32*>(workspace));
   hipLaunchKernelGGL(k_challenge<false>, dim3(grid_for(n)), dim3(256), 0, s, (const uint8_t*)R_uv,
                      (const uint8_t*)nullptr, (const uint8_t*)m, n, (uint8_t*)u, (uint8_t*)nullptr);
   hipLaunchKernelGGL(k_sign_finish, dim3(grid_for(n)), dim3(256), 0, s, (const uint8_t*)r,
@@ -1394,36 +2096,16 @@ int dsv_sign_single_dev(const void* sk, const void* m, const void* r, size_t n, 
   HIP_TRY(hipGetLastError());
   return DSV_OK;
 }
-int dsv_sign_double_dev(const void* sk, const void* m, const void* r, size_t n, void* u, void* R_uv,
-                        void* Rp_uv, void* stream) {
-  if (int rc = check_ready()) return rc;
-  if (int rc = check_n(n)) return rc;
-  if (n == 0) return DSV_OK;
-  if (!sk || !m || !r || !u || !R_uv || !Rp_uv) return fail(DSV_ERR_INVALID_ARGUMENT, "null pointer");
-  hipStream_t s = (hipStream_t)stream;
-  hipLaunchKernelGGL(k_fixed_base_points, dim3(grid_for(n)), dim3(256), 0, s, (const uint8_t*)r,
-                     (const u32*)g_ctx.table[0], n, (uint8_t*)R_uv);
-  hipLaunchKernelGGL(k_fixed_base_points, dim3(grid_for(n)), dim3(256), 0, s, (const uint8_t*)r,
-                     (const u32*)g_ctx.table[1], n, (uint8_t*)Rp_uv);
-  hipLaunchKernelGGL(k_challenge<true>, dim3(grid_for(n)), dim3(256), 0, s, (const uint8_t*)R_uv,
-                     (const uint8_t*)Rp_uv, (const uint8_t*)m, n, (uint8_t*)u, (uint8_t*)nullptr);
-  hipLaunchKernelGGL(k_sign_finish, dim3(grid_for(n)), dim3(256), 0, s, (const uint8_t*)r,
-                     (const uint8_t*)u, (const uint8_t*)sk, n, (uint8_t*)u);
-  HIP_TRY(hipGetLastError());
-  return DSV_OK;
-}
 
 int dsv_public_keys(const uint8_t* sk, int which, const uint8_t* gen_uv, size_t n, uint8_t* PK_uv) {
-  if (int r = check_ready()) return r;
-  if (int r = check_n(n)) return r;
-  if (n == 0) return DSV_OK;
-  if (!sk || !PK_uv || which < 0 || which > 1) return fail(DSV_ERR_INVALID_ARGUMENT, "bad argument");
-  std::lock_guard<std::mutex> lk(g_ctx.mu);
-  HIP_TRY(hipSetDevice(g_ctx.device));
-  if (int r = ensure_stage(align_up(n * 32, 256) + 2 * align_up(n * 64, 256) +
-                           var_table_bytes(n, 1) + 256))
+  if (n && (!sk || !PK_uv || which < 0 || which > 1)) return fail(DSV_ERR_INVALID_ARGUMENT, "bad argument");
+  DSV_HOST_PROLOGUE(n);
+  if (int r = check_canonical_scalars(sk, n, "sk")) return r;
+  DSV_HOST_LOCK();
+  if (int r = ensure_stage(ctx, align_up(n * 32, 256) + 2 * align_up(n * 64, 256) +
+                                    var_table_bytes(n, 1) + 256))
     return r;
-  Stager st(g_ctx.stage);
+  Stager st(ctx.stage);
   uint8_t *dsk = st.take(n * 32), *dg = st.take(n * 64), *dpk = st.take(n * 64),
           *dtab = st.take(var_table_bytes(n, 1));
   H2D(dsk, sk, n * 32);
@@ -1431,69 +2113,76 @@ int dsv_public_keys(const uint8_t* sk, int which, const uint8_t* gen_uv, size_t 
     H2D(dg, gen_uv, n * 64);
     hipLaunchKernelGGL(k_var_base_points, dim3(verify_grid(n)), dim3(kVerifyBlock), 0, 0, (const uint8_t*)dsk,
                        (const uint8_t*)dg, n, dpk, reinterpret_cast<u32*>(dtab));
-    HIP_TRY(hipGetLastError());
   } else {
-    if (int r = dsv_public_keys_dev(dsk, which, n, dpk, nullptr)) return r;
+    hipLaunchKernelGGL(k_fixed_base_points, dim3(grid_for(n)), dim3(256), 0, 0, (const uint8_t*)dsk,
+                       (const u32*)ctx.table[which], n, dpk);
   }
+  HIP_TRY(hipGetLastError());
   D2H(PK_uv, dpk, n * 64);
+  // scrub the secret keys and the window tables derived from them
+  HIP_TRY(hipMemsetAsync(dsk, 0, n * 32, 0));
+  if (gen_uv) HIP_TRY(hipMemsetAsync(dtab, 0, var_table_bytes(n, 1), 0));
   HIP_TRY(hipStreamSynchronize(0));
   return DSV_OK;
 }
 int dsv_sign_single(const uint8_t* sk, const uint8_t* m, const uint8_t* r, size_t n, uint8_t* u,
                     uint8_t* R_uv) {
-  if (int rc = check_ready()) return rc;
-  if (int rc = check_n(n)) return rc;
-  if (n == 0) return DSV_OK;
-  if (!sk || !m || !r || !u || !R_uv) return fail(DSV_ERR_INVALID_ARGUMENT, "null pointer");
-  std::lock_guard<std::mutex> lk(g_ctx.mu);
-  HIP_TRY(hipSetDevice(g_ctx.device));
-  if (int rc = ensure_stage(4 * align_up(n * 32, 256) + align_up(n * 64, 256))) return rc;
-  Stager st(g_ctx.stage);
+  if (n && (!sk || !m || !r || !u || !R_uv)) return fail(DSV_ERR_INVALID_ARGUMENT, "null pointer");
+  DSV_HOST_PROLOGUE(n);
+  if (int rc = check_canonical_scalars(sk, n, "sk")) return rc;
+  if (int rc = check_canonical_scalars(r, n, "nonce")) return rc;
+  DSV_HOST_LOCK();
+  if (int rc = ensure_stage(ctx, 4 * align_up(n * 32, 256) + align_up(n * 64, 256))) return rc;
+  Stager st(ctx.stage);
   uint8_t *dsk = st.take(n * 32), *dm = st.take(n * 32), *dr = st.take(n * 32),
           *du = st.take(n * 32), *dR = st.take(n * 64);
   H2D(dsk, sk, n * 32);
   H2D(dm, m, n * 32);
   H2D(dr, r, n * 32);
-  if (int rc = dsv_sign_single_dev(dsk, dm, dr, n, du, dR, nullptr)) return rc;
+  launch_sign_single(ctx, dsk, dm, dr, n, du, dR, 0);
+  HIP_TRY(hipGetLastError());
   D2H(u, du, n * 32);
   D2H(R_uv, dR, n * 64);
+  HIP_TRY(hipMemsetAsync(dsk, 0, n * 32, 0));  // scrub key and nonce
+  HIP_TRY(hipMemsetAsync(dr, 0, n * 32, 0));
   HIP_TRY(hipStreamSynchronize(0));
   return DSV_OK;
 }
 int dsv_sign_double(const uint8_t* sk, const uint8_t* m, const uint8_t* r, size_t n, uint8_t* u,
                     uint8_t* R_uv, uint8_t* Rp_uv) {
-  if (int rc = check_ready()) return rc;
-  if (int rc = check_n(n)) return rc;
-  if (n == 0) return DSV_OK;
-  if (!sk || !m || !r || !u || !R_uv || !Rp_uv) return fail(DSV_ERR_INVALID_ARGUMENT, "null pointer");
-  std::lock_guard<std::mutex> lk(g_ctx.mu);
-  HIP_TRY(hipSetDevice(g_ctx.device));
-  if (int rc = ensure_stage(4 * align_up(n * 32, 256) + 2 * align_up(n * 64, 256))) return rc;
-  Stager st(g_ctx.stage);
+  if (n && (!sk || !m || !r || !u || !R_uv || !Rp_uv)) return fail(DSV_ERR_INVALID_ARGUMENT, "null pointer");
+  DSV_HOST_PROLOGUE(n);
+  if (int rc = check_canonical_scalars(sk, n, "sk")) return rc;
+  if (int rc = check_canonical_scalars(r, n, "nonce")) return rc;
+  DSV_HOST_LOCK();
+  if (int rc = ensure_stage(ctx, 4 * align_up(n * 32, 256) + 2 * align_up(n * 64, 256))) return rc;
+  Stager st(ctx.stage);
   uint8_t *dsk = st.take(n * 32), *dm = st.take(n * 32), *dr = st.take(n * 32),
           *du = st.take(n * 32), *dR = st.take(n * 64), *dRp = st.take(n * 64);
   H2D(dsk, sk, n * 32);
   H2D(dm, m, n * 32);
   H2D(dr, r, n * 32);
-  if (int rc = dsv_sign_double_dev(dsk, dm, dr, n, du, dR, dRp, nullptr)) return rc;
+  launch_sign_double(ctx, dsk, dm, dr, n, du, dR, dRp, 0);
+  HIP_TRY(hipGetLastError());
   D2H(u, du, n * 32);
   D2H(R_uv, dR, n * 64);
   D2H(Rp_uv, dRp, n * 64);
+  HIP_TRY(hipMemsetAsync(dsk, 0, n * 32, 0));
+  HIP_TRY(hipMemsetAsync(dr, 0, n * 32, 0));
   HIP_TRY(hipStreamSynchronize(0));
   return DSV_OK;
 }
 int dsv_sign_vargen(const uint8_t* sk, const uint8_t* Gen_uv, const uint8_t* m, const uint8_t* r,
                     size_t n, uint8_t* u, uint8_t* R_uv) {
-  if (int rc = check_ready()) return rc;
-  if (int rc = check_n(n)) return rc;
-  if (n == 0) return DSV_OK;
-  if (!sk || !Gen_uv || !m || !r || !u || !R_uv) return fail(DSV_ERR_INVALID_ARGUMENT, "null pointer");
-  std::lock_guard<std::mutex> lk(g_ctx.mu);
-  HIP_TRY(hipSetDevice(g_ctx.device));
-  if (int rc = ensure_stage(4 * align_up(n * 32, 256) + 2 * align_up(n * 64, 256) +
-                            var_table_bytes(n, 1) + 256))
+  if (n && (!sk || !Gen_uv || !m || !r || !u || !R_uv)) return fail(DSV_ERR_INVALID_ARGUMENT, "null pointer");
+  DSV_HOST_PROLOGUE(n);
+  if (int rc = check_canonical_scalars(sk, n, "sk")) return rc;
+  if (int rc = check_canonical_scalars(r, n, "nonce")) return rc;
+  DSV_HOST_LOCK();
+  if (int rc = ensure_stage(ctx, 4 * align_up(n * 32, 256) + 2 * align_up(n * 64, 256) +
+                                     var_table_bytes(n, 1) + 256))
     return rc;
-  Stager st(g_ctx.stage);
+  Stager st(ctx.stage);
   uint8_t *dsk = st.take(n * 32), *dm = st.take(n * 32), *dr = st.take(n * 32),
           *du = st.take(n * 32), *dG = st.take(n * 64), *dR = st.take(n * 64),
           *dtab = st.take(var_table_bytes(n, 1));
@@ -1510,6 +2199,9 @@ int dsv_sign_vargen(const uint8_t* sk, const uint8_t* Gen_uv, const uint8_t* m, 
   HIP_TRY(hipGetLastError());
   D2H(u, du, n * 32);
   D2H(R_uv, dR, n * 64);
+  HIP_TRY(hipMemsetAsync(dsk, 0, n * 32, 0));
+  HIP_TRY(hipMemsetAsync(dr, 0, n * 32, 0));
+  HIP_TRY(hipMemsetAsync(dtab, 0, var_table_bytes(n, 1), 0));  // multiples of Gen, not secret — cheap anyway
   HIP_TRY(hipStreamSynchronize(0));
   return DSV_OK;
 }
@@ -1517,16 +2209,8 @@ int dsv_sign_vargen(const uint8_t* sk, const uint8_t* Gen_uv, const uint8_t* m, 
 // ---- wire formats ---------------------------------------------------------------------------
 int dsv_decompress_points_dev(const void* in, size_t in_stride, size_t n, void* out_uv, void* ok,
                               int accumulate, void* stream) {
-  if (int r = check_ready()) return r;
-  if (int r = check_n(n)) return r;
-  if (n == 0) return DSV_OK;
-  if (!in || !out_uv || !ok || in_stride < 32 || (in_stride & 15) || ((uintptr_t)in & 15))
-    return fail(DSV_ERR_INVALID_ARGUMENT, "bad pointer / stride (need 16-byte alignment)");
-  hipLaunchKernelGGL(k_decompress, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream,
-                     (const uint8_t*)in, in_stride, n, (uint8_t*)out_uv, (uint8_t*)ok, accumulate,
-                     TsTables{g_ctx.ts_cancel, g_ctx.ts_hash});
-  HIP_TRY(hipGetLastError());
-  return DSV_OK;
+  DSV_DEV_PROLOGUE(n, out_uv);
+  return decompress_on(ctx, in, in_stride, n, out_uv, ok, accumulate, (hipStream_t)stream);
 }
 // JubJubAffine::to_bytes: canonical v with bit 255 = lowest bit of canonical u.  Pure byte
 // shuffling on affine input, so it runs on the host.
@@ -1542,17 +2226,14 @@ int dsv_compress_points(const uint8_t* in_uv, size_t n, uint8_t* out32) {
 }
 
 int dsv_decompress_points(const uint8_t* in32, size_t n, uint8_t* out_uv, uint8_t* ok) {
-  if (int r = check_ready()) return r;
-  if (int r = check_n(n)) return r;
-  if (n == 0) return DSV_OK;
-  if (!in32 || !out_uv || !ok) return fail(DSV_ERR_INVALID_ARGUMENT, "null pointer");
-  std::lock_guard<std::mutex> lk(g_ctx.mu);
-  HIP_TRY(hipSetDevice(g_ctx.device));
-  if (int r = ensure_stage(align_up(n * 32, 256) + align_up(n * 64, 256) + align_up(n, 256))) return r;
-  Stager st(g_ctx.stage);
+  if (n && (!in32 || !out_uv || !ok)) return fail(DSV_ERR_INVALID_ARGUMENT, "null pointer");
+  DSV_HOST_PROLOGUE(n);
+  DSV_HOST_LOCK();
+  if (int r = ensure_stage(ctx, align_up(n * 32, 256) + align_up(n * 64, 256) + align_up(n, 256))) return r;
+  Stager st(ctx.stage);
   uint8_t *din = st.take(n * 32), *dout = st.take(n * 64), *dok = st.take(n);
   H2D(din, in32, n * 32);
-  if (int r = dsv_decompress_points_dev(din, 32, n, dout, dok, 0, nullptr)) return r;
+  if (int r = decompress_on(ctx, din, 32, n, dout, dok, 0, 0)) return r;
   D2H(out_uv, dout, n * 64);
   D2H(ok, dok, n);
   HIP_TRY(hipStreamSynchronize(0));
@@ -1562,25 +2243,26 @@ int dsv_decompress_points(const uint8_t* in32, size_t n, uint8_t* out_uv, uint8_
 namespace {
 // shared body of the *_wire entry points.  sig: n records of sig_bytes = 32 (u) + 32*n_sig_points;
 // pk: n records of 32*n_pk_points compressed points.  kind: 0 single, 1 double, 2 vargen.
-int verify_wire(int kind, const uint8_t* sig, const uint8_t* pk, const uint8_t* m, size_t n,
-                uint8_t* ok) {
+int verify_wire(Context& ctx, int kind, const uint8_t* sig, const uint8_t* pk, const uint8_t* m,
+                size_t n, uint8_t* ok) {
   const size_t sig_bytes = kind == 1 ? 96 : 64, pk_bytes = kind == 0 ? 32 : 64;
   const HostIn ins[3] = {{sig, sig_bytes}, {pk, pk_bytes}, {m, 32}};
-  return run_pipelined(ins, ok, n, 32 + 4 * 64 + 1, [=](const void* const* d, size_t cnt, void* dok, void* ws, Stager& x, hipStream_t st) {
+  Context* cp = &ctx;
+  return run_pipelined(ctx, ins, ok, n, 32 + 4 * 64 + 1, [=](const void* const* d, size_t cnt, void* dok, void* ws, Stager& x, hipStream_t st) {
     const uint8_t *dsig = (const uint8_t*)d[0], *dpk = (const uint8_t*)d[1];
     uint8_t *du = x.take(cnt * 32), *dR = x.take(cnt * 64), *dRp = x.take(cnt * 64),
             *dP0 = x.take(cnt * 64), *dP1 = x.take(cnt * 64), *dvalid = x.take(cnt);
     hipLaunchKernelGGL(k_gather32, dim3(grid_for(cnt)), dim3(256), 0, st, dsig, sig_bytes, cnt, du);
-    if (int r = dsv_decompress_points_dev(dsig + 32, sig_bytes, cnt, dR, dvalid, 0, st)) return r;
+    if (int r = decompress_on(*cp, dsig + 32, sig_bytes, cnt, dR, dvalid, 0, st)) return r;
     if (kind == 1)
-      if (int r = dsv_decompress_points_dev(dsig + 64, sig_bytes, cnt, dRp, dvalid, 1, st)) return r;
-    if (int r = dsv_decompress_points_dev(dpk, pk_bytes, cnt, dP0, dvalid, 1, st)) return r;
+      if (int r = decompress_on(*cp, dsig + 64, sig_bytes, cnt, dRp, dvalid, 1, st)) return r;
+    if (int r = decompress_on(*cp, dpk, pk_bytes, cnt, dP0, dvalid, 1, st)) return r;
     if (kind != 0)
-      if (int r = dsv_decompress_points_dev(dpk + 32, pk_bytes, cnt, dP1, dvalid, 1, st)) return r;
+      if (int r = decompress_on(*cp, dpk + 32, pk_bytes, cnt, dP1, dvalid, 1, st)) return r;
     int rc;
-    if (kind == 0) rc = dsv_verify_single_dev(du, dR, dP0, d[2], cnt, dok, ws, st);
-    else if (kind == 1) rc = dsv_verify_double_dev(du, dR, dRp, dP0, dP1, d[2], cnt, dok, ws, st);
-    else rc = dsv_verify_vargen_dev(du, dR, dP0, dP1, d[2], cnt, dok, ws, st);
+    if (kind == 0) rc = verify_single_on(*cp, du, dR, dP0, d[2], cnt, dok, ws, st);
+    else if (kind == 1) rc = verify_double_on(*cp, du, dR, dRp, dP0, dP1, d[2], cnt, dok, ws, st);
+    else rc = verify_vargen_on(*cp, du, dR, dP0, dP1, d[2], cnt, dok, ws, st);
     if (rc) return rc;
     hipLaunchKernelGGL(k_and_bytes, dim3(grid_for(cnt)), dim3(256), 0, st, (uint8_t*)dok,
                        (const uint8_t*)dvalid, cnt);
@@ -1592,27 +2274,21 @@ int verify_wire(int kind, const uint8_t* sig, const uint8_t* pk, const uint8_t* 
 
 int dsv_verify_single_wire(const uint8_t* sig64, const uint8_t* pk32, const uint8_t* m, size_t n,
                            uint8_t* ok) {
-  if (int r = check_ready()) return r;
-  if (int r = check_n(n)) return r;
-  if (n == 0) return DSV_OK;
-  if (!sig64 || !pk32 || !m || !ok) return fail(DSV_ERR_INVALID_ARGUMENT, "null pointer");
-  return verify_wire(0, sig64, pk32, m, n, ok);
+  if (n && (!sig64 || !pk32 || !m || !ok)) return fail(DSV_ERR_INVALID_ARGUMENT, "null pointer");
+  DSV_HOST_PROLOGUE(n);
+  return verify_wire(ctx, 0, sig64, pk32, m, n, ok);
 }
 int dsv_verify_double_wire(const uint8_t* sig96, const uint8_t* pk64, const uint8_t* m, size_t n,
                            uint8_t* ok) {
-  if (int r = check_ready()) return r;
-  if (int r = check_n(n)) return r;
-  if (n == 0) return DSV_OK;
-  if (!sig96 || !pk64 || !m || !ok) return fail(DSV_ERR_INVALID_ARGUMENT, "null pointer");
-  return verify_wire(1, sig96, pk64, m, n, ok);
+  if (n && (!sig96 || !pk64 || !m || !ok)) return fail(DSV_ERR_INVALID_ARGUMENT, "null pointer");
+  DSV_HOST_PROLOGUE(n);
+  return verify_wire(ctx, 1, sig96, pk64, m, n, ok);
 }
 int dsv_verify_vargen_wire(const uint8_t* sig64, const uint8_t* pk64, const uint8_t* m, size_t n,
                            uint8_t* ok) {
-  if (int r = check_ready()) return r;
-  if (int r = check_n(n)) return r;
-  if (n == 0) return DSV_OK;
-  if (!sig64 || !pk64 || !m || !ok) return fail(DSV_ERR_INVALID_ARGUMENT, "null pointer");
-  return verify_wire(2, sig64, pk64, m, n, ok);
+  if (n && (!sig64 || !pk64 || !m || !ok)) return fail(DSV_ERR_INVALID_ARGUMENT, "null pointer");
+  DSV_HOST_PROLOGUE(n);
+  return verify_wire(ctx, 2, sig64, pk64, m, n, ok);
 }
 
 // ---- reference-harness inputs ---------------------------------------------------------------
@@ -1632,10 +2308,8 @@ ChaChaKey stdrng_key(uint64_t state) {
 
 int dsv_stdrng_sign_inputs_dev(uint64_t seed, size_t first_item, size_t n, void* sk, void* m,
                                void* r, void* stream) {
-  if (int rc = check_ready()) return rc;
-  if (int rc = check_n(n)) return rc;
-  if (n == 0) return DSV_OK;
-  if (!sk || !m || !r) return fail(DSV_ERR_INVALID_ARGUMENT, "null pointer");
+  if (n && (!sk || !m || !r)) return fail(DSV_ERR_INVALID_ARGUMENT, "null pointer");
+  DSV_DEV_PROLOGUE(n, sk);
   hipLaunchKernelGGL(k_stdrng_triples, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream,
                      stdrng_key(seed), first_item, n, (uint8_t*)sk, (uint8_t*)m, (uint8_t*)r);
   HIP_TRY(hipGetLastError());
@@ -1643,31 +2317,44 @@ int dsv_stdrng_sign_inputs_dev(uint64_t seed, size_t first_item, size_t n, void*
 }
 int dsv_stdrng_sign_inputs(uint64_t seed, size_t first_item, size_t n, uint8_t* sk, uint8_t* m,
                            uint8_t* r) {
-  if (int rc = check_ready()) return rc;
-  if (int rc = check_n(n)) return rc;
-  if (n == 0) return DSV_OK;
-  if (!sk || !m || !r) return fail(DSV_ERR_INVALID_ARGUMENT, "null pointer");
-  std::lock_guard<std::mutex> lk(g_ctx.mu);
-  HIP_TRY(hipSetDevice(g_ctx.device));
-  if (int rc = ensure_stage(3 * align_up(n * 32, 256))) return rc;
-  Stager st(g_ctx.stage);
+  if (n && (!sk || !m || !r)) return fail(DSV_ERR_INVALID_ARGUMENT, "null pointer");
+  DSV_HOST_PROLOGUE(n);
+  DSV_HOST_LOCK();
+  if (int rc = ensure_stage(ctx, 3 * align_up(n * 32, 256))) return rc;
+  Stager st(ctx.stage);
   uint8_t *dsk = st.take(n * 32), *dm = st.take(n * 32), *dr = st.take(n * 32);
-  if (int rc = dsv_stdrng_sign_inputs_dev(seed, first_item, n, dsk, dm, dr, nullptr)) return rc;
+  hipLaunchKernelGGL(k_stdrng_triples, dim3(grid_for(n)), dim3(256), 0, 0, stdrng_key(seed),
+                     first_item, n, dsk, dm, dr);
+  HIP_TRY(hipGetLastError());
   D2H(sk, dsk, n * 32);
   D2H(m, dm, n * 32);
   D2H(r, dr, n * 32);
+  HIP_TRY(hipMemsetAsync(dsk, 0, n * 32, 0));
+  HIP_TRY(hipMemsetAsync(dr, 0, n * 32, 0));
   HIP_TRY(hipStreamSynchronize(0));
+  return DSV_OK;
+}
+int dsv_stdrng_vargen_inputs_dev(uint64_t seed, size_t first_item, size_t n, void* sk, void* g,
+                                 void* m, void* r, void* stream) {
+  if (n && (!sk || !g || !m || !r)) return fail(DSV_ERR_INVALID_ARGUMENT, "null pointer");
+  DSV_DEV_PROLOGUE(n, sk);
+  hipLaunchKernelGGL(k_stdrng_quads, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream,
+                     stdrng_key(seed), first_item, n, (uint8_t*)sk, (uint8_t*)g, (uint8_t*)m,
+                     (uint8_t*)r);
+  HIP_TRY(hipGetLastError());
   return DSV_OK;
 }
 
 int dsv_debug_table_entry(int which, int window, int digit, uint8_t out96[96]) {
-  if (int r = check_ready()) return r;
   if (which < 0 || which > 1 || window < 0 || window >= kFixedWindows || digit < 0 ||
       digit >= kFixedEntries || !out96)
     return fail(DSV_ERR_INVALID_ARGUMENT, "bad table coordinates");
+  Context* ctxp = nullptr;
+  if (int r = host_context(ctxp)) return r;
+  Context& ctx = *ctxp;
+  DSV_HOST_LOCK();
   u32 e[kEntryWords];
-  HIP_TRY(hipSetDevice(g_ctx.device));
-  HIP_TRY(hipMemcpy(e, g_ctx.table[which] + ((size_t)window * kFixedEntries + digit) * kEntryWords,
+  HIP_TRY(hipMemcpy(e, ctx.table[which] + ((size_t)window * kFixedEntries + digit) * kEntryWords,
                     sizeof e, hipMemcpyDeviceToHost));
   // entries are Montgomery (R = 2^261) canonical limbs; hand back the raw limbs as 3 x 9 x 29-bit
   // packed LE integers so the test can undo the Montgomery factor with Python integers.
@@ -1696,14 +2383,11 @@ int dsv_debug_table_entry(int which, int window, int digit, uint8_t out96[96]) {
 int dsv_fixed_window_bits(void) { return kFixedBits; }
 
 int dsv_debug_fq_mul(const uint8_t* a, const uint8_t* b, size_t n, uint8_t* out) {
-  if (int r = check_ready()) return r;
-  if (int r = check_n(n)) return r;
-  if (n == 0) return DSV_OK;
-  if (!a || !b || !out) return fail(DSV_ERR_INVALID_ARGUMENT, "null pointer");
-  std::lock_guard<std::mutex> lk(g_ctx.mu);
-  HIP_TRY(hipSetDevice(g_ctx.device));
-  if (int r = ensure_stage(3 * align_up(n * 32, 256))) return r;
-  Stager st(g_ctx.stage);
+  if (n && (!a || !b || !out)) return fail(DSV_ERR_INVALID_ARGUMENT, "null pointer");
+  DSV_HOST_PROLOGUE(n);
+  DSV_HOST_LOCK();
+  if (int r = ensure_stage(ctx, 3 * align_up(n * 32, 256))) return r;
+  Stager st(ctx.stage);
   uint8_t *da = st.take(n * 32), *db = st.take(n * 32), *dout = st.take(n * 32);
   H2D(da, a, n * 32);
   H2D(db, b, n * 32);

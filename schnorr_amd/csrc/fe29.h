@@ -7,14 +7,14 @@
 // so what costs is the carry bookkeeping, not the multiplier.  With 29-bit limbs a whole
 // 9x9 schoolbook product plus the interleaved Montgomery reduction accumulates in 64-bit
 // column registers with NO carry instruction at all: each step is one in-place
-// v_mad_u64_u32 (D = S0*S1 + D).  A multiply is 81 + 72 MADs + 72 carry/normalise ops = 225
-// VALU instructions (a squaring 189); hipcc emits exactly that from the plain C++ below.
+// v_mad_u64_u32 (D = S0*S1 + D).  A multiply is 81 + 72 MADs + 36 digit/shift ops = 189 VALU
+// instructions (a squaring 162), see fe_mont_fips below.
 // R = 2^261 leaves 6 spare bits over q (255 bits), so products of lazily-added operands
 // never need a conditional subtraction: values stay below ~8q between reductions.
 //
 // Contracts (checked by tests/test_fe29_model.py on a bit-exact Python model of this file):
 //   fe_mul/fe_sqr(a, b): max_limb(a) * max_limb(b) <= 1.5 * 2^60  and  a*b < 2^261 * q * 0.5
-//                        -> result limbs < 2^29 (limb 8 < 2^25), value < a*b/2^261 + q
+//                        -> result limbs < 2^29 (limb 0 <= 2^29, limb 8 < 2^25), value <= a*b/2^261 + q
 //   fe_add(a, b)       : limb-wise, no carry; caller keeps limbs < 2^31
 //   fe_sub2/4/8(a, b)  : a + k*q - b with a redundant-limb k*q whose limbs dominate b's
 //                        (b limbs <= 2^30 - 2, b < (k - 0.01) q), then one parallel carry pass
@@ -73,6 +73,119 @@ DSV_DEV Fe fe_zero() {
 }
 DSV_DEV Fe fe_one() { return fe_const(kOne); }
 
+// ---- Montgomery multiplication, product scanning ("FIPS"), R = 2^261 ------------------------
+// One 64-bit accumulator walks the 17 columns of a*b + M*q.  The carry out of a column is the
+// ADDEND of the first v_mad_u64_u32 of the next column, so a column costs its MADs plus exactly
+// two other instructions (digit, 64-bit shift) — no separate 64-bit carry addition.
+//
+// hipcc would not emit that on its own: LLVM's reassociation pass sorts the terms of every column
+// sum by rank and leaves the carry in the middle of the chain, which costs a v_lshl_add_u64 per
+// column (r01: 211 instructions per multiplication, now 190).  mad_pin() therefore gives every
+// partial sum a second use — the operand of an llvm.assume — because a value with two uses is a
+// leaf for the reassociation pass, so the chain stays in source order and instruction selection
+// folds each `partial + x*y` into one v_mad_u64_u32.  The assumed fact must be TRUE (else it is
+// undefined behaviour) and UNPROVABLE (else the optimiser deletes it and the pin is gone — a range
+// fact like `acc != ~0` is provable for most columns): `(acc & tok) == 0` with tok the output of
+// an `s_mov_b32 tok, 0` asm statement, i.e. really zero at run time but opaque to the compiler.
+// Every pin renews tok from the previous one, so each token has ONE user (one shared token makes
+// every known-bits query walk thousands of assumptions: 20 min of InstCombine instead of 3).
+// Assumptions are dropped before instruction selection, the asm statements (not volatile, outputs
+// then unused) die with them: the pins cost no instruction, no register and no scheduling edge.
+// (Tried and rejected: inline-asm MADs — the hazard recogniser puts an s_nop after every asm that
+// defines a VGPR its neighbour reads; empty asm "sinks" as second use — the scheduler parks them
+// at the end of the multiplication and all 153 partial sums stay live, i.e. spill.)
+//
+// q = 1 (mod 2^29)  =>  -q^-1 = -1 (mod 2^29): the quotient digit of a column with true sum A is
+// m = -A mod 2^29.  The accumulator deliberately runs ONE BEHIND the true column sum (acc = A - 1)
+// from column 1 on, which makes both the digit and the carry free of any bias:
+//   column 0 : A_0 = a0*b0,  m_0 = 2^29 - (A_0 mod 2^29) in [1, 2^29],
+//              true carry (A_0 + m_0) / 2^29 = (A_0 >> 29) + 1, kept as acc = A_0 >> 29
+//   column k : acc = A_k - 1,  m_k = ~acc mod 2^29 (= -A_k),  (A_k + m_k) / 2^29 = (acc >> 29) + 1
+//   column 9 : the missing 1 is returned through result limb 0 (which may therefore equal 2^29).
+// m_0 >= 1 is what keeps every later true column sum >= 1, i.e. acc >= 0 with unsigned shifts.
+// Result = (a*b + M*q) / 2^261 with M <= 2^261, limbs 1..7 < 2^29, limb 0 <= 2^29.
+// One multiplication is one serial MAD chain; keeping the scheduler from interleaving several of
+// them (to hide a latency that a dependent v_mad_u64_u32 chain does not have: tools/microbench
+// mad_u64_u32_chain) keeps the live set to one accumulator and one digit vector.  The fence lets
+// scalar and memory instructions cross, vector ALU instructions not.
+#ifndef DSV_SCHED_FENCE_MASK
+#define DSV_SCHED_FENCE_MASK 0x0f4  /* SALU | all VMEM (+ read, write) | all DS */
+#endif
+#ifdef DSV_NO_SCHED_FENCE
+#define DSV_SCHED_FENCE() ((void)0)
+#else
+#define DSV_SCHED_FENCE() __builtin_amdgcn_sched_barrier(DSV_SCHED_FENCE_MASK)
+#endif
+DSV_DEV void mad_pin(u64& acc, u32& tok, u32 x, u32 y) {
+  acc += (u64)x * y;
+  asm("s_mov_b32 %0, 0" : "+s"(tok));
+  __builtin_assume(((u32)acc & tok) == 0);
+}
+
+// `products(k, acc, tok)` adds the operand products of column k (k = 0..16) with mad_pin
+template <class P>
+DSV_DEV Fe fe_mont_fips(P&& products) {
+  u32 m[NL];
+  Fe r;
+  u32 tok;
+  DSV_SCHED_FENCE();
+  asm("s_mov_b32 %0, 0" : "=s"(tok));
+  u64 acc = 0;
+  products(0, acc, tok);
+  m[0] = ((~(u32)acc) & M29) + 1;
+  acc >>= 29;
+#pragma unroll
+  for (int k = 1; k < 2 * NL - 1; k++) {
+    products(k, acc, tok);
+#pragma unroll
+    for (int i = 0; i < NL; i++) {
+      const int j = k - i;
+      if (i < k && j >= 1 && j < NL) mad_pin(acc, tok, m[i], kQ29[j]);
+    }
+    if (k < NL)
+      m[k] = (~(u32)acc) & M29;
+    else
+      r.l[k - NL] = (u32)acc & M29;
+    acc >>= 29;
+  }
+  r.l[0] += 1;
+  r.l[NL - 1] = (u32)acc;
+  DSV_SCHED_FENCE();
+  return r;
+}
+
+DSV_DEV Fe fe_mul(const Fe& a, const Fe& b) {
+  return fe_mont_fips([&](int k, u64& acc, u32& tok) {
+#pragma unroll
+    for (int i = 0; i < NL; i++) {
+      const int j = k - i;
+      if (j >= 0 && j < NL) mad_pin(acc, tok, a.l[i], b.l[j]);
+    }
+  });
+}
+
+// squaring: cross terms once, against a pre-doubled operand (45 MADs instead of 81)
+DSV_DEV Fe fe_sqr(const Fe& a) {
+  u32 d[NL];
+#pragma unroll
+  for (int i = 0; i < NL; i++) d[i] = a.l[i] << 1;
+  return fe_mont_fips([&](int k, u64& acc, u32& tok) {
+#pragma unroll
+    for (int i = 0; i < NL; i++) {
+      const int j = k - i;
+      if (j > i && j < NL) mad_pin(acc, tok, d[i], a.l[j]);
+    }
+    if ((k & 1) == 0) mad_pin(acc, tok, a.l[k / 2], a.l[k / 2]);
+  });
+}
+
+// ---- dot products with ONE reduction (Hades linear layers) ----------------------------------
+// These keep the operand-scanning form: 17 column accumulators, one term at a time, so only the
+// nine limbs of ONE wave-uniform constant have to sit in SGPRs at any moment.  (r02 measured the
+// product-scanning form above for them as well: every column then touches all NT constants,
+// the scalar loads are re-issued per column, and k_challenge ran 24 % SLOWER — 5.56 against
+// 4.47 ms per 2^20 hashes, same box.)  Cost over the product-scanning form: one 64-bit addition
+// per column, because the carry cannot start a MAD chain that was finished before it existed.
 // ---- Montgomery reduction of 17 column sums c[0..16] (c[17] scratch), R = 2^261 ----------
 // q = 1 (mod 2^29)  =>  -q^-1 = -1 (mod 2^29): the quotient digit is just the negated low limb,
 // and digit * q[0] only contributes the carry that clears that limb.
@@ -99,43 +212,6 @@ DSV_DEV Fe fe_reduce_cols(u64 (&c)[18]) {
   }
   r.l[NL - 1] = (u32)k;
   return r;
-}
-
-DSV_DEV Fe fe_mul(const Fe& a, const Fe& b) {
-  u64 c[18];
-#pragma unroll
-  for (int k = 0; k < 17; k++) {
-    u64 s = (k < NL) ? (u64)M29 : 0;
-#pragma unroll
-    for (int i = 0; i < NL; i++) {
-      const int j = k - i;
-      if (j >= 0 && j < NL) s += (u64)a.l[i] * b.l[j];
-    }
-    c[k] = s;
-  }
-  c[17] = 0;
-  return fe_reduce_cols(c);
-}
-
-// squaring: cross terms once, against a pre-doubled operand (45 MADs instead of 81)
-DSV_DEV Fe fe_sqr(const Fe& a) {
-  u32 d[NL];
-#pragma unroll
-  for (int i = 0; i < NL; i++) d[i] = a.l[i] << 1;
-  u64 c[18];
-#pragma unroll
-  for (int k = 0; k < 17; k++) {
-    u64 s = (k < NL) ? (u64)M29 : 0;
-#pragma unroll
-    for (int i = 0; i < NL; i++) {
-      const int j = k - i;
-      if (j > i && j < NL) s += (u64)d[i] * a.l[j];
-    }
-    if ((k & 1) == 0) s += (u64)a.l[k / 2] * a.l[k / 2];
-    c[k] = s;
-  }
-  c[17] = 0;
-  return fe_reduce_cols(c);
 }
 
 // sum_{t<5} a[t]*b[t] with one reduction (b limbs < 2^29: constants)

@@ -212,6 +212,11 @@ def main():
         for c in rc:
             w("  %s,\n" % arr(mont(c)))
         w("};\n")
+        # first full round of the sponge's first permutation: word 0 (capacity) starts at 0 and, in
+        # the 3-input hash, word 4 is the padding 1 — their S-box outputs are constants
+        w("// (0 + rc[0])^5 and (1 + rc[4])^5: S-box outputs of the constant words in round 0\n")
+        w("#define DSV_HADES_SBOX0_CAP %s\n" % arr(mont(pow(rc[0], 5, Q))))
+        w("#define DSV_HADES_SBOX0_PAD %s\n" % arr(mont(pow(1 + rc[4], 5, Q))))
         w("static const uint32_t DSV_HADES_MDS_HOST[%d][9] = {\n" % (WIDTH * WIDTH))
         for row in m:
             for x in row:

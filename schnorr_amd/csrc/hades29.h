@@ -75,13 +75,59 @@ DSV_DEV void hades_full_round(Fe (&s)[5], const u32 (*rc)[NL], const u32 (*mat)[
   hades_mds(s, mat);
 }
 
+__device__ constexpr u32 kSbox0Cap[NL] = DSV_HADES_SBOX0_CAP;
+__device__ constexpr u32 kSbox0Pad[NL] = DSV_HADES_SBOX0_PAD;
+
+// round 0 of a permutation whose word 0 (and, with PAD, word 4) enters as the constant 0 (1): the
+// S-boxes of those words are compile-time constants — x^5 runs on words 1..3 (1..4) only
+template <bool PAD>
+DSV_DEV void hades_first_round_const(Fe (&s)[5], const u32 (*rc)[NL], const u32 (*mat)[NL]) {
+  constexpr int LAST = PAD ? 3 : 4;
+#pragma unroll
+  for (int k = 1; k <= LAST; k++) s[k] = fe_add(s[k], fe_load_const(rc[k]));
+#pragma unroll 1
+  for (int k = 1; k <= LAST; k++) {  // one inlined copy, words 1..LAST rotating through it
+    Fe t = hades_sbox(s[1]);
+#pragma unroll
+    for (int j = 1; j < LAST; j++) s[j] = s[j + 1];
+    s[LAST] = t;
+  }
+  s[0] = fe_const(kSbox0Cap);
+  if (PAD) s[4] = fe_const(kSbox0Pad);
+  hades_mds(s, mat);
+}
+// last round of a permutation of which only word 1 is read (the sponge's output): one matrix row
+DSV_DEV void hades_last_round_word1(Fe (&s)[5], const u32 (*rc)[NL], const u32 (*mat)[NL]) {
+#pragma unroll
+  for (int k = 0; k < 5; k++) s[k] = fe_add(s[k], fe_load_const(rc[k]));
+#pragma unroll 1
+  for (int k = 0; k < 5; k++) {
+    Fe t = hades_sbox(s[0]);
+    s[0] = s[1];
+    s[1] = s[2];
+    s[2] = s[3];
+    s[3] = s[4];
+    s[4] = t;
+  }
+  Fe m[5];
+#pragma unroll
+  for (int j = 0; j < 5; j++) m[j] = fe_load_const(mat[5 + j]);
+  s[1] = fe_dot5(s, m);
+}
+
 // The permutation.  The 59 partial rounds run in their sparse-matrix form (per round one S-box,
 // one dot product for the new last word, four multiply-accumulates for words 0..3 instead of
 // five dense dot products), and the four multiply-accumulates are deferred block-wise (below).
+// FIRST: 0 = generic input, 1 = word 0 is the constant 0, 2 = additionally word 4 is the constant
+// 1 (state of the 3-input hash).  WORD1_ONLY: the caller reads s[1] only (last permutation of a
+// hash); the other words are then left unspecified.
+template <int FIRST, bool WORD1_ONLY>
 DSV_DEV void hades_permute(Fe (&s)[5]) {
   constexpr int HALF = DSV_HADES_FULL / 2;
+  if (FIRST == 1) hades_first_round_const<false>(s, c_hades_rc, c_hades_mds);
+  if (FIRST == 2) hades_first_round_const<true>(s, c_hades_rc, c_hades_mds);
 #pragma unroll 1
-  for (int r = 0; r < HALF; r++)
+  for (int r = FIRST ? 1 : 0; r < HALF; r++)
     hades_full_round(s, c_hades_rc + 5 * r, r == HALF - 1 ? c_hades_pre_mds : c_hades_mds);
   // words 0..3 carry NO round constants inside the loop: their running sum K_i is folded into the
   // constant of the last word (kappa4'_i = kappa4_{i+1} + c_i . K_i) and added back once at the end.
@@ -130,23 +176,25 @@ DSV_DEV void hades_permute(Fe (&s)[5]) {
 #pragma unroll
   for (int j = 0; j < 4; j++) s[j] = fe_carry(fe_add(s[j], fe_load_const(c_hades_kfinal[j])));
 #pragma unroll 1
-  for (int r = 0; r < HALF; r++)
+  for (int r = 0; r < HALF - (WORD1_ONLY ? 1 : 0); r++)
     hades_full_round(s, c_hades_rc + 5 * (HALF + DSV_HADES_PARTIAL + r), c_hades_mds);
+  if (WORD1_ONLY)
+    hades_last_round_word1(s, c_hades_rc + 5 * (HALF + DSV_HADES_PARTIAL + HALF - 1), c_hades_mds);
 }
 
 // sponge::hash over 3 inputs: state = [0, a, b, c, 1] -> one permutation -> state[1]
 DSV_DEV Fe poseidon_hash3(const Fe& a, const Fe& b, const Fe& c) {
   Fe s[5] = {fe_zero(), a, b, c, fe_one()};
-  hades_permute(s);
+  hades_permute<2, true>(s);
   return s[1];
 }
 // 5 inputs: [0,a,b,c,d] -> perm -> s[1] += e, s[2] += 1 -> perm -> state[1]
 DSV_DEV Fe poseidon_hash5(const Fe& a, const Fe& b, const Fe& c, const Fe& d, const Fe& e) {
   Fe s[5] = {fe_zero(), a, b, c, d};
-  hades_permute(s);
+  hades_permute<1, false>(s);
   s[1] = fe_add(s[1], e);
   s[2] = fe_add(s[2], fe_one());
-  hades_permute(s);
+  hades_permute<0, true>(s);
   return s[1];
 }
 

@@ -88,3 +88,83 @@ def verify_mixed_sharded(kinds, single, double, verify_single_fn, verify_double_
     out[torch.from_numpy(idx_s).to(out.device)] = parts[0]
     out[torch.from_numpy(idx_d).to(out.device)] = parts[1]
     return out
+
+
+class MixedShardedVerifier:
+    """Cooperative verification of one mixed batch (BASELINE.json configs[4]) with the batch
+    resident in HBM: rank g holds the contiguous slice [g*n_local, (g+1)*n_local) of a global batch
+    of world*n_local items as one structure of arrays + a kind vector.
+
+    Per call (everything on the GPU, nothing synchronises with the host):
+      1. split the local kind vector on the device (stable index compaction, libdsv k_kind_*),
+      2. gather the rows of each kind into compact arrays (k_gather_rows),
+      3. run each kind through its own entry point (dsv_verify_single_dev / _double_dev),
+      4. all_gather the two per-kind verdict vectors (RCCL when the backend is "nccl"),
+      5. scatter them back into GLOBAL batch order with the index vectors obtained by splitting
+         the global kind vector (every rank ends up with all world*n_local verdicts).
+    The per-kind shard sizes must be equal on all ranks (n_single_local, n_double_local are given
+    by the caller, who knows its batch): that is what "shard each kind evenly" means for a batch the
+    ranks already hold."""
+
+    def __init__(self, n_local, n_double_local, world, rank, device, group=None):
+        import torch
+
+        from . import engine as E
+
+        self.E, self.torch = E, torch
+        self.n, self.nd, self.ns = n_local, n_double_local, n_local - n_double_local
+        self.world, self.rank, self.group, self.dev = world, rank, group, device
+        u8 = lambda *shape: torch.empty(shape, dtype=torch.uint8, device=device)
+        i32 = lambda k: torch.empty(max(k, 1), dtype=torch.int32, device=device)
+        self.idx_s, self.idx_d = i32(self.ns), i32(self.nd)
+        self.scratch = u8(E.split_scratch_bytes(n_local))
+        self.cs = {k: u8(max(self.ns, 1), w) for k, w in (("u", 32), ("R", 64), ("PK", 64), ("m", 32))}
+        self.cd = {k: u8(max(self.nd, 1), w) for k, w in (("u", 32), ("R", 64), ("Rp", 64), ("PK", 64),
+                                                          ("PKp", 64), ("m", 32))}
+        self.ok_s, self.ok_d = u8(max(self.ns, 1)), u8(max(self.nd, 1))
+        self.ws = u8(E.workspace_bytes(max(self.ns, self.nd, 1)))
+        N = world * n_local
+        self.all_s, self.all_d = u8(max(world * self.ns, 1)), u8(max(world * self.nd, 1))
+        self.gidx_s, self.gidx_d = i32(world * self.ns), i32(world * self.nd)
+        self.gscratch = u8(E.split_scratch_bytes(N))
+        self.out = u8(N)
+
+    def __call__(self, batch, global_kinds):
+        """batch: dict kinds,u,R,Rp,PK,PKp,m (local slice); global_kinds: uint8 [world*n_local].
+        Returns the global verdict vector (uint8 [world*n_local], owned by this object)."""
+        import torch.distributed as dist
+
+        E, ns, nd = self.E, self.ns, self.nd
+        E.split_kinds_dev(batch["kinds"], self.idx_s, self.idx_d, self.scratch)
+        for k, dst in self.cs.items():
+            E.gather_rows_dev(batch[k], self.idx_s, ns, dst)
+        for k, dst in self.cd.items():
+            E.gather_rows_dev(batch[k], self.idx_d, nd, dst)
+        if ns:
+            E.verify_single_dev(self.cs["u"][:ns], self.cs["R"][:ns], self.cs["PK"][:ns],
+                                self.cs["m"][:ns], self.ok_s, self.ws)
+        if nd:
+            E.verify_double_dev(self.cd["u"][:nd], self.cd["R"][:nd], self.cd["Rp"][:nd],
+                                self.cd["PK"][:nd], self.cd["PKp"][:nd], self.cd["m"][:nd],
+                                self.ok_d, self.ws)
+        if self.world > 1:
+            if ns:
+                dist.all_gather_into_tensor(self.all_s[:self.world * ns], self.ok_s[:ns], group=self.group)
+            if nd:
+                dist.all_gather_into_tensor(self.all_d[:self.world * nd], self.ok_d[:nd], group=self.group)
+            all_s, all_d = self.all_s, self.all_d
+        else:
+            all_s, all_d = self.ok_s, self.ok_d
+        # kind-k item number j of the global batch: rank-major, i.e. j-th in global order
+        E.split_kinds_dev(global_kinds, self.gidx_s, self.gidx_d, self.gscratch)
+        self.out.zero_()
+        if ns:
+            E.scatter_verdicts_dev(all_s, self.gidx_s, self.world * ns, self.out)
+        if nd:
+            E.scatter_verdicts_dev(all_d, self.gidx_d, self.world * nd, self.out)
+        return self.out
+
+    def local_counts(self):
+        """(n_single, n_double) the device found in the LAST local split (synchronises)."""
+        t = self.scratch[-256:-248].view(self.torch.int32).cpu()
+        return int(t[0]), int(t[1])

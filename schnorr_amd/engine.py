@@ -11,26 +11,40 @@ import numpy as np
 
 from . import _lib
 
-_initialised_device = None
+_initialised = set()
 
 
 def init(device=0):
-    """dsv_init: select the GPU and build the fixed-base tables (idempotent)."""
-    global _initialised_device
-    if _initialised_device is not None:
-        if _initialised_device != device:
-            raise _lib.DsvError("engine already initialised on device %d" % _initialised_device)
+    """dsv_init: create the context of one GPU (fixed-base tables, streams).  Idempotent; several
+    devices may be initialised in one process."""
+    if device in _initialised:
         return
     L = _lib.load()
     _lib.check(L.dsv_init(ctypes.c_int(device)))
-    _initialised_device = device
+    _initialised.add(device)
 
 
-def shutdown():
-    global _initialised_device
-    if _initialised_device is not None:
+def set_device(device):
+    """Device of this thread's host-buffer entry points (default: the first one initialised)."""
+    _lib.check(_lib.load().dsv_set_device(ctypes.c_int(device)))
+
+
+def initialized_devices():
+    buf = (ctypes.c_int * 16)()
+    n = _lib.load().dsv_initialized_devices(buf, 16)
+    return [buf[i] for i in range(min(n, 16))]
+
+
+def shutdown(device=None):
+    """dsv_shutdown (all devices) or dsv_shutdown_device."""
+    if not _initialised:
+        return
+    if device is None:
         _lib.check(_lib.load().dsv_shutdown())
-        _initialised_device = None
+        _initialised.clear()
+    else:
+        _lib.check(_lib.load().dsv_shutdown_device(ctypes.c_int(device)))
+        _initialised.discard(device)
 
 
 def version():
@@ -83,6 +97,35 @@ def verify_vargen(u, R, PK, Gen, m):
     ok = np.zeros(n, dtype=np.uint8)
     _lib.check(_lib.load().dsv_verify_vargen(_p(u), _p(R), _p(PK), _p(Gen), _p(m),
                                              ctypes.c_size_t(n), _p(ok)))
+    return ok
+
+
+def verify_single_multi(u, R, PK, m):
+    """dsv_verify_single_multi: one host batch sharded over every initialised device."""
+    u, R, PK, m = _arr(u, 32), _arr(R, 64), _arr(PK, 64), _arr(m, 32)
+    n = _same_n(u, R, PK, m)
+    ok = np.zeros(n, dtype=np.uint8)
+    _lib.check(_lib.load().dsv_verify_single_multi(_p(u), _p(R), _p(PK), _p(m), ctypes.c_size_t(n),
+                                                   _p(ok)))
+    return ok
+
+
+def verify_double_multi(u, R, Rp, PK, PKp, m):
+    u, R, Rp, PK, PKp, m = (_arr(u, 32), _arr(R, 64), _arr(Rp, 64), _arr(PK, 64), _arr(PKp, 64),
+                            _arr(m, 32))
+    n = _same_n(u, R, Rp, PK, PKp, m)
+    ok = np.zeros(n, dtype=np.uint8)
+    _lib.check(_lib.load().dsv_verify_double_multi(_p(u), _p(R), _p(Rp), _p(PK), _p(PKp), _p(m),
+                                                   ctypes.c_size_t(n), _p(ok)))
+    return ok
+
+
+def verify_vargen_multi(u, R, PK, Gen, m):
+    u, R, PK, Gen, m = _arr(u, 32), _arr(R, 64), _arr(PK, 64), _arr(Gen, 64), _arr(m, 32)
+    n = _same_n(u, R, PK, Gen, m)
+    ok = np.zeros(n, dtype=np.uint8)
+    _lib.check(_lib.load().dsv_verify_vargen_multi(_p(u), _p(R), _p(PK), _p(Gen), _p(m),
+                                                   ctypes.c_size_t(n), _p(ok)))
     return ok
 
 
@@ -208,10 +251,10 @@ def stdrng_sign_inputs(seed, n, first_item=0):
 
 
 def stdrng_sign_inputs_dev(seed, sk, m, r, first_item=0, stream=None):
-    n = sk.shape[0]
+    n, dev = _rows((sk, 32, "sk"), (m, 32, "m"), (r, 32, "r"))
     _lib.check(_lib.load().dsv_stdrng_sign_inputs_dev(
         ctypes.c_uint64(seed), ctypes.c_size_t(first_item), ctypes.c_size_t(n), _tp(sk, 32),
-        _tp(m, 32), _tp(r, 32), _stream_ptr(stream)))
+        _tp(m, 32), _tp(r, 32), _stream_ptr(stream, dev)))
 
 
 def debug_table_entry(which, window, digit):
@@ -234,97 +277,232 @@ def debug_fq_mul(a, b):
 
 
 # ------------------------------------------------------------------ HBM-resident path (torch)
-def _tp(t, width):
+# Every wrapper checks what the C ABI cannot: dtype, device, contiguity, row width, that all
+# arrays of a call have the same number of rows and live on one GPU, and that verdict / workspace
+# buffers are large enough — a mismatched caller gets a ValueError, not an out-of-bounds kernel.
+def _t(t, width=None, name="tensor"):
     import torch
 
-    if not (isinstance(t, torch.Tensor) and t.is_cuda and t.dtype == torch.uint8 and
-            t.is_contiguous()):
-        raise ValueError("expected a contiguous uint8 CUDA tensor")
-    if t.dim() != 2 or t.shape[1] != width:
-        raise ValueError("expected shape [n, %d], got %r" % (width, tuple(t.shape)))
+    if not (isinstance(t, torch.Tensor) and t.is_cuda and t.is_contiguous()):
+        raise ValueError("%s: expected a contiguous CUDA tensor" % name)
+    if width is not None:
+        if t.dtype != torch.uint8 or t.dim() != 2 or t.shape[1] != width:
+            raise ValueError("%s: expected uint8 [n, %d], got %s %r" % (name, width, t.dtype, tuple(t.shape)))
+    return t
+
+
+def _rows(*named):
+    """named: (tensor, width, name) triples -> n; all on one device, all with n rows"""
+    n = named[0][0].shape[0]
+    dev = named[0][0].device
+    for t, w, name in named:
+        _t(t, w, name)
+        if t.shape[0] != n:
+            raise ValueError("batch arrays disagree on n: %s has %d rows, expected %d" % (name, t.shape[0], n))
+        if t.device != dev:
+            raise ValueError("%s is on %s, the rest of the batch on %s" % (name, t.device, dev))
+    return n, dev
+
+
+def _bytes_out(t, need, dev, name):
+    import torch
+
+    _t(t, None, name)
+    if t.dtype != torch.uint8 or t.numel() < need:
+        raise ValueError("%s: need a uint8 CUDA tensor of >= %d elements, got %s x %d"
+                         % (name, need, t.dtype, t.numel()))
+    if t.device != dev:
+        raise ValueError("%s is on %s, the batch on %s" % (name, t.device, dev))
     return ctypes.c_void_p(t.data_ptr())
+
+
+def _tp(t, width):
+    return ctypes.c_void_p(_t(t, width).data_ptr())
 
 
 def workspace_bytes(n):
     return int(_lib.load().dsv_workspace_bytes(ctypes.c_size_t(n)))
 
 
-def _stream_ptr(stream):
+def mixed_workspace_bytes(n):
+    return int(_lib.load().dsv_mixed_workspace_bytes(ctypes.c_size_t(n)))
+
+
+def split_scratch_bytes(n):
+    return int(_lib.load().dsv_split_scratch_bytes(ctypes.c_size_t(n)))
+
+
+def _stream_ptr(stream, dev=None):
     import torch
 
-    s = stream if stream is not None else torch.cuda.current_stream()
+    s = stream if stream is not None else torch.cuda.current_stream(dev)
     return ctypes.c_void_p(s.cuda_stream)
 
 
 def verify_single_dev(u, R, PK, m, ok, workspace, stream=None):
-    """Enqueue on `stream` (default: torch's current stream); does not synchronise."""
-    n = u.shape[0]
+    """Enqueue on `stream` (default: torch's current stream of the batch's device); does not
+    synchronise."""
+    n, dev = _rows((u, 32, "u"), (R, 64, "R"), (PK, 64, "PK"), (m, 32, "m"))
     _lib.check(_lib.load().dsv_verify_single_dev(
         _tp(u, 32), _tp(R, 64), _tp(PK, 64), _tp(m, 32), ctypes.c_size_t(n),
-        ctypes.c_void_p(ok.data_ptr()), ctypes.c_void_p(workspace.data_ptr()), _stream_ptr(stream)))
+        _bytes_out(ok, n, dev, "ok"), _bytes_out(workspace, workspace_bytes(n), dev, "workspace"),
+        _stream_ptr(stream, dev)))
 
 
 def verify_double_dev(u, R, Rp, PK, PKp, m, ok, workspace, stream=None):
-    n = u.shape[0]
+    n, dev = _rows((u, 32, "u"), (R, 64, "R"), (Rp, 64, "Rp"), (PK, 64, "PK"), (PKp, 64, "PKp"),
+                   (m, 32, "m"))
     _lib.check(_lib.load().dsv_verify_double_dev(
         _tp(u, 32), _tp(R, 64), _tp(Rp, 64), _tp(PK, 64), _tp(PKp, 64), _tp(m, 32),
-        ctypes.c_size_t(n), ctypes.c_void_p(ok.data_ptr()), ctypes.c_void_p(workspace.data_ptr()),
-        _stream_ptr(stream)))
+        ctypes.c_size_t(n), _bytes_out(ok, n, dev, "ok"),
+        _bytes_out(workspace, workspace_bytes(n), dev, "workspace"), _stream_ptr(stream, dev)))
 
 
 def verify_vargen_dev(u, R, PK, Gen, m, ok, workspace, stream=None):
-    n = u.shape[0]
+    n, dev = _rows((u, 32, "u"), (R, 64, "R"), (PK, 64, "PK"), (Gen, 64, "Gen"), (m, 32, "m"))
     _lib.check(_lib.load().dsv_verify_vargen_dev(
         _tp(u, 32), _tp(R, 64), _tp(PK, 64), _tp(Gen, 64), _tp(m, 32), ctypes.c_size_t(n),
-        ctypes.c_void_p(ok.data_ptr()), ctypes.c_void_p(workspace.data_ptr()), _stream_ptr(stream)))
+        _bytes_out(ok, n, dev, "ok"), _bytes_out(workspace, workspace_bytes(n), dev, "workspace"),
+        _stream_ptr(stream, dev)))
 
 
 def verify_core_dev(u, c, valid, PK, R, ok, workspace, which=0, accumulate=False, stream=None):
-    n = u.shape[0]
+    n, dev = _rows((u, 32, "u"), (c, 32, "c"), (PK, 64, "PK"), (R, 64, "R"))
     _lib.check(_lib.load().dsv_verify_core_dev(
-        _tp(u, 32), _tp(c, 32), ctypes.c_void_p(valid.data_ptr()), _tp(PK, 64), _tp(R, 64),
+        _tp(u, 32), _tp(c, 32), _bytes_out(valid, n, dev, "valid"), _tp(PK, 64), _tp(R, 64),
         ctypes.c_int(which), ctypes.c_int(1 if accumulate else 0), ctypes.c_size_t(n),
-        ctypes.c_void_p(ok.data_ptr()), ctypes.c_void_p(workspace.data_ptr()), _stream_ptr(stream)))
+        _bytes_out(ok, n, dev, "ok"), _bytes_out(workspace, workspace_bytes(n), dev, "workspace"),
+        _stream_ptr(stream, dev)))
+
+
+def verify_core_double_dev(u, c, valid, PK, R, PKp, Rp, ok, workspace, stream=None):
+    n, dev = _rows((u, 32, "u"), (c, 32, "c"), (PK, 64, "PK"), (R, 64, "R"), (PKp, 64, "PKp"),
+                   (Rp, 64, "Rp"))
+    _lib.check(_lib.load().dsv_verify_core_double_dev(
+        _tp(u, 32), _tp(c, 32), _bytes_out(valid, n, dev, "valid"), _tp(PK, 64), _tp(R, 64),
+        _tp(PKp, 64), _tp(Rp, 64), ctypes.c_size_t(n), _bytes_out(ok, n, dev, "ok"),
+        _bytes_out(workspace, workspace_bytes(n), dev, "workspace"), _stream_ptr(stream, dev)))
+
+
+def verify_mixed_dev(kinds, u, R, Rp, PK, PKp, m, n_double, ok, workspace, stream=None):
+    """dsv_verify_mixed_dev: kinds uint8 [n] (0 single, 1 double), SoA over all n items."""
+    n, dev = _rows((u, 32, "u"), (R, 64, "R"), (Rp, 64, "Rp"), (PK, 64, "PK"), (PKp, 64, "PKp"),
+                   (m, 32, "m"))
+    _lib.check(_lib.load().dsv_verify_mixed_dev(
+        _bytes_out(kinds, n, dev, "kinds"), _tp(u, 32), _tp(R, 64), _tp(Rp, 64), _tp(PK, 64),
+        _tp(PKp, 64), _tp(m, 32), ctypes.c_size_t(n), ctypes.c_size_t(int(n_double)),
+        _bytes_out(ok, n, dev, "ok"), _bytes_out(workspace, mixed_workspace_bytes(n), dev, "workspace"),
+        _stream_ptr(stream, dev)))
+
+
+def _idx(t, need, dev, name):
+    import torch
+
+    _t(t, None, name)
+    if t.dtype not in (torch.int32, torch.uint32) or t.numel() < need or t.device != dev:
+        raise ValueError("%s: need a 32-bit index tensor of >= %d elements on %s" % (name, need, dev))
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def split_kinds_dev(kinds, idx_single, idx_double, scratch, stream=None):
+    """Stable split of the index vector by kind; returns nothing — the two counts are the last two
+    int32 of `scratch` (view: scratch[-256:-248].view(torch.int32))."""
+    n = kinds.numel()
+    dev = kinds.device
+    _lib.check(_lib.load().dsv_split_kinds_dev(
+        _bytes_out(kinds, n, dev, "kinds"), ctypes.c_size_t(n),
+        _idx(idx_single, 0, dev, "idx_single"), ctypes.c_size_t(idx_single.numel()),
+        _idx(idx_double, 0, dev, "idx_double"), ctypes.c_size_t(idx_double.numel()),
+        _bytes_out(scratch, split_scratch_bytes(n), dev, "scratch"), _stream_ptr(stream, dev)))
+
+
+def gather_rows_dev(src, idx, count, dst, stream=None):
+    """dst[j] = src[idx[j]] for j < count; src/dst uint8 [*, row_bytes], row_bytes % 16 == 0."""
+    _t(src, src.shape[1], "src")
+    _t(dst, src.shape[1], "dst")
+    dev = src.device
+    if dst.shape[0] < count or dst.device != dev:
+        raise ValueError("dst too small or on another device")
+    _lib.check(_lib.load().dsv_gather_rows_dev(
+        ctypes.c_void_p(src.data_ptr()), ctypes.c_size_t(src.shape[1]), _idx(idx, count, dev, "idx"),
+        ctypes.c_size_t(count), ctypes.c_void_p(dst.data_ptr()), _stream_ptr(stream, dev)))
+
+
+def scatter_verdicts_dev(src, idx, count, dst, stream=None):
+    """dst[idx[j]] = src[j] for j < count (uint8 verdicts back into batch order)."""
+    dev = dst.device
+    _lib.check(_lib.load().dsv_scatter_verdicts_dev(
+        _bytes_out(src, count, dev, "src"), _idx(idx, count, dev, "idx"), ctypes.c_size_t(count),
+        _bytes_out(dst, 0, dev, "dst"), _stream_ptr(stream, dev)))
 
 
 def challenge_double_dev(R, Rp, m, c, valid=None, stream=None):
-    n = m.shape[0]
+    n, dev = _rows((R, 64, "R"), (Rp, 64, "Rp"), (m, 32, "m"), (c, 32, "c"))
     _lib.check(_lib.load().dsv_challenge_double_dev(
-        _tp(R, 64), _tp(Rp, 64), _tp(m, 32), ctypes.c_size_t(n), ctypes.c_void_p(c.data_ptr()),
-        ctypes.c_void_p(valid.data_ptr() if valid is not None else 0), _stream_ptr(stream)))
+        _tp(R, 64), _tp(Rp, 64), _tp(m, 32), ctypes.c_size_t(n), _tp(c, 32),
+        _bytes_out(valid, n, dev, "valid") if valid is not None else ctypes.c_void_p(0),
+        _stream_ptr(stream, dev)))
 
 
 def challenge_single_dev(R, m, c, valid=None, stream=None):
-    n = m.shape[0]
+    n, dev = _rows((R, 64, "R"), (m, 32, "m"), (c, 32, "c"))
     _lib.check(_lib.load().dsv_challenge_single_dev(
-        _tp(R, 64), _tp(m, 32), ctypes.c_size_t(n), ctypes.c_void_p(c.data_ptr()),
-        ctypes.c_void_p(valid.data_ptr() if valid is not None else 0), _stream_ptr(stream)))
+        _tp(R, 64), _tp(m, 32), ctypes.c_size_t(n), _tp(c, 32),
+        _bytes_out(valid, n, dev, "valid") if valid is not None else ctypes.c_void_p(0),
+        _stream_ptr(stream, dev)))
 
 
 def decompress_points_dev(comp, out_uv, ok, in_stride=32, accumulate=False, stream=None):
     """comp: uint8 CUDA tensor holding one 32-byte record every in_stride bytes."""
     n = out_uv.shape[0]
+    dev = out_uv.device
+    _t(comp, None, "comp")
+    if comp.numel() * comp.element_size() < (n - 1) * in_stride + 32 or comp.device != dev:
+        raise ValueError("comp holds fewer than n records of stride %d (or is on another device)" % in_stride)
     _lib.check(_lib.load().dsv_decompress_points_dev(
         ctypes.c_void_p(comp.data_ptr()), ctypes.c_size_t(in_stride), ctypes.c_size_t(n),
-        _tp(out_uv, 64), ctypes.c_void_p(ok.data_ptr()), ctypes.c_int(1 if accumulate else 0),
-        _stream_ptr(stream)))
+        _tp(out_uv, 64), _bytes_out(ok, n, dev, "ok"), ctypes.c_int(1 if accumulate else 0),
+        _stream_ptr(stream, dev)))
 
 
 def sign_single_dev(sk, m, r, u, R, stream=None):
-    n = sk.shape[0]
+    n, dev = _rows((sk, 32, "sk"), (m, 32, "m"), (r, 32, "r"), (u, 32, "u"), (R, 64, "R"))
     _lib.check(_lib.load().dsv_sign_single_dev(
         _tp(sk, 32), _tp(m, 32), _tp(r, 32), ctypes.c_size_t(n), _tp(u, 32), _tp(R, 64),
-        _stream_ptr(stream)))
+        _stream_ptr(stream, dev)))
 
 
 def sign_double_dev(sk, m, r, u, R, Rp, stream=None):
-    n = sk.shape[0]
+    n, dev = _rows((sk, 32, "sk"), (m, 32, "m"), (r, 32, "r"), (u, 32, "u"), (R, 64, "R"), (Rp, 64, "Rp"))
     _lib.check(_lib.load().dsv_sign_double_dev(
         _tp(sk, 32), _tp(m, 32), _tp(r, 32), ctypes.c_size_t(n), _tp(u, 32), _tp(R, 64),
-        _tp(Rp, 64), _stream_ptr(stream)))
+        _tp(Rp, 64), _stream_ptr(stream, dev)))
 
 
 def public_keys_dev(sk, which, PK, stream=None):
-    n = sk.shape[0]
+    n, dev = _rows((sk, 32, "sk"), (PK, 64, "PK"))
     _lib.check(_lib.load().dsv_public_keys_dev(
-        _tp(sk, 32), ctypes.c_int(which), ctypes.c_size_t(n), _tp(PK, 64), _stream_ptr(stream)))
+        _tp(sk, 32), ctypes.c_int(which), ctypes.c_size_t(n), _tp(PK, 64), _stream_ptr(stream, dev)))
+
+
+def public_keys_vargen_dev(sk, Gen, PK, workspace, stream=None):
+    n, dev = _rows((sk, 32, "sk"), (Gen, 64, "Gen"), (PK, 64, "PK"))
+    _lib.check(_lib.load().dsv_public_keys_vargen_dev(
+        _tp(sk, 32), _tp(Gen, 64), ctypes.c_size_t(n), _tp(PK, 64),
+        _bytes_out(workspace, workspace_bytes(n), dev, "workspace"), _stream_ptr(stream, dev)))
+
+
+def sign_vargen_dev(sk, Gen, m, r, u, R, workspace, stream=None):
+    n, dev = _rows((sk, 32, "sk"), (Gen, 64, "Gen"), (m, 32, "m"), (r, 32, "r"), (u, 32, "u"),
+                   (R, 64, "R"))
+    _lib.check(_lib.load().dsv_sign_vargen_dev(
+        _tp(sk, 32), _tp(Gen, 64), _tp(m, 32), _tp(r, 32), ctypes.c_size_t(n), _tp(u, 32),
+        _tp(R, 64), _bytes_out(workspace, workspace_bytes(n), dev, "workspace"),
+        _stream_ptr(stream, dev)))
+
+
+def stdrng_vargen_inputs_dev(seed, sk, g, m, r, first_item=0, stream=None):
+    n, dev = _rows((sk, 32, "sk"), (g, 32, "g"), (m, 32, "m"), (r, 32, "r"))
+    _lib.check(_lib.load().dsv_stdrng_vargen_inputs_dev(
+        ctypes.c_uint64(seed), ctypes.c_size_t(first_item), ctypes.c_size_t(n), _tp(sk, 32),
+        _tp(g, 32), _tp(m, 32), _tp(r, 32), _stream_ptr(stream, dev)))

@@ -4,7 +4,8 @@ nonce are consecutive draws of `StdRng::seed_from_u64(seed)` (ChaCha12, each `fr
 64 bytes — dsv_stdrng_sign_inputs), then sig = sign(sk, m, nonce), pk = sk*G.  Every 16th item is
 corrupted in a known pattern so the expected verdict vector is non-trivial.
 `first_item` selects a slice of the one stream, so N ranks hold consecutive shards of one batch.
-(The var-generator helper still draws 251/254-bit uniform integers with torch's generator.)
+The var-generator batches follow the same rule with four draws per item (sk, generator scalar,
+message, nonce: src/keys/secret.rs:371-373, tests/schnorr_var_generator.rs:16-22).
 """
 import torch
 
@@ -82,21 +83,20 @@ def gen_double(n, seed, device="cuda:0", tamper=True, first_item=0):
     return batch
 
 
-def gen_vargen(n, seed, device="cuda:0", tamper=True):
-    """Var-generator scheme (benches/signature_var_generator.rs:50-63 shape): sk, generator scalar
-    g, message, nonce; Gen = g*G, PK = sk*Gen, R = r*Gen.  Generated through the host entry points
-    (the variable-base sign/derive kernels have no device-pointer form), then moved to HBM."""
-    gen = torch.Generator(device=device)
-    gen.manual_seed(seed)
-    sk = _rand_scalars(n, 0x07, gen, device).cpu().numpy()
-    g = _rand_scalars(n, 0x07, gen, device).cpu().numpy()
-    r = _rand_scalars(n, 0x07, gen, device).cpu().numpy()
-    m = _rand_scalars(n, 0x3F, gen, device).cpu().numpy()
-    Gen = E.public_keys(g, 0)
-    PK = E.public_keys(sk, 0, Gen)
-    u, R = E.sign_vargen(sk, Gen, m, r)
-    to = lambda a: torch.from_numpy(a).to(device).contiguous()
-    batch = {"u": to(u), "R": to(R), "PK": to(PK), "Gen": to(Gen), "m": to(m)}
+def gen_vargen(n, seed, device="cuda:0", tamper=True, first_item=0):
+    """Var-generator scheme (benches/signature_var_generator.rs:50-63 shape): per item sk, generator
+    scalar g, message and nonce are consecutive `from_bytes_wide` draws of StdRng(seed);
+    Gen = g*G, PK = sk*Gen, R = r*Gen — all computed on the GPU."""
+    new = lambda w: torch.empty((n, w), dtype=torch.uint8, device=device)
+    sk, g, m, r = new(32), new(32), new(32), new(32)
+    E.stdrng_vargen_inputs_dev(seed, sk, g, m, r, first_item=first_item)
+    Gen, PK, u, R = new(64), new(64), new(32), new(64)
+    ws = torch.empty(E.workspace_bytes(n), dtype=torch.uint8, device=device)
+    E.public_keys_dev(g, 0, Gen)
+    E.public_keys_vargen_dev(sk, Gen, PK, ws)
+    E.sign_vargen_dev(sk, Gen, m, r, u, R, ws)
+    torch.cuda.synchronize(device)
+    batch = {"u": u, "R": R, "PK": PK, "Gen": Gen, "m": m}
     if tamper:
         expected = _tamper(batch, n)
         idx = torch.arange(8, n, TAMPER_PERIOD, device=device)
@@ -106,3 +106,27 @@ def gen_vargen(n, seed, device="cuda:0", tamper=True):
     else:
         batch["expected"] = torch.ones(n, dtype=torch.uint8, device=device)
     return batch
+
+
+def gen_mixed(n, seed, device="cuda:0", tamper=True, first_item=0):
+    """BASELINE.json configs[4] shape: n items, single (kind 0) on even and double (kind 1) on odd
+    positions, as ONE structure of arrays (Rp / PKp rows of single items are zero).  The n/2
+    singles are items first_item/2.. of StdRng(seed), the doubles the same range of
+    StdRng(seed + 1), so consecutive `first_item` ranges of N ranks tile one global batch."""
+    assert n % 2 == 0 and first_item % 2 == 0
+    h = n // 2
+    bs = gen_single(h, seed, device, tamper, first_item // 2)
+    bd = gen_double(h, seed + 1, device, tamper, first_item // 2)
+    out = {"kinds": (torch.arange(n, device=device) & 1).to(torch.uint8)}
+    for key, w in (("u", 32), ("R", 64), ("Rp", 64), ("PK", 64), ("PKp", 64), ("m", 32)):
+        t = torch.zeros((n, w), dtype=torch.uint8, device=device)
+        if key in bs:
+            t[0::2] = bs[key]
+        t[1::2] = bd[key]
+        out[key] = t.contiguous()
+    exp = torch.empty(n, dtype=torch.uint8, device=device)
+    exp[0::2] = bs["expected"]
+    exp[1::2] = bd["expected"]
+    out["expected"] = exp
+    out["n_double"] = h
+    return out

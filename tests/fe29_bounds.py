@@ -82,6 +82,49 @@ def canonical():
 
 
 # ---- fe29.h ---------------------------------------------------------------------------------
+def _fips(cols, vprod):
+    """fe_mont_fips on column maxima: the accumulator of column k holds the carry, the operand
+    products and the digit products m_i * q_j (m_0 <= 2^29, m_i <= 2^29 - 1); it only grows inside
+    a column, so its final value is the value to bound."""
+    mmax = [M29 + 1] + [M29] * (NL - 1)
+    out = []
+    acc = cols[0]
+    _check(acc < U64, "column 0 overflows 64 bits")
+    acc >>= LB
+    for k in range(1, 2 * NL - 1):
+        acc += cols[k]
+        for i in range(NL):
+            j = k - i
+            if i < k and 1 <= j < NL:
+                acc += mmax[i] * Q29[j]
+        _check(acc < U64, "column %d overflows 64 bits" % k)
+        if k >= NL:
+            out.append(min(acc, M29))
+        acc >>= LB
+    out[0] += 1
+    _check(acc < U32, "top limb of a product exceeds 32 bits")
+    out.append(acc)
+    # value: (a*b + M*q) / 2^261 with M <= 2^261
+    v = (vprod + (1 << RBITS) * Q) >> RBITS
+    return B(out, v)
+
+
+def mul(a, b):
+    for x in a.l + b.l:
+        _check(x < U32, "multiplier limb exceeds 32 bits")
+    c = [0] * 17
+    for i in range(NL):
+        for j in range(NL):
+            c[i + j] += a.l[i] * b.l[j]
+    return _fips(c, a.v * b.v)
+
+
+def sqr(a):
+    for x in a.l:
+        _check(2 * x < U32, "doubled limb of a squaring exceeds 32 bits")
+    return mul(a, a)
+
+
 def _reduce(cols, vprod):
     """fe_reduce_cols on column maxima (without the +M29 bias, added here like the device does)"""
     c = list(cols) + [0]
@@ -105,24 +148,6 @@ def _reduce(cols, vprod):
     # value: (a*b + m*q) / 2^261 with m < 2^261
     v = (vprod + ((1 << RBITS) - 1) * Q) >> RBITS
     return B(out, v)
-
-
-def mul(a, b):
-    for x in a.l + b.l:
-        _check(x < U32, "multiplier limb exceeds 32 bits")
-    c = [0] * 17
-    for i in range(NL):
-        for j in range(NL):
-            c[i + j] += a.l[i] * b.l[j]
-    for k, x in enumerate(c):
-        _check(x + M29 < U64, "product column %d overflows 64 bits" % k)
-    return _reduce(c, a.v * b.v)
-
-
-def sqr(a):
-    for x in a.l:
-        _check(2 * x < U32, "doubled limb of a squaring exceeds 32 bits")
-    return mul(a, a)
 
 
 def dot(avec, bvec):

@@ -48,6 +48,66 @@ def to_mont_int(x):
     return from_int(x * RMONT % Q)
 
 
+def fips(cols):
+    """fe_mont_fips (fe29.h): one 64-bit accumulator over the 17 columns; `cols[k]` = sum of the
+    operand products of column k.  The accumulator runs one behind the true column sum from
+    column 1 on; result limb 0 takes the missing 1 back."""
+    assert len(cols) == 2 * NL - 1
+    m = [0] * NL
+    r = [0] * NL
+    acc = cols[0]
+    assert acc < U64
+    m[0] = ((~acc) & M29) + 1
+    assert (acc + m[0]) & M29 == 0 and (acc + m[0]) >> LB == (acc >> LB) + 1
+    acc >>= LB
+    true_carry = acc + 1
+    for k in range(1, 2 * NL - 1):
+        acc += cols[k]
+        for i in range(NL):
+            j = k - i
+            if i < k and 1 <= j < NL:
+                acc += m[i] * Q29[j]
+        assert acc < U64, "column %d overflows 64 bits" % k
+        stats["max_col"] = max(stats["max_col"], acc)
+        if k <= NL:
+            assert acc + 1 == true_carry + cols[k] + sum(m[i] * Q29[k - i] for i in range(NL)
+                                                          if i < k and 1 <= k - i < NL)
+        if k < NL:
+            m[k] = (~acc) & M29
+            assert (acc + 1 + m[k]) & M29 == 0
+            true_carry = (acc + 1 + m[k]) >> LB
+            assert true_carry == (acc >> LB) + 1
+        else:
+            r[k - NL] = acc & M29
+        acc >>= LB
+    r[0] += 1
+    assert acc < U32
+    r[NL - 1] = acc
+    return r
+
+
+def _cols(pairs):
+    c = [0] * (2 * NL - 1)
+    for a, b in pairs:
+        for l in a + b:
+            assert 0 <= l < U32
+            stats["max_limb_in"] = max(stats["max_limb_in"], l)
+        for i in range(NL):
+            for j in range(NL):
+                c[i + j] += a[i] * b[j]
+    return c
+
+
+def mul(a, b):
+    return fips(_cols([(a, b)]))
+
+
+def sqr(a):
+    for l in a:
+        assert 2 * l < U32
+    return mul(a, a)
+
+
 def reduce_cols(c):
     """columns 0..8 arrive pre-biased by +M29 (see fe29.h)"""
     k = 0
@@ -72,26 +132,6 @@ def reduce_cols(c):
     assert k < U32
     r.append(k)
     return r
-
-
-def mul(a, b):
-    for l in a + b:
-        assert 0 <= l < U32
-        stats["max_limb_in"] = max(stats["max_limb_in"], l)
-    c = [0] * 17
-    for i in range(NL):
-        for j in range(NL):
-            c[i + j] += a[i] * b[j]
-    for x in c:
-        assert x < U64, "column overflow in product"
-        stats["max_col"] = max(stats["max_col"], x)
-    return reduce_cols(c)
-
-
-def sqr(a):
-    for l in a:
-        assert 2 * l < U32
-    return mul(a, a)
 
 
 def dot(avec, bvec):

@@ -679,8 +679,9 @@ def test_wire_and_ext_entries_multi_chunk(engine):
 
 def test_concurrent_callers_on_their_own_streams(engine):
     """include/dsv.h: calls on different streams may run concurrently.  Two host threads enqueue
-    split batches (they share the library's two internal streams) and a third uses the host entry
-    point at the same time; every verdict vector must match its construction-time pattern."""
+    split batches (each caller stream gets its own pair of internal streams) and a third uses the
+    host entry point at the same time; every verdict vector must match its construction-time
+    pattern."""
     import threading
     import torch
     from schnorr_amd import workload as W

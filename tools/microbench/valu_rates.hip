@@ -68,6 +68,17 @@ DEF_KERNEL_U32(dot4_u32_u8, "v_dot4_u32_u8 %0, %1, %2, %0")
 DEF_KERNEL_U32(pk_mul_lo_u16, "v_pk_mul_lo_u16 %0, %0, %1")
 DEF_KERNEL_U32(pk_mad_u16, "v_pk_mad_u16 %0, %0, %1, %2")
 DEF_KERNEL_U32(cndmask, "v_cndmask_b32 %0, %0, %1, vcc")
+// r02: the cheap VOP1/VOP2 forms (is everything without a carry double rate, or only v_add_u32?)
+DEF_KERNEL_U32(and_b32, "v_and_b32 %0, %0, %1")
+DEF_KERNEL_U32(or_b32, "v_or_b32 %0, %0, %1")
+DEF_KERNEL_U32(xor_b32, "v_xor_b32 %0, %0, %1")
+DEF_KERNEL_U32(sub_u32, "v_sub_u32 %0, %0, %1")
+DEF_KERNEL_U32(lshrrev_b32, "v_lshrrev_b32 %0, 3, %0")
+DEF_KERNEL_U32(lshlrev_b32, "v_lshlrev_b32 %0, 1, %0")
+DEF_KERNEL_U32(not_b32, "v_not_b32 %0, %0")
+DEF_KERNEL_U32(mov_b32, "v_mov_b32 %0, %1")
+DEF_KERNEL_U32(bitop3, "v_bitop3_b32 %0, %0, %1, %0 bitop3:0xc")
+DEF_KERNEL_U32(add_u32_nop, "v_add_u32 %0, %0, %1\n s_nop 0")
 
 #define DEF_KERNEL_U64(NAME, ASMSTR)                                           \
   __global__ void __launch_bounds__(256) k_##NAME(uint32_t* out, uint32_t s) { \
@@ -92,6 +103,9 @@ DEF_KERNEL_U64(mad_u64_u32, "v_mad_u64_u32 %0, vcc, %1, %2, %0")
 DEF_KERNEL_U64(mad_u64_u32_sgprcarry, "v_mad_u64_u32 %0, s[10:11], %1, %2, %0")
 DEF_KERNEL_U64(lshl_add_u64, "v_lshl_add_u64 %0, %0, 0, %3")
 DEF_KERNEL_U64(lshlrev_b64, "v_lshlrev_b64 %0, 1, %0")
+DEF_KERNEL_U64(lshrrev_b64, "v_lshrrev_b64 %0, 29, %0")
+// what a hazard no-op between two dependent MADs costs (inline-asm MAD chains get one each)
+DEF_KERNEL_U64(mad_u64_u32_nop, "v_mad_u64_u32 %0, s[10:11], %1, %2, %0\n s_nop 0")
 DEF_KERNEL_U64(fma_f64, "v_fma_f64 %0, %0, %3, %3")
 DEF_KERNEL_U64(add_f64, "v_add_f64 %0, %0, %3")
 DEF_KERNEL_U64(mul_f64, "v_mul_f64 %0, %0, %3")
@@ -189,7 +203,10 @@ int main(int argc, char** argv) {
       E(mul_u32_u24), E(mul_hi_u32_u24), E(mad_u32_u24), E(mad_u32_u16),
       E(fma_f32), E(alignbit), E(lshl_add), E(and_or), E(xad), E(dot2_u32_u16),
       E(dot4_u32_u8), E(pk_mul_lo_u16), E(pk_mad_u16), E(cndmask),
-      E(mad_u64_u32), E(mad_u64_u32_sgprcarry), E(lshl_add_u64), E(lshlrev_b64),
+      E(and_b32), E(or_b32), E(xor_b32), E(sub_u32), E(lshrrev_b32), E(lshlrev_b32), E(not_b32),
+      E(mov_b32), E(bitop3), E(add_u32_nop),
+      E(mad_u64_u32), E(mad_u64_u32_sgprcarry), E(lshl_add_u64), E(lshlrev_b64), E(lshrrev_b64),
+      E(mad_u64_u32_nop),
       E(fma_f64), E(add_f64), E(mul_f64), E(pk_fma_f32), E(pk_add_f32),
       E(cvt_f64_u32), E(pk_mul_f32),
       {"mad_addc_pair", k_mad_addc_pair, 32},
@@ -202,7 +219,7 @@ int main(int argc, char** argv) {
 
   printf("%-24s %6s %12s %14s %10s\n", "instr", "w/SIMD", "ms", "Gwaveinst/s",
          "cyc/inst");
-  for (int wps : {1, 2, 4, 8}) {
+  for (int wps : {1, 2, 4}) {
     for (auto& e : es) {
       // 256-thread blocks = 4 waves = one per SIMD; wps blocks per CU; x8 rounds
       int blocks = cus * wps * 8;

@@ -35,6 +35,7 @@ def main():
                         g.write(line)
     acc = defaultdict(lambda: defaultdict(list))
     dur = defaultdict(list)
+    clk = defaultdict(list)   # GRBM_GUI_ACTIVE / 8 XCDs / duration of the SAME dispatch = held GHz
     for path in glob.glob(os.path.join(src, "pmc_*", "**", "*counter_collection.csv"), recursive=True):
         seen = set()
         with open(path) as f:
@@ -43,6 +44,10 @@ def main():
                 if not k.startswith("dsv::"):
                     continue
                 acc[k][row["Counter_Name"]].append(float(row["Counter_Value"]))
+                if row["Counter_Name"] == "GRBM_GUI_ACTIVE":
+                    d_ns = float(row["End_Timestamp"]) - float(row["Start_Timestamp"])
+                    if d_ns > 0:
+                        clk[k].append(float(row["Counter_Value"]) / 8.0 / d_ns)
                 key = (path, row["Dispatch_Id"])
                 if key not in seen:
                     seen.add(key)
@@ -52,6 +57,8 @@ def main():
         out[k] = {c: {"avg_per_launch": sum(v) / len(v), "launches": len(v)}
                   for c, v in sorted(counters.items())}
         out[k]["avg_duration_ns_under_pmc"] = sum(dur[k]) / len(dur[k])
+        if clk[k]:
+            out[k]["clock_held_ghz"] = sum(clk[k]) / len(clk[k])
     with open(prefix + "_pmc_summary.json", "w") as f:
         json.dump(out, f, indent=1)
     dom = [k for k in out if k.startswith("dsv::k_verify_fixed_half")]
@@ -76,6 +83,9 @@ def main():
         for c in ("SQ_INSTS_VALU", "SQ_WAVE_CYCLES", "GRBM_GUI_ACTIVE"):
             if c in d:
                 latest[c] = d[c]["avg_per_launch"]
+        latest["avg_duration_ns_under_pmc"] = d["avg_duration_ns_under_pmc"]
+        if "clock_held_ghz" in d:
+            latest["clock_held_ghz"] = d["clock_held_ghz"]
         if stats:
             latest["avg_duration_ns"] = float(stats["AverageNs"])
         hk = [k for k in out if k.startswith("dsv::k_challenge<false>")]
