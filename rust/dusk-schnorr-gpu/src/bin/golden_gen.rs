@@ -2,7 +2,11 @@
 //! hash (Hades constants, sponge padding, 250-bit truncation) can be pinned — the one thing
 //! nothing in the reference tree pins.  Run on a machine with cargo + crates.io:
 //!     cargo run --bin golden_gen > ../../tests/golden/reference_vectors.txt
-//! and compare with tests/golden/vectors.json (same field names).
+//! and commit that file: tests/reference_fixtures.py parses exactly this line format, and
+//! tests/test_oracle.py::test_reference_fixtures_pin_the_oracle (CPU) and
+//! tests/test_gpu_parity.py::test_reference_fixtures_on_gpu (GPU) then check the oracle and the
+//! HIP engine against it — no code change needed.  (tests/golden/predicted_reference.json is what
+//! this repository PREDICTS the `sig` lines to be.)
 use dusk_bls12_381::BlsScalar;
 use dusk_bytes::Serializable;
 use dusk_schnorr::{PublicKey, SecretKey};

@@ -18,13 +18,17 @@ use dusk_schnorr::{
 #[allow(non_snake_case)]
 extern "C" {
     fn dsv_init(device: c_int) -> c_int;
+    fn dsv_device_count() -> c_int;
     fn dsv_last_error() -> *const c_char;
-    fn dsv_verify_single(u: *const u8, R_uv: *const u8, PK_uv: *const u8, m: *const u8, n: usize,
-                         ok: *mut u8) -> c_int;
-    fn dsv_verify_double(u: *const u8, R_uv: *const u8, Rp_uv: *const u8, PK_uv: *const u8,
-                         PKp_uv: *const u8, m: *const u8, n: usize, ok: *mut u8) -> c_int;
-    fn dsv_verify_vargen(u: *const u8, R_uv: *const u8, PK_uv: *const u8, Gen_uv: *const u8,
-                         m: *const u8, n: usize, ok: *mut u8) -> c_int;
+    // the *_multi entry points shard one host batch over EVERY initialised device (contiguous
+    // shards, one host thread per device, no collective); with one device they are the plain
+    // dsv_verify_single / _double / _vargen
+    fn dsv_verify_single_multi(u: *const u8, R_uv: *const u8, PK_uv: *const u8, m: *const u8,
+                               n: usize, ok: *mut u8) -> c_int;
+    fn dsv_verify_double_multi(u: *const u8, R_uv: *const u8, Rp_uv: *const u8, PK_uv: *const u8,
+                               PKp_uv: *const u8, m: *const u8, n: usize, ok: *mut u8) -> c_int;
+    fn dsv_verify_vargen_multi(u: *const u8, R_uv: *const u8, PK_uv: *const u8, Gen_uv: *const u8,
+                               m: *const u8, n: usize, ok: *mut u8) -> c_int;
 }
 
 /// Engine failure (no GPU, HIP error).  Never a verdict.
@@ -39,9 +43,22 @@ fn check(rc: c_int) -> Result<(), EngineError> {
     Err(EngineError(rc, msg))
 }
 
-/// Select the GPU and build the fixed-base tables (idempotent).
+/// Create the context of one GPU: fixed-base tables, streams (idempotent).
 pub fn init(device: i32) -> Result<(), EngineError> {
     check(unsafe { dsv_init(device) })
+}
+
+/// Initialise every GPU of the node (8 on an MI355X node); `verify_batch*` then shard over all
+/// of them.  Idempotent and cheap after the first call.
+pub fn init_all() -> Result<usize, EngineError> {
+    let n = unsafe { dsv_device_count() };
+    if n <= 0 {
+        init(0)?; // reports DSV_ERR_NO_DEVICE with its message
+    }
+    for d in 0..n {
+        init(d)?;
+    }
+    Ok(n as usize)
 }
 
 fn push_point(dst: &mut Vec<u8>, p: &JubJubExtended) {
@@ -69,9 +86,9 @@ pub fn verify_batch(sigs: &[Signature], pks: &[PublicKey], msgs: &[BlsScalar])
         m.extend_from_slice(&msgs[i].to_bytes());
     }
     let mut ok = vec![0u8; n];
-    init(0)?;
+    init_all()?;
     check(unsafe {
-        dsv_verify_single(u.as_ptr(), r.as_ptr(), pk.as_ptr(), m.as_ptr(), n, ok.as_mut_ptr())
+        dsv_verify_single_multi(u.as_ptr(), r.as_ptr(), pk.as_ptr(), m.as_ptr(), n, ok.as_mut_ptr())
     })?;
     Ok(verdicts(ok))
 }
@@ -91,10 +108,10 @@ pub fn verify_batch_double(sigs: &[SignatureDouble], pks: &[PublicKeyDouble], ms
         m.extend_from_slice(&msgs[i].to_bytes());
     }
     let mut ok = vec![0u8; n];
-    init(0)?;
+    init_all()?;
     check(unsafe {
-        dsv_verify_double(u.as_ptr(), r.as_ptr(), rp.as_ptr(), pk.as_ptr(), pkp.as_ptr(),
-                          m.as_ptr(), n, ok.as_mut_ptr())
+        dsv_verify_double_multi(u.as_ptr(), r.as_ptr(), rp.as_ptr(), pk.as_ptr(), pkp.as_ptr(),
+                                m.as_ptr(), n, ok.as_mut_ptr())
     })?;
     Ok(verdicts(ok))
 }
@@ -113,10 +130,10 @@ pub fn verify_batch_var_gen(sigs: &[SignatureVarGen], pks: &[PublicKeyVarGen], m
         m.extend_from_slice(&msgs[i].to_bytes());
     }
     let mut ok = vec![0u8; n];
-    init(0)?;
+    init_all()?;
     check(unsafe {
-        dsv_verify_vargen(u.as_ptr(), r.as_ptr(), pk.as_ptr(), g.as_ptr(), m.as_ptr(), n,
-                          ok.as_mut_ptr())
+        dsv_verify_vargen_multi(u.as_ptr(), r.as_ptr(), pk.as_ptr(), g.as_ptr(), m.as_ptr(), n,
+                                ok.as_mut_ptr())
     })?;
     Ok(verdicts(ok))
 }

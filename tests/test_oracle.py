@@ -207,3 +207,70 @@ def test_stdrng_restatement_and_predicted_reference_vectors():
         sig = unhex(rec["sig_bytes"]).reshape(1, 64)
         pk = unhex(rec["pk_bytes"]).reshape(1, 32)
         assert int(O.verify_single_wire(sig, pk, unhex(rec["m"]).reshape(1, 32))[0]) == 1
+
+
+def _check_reference_records(recs, verify_wire, verify_plain, decompress):
+    """shared by the CPU (oracle) and GPU (engine) forms of the hand-off test"""
+    n_sig = 0
+    for r in recs:
+        if r["kind"] == "sponge_hash_1_2_3_le":
+            assert M.le32(M.sponge_hash([1, 2, 3])).hex() == r["hex"], "Poseidon sponge differs from the crate"
+        elif r["kind"] == "truncated_hash_1_2_3_le":
+            assert M.le32(M.truncated_hash([1, 2, 3])).hex() == r["hex"], "250-bit truncation differs"
+        elif r["kind"] == "sig":
+            n_sig += 1
+            u, m = unhex(r["u"]).reshape(1, 32), unhex(r["m"]).reshape(1, 32)
+            R, PK = unhex(r["R"]).reshape(1, 64), unhex(r["PK"]).reshape(1, 64)
+            assert int(verify_plain(u, R, PK, m)[0]) == int(r["verdict"]), ("verdict", r["i"])
+            sig, pk = unhex(r["sig_bytes"]).reshape(1, 64), unhex(r["pk_bytes"]).reshape(1, 32)
+            assert int(verify_wire(sig, pk, m)[0]) == int(r["verdict"]), ("wire verdict", r["i"])
+            # the crate's own PK = sk * G and serialisation
+            sk = M.from_le(unhex(r["sk"]))
+            assert M.point_bytes(M.pmul(M.GEN, sk)).hex() == r["PK"], ("PK = sk*G", r["i"])
+            assert M.compress(H.to_int_point(PK[0])).hex() == r["pk_bytes"]
+            assert r["sig_bytes"] == r["u"] + M.compress(H.to_int_point(R[0])).hex()
+        elif r["kind"] == "from_bytes":
+            out, ok = decompress(unhex(r["enc"]).reshape(1, 32))
+            assert bool(ok[0]) == r["ok"], ("from_bytes accept/reject", r["i"])
+            if r["ok"]:
+                assert bytes(out[0]).hex() == r["u"] + r["v"], ("from_bytes value", r["i"])
+    return n_sig
+
+
+def test_reference_fixtures_pin_the_oracle():
+    """PARITY HAND-OFF: fixtures dumped from the real dusk-schnorr (tests/reference_fixtures.py,
+    rust/dusk-schnorr-gpu/src/bin/golden_gen.rs), when someone has dropped them into
+    tests/golden/, must agree with the oracle: raw sponge, truncation, sign / key bytes, verdicts,
+    decompression edge cases.  Skipped (parity stays "unpinned") while there is none."""
+    import reference_fixtures as RF
+    recs = RF.load()
+    if not recs:
+        pytest.skip("no tests/golden/reference_* fixture present: parity unpinned (DESIGN.md §2)")
+    n = _check_reference_records(recs, O.verify_single_wire, O.verify_single, O.decompress)
+    assert n >= 1
+
+
+def test_reference_fixture_parser_on_a_synthetic_file(tmp_path, monkeypatch):
+    """the hand-off path itself is exercised: a file in golden_gen.rs's format built from the
+    PREDICTED vectors parses and passes; one corrupted challenge-dependent byte fails."""
+    import reference_fixtures as RF
+    P = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "predicted_reference.json")))
+    lines = ["sponge_hash_1_2_3_le " + M.le32(M.sponge_hash([1, 2, 3])).hex(),
+             "truncated_hash_1_2_3_le " + M.le32(M.truncated_hash([1, 2, 3])).hex()]
+    for rec in P["seed_2321"][:3]:
+        lines.append("sig %d sk %s m %s u %s R %s PK %s sig_bytes %s pk_bytes %s verdict true"
+                     % (rec["i"], rec["sk"], rec["m"], rec["u"], rec["R"], rec["PK"], rec["sig_bytes"],
+                        rec["pk_bytes"]))
+    one = M.le32(1).hex()
+    lines.append("from_bytes 0 %s ok u %s v %s" % (one, M.le32(0).hex(), one))
+    (tmp_path / "reference_synthetic.txt").write_text("\n".join(lines) + "\n")
+    monkeypatch.setattr(RF, "GOLDEN_DIR", str(tmp_path))
+    recs = RF.load()
+    assert len(recs) == 6
+    assert _check_reference_records(recs, O.verify_single_wire, O.verify_single, O.decompress) == 3
+    bad = [dict(r) for r in recs]
+    u = bytearray(unhex(bad[2]["u"]).tobytes())
+    u[0] ^= 1
+    bad[2]["u"] = bytes(u).hex()
+    with pytest.raises(AssertionError):
+        _check_reference_records(bad, O.verify_single_wire, O.verify_single, O.decompress)

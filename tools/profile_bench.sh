@@ -11,7 +11,7 @@ export TMPDIR=/tmp
 OUT=${1:-gpurun_out/prof}
 ARGS="bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-double"
 mkdir -p $OUT
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $ARGS > $OUT/trace.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline > $OUT/trace.log 2>&1   # incl. double / vargen / mixed kernels
 export DSV_SPLIT=0
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_nosplit -- python3 $ARGS > $OUT/trace_nosplit.log 2>&1
 rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAVES SQ_INSTS_SALU SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --kernel-trace --output-format csv -d $OUT/pmc_sq -- python3 $ARGS > $OUT/pmc_sq.log 2>&1
