@@ -1032,6 +1032,7 @@ struct Context {
   int device = -1;
   bool half_scalars = true;  // DSV_VERIFY_ALGO=classic selects the 250-bit chain instead
   bool split = true;         // DSV_SPLIT=0: one stream, whole batch per launch
+  bool fuse_double = true;   // DSV_DOUBLE_FUSED=0: two single-equation launches per double batch (r01; A/B)
   u32* table[2] = {nullptr, nullptr};  // fixed-base tables for G, G'
   u32* ts_cancel = nullptr;            // square-root tables (decode29.h)
   uint8_t* ts_hash = nullptr;
@@ -1208,7 +1209,7 @@ void launch_verify_fixed(const Context& ctx, bool accumulate, const void* u, con
 void launch_verify_fixed_double(const Context& ctx, const void* u, const void* c, const void* PK_uv,
                                 const void* R_uv, const void* PKp_uv, const void* Rp_uv,
                                 const void* valid, size_t n, void* ok, u32* tables, hipStream_t s) {
-  if (ctx.half_scalars) {
+  if (ctx.half_scalars && ctx.fuse_double) {
     const ChainOperands op0{(const uint8_t*)PK_uv, (const uint8_t*)R_uv, ctx.table[0]};
     const ChainOperands op1{(const uint8_t*)PKp_uv, (const uint8_t*)Rp_uv, ctx.table[1]};
     hipLaunchKernelGGL((k_verify_fixed_half<false, 2>), dim3(verify_grid(n)), dim3(kVerifyBlock), 0,
@@ -1378,6 +1379,8 @@ int dsv_init(int device) {
   HIP_TRY(hipDeviceSynchronize());
   const char* split = getenv("DSV_SPLIT");
   ctx.split = !(split && strcmp(split, "0") == 0);
+  const char* fused = getenv("DSV_DOUBLE_FUSED");
+  ctx.fuse_double = !(fused && strcmp(fused, "0") == 0);
   const char* algo = getenv("DSV_VERIFY_ALGO");
   ctx.half_scalars = !(algo && strcmp(algo, "classic") == 0);
   ctx.ready.store(true, std::memory_order_release);
