@@ -171,7 +171,15 @@ def main():
     dev = "cuda:%d" % dev_index
 
     dist = None
-    if world > 1:
+    # DSV_BENCH_FORCE_DIST=1: create the process group even for one rank, so that a one-GPU box
+    # exercises the real RCCL collectives (all_gather / all_reduce / barrier over one rank)
+    force_dist = world == 1 and os.environ.get("DSV_BENCH_FORCE_DIST") == "1"
+    if force_dist:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", str(_free_port()))
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
+    if world > 1 or force_dist:
         import torch.distributed as dist
 
         if backend == "nccl":
@@ -186,8 +194,10 @@ def main():
     E.init(dev_index)
     n = 1 << args.log2_batch
 
+    multi = dist is not None
+
     def sync_all():
-        if world > 1:
+        if multi:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -203,7 +213,7 @@ def main():
         sync_all()
         dt = time.perf_counter() - t0
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        if world > 1:
+        if multi:
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
 
@@ -211,15 +221,15 @@ def main():
     def run_mixed(steps, warmup):
         mb = W.gen_mixed(n, seed=2321, device=dev, first_item=rank * n)
         gk = (torch.arange(world * n, device=dev) & 1).to(torch.uint8)   # the global kind vector
-        ver = MixedShardedVerifier(n, mb["n_double"], world, rank, dev)
-        if world > 1:
+        ver = MixedShardedVerifier(n, mb["n_double"], world, rank, dev, collective=multi)
+        if multi:
             ver(mb, gk)                          # communicator set-up is not a step
         dtm = timed(lambda: ver(mb, gk), steps, warmup)
         out_all = ver(mb, gk)
         torch.cuda.synchronize()
         mine = out_all[rank * n:(rank + 1) * n]
         bad = int((mine != mb["expected"]).sum().item())
-        if world > 1:                            # the gathered verdicts of the OTHER ranks
+        if multi:                                # the gathered verdicts of the OTHER ranks
             exp_all = torch.empty(world * n, dtype=torch.uint8, device=dev)
             dist.all_gather_into_tensor(exp_all, mb["expected"])
             bad += int((out_all != exp_all).sum().item())
@@ -237,8 +247,8 @@ def main():
         "metric": METRIC, "unit": "verifies/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "u32x9 (29-bit limbs, u64 accumulate)",
-        "world_size": world, "backend": ("rccl" if backend == "nccl" else backend) if world > 1 else "none",
-        "rccl_version": ".".join(map(str, torch.cuda.nccl.version())) if world > 1 and backend == "nccl" else None,
+        "world_size": world, "backend": ("rccl" if backend == "nccl" else backend) if multi else "none",
+        "rccl_version": ".".join(map(str, torch.cuda.nccl.version())) if multi and backend == "nccl" else None,
         "launcher": "self-spawned" if os.environ.get("DSV_BENCH_SPAWNED") else
                     ("torch.distributed.run" if world > 1 else "single process"),
     }
@@ -249,10 +259,10 @@ def main():
                    data="synthetic: reference harness inputs (StdRng 2321 / 2322), GPU-signed, every "
                         "16th item of each kind corrupted",
                    config={"workload": res["workload"], "batch_per_gpu": n, "parallelism": "dp%d" % world,
-                           "collective": "2 x all_gather of per-kind verdict bytes" if world > 1 else "none"})
+                           "collective": "2 x all_gather of per-kind verdict bytes" if multi else "none"})
         if rank == 0:
             print(json.dumps(out))
-        if world > 1:
+        if multi:
             dist.barrier()
             dist.destroy_process_group()
         return
@@ -263,14 +273,14 @@ def main():
     ws = torch.empty(E.workspace_bytes(n), dtype=torch.uint8, device=dev)
     c = torch.empty((n, 32), dtype=torch.uint8, device=dev)
     valid = torch.empty(n, dtype=torch.uint8, device=dev)
-    gathered = torch.empty(world * n, dtype=torch.uint8, device=dev) if world > 1 else None
+    gathered = torch.empty(world * n, dtype=torch.uint8, device=dev) if multi else None
 
     def step():
         E.verify_single_dev(batch["u"], batch["R"], batch["PK"], batch["m"], ok, ws)
-        if world > 1:
+        if multi:
             dist.all_gather_into_tensor(gathered, ok)
 
-    if world > 1:
+    if multi:
         dist.all_gather_into_tensor(gathered, ok)  # RCCL connects lazily: not a step
     dt = timed(step, args.steps, args.warmup)
     ok_api = ok.clone()
@@ -293,7 +303,7 @@ def main():
 
     mism = int((ok != batch["expected"]).sum().item())
     mism_api = int((ok_api != batch["expected"]).sum().item())
-    if world > 1:
+    if multi:
         mine = gathered[rank * n:(rank + 1) * n]
         mism += int((mine != batch["expected"]).sum().item())
     if mism or mism_api:
@@ -308,7 +318,7 @@ def main():
                                    "`value` is this figure, `double` / `vargen` / `mixed` ride along"
                                    % args.log2_batch,
                        "batch_per_gpu": n, "parallelism": "dp%d" % world,
-                       "collective": "all_gather of verdict bytes" if world > 1 else "none"})
+                       "collective": "all_gather of verdict bytes" if multi else "none"})
 
     kernels = {}
 
@@ -507,7 +517,7 @@ def main():
 
     if rank == 0:
         print(json.dumps(out))
-    if world > 1:
+    if multi:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -106,7 +106,7 @@ class MixedShardedVerifier:
     by the caller, who knows its batch): that is what "shard each kind evenly" means for a batch the
     ranks already hold."""
 
-    def __init__(self, n_local, n_double_local, world, rank, device, group=None):
+    def __init__(self, n_local, n_double_local, world, rank, device, group=None, collective=None):
         import torch
 
         from . import engine as E
@@ -114,6 +114,8 @@ class MixedShardedVerifier:
         self.E, self.torch = E, torch
         self.n, self.nd, self.ns = n_local, n_double_local, n_local - n_double_local
         self.world, self.rank, self.group, self.dev = world, rank, group, device
+        # collective=True runs the all_gathers even for one rank (RCCL rehearsal on a one-GPU box)
+        self.collective = world > 1 if collective is None else collective
         u8 = lambda *shape: torch.empty(shape, dtype=torch.uint8, device=device)
         i32 = lambda k: torch.empty(max(k, 1), dtype=torch.int32, device=device)
         self.idx_s, self.idx_d = i32(self.ns), i32(self.nd)
@@ -147,7 +149,7 @@ class MixedShardedVerifier:
             E.verify_double_dev(self.cd["u"][:nd], self.cd["R"][:nd], self.cd["Rp"][:nd],
                                 self.cd["PK"][:nd], self.cd["PKp"][:nd], self.cd["m"][:nd],
                                 self.ok_d, self.ws)
-        if self.world > 1:
+        if self.collective:
             if ns:
                 dist.all_gather_into_tensor(self.all_s[:self.world * ns], self.ok_s[:ns], group=self.group)
             if nd:

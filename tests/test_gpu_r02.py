@@ -334,27 +334,14 @@ def test_many_device_callers_then_shutdown_contract(engine):
     assert torch.equal(ok, b["expected"])
 
 
-def _run_bench(args, extra_env):
-    env = dict(os.environ)
-    env.update(extra_env)
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, cwd=ROOT, env=env,
-                       capture_output=True, text=True, timeout=900)
-    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
-    lines = [l for l in r.stdout.strip().splitlines() if l.startswith("{")]
-    assert len(lines) == 1, r.stdout[-1500:]
-    return json.loads(lines[0])
-
-
 def test_bench_spawns_its_own_ranks_and_runs_the_mixed_config():
     """`python bench.py --gpus 2` from a plain shell (no torchrun, WORLD_SIZE
     unset) starts two fresh ranks itself.  On this one-GPU box both ranks share GPU 0 and the
     gather runs over gloo (RCCL refuses two ranks on one device); the code path is the one the
     8-GPU run takes: per-rank shards of one StdRng stream, HIP engine, all_gather inside the
     timed region, and the configs[4] mixed batch with its device-side split."""
-    env = {"DSV_BENCH_DEVICE": "0", "DSV_BENCH_BACKEND": "gloo"}
-    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
-        env[k] = ""
-    clean = {k: v for k, v in os.environ.items() if k not in env}
+    drop = ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")
+    clean = {k: v for k, v in os.environ.items() if k not in drop}
     clean.update({"DSV_BENCH_DEVICE": "0", "DSV_BENCH_BACKEND": "gloo"})
 
     def run(args):
@@ -371,6 +358,22 @@ def test_bench_spawns_its_own_ranks_and_runs_the_mixed_config():
     assert d["mixed"]["n_gpus"] == 2 and d["mixed"]["value"] > 0
     m = run(["--gpus", "2", "--steps", "2", "--warmup", "1", "--log2-batch", "15", "--config", "mixed"])
     assert m["world_size"] == 2 and m["value"] > 0 and "configs[4]" in m["config"]["workload"]
+
+
+def test_bench_collectives_over_rccl_with_one_rank():
+    """The RCCL half of the multi-GPU path on a one-GPU box: DSV_BENCH_FORCE_DIST=1 creates the
+    "nccl" process group for a single rank, so the timed steps run the real RCCL all_gather /
+    all_reduce / barrier (with N ranks only the communicator is wider)."""
+    drop = ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "DSV_BENCH_BACKEND")
+    env = {k: v for k, v in os.environ.items() if k not in drop}
+    env["DSV_BENCH_FORCE_DIST"] = "1"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1",
+                        "--log2-batch", "16", "--no-cpu-baseline"], cwd=ROOT, env=env,
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    d = json.loads([l for l in r.stdout.strip().splitlines() if l.startswith("{")][0])
+    assert d["backend"] == "rccl" and d["rccl_version"] and d["world_size"] == 1
+    assert d["config"]["collective"].startswith("all_gather") and d["mixed"]["value"] > 0
 
 
 def _sharded_worker(rank, world, port, q):
