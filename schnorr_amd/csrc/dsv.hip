@@ -165,6 +165,7 @@ struct Context {
   bool half_scalars = true;  // DSV_VERIFY_ALGO=classic selects the 250-bit chain instead
   bool split = true;         // DSV_SPLIT=0: one stream, whole batch per launch
   bool fuse_double = true;   // DSV_DOUBLE_FUSED=0: two single-equation launches per double batch (r01; A/B)
+  bool quad = true;          // DSV_QUAD=0: batches of <= 2^14 items also take the one-lane-per-signature kernel
   u32* table[2] = {nullptr, nullptr};  // fixed-base tables for G, G'
   u32* ts_cancel = nullptr;            // square-root tables (decode29.h)
   uint8_t* ts_hash = nullptr;
@@ -320,6 +321,17 @@ void launch_verify_fixed(const Context& ctx, bool accumulate, const void* u, con
                          const void* PK_uv, const void* R_uv, int which, const void* valid,
                          size_t n, void* ok, u32* tables, hipStream_t s) {
   const dim3 grid(verify_grid(n)), block(kVerifyBlock);
+  if (ctx.half_scalars && ctx.quad && n <= kQuadMaxItems) {  // small batch: four lanes per signature
+    const ChainOperands op{(const uint8_t*)PK_uv, (const uint8_t*)R_uv, ctx.table[which]};
+    const dim3 qgrid((unsigned)((4 * n + kQuadBlock - 1) / kQuadBlock)), qblock(kQuadBlock);
+    if (accumulate)
+      hipLaunchKernelGGL((k_verify_fixed_half_quad<true, 1>), qgrid, qblock, 0, s, (const uint8_t*)u,
+                         (const uint8_t*)c, op, op, (const uint8_t*)valid, n, (uint8_t*)ok, tables);
+    else
+      hipLaunchKernelGGL((k_verify_fixed_half_quad<false, 1>), qgrid, qblock, 0, s, (const uint8_t*)u,
+                         (const uint8_t*)c, op, op, (const uint8_t*)valid, n, (uint8_t*)ok, tables);
+    return;
+  }
   if (ctx.half_scalars) {
     const ChainOperands op{(const uint8_t*)PK_uv, (const uint8_t*)R_uv, ctx.table[which]};
     if (accumulate)
@@ -344,6 +356,13 @@ void launch_verify_fixed_double(const Context& ctx, const void* u, const void* c
   if (ctx.half_scalars && ctx.fuse_double) {
     const ChainOperands op0{(const uint8_t*)PK_uv, (const uint8_t*)R_uv, ctx.table[0]};
     const ChainOperands op1{(const uint8_t*)PKp_uv, (const uint8_t*)Rp_uv, ctx.table[1]};
+    if (ctx.quad && n <= kQuadMaxItems) {
+      hipLaunchKernelGGL((k_verify_fixed_half_quad<false, 2>),
+                         dim3((unsigned)((4 * n + kQuadBlock - 1) / kQuadBlock)), dim3(kQuadBlock), 0, s,
+                         (const uint8_t*)u, (const uint8_t*)c, op0, op1, (const uint8_t*)valid, n,
+                         (uint8_t*)ok, tables);
+      return;
+    }
     hipLaunchKernelGGL((k_verify_fixed_half<false, 2>), dim3(verify_grid(n)), dim3(kVerifyBlock), 0,
                        s, (const uint8_t*)u, (const uint8_t*)c, op0, op1, (const uint8_t*)valid, n,
                        (uint8_t*)ok, tables);
@@ -511,6 +530,8 @@ int dsv_init(int device) {
   HIP_TRY(hipDeviceSynchronize());
   const char* split = getenv("DSV_SPLIT");
   ctx.split = !(split && strcmp(split, "0") == 0);
+  const char* quad = getenv("DSV_QUAD");
+  ctx.quad = !(quad && strcmp(quad, "0") == 0);
   const char* fused = getenv("DSV_DOUBLE_FUSED");
   ctx.fuse_double = !(fused && strcmp(fused, "0") == 0);
   const char* algo = getenv("DSV_VERIFY_ALGO");

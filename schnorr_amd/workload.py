@@ -20,6 +20,13 @@ def _rand_scalars(n, top_mask, gen, device):
     return x.contiguous()
 
 
+def _arange(lo, hi, step, device):
+    """torch.arange that tolerates an empty range (tiny batches)"""
+    if hi <= lo:
+        return torch.empty(0, dtype=torch.int64, device=device)
+    return torch.arange(lo, hi, step, device=device)
+
+
 def _tamper(batch, n):
     """Corrupt items i = 0 (mod 16), cycling 4 classes; returns expected verdicts."""
     dev = batch["u"].device
@@ -74,7 +81,7 @@ def gen_double(n, seed, device="cuda:0", tamper=True, first_item=0):
     if tamper:
         expected = _tamper(batch, n)
         # additionally break ONLY the primed half of items i = 8 (mod 16)
-        idx = torch.arange(8, n, TAMPER_PERIOD, device=u.device)
+        idx = _arange(8, n, TAMPER_PERIOD, u.device)
         batch["PKp"][idx] = batch["PKp"][(idx + 1) % n]
         expected[idx] = 0
         batch["expected"] = expected
@@ -99,7 +106,7 @@ def gen_vargen(n, seed, device="cuda:0", tamper=True, first_item=0):
     batch = {"u": u, "R": R, "PK": PK, "Gen": Gen, "m": m}
     if tamper:
         expected = _tamper(batch, n)
-        idx = torch.arange(8, n, TAMPER_PERIOD, device=device)
+        idx = _arange(8, n, TAMPER_PERIOD, device)
         batch["Gen"][idx] = batch["Gen"][(idx + 1) % n]      # wrong generator
         expected[idx] = 0
         batch["expected"] = expected

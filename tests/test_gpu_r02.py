@@ -71,6 +71,30 @@ def test_fused_double_kernel_equals_two_single_equation_passes(engine):
     assert 0 < want.sum() < n
 
 
+@pytest.mark.parametrize("n", [2, 5, 63, 64, 65, (1 << 14) - 1, 1 << 14, (1 << 14) + 1])
+def test_four_lane_kernel_boundary_sizes(engine, n):
+    """Batches of <= 2^14 items take k_verify_fixed_half_quad (four lanes per signature, quad29.h),
+    larger ones the one-lane kernel: ragged sizes around the workgroup (64 items) and around the
+    switch-over, single and double, against the expected pattern and an oracle sample."""
+    import torch
+    from schnorr_amd import workload as W
+    ws = torch.empty(engine.workspace_bytes(n), dtype=torch.uint8, device="cuda:0")
+    for kind in ("single", "double"):
+        b = (W.gen_single if kind == "single" else W.gen_double)(n, seed=900 + n % 97)
+        ok = torch.full((n,), 9, dtype=torch.uint8, device="cuda:0")
+        if kind == "single":
+            engine.verify_single_dev(b["u"], b["R"], b["PK"], b["m"], ok, ws)
+        else:
+            engine.verify_double_dev(b["u"], b["R"], b["Rp"], b["PK"], b["PKp"], b["m"], ok, ws)
+        torch.cuda.synchronize()
+        assert torch.equal(ok, b["expected"]), (kind, n)
+        k = min(n, 96)
+        cols = ("u", "R", "PK", "m") if kind == "single" else ("u", "R", "Rp", "PK", "PKp", "m")
+        sub = [b[c][:k].cpu().numpy() for c in cols]
+        want = (O.verify_single if kind == "single" else O.verify_double)(*sub, nthreads=8)
+        assert np.array_equal(want, ok[:k].cpu().numpy()), (kind, n)
+
+
 @pytest.mark.parametrize("n", [1, 15, 16, 17, 4095, 4096, 4097, 100003])
 def test_split_kinds_matches_numpy(engine, n):
     import torch

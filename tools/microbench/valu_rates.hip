@@ -79,6 +79,9 @@ DEF_KERNEL_U32(not_b32, "v_not_b32 %0, %0")
 DEF_KERNEL_U32(mov_b32, "v_mov_b32 %0, %1")
 DEF_KERNEL_U32(bitop3, "v_bitop3_b32 %0, %0, %1, %0 bitop3:0xc")
 DEF_KERNEL_U32(add_u32_nop, "v_add_u32 %0, %0, %1\n s_nop 0")
+// selects and quad exchanges (costing a 4-lanes-per-signature group law)
+DEF_KERNEL_U32(cndmask_sgpr, "v_cndmask_b32 %0, %0, %1, s[10:11]")
+DEF_KERNEL_U32(mov_dpp_quad, "v_mov_b32_dpp %0, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf")
 
 #define DEF_KERNEL_U64(NAME, ASMSTR)                                           \
   __global__ void __launch_bounds__(256) k_##NAME(uint32_t* out, uint32_t s) { \
@@ -204,7 +207,7 @@ int main(int argc, char** argv) {
       E(fma_f32), E(alignbit), E(lshl_add), E(and_or), E(xad), E(dot2_u32_u16),
       E(dot4_u32_u8), E(pk_mul_lo_u16), E(pk_mad_u16), E(cndmask),
       E(and_b32), E(or_b32), E(xor_b32), E(sub_u32), E(lshrrev_b32), E(lshlrev_b32), E(not_b32),
-      E(mov_b32), E(bitop3), E(add_u32_nop),
+      E(mov_b32), E(bitop3), E(add_u32_nop), E(cndmask_sgpr), E(mov_dpp_quad),
       E(mad_u64_u32), E(mad_u64_u32_sgprcarry), E(lshl_add_u64), E(lshlrev_b64), E(lshrrev_b64),
       E(mad_u64_u32_nop),
       E(fma_f64), E(add_f64), E(mul_f64), E(pk_fma_f32), E(pk_add_f32),
