@@ -43,7 +43,13 @@ inline void check(int rc, const char* what) {
                              dsv_last_error());
 }
 inline void ensure_init() {
-  static const bool once = (check(dsv_init(0), "dsv_init"), true);
+  // every GPU of the node: verify_batch* shard over all of them (dsv_verify_*_multi)
+  static const bool once = [] {
+    const int count = dsv_device_count();
+    if (count <= 0) check(dsv_init(0), "dsv_init");  // reports DSV_ERR_NO_DEVICE
+    for (int d = 0; d < count; d++) check(dsv_init(d), "dsv_init");
+    return true;
+  }();
   (void)once;
 }
 // x mod m for a 512-bit little-endian x and a 256-bit little-endian modulus (shift-subtract)
@@ -386,8 +392,8 @@ inline std::vector<bool> verify_batch(const std::vector<Signature>& sigs,
     std::memcpy(&pk[64 * i], pks[i].pk.uv.data(), 64);
     std::memcpy(&m[32 * i], msgs[i].bytes.data(), 32);
   }
-  detail::check(dsv_verify_single(u.data(), r.data(), pk.data(), m.data(), n, ok.data()),
-                "dsv_verify_single");
+  detail::check(dsv_verify_single_multi(u.data(), r.data(), pk.data(), m.data(), n, ok.data()),
+                "dsv_verify_single_multi");
   std::vector<bool> out(n);
   for (size_t i = 0; i < n; i++) out[i] = ok[i] == 1;
   return out;
@@ -408,8 +414,8 @@ inline std::vector<bool> verify_batch_double(const std::vector<SignatureDouble>&
     std::memcpy(&pkp[64 * i], pks[i].pk_prime_.uv.data(), 64);
     std::memcpy(&m[32 * i], msgs[i].bytes.data(), 32);
   }
-  detail::check(dsv_verify_double(u.data(), r.data(), rp.data(), pk.data(), pkp.data(), m.data(),
-                                  n, ok.data()), "dsv_verify_double");
+  detail::check(dsv_verify_double_multi(u.data(), r.data(), rp.data(), pk.data(), pkp.data(),
+                                        m.data(), n, ok.data()), "dsv_verify_double_multi");
   std::vector<bool> out(n);
   for (size_t i = 0; i < n; i++) out[i] = ok[i] == 1;
   return out;
@@ -429,8 +435,8 @@ inline std::vector<bool> verify_batch_var_gen(const std::vector<SignatureVarGen>
     std::memcpy(&g[64 * i], pks[i].generator_.uv.data(), 64);
     std::memcpy(&m[32 * i], msgs[i].bytes.data(), 32);
   }
-  detail::check(dsv_verify_vargen(u.data(), r.data(), pk.data(), g.data(), m.data(), n, ok.data()),
-                "dsv_verify_vargen");
+  detail::check(dsv_verify_vargen_multi(u.data(), r.data(), pk.data(), g.data(), m.data(), n,
+                                        ok.data()), "dsv_verify_vargen_multi");
   std::vector<bool> out(n);
   for (size_t i = 0; i < n; i++) out[i] = ok[i] == 1;
   return out;

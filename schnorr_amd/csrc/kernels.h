@@ -231,14 +231,22 @@ constexpr int kVerifyBlock = 64;        // ONE wave per workgroup: a finished wa
 #endif
 constexpr unsigned kMaxVerifyGrid = DSV_MAX_VERIFY_GRID;
 
+// -DDSV_TABLE_NT=1 / 2: non-temporal stores (1) or stores and loads (2) for the per-lane window
+// tables, so that this write-once / read-few stream does not displace the L2-resident fixed-base
+// tables (A/B knob; see DESIGN.md §6 for the measurement)
+#ifndef DSV_TABLE_NT
+#define DSV_TABLE_NT 0
+#endif
 DSV_DEV void store_fe_words(u32* p, const Fe& a) {
 #pragma unroll
-  for (int i = 0; i < NL; i++) p[i] = a.l[i];
+  for (int i = 0; i < NL; i++) {
+    if (DSV_TABLE_NT >= 1) __builtin_nontemporal_store(a.l[i], p + i); else p[i] = a.l[i];
+  }
 }
 DSV_DEV Fe load_fe_words(const u32* p) {
   Fe r;
 #pragma unroll
-  for (int i = 0; i < NL; i++) r.l[i] = p[i];
+  for (int i = 0; i < NL; i++) r.l[i] = DSV_TABLE_NT >= 2 ? __builtin_nontemporal_load(p + i) : p[i];
   return r;
 }
 DSV_DEV void store_var_entry(u32* lane_tbl, int e, const Niels& n) {
