@@ -589,7 +589,12 @@ int dsv_initialized_devices(int* out, int cap) {
 }
 
 size_t dsv_workspace_bytes(size_t n) {
-  return align_up(n * 32, 256) + align_up(n, 256) + var_table_bytes(n, 2) + 256;
+  // window tables: one launch over n items, or (run_split) two concurrent launches over
+  // kSplitItems items each — whichever is larger (they differ when -DDSV_MAX_VERIFY_GRID < 2048)
+  size_t tables = var_table_bytes(n, 2);
+  if (n >= 2 * kSplitItems && tables < 2 * var_table_bytes(kSplitItems, 2))
+    tables = 2 * var_table_bytes(kSplitItems, 2);
+  return align_up(n * 32, 256) + align_up(n, 256) + tables + 256;
 }
 
 // ---- device-pointer entry points --------------------------------------------------------

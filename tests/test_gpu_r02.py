@@ -358,6 +358,26 @@ def test_many_device_callers_then_shutdown_contract(engine):
     assert torch.equal(ok, b["expected"])
 
 
+def test_more_caller_streams_than_lanes(engine):
+    """A context owns 8 sub-batch lanes; the 9th distinct caller stream shares one by hashing.
+    Twelve streams with a large (sub-batched) call each, all in flight together: every call still
+    behaves as one enqueue on its own stream."""
+    import torch
+    from schnorr_amd import workload as W
+    n = (1 << 17) + 77
+    b = W.gen_single(n, seed=41)
+    streams = [torch.cuda.Stream() for _ in range(12)]
+    oks = [torch.zeros(n, dtype=torch.uint8, device="cuda:0") for _ in streams]
+    wss = [torch.empty(engine.workspace_bytes(n), dtype=torch.uint8, device="cuda:0") for _ in streams]
+    torch.cuda.synchronize()
+    for st, ok, ws in zip(streams, oks, wss):
+        engine.verify_single_dev(b["u"], b["R"], b["PK"], b["m"], ok, ws, stream=st)
+    for st in streams:
+        st.synchronize()
+    for ok in oks:
+        assert torch.equal(ok, b["expected"])
+
+
 def test_bench_spawns_its_own_ranks_and_runs_the_mixed_config():
     """`python bench.py --gpus 2` from a plain shell (no torchrun, WORLD_SIZE
     unset) starts two fresh ranks itself.  On this one-GPU box both ranks share GPU 0 and the
