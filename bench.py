@@ -341,9 +341,12 @@ def main():
         hm, hs, ht, hr = _hash_counts(False)
         kernel_block("k_challenge<false>", hash_ms, n, hm, hs, ht, hr, other=600)
         pmc = _pmc()
-        traffic = clock = None
+        traffic = clock = valu_busy = None
         if pmc:
             traffic = (pmc["FETCH_SIZE_KB"] + pmc["WRITE_SIZE_KB"]) * 1024.0 * n / pmc["batch"]
+            if "SQ_INSTS_VALU" in pmc and "GRBM_GUI_ACTIVE" in pmc:
+                # north_star's "VALU-busy": issue slots taken by VALU instructions in the PMC pass
+                valu_busy = pmc["SQ_INSTS_VALU"] * 4.0 / (N_CU * SIMD_PER_CU * pmc["GRBM_GUI_ACTIVE"] / 8.0)
             clock = pmc.get("clock_held_ghz")
             if clock is None and "GRBM_GUI_ACTIVE" in pmc and "avg_duration_ns" in pmc:
                 clock = pmc["GRBM_GUI_ACTIVE"] / 8.0 / pmc["avg_duration_ns"]
@@ -359,6 +362,7 @@ def main():
             "mad_frac": dom["mad_frac"],
             "valu_issue_frac": dom["valu_issue_frac"],
             "clock_held_ghz": clock,
+            "valu_busy_from_pmc": valu_busy,
             "traffic": traffic,
             "traffic_ratio": traffic / algo if traffic else None,
             "step_mad_frac": (_mads(vm, vs) + _mads(hm, hs, ht, hr)) * n / (dt / args.steps) / MAD_PEAK,

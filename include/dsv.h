@@ -117,7 +117,9 @@ int dsv_verify_vargen_multi(const uint8_t *u, const uint8_t *R_uv, const uint8_t
  * Ordering: everything the call enqueues happens after the work already on `stream` and before
  * anything enqueued on `stream` afterwards.  Batches of >= 2^17 items are cut into 2^16-item
  * parts that run on two library-owned streams forked from / joined to `stream` by events
- * (DSV_SPLIT=0 in the environment at dsv_init keeps every launch on `stream` itself). */
+ * (DSV_SPLIT=0 in the environment at dsv_init keeps every launch on `stream` itself).  Batches of
+ * <= 2^14 items run a four-lanes-per-signature kernel that trades throughput for latency
+ * (DSV_QUAD=0 keeps them on the one-lane kernel).  Same verdicts on every path. */
 size_t dsv_workspace_bytes(size_t n);
 int dsv_verify_single_dev(const void *u, const void *R_uv, const void *PK_uv, const void *m,
                           size_t n, void *ok, void *workspace, void *stream);

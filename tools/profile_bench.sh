@@ -11,11 +11,18 @@ export TMPDIR=/tmp
 OUT=${1:-gpurun_out/prof}
 ARGS="bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-double"
 mkdir -p $OUT
+step() { echo "[profile_bench] $1"; }
+step "rocprofv3 --kernel-trace --stats --output-format"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline > $OUT/trace.log 2>&1   # incl. double / vargen / mixed kernels
+step "export DSV_SPLIT=0"
 export DSV_SPLIT=0
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_nosplit -- python3 $ARGS > $OUT/trace_nosplit.log 2>&1
+step "rocprofv3 --pmc SQ_INSTS_VALU"
 rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAVES SQ_INSTS_SALU SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --kernel-trace --output-format csv -d $OUT/pmc_sq -- python3 $ARGS > $OUT/pmc_sq.log 2>&1
+step "rocprofv3 --pmc SQ_INSTS_VMEM_RD"
 rocprofv3 --pmc SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_WAIT_ANY SQ_IFETCH SQ_INST_LEVEL_VMEM GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT/pmc_sq2 -- python3 $ARGS > $OUT/pmc_sq2.log 2>&1 || true
+step "rocprofv3 --pmc FETCH_SIZE"
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -- python3 $ARGS > $OUT/pmc_fetch.log 2>&1
+step "rocprofv3 --pmc WRITE_SIZE"
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -- python3 $ARGS > $OUT/pmc_write.log 2>&1
 find $OUT -name "*.csv" | head -50
