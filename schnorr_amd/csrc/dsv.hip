@@ -167,6 +167,8 @@ struct Context {
   bool fuse_double = true;   // DSV_DOUBLE_FUSED=0: two single-equation launches per double batch (r01; A/B)
   bool quad = true;          // DSV_QUAD=0: batches of <= 2^14 items also take the one-lane-per-signature kernel
   u32* table[2] = {nullptr, nullptr};  // fixed-base tables for G, G'
+  u32* lds_table = nullptr;            // A/B (-DDSV_FIXED_LDS_BITS): narrow-window table of G, staged in LDS
+  bool fixed_lds = false;              // DSV_FIXED_LDS=1 at dsv_init (only in such a build)
   u32* ts_cancel = nullptr;            // square-root tables (decode29.h)
   uint8_t* ts_hash = nullptr;
   // host-pointer entry points of this device serialise here (they share the staging below)
@@ -332,6 +334,16 @@ void launch_verify_fixed(const Context& ctx, bool accumulate, const void* u, con
                          (const uint8_t*)c, op, op, (const uint8_t*)valid, n, (uint8_t*)ok, tables);
     return;
   }
+  if (DSV_FIXED_LDS_BITS && ctx.half_scalars && ctx.fixed_lds && !accumulate && which == 0) {
+    // A/B: 8-wave workgroups, one per CU at most, table of G staged in LDS
+    const ChainOperands op{(const uint8_t*)PK_uv, (const uint8_t*)R_uv, ctx.lds_table};
+    unsigned g = grid_for(n, kLdsBlock);
+    if (g > 256) g = 256;
+    hipLaunchKernelGGL((k_verify_fixed_half<false, 1, kLdsBlock, true>), dim3(g), dim3(kLdsBlock),
+                       kLdsTableWords * 4, s, (const uint8_t*)u, (const uint8_t*)c, op, op,
+                       (const uint8_t*)valid, n, (uint8_t*)ok, tables);
+    return;
+  }
   if (ctx.half_scalars) {
     const ChainOperands op{(const uint8_t*)PK_uv, (const uint8_t*)R_uv, ctx.table[which]};
     if (accumulate)
@@ -450,6 +462,8 @@ void release_context(Context& ctx) {
     if (ctx.table[g]) (void)hipFree(ctx.table[g]);
     ctx.table[g] = nullptr;
   }
+  if (ctx.lds_table) (void)hipFree(ctx.lds_table);
+  ctx.lds_table = nullptr;
   if (ctx.ts_cancel) (void)hipFree(ctx.ts_cancel);
   if (ctx.ts_hash) (void)hipFree(ctx.ts_hash);
   ctx.ts_cancel = nullptr;
@@ -524,8 +538,21 @@ int dsv_init(int device) {
   for (int g = 0; g < 2; g++) {
     HIP_TRY(hipMalloc(&ctx.table[g], kTableBytes));
     const int total = kFixedWindows * kFixedEntries;
-    hipLaunchKernelGGL(k_build_fixed_table, dim3((total + 63) / 64), dim3(64), 0, 0, ctx.table[g], g);
+    hipLaunchKernelGGL(k_build_fixed_table, dim3((total + 63) / 64), dim3(64), 0, 0, ctx.table[g], g,
+                       kFixedBits, kEntryWords);
     HIP_TRY(hipGetLastError());
+  }
+  if (DSV_FIXED_LDS_BITS) {
+    const char* lds = getenv("DSV_FIXED_LDS");
+    ctx.fixed_lds = lds && strcmp(lds, "1") == 0;
+    HIP_TRY(hipMalloc(&ctx.lds_table, (size_t)kLdsTableWords * 4));
+    const int total = kLdsWindows * kLdsEntries;
+    hipLaunchKernelGGL(k_build_fixed_table, dim3((total + 63) / 64), dim3(64), 0, 0, ctx.lds_table, 0,
+                       kLdsBits, kLdsEntryWords);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipFuncSetAttribute(
+        reinterpret_cast<const void*>(&k_verify_fixed_half<false, 1, kLdsBlock, true>),
+        hipFuncAttributeMaxDynamicSharedMemorySize, kLdsTableWords * 4));
   }
   HIP_TRY(hipDeviceSynchronize());
   const char* split = getenv("DSV_SPLIT");

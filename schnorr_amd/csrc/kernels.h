@@ -101,10 +101,14 @@ DSV_DEV Ext ext_mul_words(const Ext& p, const u32 (&s)[8]) {
 // init: fixed-base tables.  table[w][d] = affine niels of (d * 2^(kFixedBits*w)) * Gen, d = 0 ..
 // 2^(kFixedBits-1), canonical limbs (+ the negated 2d*uv).
 // ------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(64) k_build_fixed_table(u32* __restrict__ table, int which) {
+// bits / entry_words: the shipped table (kFixedBits, 4 fields) or the LDS-staged A/B variant
+// (DSV_FIXED_LDS_BITS, 3 fields: no stored negation)
+__global__ void __launch_bounds__(64) k_build_fixed_table(u32* __restrict__ table, int which, int bits,
+                                                          int entry_words) {
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= kFixedWindows * kFixedEntries) return;
-  const int w = idx / kFixedEntries, d = idx % kFixedEntries;
+  const int windows = (253 + bits - 1) / bits, entries = (1 << (bits - 1)) + 1;
+  if (idx >= windows * entries) return;
+  const int w = idx / entries, d = idx % entries;
   const u32 gu[NL] = DSV_GEN_U, gv[NL] = DSV_GEN_V, nu[NL] = DSV_GENN_U, nv[NL] = DSV_GENN_V;
   Ext g = which == 0 ? ext_from_affine(fe_const(gu), fe_const(gv))
                      : ext_from_affine(fe_const(nu), fe_const(nv));
@@ -112,7 +116,7 @@ __global__ void __launch_bounds__(64) k_build_fixed_table(u32* __restrict__ tabl
   u32 s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   // (entries whose scalar would not fit 256 bits are never looked up: a digit there is 0 or 1
   //  and 1 << pos < 2^253)
-  const int pos = kFixedBits * w, wi = pos >> 5, sh = pos & 31;
+  const int pos = bits * w, wi = pos >> 5, sh = pos & 31;
   const u64 v = (u64)(u32)d << sh;
 #pragma unroll
   for (int i = 0; i < 8; i++) {
@@ -127,13 +131,13 @@ __global__ void __launch_bounds__(64) k_build_fixed_table(u32* __restrict__ tabl
   Fe t2d = fe_mul(fe_mul(u, v2), fe_const(kD2));
   Fe nt2d = fe_canon(fe_neg2(t2d));
   t2d = fe_canon(t2d);
-  u32* e = table + (size_t)idx * kEntryWords;
+  u32* e = table + (size_t)idx * entry_words;
 #pragma unroll
   for (int i = 0; i < NL; i++) {
     e[i] = vpu.l[i];
     e[NL + i] = vmu.l[i];
     e[2 * NL + i] = t2d.l[i];
-    e[3 * NL + i] = nt2d.l[i];
+    if (entry_words > 3 * NL) e[3 * NL + i] = nt2d.l[i];
   }
 }
 
@@ -200,6 +204,60 @@ DSV_DEV Ext fixed_base_accumulate(Ext acc, const u32 (&s)[8], const u32* __restr
     for (int i = 0; i < 8; i++) y[i] = __funnelshift_r(y[i], y[i + 1], kFixedBits);
     y[8] >>= kFixedBits;
     ANiels e = load_aniels(table, w, d);
+    acc = ext_add_aniels(acc, e);
+  }
+  return acc;
+}
+
+// ---- A/B: the fixed-base table staged in LDS (north_star: "LDS-staged windowed fixed-base tables")
+// -DDSV_FIXED_LDS_BITS=5: signed 5-bit windows, 51 windows x 17 entries x 108 B = 93.6 KB, copied
+// into LDS once per (persistent, 512-thread) workgroup; 6 bits: 43 x 33 x 108 B = 153 KB.  The 160 KB
+// of LDS cannot hold the 11-bit table (3.4 MB), so staging costs 51 (43) mixed additions instead
+// of 23.  Single-equation kernel only (two generators do not fit).  Measurement: DESIGN.md §6.
+#ifndef DSV_FIXED_LDS_BITS
+#define DSV_FIXED_LDS_BITS 0
+#endif
+constexpr int kLdsBits = DSV_FIXED_LDS_BITS ? DSV_FIXED_LDS_BITS : 5;
+constexpr int kLdsWindows = (253 + kLdsBits - 1) / kLdsBits;
+constexpr int kLdsHalf = 1 << (kLdsBits - 1);
+constexpr int kLdsEntries = kLdsHalf + 1;
+constexpr int kLdsEntryWords = 3 * NL;
+constexpr int kLdsTableWords = kLdsWindows * kLdsEntries * kLdsEntryWords;
+constexpr int kLdsBlock = 512;  // 8 waves share one copy of the table
+
+DSV_DEV Ext fixed_base_accumulate_lds(Ext acc, const u32 (&s)[8], const u32* lds_table) {
+  u32 y[9];
+  {
+    u32 carry = 0;
+#pragma unroll
+    for (int i = 0; i < 9; i++) {
+      u32 bias = 0;
+#pragma unroll
+      for (int k = 0; k < kLdsWindows; k++) {
+        const int pos = kLdsBits * k + kLdsBits - 1;
+        if ((pos >> 5) == i) bias |= 1u << (pos & 31);
+      }
+      const u64 t = (u64)(i < 8 ? s[i] : 0u) + bias + carry;
+      y[i] = (u32)t;
+      carry = (u32)(t >> 32);
+    }
+  }
+#pragma unroll 1
+  for (int w = 0; w < kLdsWindows; w++) {
+    const int d = (int)(y[0] & ((1u << kLdsBits) - 1)) - kLdsHalf;
+#pragma unroll
+    for (int i = 0; i < 8; i++) y[i] = __funnelshift_r(y[i], y[i + 1], kLdsBits);
+    y[8] >>= kLdsBits;
+    const bool neg = d < 0;
+    const u32* p = lds_table + (w * kLdsEntries + (neg ? -d : d)) * kLdsEntryWords;
+    ANiels e;
+#pragma unroll
+    for (int i = 0; i < NL; i++) {
+      e.vpu.l[i] = p[(neg ? NL : 0) + i];
+      e.vmu.l[i] = p[(neg ? 0 : NL) + i];
+      e.t2d.l[i] = p[2 * NL + i];
+    }
+    e.t2d = fe_select(neg, fe_neg2(e.t2d), e.t2d);
     acc = ext_add_aniels(acc, e);
   }
   return acc;
@@ -404,11 +462,20 @@ struct ChainOperands {
   const uint8_t* R_uv;
   const u32* table;  // fixed-base table of the generator that goes with this (PK, R) pair
 };
-template <bool ACCUM, int NCHAIN>
-__global__ void __launch_bounds__(kVerifyBlock, DSV_WAVES_VERIFY)
+// BLOCK / LDS: the shipped kernel runs single-wave workgroups with the fixed-base table in L2
+// (BLOCK = 64, LDS = false); the A/B variant runs 8-wave workgroups that stage a narrower table in
+// LDS first (op0.table then points at the DSV_FIXED_LDS_BITS-bit table in global memory).
+template <bool ACCUM, int NCHAIN, int BLOCK = kVerifyBlock, bool LDS = false>
+__global__ void __launch_bounds__(BLOCK, BLOCK == kVerifyBlock ? DSV_WAVES_VERIFY : 1)
 k_verify_fixed_half(const uint8_t* __restrict__ u, const uint8_t* __restrict__ c,
                     ChainOperands op0, ChainOperands op1, const uint8_t* __restrict__ valid,
                     size_t n, uint8_t* __restrict__ ok, u32* __restrict__ var_tables) {
+  extern __shared__ u32 lds_table[];
+  if (LDS) {
+    for (int k = threadIdx.x; k < kLdsTableWords; k += BLOCK) lds_table[k] = op0.table[k];
+    __syncthreads();
+  }
+  constexpr int kVerifyBlock = BLOCK;  // shadows the namespace constant inside this kernel
   u32* tpk = var_tables + ((size_t)blockIdx.x * kVerifyBlock + threadIdx.x) * (2 * kVarLaneWords);
   u32* tr = tpk + kVarLaneWords;
 #pragma unroll 1
@@ -471,7 +538,7 @@ k_verify_fixed_half(const uint8_t* __restrict__ u, const uint8_t* __restrict__ c
         acc = ext_add_niels(acc, load_var_entry(tpk, sdigit4(ya, k)));
         acc = ext_add_niels(acc, load_var_entry(tr, rsign * sdigit4(yb, k)));
       }
-      acc = fixed_base_accumulate(acc, w, op.table);
+      acc = LDS ? fixed_base_accumulate_lds(acc, w, lds_table) : fixed_base_accumulate(acc, w, op.table);
       // T == O  <=>  u == 0 and v == z
       good &= (bool)((int)fe_is_zero_canon(fe_canon(acc.u)) & (int)fe_equal(acc.v, acc.z));
     }
