@@ -370,6 +370,72 @@ DSV_DEV Ext ext_mul16(const Ext& p) {
   return ext_double(q);
 }
 
+// ---- A/B: window width of the half-scalar chain (-DDSV_HALF_WINDOW_BITS=3; shipped: 4) ----------
+// W-bit signed windows: entries |d| = 0 .. 2^(W-1), digits in [-2^(W-1), 2^(W-1)).  Only
+// k_verify_fixed_half uses these; every other kernel keeps the 4-bit forms above.
+#ifndef DSV_HALF_WINDOW_BITS
+#define DSV_HALF_WINDOW_BITS 4
+#endif
+constexpr int kHalfW = DSV_HALF_WINDOW_BITS;
+constexpr int kHalfEntries = (1 << (kHalfW - 1)) + 1;
+constexpr int kHalfLaneWords = kHalfEntries * kVarEntryWords;
+static_assert(kHalfW == 3 || kHalfW == 4, "window width of the half-scalar chain");
+template <int W>
+DSV_DEV u32 recode_bias_word(int i) {  // bits W*k + W-1 that fall into word i
+  u32 b = 0;
+#pragma unroll
+  for (int k = 0; k * W + W - 1 < 256; k++)
+    if (((k * W + W - 1) >> 5) == i) b |= 1u << ((k * W + W - 1) & 31);
+  return b;
+}
+template <int W>
+DSV_DEV void recode_signed_w(u32 (&y)[8], const u32 (&s)[8]) {
+  u32 carry = 0;
+#pragma unroll
+  for (int i = 0; i < 8; i++) {
+    u64 t = (u64)s[i] + recode_bias_word<W>(i) + carry;
+    y[i] = (u32)t;
+    carry = (u32)(t >> 32);
+  }
+}
+template <int W>
+DSV_DEV int sdigit_w(const u32 (&y)[8], int k) {
+  if (W == 4) return sdigit4(y, k);
+  const int pos = W * k, wi = pos >> 5, off = pos & 31;
+  u32 lo = 0, hi = 0;
+#pragma unroll
+  for (int i = 0; i < 8; i++) {  // dynamic word pick without a dynamically indexed register
+    lo = i == wi ? y[i] : lo;
+    hi = i == wi + 1 ? y[i] : hi;
+  }
+  const u64 two = ((u64)hi << 32) | lo;
+  return (int)((two >> off) & ((1u << W) - 1)) - (1 << (W - 1));
+}
+template <int N>
+DSV_DEV void build_var_table_n(u32* lane_tbl, const Fe& pu, const Fe& pv) {
+  Ext p = ext_from_affine(pu, pv);
+  Niels n1 = ext_to_niels(p);
+  store_var_entry(lane_tbl, 0, niels_identity());
+  store_var_entry(lane_tbl, 1, n1);
+  Ext cur = p;
+#pragma unroll 1
+  for (int i = 2; i < N; i++) {
+    cur = ext_add_niels(cur, n1);
+    store_var_entry(lane_tbl, i, ext_to_niels(cur));
+  }
+}
+template <int W>
+DSV_DEV Ext ext_mul_pow2(const Ext& p) {  // 2^W * p
+  Fe u = p.u, v = p.v, z = p.z;
+#pragma unroll 1
+  for (int j = 0; j < W - 1; j++) ext_double_uvz(u, v, z);
+  Ext q;
+  q.u = u;
+  q.v = v;
+  q.z = z;
+  return ext_double(q);
+}
+
 // s * P, signed 4-bit fixed windows, MSB first: acc = 16*acc + T[digit].  TOP = index of the
 // highest possibly non-zero digit (62 for a 250-bit challenge, 63 for a 252-bit Fr scalar); the
 // first window is a plain addition onto the identity (no doublings of the identity).
@@ -476,8 +542,8 @@ k_verify_fixed_half(const uint8_t* __restrict__ u, const uint8_t* __restrict__ c
     __syncthreads();
   }
   constexpr int kVerifyBlock = BLOCK;  // shadows the namespace constant inside this kernel
-  u32* tpk = var_tables + ((size_t)blockIdx.x * kVerifyBlock + threadIdx.x) * (2 * kVarLaneWords);
-  u32* tr = tpk + kVarLaneWords;
+  u32* tpk = var_tables + ((size_t)blockIdx.x * kVerifyBlock + threadIdx.x) * (2 * kHalfLaneWords);
+  u32* tr = tpk + kHalfLaneWords;
 #pragma unroll 1
   for (size_t base = (size_t)blockIdx.x * kVerifyBlock; base < n;
        base += (size_t)gridDim.x * kVerifyBlock) {
@@ -491,14 +557,15 @@ k_verify_fixed_half(const uint8_t* __restrict__ u, const uint8_t* __restrict__ c
       u32 cs[8], a[8], b[8];
       load_words8(cs, c, i);
       half_scalars(a, b, b_neg, cs);
-      recode_signed4(ya, a);
-      recode_signed4(yb, b);
+      recode_signed_w<kHalfW>(ya, a);
+      recode_signed_w<kHalfW>(yb, b);
       // index of the highest non-zero signed digit of either scalar (a zero digit is nibble 8)
       u32 nz[8];
 #pragma unroll
-      for (int k = 0; k < 8; k++) nz[k] = (ya[k] ^ 0x88888888u) | (yb[k] ^ 0x88888888u);
+      for (int k = 0; k < 8; k++)
+        nz[k] = (ya[k] ^ recode_bias_word<kHalfW>(k)) | (yb[k] ^ recode_bias_word<kHalfW>(k));
       const int nzbits = bitlen8(nz);
-      top = nzbits > 0 ? (nzbits - 1) >> 2 : 0;
+      top = nzbits > 0 ? (nzbits - 1) / kHalfW : 0;
       u32 us[8];
       load_words8(us, u, i);
       const bool u_ok = words_lt(us, kR32);
@@ -521,22 +588,22 @@ k_verify_fixed_half(const uint8_t* __restrict__ u, const uint8_t* __restrict__ c
         Fe pku, pkv;
         good &= load_fq(pku, op.PK_uv, 2 * i);
         good &= load_fq(pkv, op.PK_uv, 2 * i + 1);
-        build_var_table(tpk, pku, pkv);
+        build_var_table_n<kHalfEntries>(tpk, pku, pkv);
       }
       {
         Fe ru, rv;
         good &= load_fq(ru, op.R_uv, 2 * i);
         good &= load_fq(rv, op.R_uv, 2 * i + 1);
-        build_var_table(tr, ru, rv);
+        build_var_table_n<kHalfEntries>(tr, ru, rv);
       }
       // T = a*PK + (b_neg ? +|b| : -|b|) * R  (+ w*G below)
-      Ext acc = ext_add_niels(ext_identity(), load_var_entry(tpk, sdigit4(ya, top)));
-      acc = ext_add_niels(acc, load_var_entry(tr, rsign * sdigit4(yb, top)));
+      Ext acc = ext_add_niels(ext_identity(), load_var_entry(tpk, sdigit_w<kHalfW>(ya, top)));
+      acc = ext_add_niels(acc, load_var_entry(tr, rsign * sdigit_w<kHalfW>(yb, top)));
 #pragma unroll 1
       for (int k = top - 1; k >= 0; k--) {
-        acc = ext_mul16(acc);
-        acc = ext_add_niels(acc, load_var_entry(tpk, sdigit4(ya, k)));
-        acc = ext_add_niels(acc, load_var_entry(tr, rsign * sdigit4(yb, k)));
+        acc = ext_mul_pow2<kHalfW>(acc);
+        acc = ext_add_niels(acc, load_var_entry(tpk, sdigit_w<kHalfW>(ya, k)));
+        acc = ext_add_niels(acc, load_var_entry(tr, rsign * sdigit_w<kHalfW>(yb, k)));
       }
       acc = LDS ? fixed_base_accumulate_lds(acc, w, lds_table) : fixed_base_accumulate(acc, w, op.table);
       // T == O  <=>  u == 0 and v == z
