@@ -164,6 +164,7 @@ def main():
         w("// R^2 mod q, plain limbs: to_mont(x) = mont_mul(x, R2)\n")
         w("#define DSV_R2 %s\n" % arr(limbs(RMONT * RMONT % Q)))
         w("#define DSV_ONE %s\n" % arr(mont(1)))
+        w("#define DSV_ONE_LIST %s\n" % arr(mont(1))[1:-1])
         w("#define DSV_D2 %s\n" % arr(mont(2 * D)))
         w("#define DSV_D %s\n" % arr(mont(D)))
         w("#define DSV_GEN_U %s\n#define DSV_GEN_V %s\n" % (arr(mont(GEN[0])), arr(mont(GEN[1]))))

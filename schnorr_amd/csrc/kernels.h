@@ -315,10 +315,22 @@ DSV_DEV void store_var_entry(u32* lane_tbl, int e, const Niels& n) {
   store_fe_words(p + 3 * NL, n.t2d);
   if (DSV_VAR_NEG_T2D) store_fe_words(p + 4 * NL, fe_neg2(n.t2d));
 }
+// Entry 0 (the identity) is the same for every lane: it is read from ONE shared copy instead of
+// being written into every lane's table (-DDSV_SHARED_IDENTITY=0 restores the per-lane copy;
+// one ninth of the table writes, A/B in DESIGN.md §3).
+#ifndef DSV_SHARED_IDENTITY
+#define DSV_SHARED_IDENTITY 1
+#endif
+__device__ const u32 kIdentityEntry[5 * NL] = {
+    // v+u = 1, v-u = 1, z = 1 (Montgomery form), 2d*t = 0, -(2d*t) = 0
+#define DSV_ONE_LIMBS_ DSV_ONE_LIST
+    DSV_ONE_LIMBS_, DSV_ONE_LIMBS_, DSV_ONE_LIMBS_, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0
+#undef DSV_ONE_LIMBS_
+};
 DSV_DEV Niels load_var_entry(const u32* lane_tbl, int d) {
   const bool neg = d < 0;
   const int mag = neg ? -d : d;
-  const u32* p = lane_tbl + mag * kVarEntryWords;
+  const u32* p = (DSV_SHARED_IDENTITY && mag == 0) ? kIdentityEntry : lane_tbl + mag * kVarEntryWords;
   Niels n;
   n.vpu = load_fe_words(p + (neg ? NL : 0));
   n.vmu = load_fe_words(p + (neg ? 0 : NL));
@@ -334,7 +346,7 @@ DSV_DEV Niels load_var_entry(const u32* lane_tbl, int d) {
 DSV_DEV void build_var_table(u32* lane_tbl, const Fe& pu, const Fe& pv) {
   Ext p = ext_from_affine(pu, pv);
   Niels n1 = ext_to_niels(p);
-  store_var_entry(lane_tbl, 0, niels_identity());
+  if (!DSV_SHARED_IDENTITY) store_var_entry(lane_tbl, 0, niels_identity());
   store_var_entry(lane_tbl, 1, n1);
   Ext cur = p;
 #pragma unroll 1
@@ -415,7 +427,7 @@ template <int N>
 DSV_DEV void build_var_table_n(u32* lane_tbl, const Fe& pu, const Fe& pv) {
   Ext p = ext_from_affine(pu, pv);
   Niels n1 = ext_to_niels(p);
-  store_var_entry(lane_tbl, 0, niels_identity());
+  if (!DSV_SHARED_IDENTITY) store_var_entry(lane_tbl, 0, niels_identity());
   store_var_entry(lane_tbl, 1, n1);
   Ext cur = p;
 #pragma unroll 1
