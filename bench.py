@@ -467,8 +467,15 @@ def main():
         ts = time.perf_counter()
         O.keygen_sign_single(1024, 0xBEEF, nthreads=1)  # BASELINE configs[0] shape: keygen + sign
         t_sign = time.perf_counter() - ts
+        cpu_model = "unknown"
+        try:
+            with open("/proc/cpuinfo") as f:
+                cpu_model = next(l.split(":", 1)[1].strip() for l in f if l.startswith("model name"))
+        except Exception:
+            pass
         out["cpu_baseline"] = {
             "value": sample / tc, "unit": "verifies/s", "cores": cores, "kind": "port",
+            "cpu": cpu_model,
             "sample": "first %d items of the same batch, %d threads, %.1f s wall; "
                       "1 thread: %.0f verifies/s on %d items; configs[0] shape (1024 x keygen+sign, "
                       "1 thread): %.0f /s" % (sample, cores, tc, one / t1, one, 1024 / t_sign),
