@@ -70,8 +70,10 @@ def _hash_counts(double):
     def perm(first_const, word1_only):
         sbox = 5 * 8 + 59 - first_const
         dots5 = 5 * 8 - (4 if word1_only else 0)
-        terms = 5 * dots5 + 14 * (5 + 6 + 7 + 8 + 4 * 5) + (5 + 6 + 7 + 4 * 4)
-        ndots = dots5 + 14 * 8 + 7
+        # partial rounds as one scalar recurrence: 4 start-up rows (7, 9, 11, 13 terms), 54 rounds of
+        # 10 terms, 5 rows of 10 to rebuild the state
+        terms = 5 * dots5 + (7 + 9 + 11 + 13) + 54 * 10 + 5 * 10
+        ndots = dots5 + 4 + 54 + 5
         return sbox, terms, ndots
     if double:
         a, b = perm(1, False), perm(0, True)

@@ -531,6 +531,7 @@ int dsv_init(int device) {
                             sizeof(DSV_HADES_BLOCKS_HOST)));
   HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(c_hades_kfinal), DSV_HADES_KFINAL_HOST,
                             sizeof(DSV_HADES_KFINAL_HOST)));
+  HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(c_hades_arma), DSV_HADES_ARMA_HOST, sizeof(DSV_HADES_ARMA_HOST)));
   HIP_TRY(hipMalloc(&ctx.ts_cancel, sizeof(DSV_TS_CANCEL_HOST)));
   HIP_TRY(hipMemcpy(ctx.ts_cancel, DSV_TS_CANCEL_HOST, sizeof(DSV_TS_CANCEL_HOST), hipMemcpyHostToDevice));
   HIP_TRY(hipMalloc(&ctx.ts_hash, sizeof(DSV_TS_HASH_HOST)));

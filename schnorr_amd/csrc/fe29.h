@@ -253,6 +253,26 @@ DSV_DEV Fe fe_dot_const(const Fe (&a)[NT], const u32 (*k)[NL]) {
   return fe_reduce_cols(c);
 }
 
+// the same plus a constant: result = sum a[t] * k[t] + C, where start[0..8] = plain limbs of C * R^2
+// mod q, each already increased by the reduction's 2^29 - 1 bias (generator: init_limbs) — the
+// constant costs nothing: it replaces the bias the column accumulators start from anyway
+template <int NT>
+DSV_DEV Fe fe_dot_const_plus(const Fe (&a)[NT], const u32 (*k)[NL], const u32* start) {
+  u64 c[18];
+#pragma unroll
+  for (int col = 0; col < 17; col++) c[col] = (col < NL) ? (u64)start[col] : 0;
+  c[17] = 0;
+#pragma unroll
+  for (int t = 0; t < NT; t++) {
+#pragma unroll
+    for (int i = 0; i < NL; i++) {
+#pragma unroll
+      for (int j = 0; j < NL; j++) c[i + j] += (u64)a[t].l[i] * k[t][j];
+    }
+  }
+  return fe_reduce_cols(c);
+}
+
 DSV_DEV Fe fe_add(const Fe& a, const Fe& b) {
   Fe r;
 #pragma unroll

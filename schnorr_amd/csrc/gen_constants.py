@@ -126,6 +126,102 @@ def sparse_partial_rounds(rc, m):
     return pre, kappa, bs, cs, ds
 
 
+def _matvec(A, v):
+    return [sum(A[i][j] * v[j] for j in range(len(v))) % Q for i in range(len(A))]
+
+
+def arma_partial_rounds(rc, m):
+    """The 59 partial rounds as ONE scalar recurrence (hades29.h: hades_partial_rounds_arma).
+
+    Partial round r (dusk-hades order): w = x_r + k_r; a_r = w[4]; z_r = a_r^5; w[4] <- z_r;
+    x_{r+1} = M w.  With e = e_4 and g_r = z_r - a_r:  x_{r+1} = M (x_r + k_r) + g_r M e, so the
+    S-box inputs are the output of a 5-dimensional linear system driven by g.  By Cayley-Hamilton
+    (M^5 = sum c_i M^i) they satisfy
+        a_{r+5} = sum_{i<5} c_i a_{r+i} + sum_{t<5} beta_t g_{r+t} + gamma_r,
+        beta_t = h_{5-t} - sum_{i>t} c_i h_{i-t},   h_j = e^T M^j e,
+    i.e. ten products and ONE reduction per round (a, z = a^5 are the only state), against 11.5
+    products and two reductions in the blocked sparse form.  The first five inputs come straight
+    from x_0, and x_59 is rebuilt from the last five (a, z) pairs through the observability matrix.
+    Returns a dict of plain integers mod q; `selftest` has compared it with the dense rounds."""
+    W, P = WIDTH, PARTIAL
+    e = [0, 0, 0, 0, 1]
+    k = [rc[(FULL // 2) * W + r * W:(FULL // 2) * W + (r + 1) * W] for r in range(P)]
+    ident = [[1 if i == j else 0 for j in range(W)] for i in range(W)]
+    Mp = [ident]
+    for _ in range(6):
+        Mp.append(_matmul(Mp[-1], m))
+    # characteristic polynomial from the Krylov sequence of e
+    K = [[_matvec(Mp[j], e)[i] for j in range(W)] for i in range(W)]      # columns M^j e
+    c = _matvec(_inv(K), _matvec(Mp[5], e))
+    comb = [[sum(c[i] * Mp[i][a][b] for i in range(W)) % Q for b in range(W)] for a in range(W)]
+    assert comb == Mp[5], "Cayley-Hamilton check failed (e_4 not cyclic?)"
+    h = [Mp[j][4][4] for j in range(7)]
+    beta = [(h[5 - t] - sum(c[i] * h[i - t] for i in range(t + 1, W))) % Q for t in range(W)]
+    # kappa_r = e^T (k_r + sum_{s<r} M^{r-s} k_s)
+    kappa, acc = [], [0] * W
+    for r in range(P):
+        wv = [(acc[i] + k[r][i]) % Q for i in range(W)]
+        kappa.append(wv[4])
+        acc = _matvec(m, wv)
+    gamma = [(kappa[r + 5] - sum(c[i] * kappa[r + i] for i in range(W))) % Q for r in range(P - 5)]
+    # a_r for r = 1..4:  (e^T M^r) x_0 + sum_{s<r} h_{r-s} (z_s - a_s) + kappa_r
+    init = []
+    for r in range(1, 5):
+        row_x = Mp[r][4][:]
+        pairs = [((-h[r - s_]) % Q, h[r - s_]) for s_ in range(r)]            # (coef a_s, coef z_s)
+        init.append({"x": row_x, "az": pairs, "const": kappa[r]})
+    # x_59 from (a, z)_{54..58}
+    b0 = P - 5
+    O = [Mp[j][4][:] for j in range(W)]                                        # rows e^T M^j
+    Oi = _inv(O)
+    H = [[h[j - t] if t < j else 0 for t in range(W)] for j in range(W)]
+    kp = []
+    acc = [0] * W
+    for j in range(W):
+        wv = [(acc[i] + k[b0 + j][i]) % Q for i in range(W)]
+        kp.append(wv[4])
+        acc = _matvec(m, wv)
+    M5Oi = _matmul(Mp[5], Oi)
+    cols = [[_matvec(Mp[5 - t], e)[i] for t in range(W)] for i in range(W)]    # column t = M^{5-t} e
+    M5OiH = _matmul(M5Oi, H)
+    G = [[(cols[i][t] - M5OiH[i][t]) % Q for t in range(W)] for i in range(W)]
+    Fa = [[(M5Oi[i][t] - G[i][t]) % Q for t in range(W)] for i in range(W)]
+    fconst = [(-x) % Q for x in _matvec(M5Oi, kp)]
+    for t in range(W):
+        v = _matvec(Mp[5 - t], k[b0 + t])
+        fconst = [(fconst[i] + v[i]) % Q for i in range(W)]
+    out = {"k0": k[0][4], "init": init, "ca": [(c[i] - beta[i]) % Q for i in range(W)], "cz": beta,
+           "gamma": gamma, "Fa": Fa, "Fz": G, "fconst": fconst}
+    # ---- self-test against the dense definition
+    import random as _random
+    rnd = _random.Random(7)
+    for _ in range(3):
+        x0 = [rnd.randrange(Q) for _ in range(W)]
+        x, a_ref = list(x0), []
+        for r in range(P):
+            wv = [(x[i] + k[r][i]) % Q for i in range(W)]
+            a_ref.append(wv[4])
+            wv[4] = pow(wv[4], 5, Q)
+            x = _matvec(m, wv)
+        a = [(x0[4] + out["k0"]) % Q]
+        z = [pow(a[0], 5, Q)]
+        for r in range(1, 5):
+            it = init[r - 1]
+            v = sum(it["x"][i] * x0[i] for i in range(W)) + it["const"]
+            v += sum(ca * a[s_] + cz * z[s_] for s_, (ca, cz) in enumerate(it["az"]))
+            a.append(v % Q)
+            z.append(pow(a[-1], 5, Q))
+        for r in range(5, P):
+            v = gamma[r - 5] + sum(out["ca"][i] * a[r - 5 + i] + out["cz"][i] * z[r - 5 + i] for i in range(W))
+            a.append(v % Q)
+            z.append(pow(a[-1], 5, Q))
+        assert a == a_ref, "ARMA recurrence disagrees with the dense partial rounds"
+        xf = [(sum(Fa[i][t] * a[b0 + t] + G[i][t] * z[b0 + t] for t in range(W)) + fconst[i]) % Q
+              for i in range(W)]
+        assert xf == x, "state reconstruction disagrees with the dense partial rounds"
+    return out
+
+
 def arr(v):
     return "{" + ", ".join("0x%08xu" % x for x in v) + "}"
 
@@ -278,6 +374,47 @@ def main():
         w("static const uint32_t DSV_HADES_KFINAL_HOST[%d][9] = {\n" % (WIDTH - 1))
         for x in K:
             w("  %s,\n" % arr(mont(x)))
+        w("};\n")
+        # ---- partial rounds as one scalar recurrence (arma_partial_rounds)
+        A = arma_partial_rounds(rc, m)
+        RR = RMONT * RMONT % Q
+
+        def init_limbs(const):
+            """column-0..8 start values of a dot product that must come out as dot + const:
+            plain limbs of const * R^2 (the reduction divides by R, leaving const * R = its
+            Montgomery form) plus the reduction's 2^29 - 1 bias"""
+            return [x + MASK for x in limbs(const * RR % Q)]
+
+        def check_cols(consts, what):
+            # 64-bit column bound with every state limb at 2^29 + 8 and start values < 2^30
+            for col in range(17):
+                tot = sum(((1 << 29) + 8) * mont(cst)[col - a_] for cst in consts for a_ in range(9)
+                          if 0 <= col - a_ < 9)
+                assert tot + (1 << 30) + 8 * (1 << 58) + (1 << 37) < (1 << 64), "column overflow: " + what
+
+        rows = [mont(A["k0"])]
+        for it in A["init"]:
+            cs = it["x"] + [v for pair in it["az"] for v in pair]
+            check_cols(cs, "ARMA init")
+            rows += [mont(v) for v in cs] + [init_limbs(it["const"])]
+        off_rec = len(rows)
+        rec = A["ca"] + A["cz"]
+        check_cols(rec, "ARMA recurrence")
+        rows += [mont(v) for v in rec]
+        off_gamma = len(rows)
+        rows += [init_limbs(g) for g in A["gamma"]]
+        off_final = len(rows)
+        for j in range(WIDTH):
+            cs = A["Fa"][j] + A["Fz"][j]
+            check_cols(cs, "ARMA final")
+            rows += [mont(v) for v in cs] + [init_limbs(A["fconst"][j])]
+        w("// partial rounds as one scalar recurrence (generator: arma_partial_rounds).  Rows: k0 | for r = 1..4:\n")
+        w("// 5 + 2r multipliers + start limbs | 10 recurrence multipliers | 54 start-limb rows | 5 x (10 + 1)\n")
+        w("#define DSV_HADES_ARMA_REC %d\n#define DSV_HADES_ARMA_GAMMA %d\n#define DSV_HADES_ARMA_FINAL %d\n"
+          % (off_rec, off_gamma, off_final))
+        w("static const uint32_t DSV_HADES_ARMA_HOST[%d][9] = {\n" % len(rows))
+        for r_ in rows:
+            w("  %s,\n" % arr(r_))
         w("};\n")
     print("wrote", path)
 

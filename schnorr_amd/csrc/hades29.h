@@ -23,6 +23,11 @@ __constant__ u32 c_hades_pre_mds[DSV_HADES_WIDTH * DSV_HADES_WIDTH][NL];
 __constant__ u32 c_hades_kappa0[DSV_HADES_WIDTH][NL];
 __constant__ u32 c_hades_kfinal[DSV_HADES_WIDTH - 1][NL];
 __constant__ u32 c_hades_blocks[sizeof(DSV_HADES_BLOCKS_HOST) / sizeof(DSV_HADES_BLOCKS_HOST[0])][NL];
+// the partial rounds as one scalar recurrence (gen_constants.py: arma_partial_rounds)
+#ifndef DSV_HADES_ARMA
+#define DSV_HADES_ARMA 1  /* 0: the r01 blocked sparse form (A/B) */
+#endif
+__constant__ u32 c_hades_arma[sizeof(DSV_HADES_ARMA_HOST) / sizeof(DSV_HADES_ARMA_HOST[0])][NL];
 
 DSV_DEV Fe fe_load_const(const u32* p) {
   Fe r;
@@ -115,6 +120,65 @@ DSV_DEV void hades_last_round_word1(Fe (&s)[5], const u32 (*rc)[NL], const u32 (
   s[1] = fe_dot5(s, m);
 }
 
+// The 59 partial rounds as ONE scalar recurrence.  Only the S-box inputs a_r and outputs
+// z_r = a_r^5 are carried: a_{r+5} is a fixed 10-term combination of (a, z)_{r..r+4} plus a round
+// constant (Cayley-Hamilton on the 5x5 matrix; derivation and self-test against the dense rounds
+// in gen_constants.py: arma_partial_rounds) — ten products and ONE reduction per round, the
+// constant riding in the start values of the column sums.  a_1..a_4 come from the state that
+// enters the partial rounds, the state that leaves them is rebuilt from (a, z)_{54..58}.
+DSV_DEV void hades_partial_rounds_arma(Fe (&s)[5]) {
+  static_assert(DSV_HADES_PARTIAL == 59, "window bookkeeping below is written for 59 rounds");
+  const u32(*k)[NL] = c_hades_arma;
+  Fe A[5], Z[5];
+  A[0] = fe_carry(fe_add(s[4], fe_load_const(k[0])));
+  k += 1;
+  asm volatile("" : "+s"(k));  // (see the loop below: keeps the scalar loads of each dot product local)
+  Z[0] = hades_sbox(A[0]);
+  { const Fe t[7] = {s[0], s[1], s[2], s[3], s[4], A[0], Z[0]};
+    A[1] = fe_dot_const_plus<7>(t, k, k[7]); k += 8; asm volatile("" : "+s"(k)); Z[1] = hades_sbox(A[1]); }
+  { const Fe t[9] = {s[0], s[1], s[2], s[3], s[4], A[0], Z[0], A[1], Z[1]};
+    A[2] = fe_dot_const_plus<9>(t, k, k[9]); k += 10; asm volatile("" : "+s"(k)); Z[2] = hades_sbox(A[2]); }
+  { const Fe t[11] = {s[0], s[1], s[2], s[3], s[4], A[0], Z[0], A[1], Z[1], A[2], Z[2]};
+    A[3] = fe_dot_const_plus<11>(t, k, k[11]); k += 12; asm volatile("" : "+s"(k)); Z[3] = hades_sbox(A[3]); }
+  { const Fe t[13] = {s[0], s[1], s[2], s[3], s[4], A[0], Z[0], A[1], Z[1], A[2], Z[2], A[3], Z[3]};
+    A[4] = fe_dot_const_plus<13>(t, k, k[13]); Z[4] = hades_sbox(A[4]); }
+  const u32(*rec)[NL] = c_hades_arma + DSV_HADES_ARMA_REC;
+  const u32(*gam)[NL] = c_hades_arma + DSV_HADES_ARMA_GAMMA;
+  // One round per loop iteration, the window (oldest -> newest) shifted by register moves (72
+  // v_mov, ~3 % of a round): an unrolled-by-5 body with rotating slot names spills 136-163 VGPRs
+  // whatever is pinned or fenced (A/B: 4 % slower than the blocked form).
+  // The ten multipliers are the same in every round; left to itself the compiler loads all 90
+  // words once and keeps them in SGPRs, which spills (421 SGPR spills, 8 k v_readlane, hash 37 %
+  // SLOWER).  Laundering the table pointer after every dot product makes each round re-load its
+  // constants — issued under the S-box that follows, nine SGPRs at a time.
+#pragma unroll 1
+  for (int r = 5; r < DSV_HADES_PARTIAL; r++) {
+    const Fe t[10] = {A[0], A[1], A[2], A[3], A[4], Z[0], Z[1], Z[2], Z[3], Z[4]};
+    const Fe an = fe_dot_const_plus<10>(t, rec, gam[0]);
+    gam += 1;
+    asm volatile("" : "+s"(rec));
+    const Fe zn = hades_sbox(an);
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      A[i] = A[i + 1];
+      Z[i] = Z[i + 1];
+    }
+    A[4] = an;
+    Z[4] = zn;
+  }
+  const u32(*fin)[NL] = c_hades_arma + DSV_HADES_ARMA_FINAL;
+  const Fe t[10] = {A[0], A[1], A[2], A[3], A[4], Z[0], Z[1], Z[2], Z[3], Z[4]};
+#pragma unroll 1
+  for (int j = 0; j < 5; j++) {  // one inlined copy: rotate the output through s[]
+    const Fe r = fe_dot_const_plus<10>(t, fin + 11 * j, fin[11 * j + 10]);
+    s[0] = s[1];
+    s[1] = s[2];
+    s[2] = s[3];
+    s[3] = s[4];
+    s[4] = r;
+  }
+}
+
 // The permutation.  The 59 partial rounds run in their sparse-matrix form (per round one S-box,
 // one dot product for the new last word, four multiply-accumulates for words 0..3 instead of
 // five dense dot products), and the four multiply-accumulates are deferred block-wise (below).
@@ -128,7 +192,11 @@ DSV_DEV void hades_permute(Fe (&s)[5]) {
   if (FIRST == 2) hades_first_round_const<true>(s, c_hades_rc, c_hades_mds);
 #pragma unroll 1
   for (int r = FIRST ? 1 : 0; r < HALF; r++)
-    hades_full_round(s, c_hades_rc + 5 * r, r == HALF - 1 ? c_hades_pre_mds : c_hades_mds);
+    hades_full_round(s, c_hades_rc + 5 * r,
+                     (!DSV_HADES_ARMA && r == HALF - 1) ? c_hades_pre_mds : c_hades_mds);
+  if (DSV_HADES_ARMA) {
+    hades_partial_rounds_arma(s);
+  } else {
   // words 0..3 carry NO round constants inside the loop: their running sum K_i is folded into the
   // constant of the last word (kappa4'_i = kappa4_{i+1} + c_i . K_i) and added back once at the end.
   // Rounds run in blocks of 4 (gen_constants.py): inside a block words 0..3 stay untouched and
@@ -175,6 +243,7 @@ DSV_DEV void hades_permute(Fe (&s)[5]) {
   }
 #pragma unroll
   for (int j = 0; j < 4; j++) s[j] = fe_carry(fe_add(s[j], fe_load_const(c_hades_kfinal[j])));
+  }
 #pragma unroll 1
   for (int r = 0; r < HALF - (WORD1_ONLY ? 1 : 0); r++)
     hades_full_round(s, c_hades_rc + 5 * (HALF + DSV_HADES_PARTIAL + r), c_hades_mds);

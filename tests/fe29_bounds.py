@@ -165,6 +165,27 @@ def dot(avec, bvec):
     return _reduce(c, vprod)
 
 
+def dot_plus(avec, bvec, start):
+    """fe_dot_const_plus: columns 0..8 start from `start` (< 2^30 each, bias included)"""
+    c = [0] * 17
+    vprod = 0
+    for a, b in zip(avec, bvec):
+        for x in a.l + b.l:
+            _check(x < U32, "multiplier limb exceeds 32 bits")
+        for i in range(NL):
+            for j in range(NL):
+                c[i + j] += a.l[i] * b.l[j]
+        vprod += a.v * b.v
+    for i in range(NL):
+        _check(M29 <= start.l[i] < (1 << 30), "start limb out of range")
+        c[i] += start.l[i] - M29
+    for k, x in enumerate(c):
+        _check(x + M29 < U64, "dot-product column %d overflows 64 bits" % k)
+    # the start limbs carry const * R^2 mod q < q: adds < q / R... one more q to the value bound
+    r = _reduce(c, vprod + (Q << RBITS))
+    return r
+
+
 def add(a, b):
     r = [x + y for x, y in zip(a.l, b.l)]
     for x in r:
@@ -328,11 +349,47 @@ def hades_full_round(s, rc, mat):
     return [dot(s, [mat[k * 5 + j] for j in range(5)]) for k in range(5)]
 
 
-def hades_permute(s):
+def hades_partial_rounds_arma(s):
+    """hades29.h: hades_partial_rounds_arma with the ACTUAL constants and worst-case operands"""
+    text = open(_HDR).read()
+    off = {n: int(re.search(r"#define DSV_HADES_ARMA_%s (\d+)" % n, text).group(1))
+           for n in ("REC", "GAMMA", "FINAL")}
+    k = _load_table("DSV_HADES_ARMA_HOST")
+    A, Z = [None] * 5, [None] * 5
+    A[0] = carry(add(s[4], k[0]))
+    Z[0] = sbox(A[0])
+    pos = 1
+    for r in range(1, 5):
+        t = list(s)
+        for j in range(r):
+            t += [A[j], Z[j]]
+        nt = 5 + 2 * r
+        A[r] = dot_plus(t, k[pos:pos + nt], k[pos + nt])
+        Z[r] = sbox(A[r])
+        pos += nt + 1
+    rec = k[off["REC"]:off["REC"] + 10]
+    for r in range(5, 59):
+        p = r % 5
+        t = [A[(p + i) % 5] for i in range(5)] + [Z[(p + i) % 5] for i in range(5)]
+        A[p] = dot_plus(t, rec, k[off["GAMMA"] + r - 5])
+        Z[p] = sbox(A[p])
+    t = [A[4], A[0], A[1], A[2], A[3], Z[4], Z[0], Z[1], Z[2], Z[3]]
+    f = off["FINAL"]
+    return [dot_plus(t, k[f + 11 * j:f + 11 * j + 10], k[f + 11 * j + 10]) for j in range(5)]
+
+
+def hades_permute(s, arma=True):
     """hades29.h: hades_permute with the ACTUAL constants (exact limbs) and worst-case state"""
     rc, mds, pre = (_load_table("DSV_HADES_%s_HOST" % n) for n in ("RC", "MDS", "PRE_MDS"))
     k0, blk, kf = (_load_table("DSV_HADES_%s_HOST" % n) for n in ("KAPPA0", "BLOCKS", "KFINAL"))
     s = list(s)
+    if arma:
+        for r in range(4):
+            s = hades_full_round(s, rc[5 * r:5 * r + 5], mds)
+        s = hades_partial_rounds_arma(s)
+        for r in range(4):
+            s = hades_full_round(s, rc[5 * (4 + 59 + r):5 * (4 + 59 + r) + 5], mds)
+        return s
     for r in range(4):
         s = hades_full_round(s, rc[5 * r:5 * r + 5], pre if r == 3 else mds)
     s[4] = add(s[4], k0[4])
@@ -357,16 +414,16 @@ def hades_permute(s):
     return s
 
 
-def prove_hades():
+def prove_hades(arma=True):
     """poseidon_hash3 / poseidon_hash5 on worst-case inputs (fe_to_mont of any canonical word),
     then the truncation's fe_from_mont (fe_canon needs < 16 q and limbs < 2^31)."""
     m = mul(canonical(), canonical())
     zero, one = B([0] * NL), canonical()
-    out3 = hades_permute([zero, m, m, m, one])
-    s = hades_permute([zero, m, m, m, m])
+    out3 = hades_permute([zero, m, m, m, one], arma)
+    s = hades_permute([zero, m, m, m, m], arma)
     s[1] = add(s[1], m)
     s[2] = add(s[2], one)
-    out5 = hades_permute(s)
+    out5 = hades_permute(s, arma)
     for o in (out3[1], out5[1]):
         h = mul(o, B([1] + [0] * (NL - 1)))
         for x in h.l:

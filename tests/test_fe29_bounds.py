@@ -32,9 +32,11 @@ def test_prover_rejects_a_broken_variant():
         bad_double({"u": n, "v": n, "z": n, "t1": n, "t2": n})
 
 
-def test_hades_permutation_cannot_overflow_with_the_shipped_constants():
-    out = FB.prove_hades()
-    assert out["hash3"].v < 2 * FB.Q and out["hash5"].v < 2 * FB.Q
+@pytest.mark.parametrize("arma", [True, False])
+def test_hades_permutation_cannot_overflow_with_the_shipped_constants(arma):
+    """both forms of the partial rounds: the shipped scalar recurrence and the r01 blocked form"""
+    out = FB.prove_hades(arma)
+    assert out["hash3"].v < 3 * FB.Q and out["hash5"].v < 3 * FB.Q
 
 
 def test_point_decompression_field_code_cannot_overflow():

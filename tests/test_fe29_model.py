@@ -90,6 +90,7 @@ def test_sparse_hades_permutation_matches_naive_model_and_keeps_bounds():
     states = [[rnd.randrange(F.Q) for _ in range(5)] for _ in range(3)]
     states += [[0] * 5, [F.Q - 1] * 5, [0, 1, 2, 3, 4]]
     for st in states:
-        got = F.hades_permute([F.to_mont_int(x) for x in st])
-        assert [F.val(F.from_mont(x)) for x in got] == M.hades_permute(st)
+        for arma in (True, False):   # the shipped scalar-recurrence form and the r01 blocked form
+            got = F.hades_permute([F.to_mont_int(x) for x in st], arma=arma)
+            assert [F.val(F.from_mont(x)) for x in got] == M.hades_permute(st), arma
     assert F.stats["max_col"] < (1 << 64)
