@@ -935,21 +935,28 @@ int run_pipelined(Context& ctx, const HostIn (&ins)[NIN], uint8_t* ok, size_t n,
     return fail(DSV_ERR_NOT_INITIALIZED, "device %d was shut down", ctx.device);
   DSV_ON_DEVICE(ctx);
   const size_t chunk = n < kPipeChunk ? n : kPipeChunk;
-  size_t in_off[NIN + 1];  // offsets inside a slot, the same on both sides
-  in_off[0] = 0;
-  for (size_t k = 0; k < NIN; k++) in_off[k + 1] = in_off[k] + align_up(chunk * ins[k].bytes, 256);
-  const size_t ok_off = in_off[NIN];
-  const size_t host_need = ok_off + align_up(chunk, 256);
+  // slot capacity: offsets of a FULL chunk (a shorter chunk packs its arrays tighter, see below)
+  size_t cap_off = 0;
+  for (size_t k = 0; k < NIN; k++) cap_off += align_up(chunk * ins[k].bytes, 256);
+  const size_t host_need = cap_off + align_up(chunk, 256);
   const size_t ws_bytes = align_up(dsv_workspace_bytes(chunk), 256);
   const size_t dev_need = host_need + ws_bytes + chunk * extra_item_bytes + 16 * 256;
-  const size_t nchunks = (n + chunk - 1) / chunk;
+  // ramp: the first two chunks are short (2^15, 2^16 items) so that the GPU starts after ~0.3 ms
+  // of staging instead of a full chunk's ~1.5 ms; from the third on every chunk is kPipeChunk
+  auto chunk_len = [&](size_t c, size_t left) {
+    size_t want = c == 0 ? kPipeChunk / 4 : (c == 1 ? kPipeChunk / 2 : kPipeChunk);
+    if (n <= kPipeChunk) want = n;  // one small call: no ramp
+    return left < want ? left : want;
+  };
+  size_t nchunks = 0;
+  for (size_t left = n; left; nchunks++) left -= chunk_len(nchunks, left);
   const int nslots = nchunks < (size_t)kPipeSlots ? (int)nchunks : kPipeSlots;
   for (int sl = 0; sl < nslots; sl++)
     if (int r = ensure_pipe_slot(ctx, sl, dev_need, host_need)) return r;
-  size_t slot_first[kPipeSlots] = {}, slot_cnt[kPipeSlots] = {};  // verdicts parked in a slot
+  size_t slot_first[kPipeSlots] = {}, slot_cnt[kPipeSlots] = {}, slot_ok_off[kPipeSlots] = {};
   auto drain = [&](int sl) -> int {
     HIP_TRY(hipStreamSynchronize(ctx.pipe_stream[sl]));
-    if (slot_cnt[sl]) memcpy(ok + slot_first[sl], ctx.pipe_host[sl] + ok_off, slot_cnt[sl]);
+    if (slot_cnt[sl]) memcpy(ok + slot_first[sl], ctx.pipe_host[sl] + slot_ok_off[sl], slot_cnt[sl]);
     slot_cnt[sl] = 0;
     return DSV_OK;
   };
@@ -957,10 +964,14 @@ int run_pipelined(Context& ctx, const HostIn (&ins)[NIN], uint8_t* ok, size_t n,
   for (size_t c = 0; done < n; c++) {
     const int sl = (int)(c % kPipeSlots);
     hipStream_t st = ctx.pipe_stream[sl];
-    const size_t cnt = n - done < chunk ? n - done : chunk;
+    const size_t cnt = chunk_len(c, n - done);
     if (int r = drain(sl)) return r;  // slot free again, its verdicts delivered
     uint8_t* host = ctx.pipe_host[sl];
     uint8_t* dev = ctx.pipe_stage[sl];
+    size_t in_off[NIN + 1];  // offsets inside the slot for THIS chunk, the same on both sides
+    in_off[0] = 0;
+    for (size_t k = 0; k < NIN; k++) in_off[k + 1] = in_off[k] + align_up(cnt * ins[k].bytes, 256);
+    const size_t ok_off = in_off[NIN];
     size_t bytes = 0;
     for (size_t k = 0; k < NIN; k++) bytes += cnt * ins[k].bytes;
     const int T = bytes >= ((size_t)1 << 20) ? host_copy_threads() : 1;
@@ -984,6 +995,7 @@ int run_pipelined(Context& ctx, const HostIn (&ins)[NIN], uint8_t* ok, size_t n,
     HIP_TRY(hipMemcpyAsync(host + ok_off, dok, cnt, hipMemcpyDeviceToHost, st));
     slot_first[sl] = done;
     slot_cnt[sl] = cnt;
+    slot_ok_off[sl] = ok_off;
     done += cnt;
   }
   for (int sl = 0; sl < nslots; sl++)
