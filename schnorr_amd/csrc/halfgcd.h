@@ -61,12 +61,40 @@ DSV_DEV double to_double8(const u32 (&x)[8]) {
 // out: a (magnitude, 8 words), b (magnitude, 8 words, only 5 can be non-zero), b_neg.
 // a = (b_neg ? -b : b) * c  (mod 8r),  b odd.   c < 2^250.
 //
-// Euclid on (8r, c) with quotient ESTIMATES: each iteration makes A >= B by a conditional swap,
-// takes qe = floor(A/B * (1 - 2^-30)) from double-precision images of A and B (qe <= true
-// quotient, clamped to [1, 2^31)), and does A -= qe*B, tA += qe*tB.  A swap happens exactly when
-// A has become the true remainder, so the (remainder, cofactor) pairs at swap time are those of
-// the exact algorithm (tests/pymodel.py: half_scalars) whatever the estimates were; an
-// under-estimate only costs an extra iteration.  ~80 iterations of ~130 instructions.
+// Euclid on (8r, c) with quotient ESTIMATES and ALTERNATING roles: a half-step reduces X by Y with
+// qe = floor(X/Y * (1 - 2^-30)) taken from double-precision images (qe <= true quotient, clamped
+// below 2^31; qe = 0 when X < Y), X -= qe*Y, tX += qe*tY; first (X, Y) = (A, B), then (B, A), and
+// so on — no trial subtraction, no conditional swap of the 13 words, and only the operand that
+// changed is converted to a double again (r01 compared, swapped and converted both operands in
+// every iteration: 208 instructions per Euclidean step as compiled; same-box A/B +0.95 % on the
+// whole verification step, profiles/r02/ab_alternating_halfgcd.txt).  An under-estimate leaves X >= Y;
+// the following half-step then has quotient 0 and changes nothing, and the one after it finishes
+// the job, so every value that drops below the other is a true Euclidean remainder and the
+// (remainder, cofactor) pairs are those of the exact algorithm (tests/pymodel.py: half_scalars).
+// The loop ends at the first remainder below 2^128 (its partner is still >= 2^128).  Cofactors of
+// the A side are <= 0, those of the B side >= 0 (magnitudes are stored), so the sign of the final
+// cofactor is known from the side it is on.
+DSV_DEV void half_step(u32 (&X)[8], u32 (&tX)[5], const u32 (&Y)[8], const u32 (&tY)[5], double dX,
+                       double dY) {
+  const double qd = dX / dY * (1.0 - 0x1p-30);
+  const u32 qe = qd >= 2147483647.0 ? 2147483647u : (u32)qd;
+  u32 mc = 0, borrow = 0;
+#pragma unroll
+  for (int i = 0; i < 8; i++) {
+    const u64 p = (u64)qe * Y[i] + mc;
+    mc = (u32)(p >> 32);
+    const u64 d = (u64)X[i] - (u32)p - borrow;
+    X[i] = (u32)d;
+    borrow = (u32)(d >> 63);
+  }
+  u32 carry = 0;
+#pragma unroll
+  for (int i = 0; i < 5; i++) {
+    const u64 p = (u64)qe * tY[i] + tX[i] + carry;
+    tX[i] = (u32)p;
+    carry = (u32)(p >> 32);
+  }
+}
 DSV_DEV void half_scalars(u32 (&a)[8], u32 (&b)[8], bool& b_neg, const u32 (&c)[8]) {
   u32 A[8], B[8], tA[5] = {0, 0, 0, 0, 0}, tB[5] = {1, 0, 0, 0, 0};
 #pragma unroll
@@ -74,52 +102,38 @@ DSV_DEV void half_scalars(u32 (&a)[8], u32 (&b)[8], bool& b_neg, const u32 (&c)[
     A[i] = kN8R[i];
     B[i] = c[i];
   }
-  bool neg = false;  // sign of the cofactor paired with B
   bool done = below_2_128(B);
+  bool final_is_A = false;
+  double dA = to_double8(A), dB = to_double8(B);
 #pragma unroll 1
   for (int it = 0; it < kHalfGcdMaxIter && !done; it++) {
-    u32 D[8];
-    const bool lt = sub8(D, A, B);
-    // conditional swap: (A, tA) <-> (B, tB); cofactor signs alternate
+    half_step(A, tA, B, tB, dA, dB);
+    dA = to_double8(A);
+    if (below_2_128(A)) {
+      done = true;
+      final_is_A = true;
+    } else {
+      half_step(B, tB, A, tA, dB, dA);
+      dB = to_double8(B);
+      done = below_2_128(B);
+    }
+  }
+  // from here on (B, tB) is the final pair and (A, tA) the one before it
+  if (final_is_A) {
 #pragma unroll
     for (int i = 0; i < 8; i++) {
-      const u32 x = A[i], y = B[i];
-      A[i] = lt ? y : x;
-      B[i] = lt ? x : y;
+      const u32 x = A[i];
+      A[i] = B[i];
+      B[i] = x;
     }
 #pragma unroll
     for (int i = 0; i < 5; i++) {
-      const u32 x = tA[i], y = tB[i];
-      tA[i] = lt ? y : x;
-      tB[i] = lt ? x : y;
-    }
-    neg = neg != lt;
-    done = lt && below_2_128(B);
-    if (!done) {
-      // A >= B >= 2^128 here.  qe in [1, 2^31), qe <= floor(A / B)
-      const double qd = to_double8(A) / to_double8(B) * (1.0 - 0x1p-30);
-      u32 qe = qd >= 2147483647.0 ? 2147483647u : (u32)qd;
-      qe = qe < 1u ? 1u : qe;
-      // A -= qe * B
-      u32 mc = 0, borrow = 0;
-#pragma unroll
-      for (int i = 0; i < 8; i++) {
-        const u64 p = (u64)qe * B[i] + mc;
-        mc = (u32)(p >> 32);
-        const u64 d = (u64)A[i] - (u32)p - borrow;
-        A[i] = (u32)d;
-        borrow = (u32)(d >> 63);
-      }
-      // tA += qe * tB
-      u32 carry = 0;
-#pragma unroll
-      for (int i = 0; i < 5; i++) {
-        const u64 p = (u64)qe * tB[i] + tA[i] + carry;
-        tA[i] = (u32)p;
-        carry = (u32)(p >> 32);
-      }
+      const u32 x = tA[i];
+      tA[i] = tB[i];
+      tB[i] = x;
     }
   }
+  const bool neg = final_is_A;  // sign of the cofactor paired with B
   const bool use_b = (tB[0] & 1) != 0;
   if (use_b) {
 #pragma unroll
