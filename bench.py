@@ -95,8 +95,8 @@ def _valu(m, s, dot_terms=0, dot_reds=0, other=0):
 
 
 # lane-instructions outside multiplications: limb-wise add / biased subtract / carry passes of the
-# group law, half-gcd (~13 k), recoding, conversions, identity test
-VERIFY_OTHER = 33.1 * (4 * 91 + 2 * 145) + 16 * 145 + 23 * 150 + 13000 + 1500 + 66 * 60
+# group law, half-gcd (~8 k since r02's alternating-role loop), recoding, conversions, identity test
+VERIFY_OTHER = 33.1 * (4 * 91 + 2 * 145) + 16 * 145 + 23 * 150 + 8000 + 1500 + 66 * 60
 ALGO_BYTES = {"single": 193, "double": 321, "vargen": 257}
 MAD_CYCLES = 4.12        # v_mad_u64_u32 (SGPR carry-out) per wave64, 2 waves/SIMD: profiles/r02/valu_rates.txt
 N_CU, SIMD_PER_CU, CLOCK_HZ = 256, 4, 2.4e9
@@ -397,7 +397,7 @@ def main():
         if int((okd != bd["expected"]).sum().item()):
             raise SystemExit("fused double kernel: verdicts differ from the expected pattern")
         vm2, vs2 = _verify_counts(2)
-        kernel_block("k_verify_fixed_half<false,2>", cd_ms, n, vm2, vs2, other=2 * VERIFY_OTHER - 14500,
+        kernel_block("k_verify_fixed_half<false,2>", cd_ms, n, vm2, vs2, other=2 * VERIFY_OTHER - 9500,
                      algo_bytes=ALGO_BYTES["double"])
         hm2, hs2, ht2, hr2 = _hash_counts(True)
         kernel_block("k_challenge<true>", hd_ms, n, hm2, hs2, ht2, hr2, other=900)
