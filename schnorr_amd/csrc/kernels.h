@@ -348,10 +348,11 @@ DSV_DEV void build_var_table(u32* lane_tbl, const Fe& pu, const Fe& pv) {
   Niels n1 = ext_to_niels(p);
   if (!DSV_SHARED_IDENTITY) store_var_entry(lane_tbl, 0, niels_identity());
   store_var_entry(lane_tbl, 1, n1);
+  const ANiels a1 = {n1.vpu, n1.vmu, n1.t2d};  // P is affine: every step is a mixed addition (7M)
   Ext cur = p;
 #pragma unroll 1
   for (int i = 2; i < kVarEntries; i++) {
-    cur = ext_add_niels(cur, n1);
+    cur = ext_add_aniels(cur, a1);
     store_var_entry(lane_tbl, i, ext_to_niels(cur));
   }
 }
@@ -429,10 +430,11 @@ DSV_DEV void build_var_table_n(u32* lane_tbl, const Fe& pu, const Fe& pv) {
   Niels n1 = ext_to_niels(p);
   if (!DSV_SHARED_IDENTITY) store_var_entry(lane_tbl, 0, niels_identity());
   store_var_entry(lane_tbl, 1, n1);
+  const ANiels a1 = {n1.vpu, n1.vmu, n1.t2d};  // P is affine: every step is a mixed addition (7M)
   Ext cur = p;
 #pragma unroll 1
   for (int i = 2; i < N; i++) {
-    cur = ext_add_niels(cur, n1);
+    cur = ext_add_aniels(cur, a1);
     store_var_entry(lane_tbl, i, ext_to_niels(cur));
   }
 }
@@ -609,7 +611,7 @@ k_verify_fixed_half(const uint8_t* __restrict__ u, const uint8_t* __restrict__ c
         build_var_table_n<kHalfEntries>(tr, ru, rv);
       }
       // T = a*PK + (b_neg ? +|b| : -|b|) * R  (+ w*G below)
-      Ext acc = ext_add_niels(ext_identity(), load_var_entry(tpk, sdigit_w<kHalfW>(ya, top)));
+      Ext acc = ext_from_niels(load_var_entry(tpk, sdigit_w<kHalfW>(ya, top)));
       acc = ext_add_niels(acc, load_var_entry(tr, rsign * sdigit_w<kHalfW>(yb, top)));
 #pragma unroll 1
       for (int k = top - 1; k >= 0; k--) {

@@ -269,6 +269,13 @@ def ext_add_aniels(p, n):
     return _add_tail(a, b, c, d)
 
 
+def ext_from_niels(n):
+    cu = sub(n["vpu"], n["vmu"], 4)
+    cv = add(n["vpu"], n["vmu"])
+    d = dbl(n["z"])
+    return {"u": mul(cu, d), "v": mul(cv, d), "z": sqr(d), "t1": cu, "t2": cv}
+
+
 def ext_to_niels(p, d2):
     return {"vpu": carry(add(p["v"], p["u"])), "vmu": sub(p["v"], p["u"], 2), "z": p["z"],
             "t2d": mul(mul(p["t1"], p["t2"]), d2)}
@@ -314,6 +321,9 @@ def prove_group_law(max_rounds=40):
         nxt = join_pt(acc, ext_double(acc))
         nxt = join_pt(nxt, ext_add_niels(acc, niels))
         nxt = join_pt(nxt, ext_add_aniels(acc, fixed))
+        # table build: i*P + P with P's own (affine, z = 1) niels form; chain start: O + entry
+        nxt = join_pt(nxt, ext_add_aniels(acc, {k: niels[k] for k in ("vpu", "vmu", "t2d")}))
+        nxt = join_pt(nxt, ext_from_niels(niels))
         nn = join_pt(niels, table_entry(nxt, d2))
         if rnd >= 2:
             nxt = {k: widen(v) for k, v in nxt.items()}

@@ -289,6 +289,13 @@ def ext_add_aniels(p, n):
     return _add_tail(a, b, c, d)
 
 
+def ext_from_niels(n):
+    cu = sub(n["vpu"], n["vmu"], 4)
+    cv = add(n["vpu"], n["vmu"])
+    d = dbl(n["z"])
+    return {"u": mul(cu, d), "v": mul(cv, d), "z": sqr(d), "t1": cu, "t2": cv}
+
+
 def ext_to_niels(p):
     return {"vpu": carry(add(p["v"], p["u"])), "vmu": sub(p["v"], p["u"], 2), "z": p["z"],
             "t2d": mul(mul(p["t1"], p["t2"]), D2)}

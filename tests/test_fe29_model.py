@@ -72,6 +72,25 @@ def test_group_law_chain_matches_affine_model_and_keeps_bounds():
         assert F.equal(acc["u"], F.mul(ru, acc["z"])) and F.equal(acc["v"], F.mul(rv, acc["z"]))
 
 
+def test_chain_start_and_mixed_table_build_match_the_affine_model():
+    """ext_from_niels(n) == O + n, and the table build by mixed additions (P affine) gives i*P"""
+    for _ in range(3):
+        P = M.pmul(M.GEN, rnd.randrange(1, M.R_ORDER))
+        p = F.ext_from_affine(F.to_mont_int(P[0]), F.to_mont_int(P[1]))
+        n1 = F.ext_to_niels(p)
+        a1 = {k: n1[k] for k in ("vpu", "vmu", "t2d")}
+        cur = p
+        for i in range(2, 9):
+            cur = F.ext_add_aniels(cur, a1)
+            assert F.affine_of(cur) == M.pmul(P, i)
+            assert F.affine_of(F.ext_from_niels(F.ext_to_niels(cur))) == M.pmul(P, i)
+            # and the result feeds the next operations like any other accumulator
+            nxt = F.ext_add_niels(F.ext_double(F.ext_from_niels(F.ext_to_niels(cur))), n1)
+            assert F.affine_of(nxt) == M.pmul(P, 2 * i + 1)
+    ident = {"vpu": list(F.ONE), "vmu": list(F.ONE), "z": list(F.ONE), "t2d": [0] * 9}
+    assert F.affine_of(F.ext_from_niels(ident)) == (0, 1)
+
+
 def test_identity_and_torsion_through_the_formulas():
     ident = F.ext_identity()
     d = F.ext_double(ident)
