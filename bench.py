@@ -55,13 +55,13 @@ FIXED_ADDS = 23                        # signed 11-bit windows over 253 bits
 
 def _verify_counts(chains=1):
     """(multiplications, squarings) per verdict of k_verify_fixed_half<., chains>"""
-    table = 7 * 8 + 8 * 2                              # |d|P, d = 2..8: 7 additions; 8 to_niels
+    table = 7 * 7 + 8 * 2                              # |d|P, d = 2..8: 7 mixed additions; 8 to_niels
     dbl_m, dbl_s, add_m = 4, 3, 8
     per_chain_m = (4 + 2 * table                       # PK, R to Montgomery form; two tables
-                   + 2 * add_m                         # top window: two additions onto O
+                   + 2 + add_m                         # top window: O + entry (2M + 1S), one addition
                    + (WINDOWS - 1) * (4 * dbl_m + 2 * add_m)
                    + FIXED_ADDS * 7)                   # += (b*u)*G, mixed additions
-    per_chain_s = (WINDOWS - 1) * 4 * dbl_s
+    per_chain_s = (WINDOWS - 1) * 4 * dbl_s + 1
     return chains * per_chain_m, chains * per_chain_s
 
 
