@@ -134,6 +134,23 @@ DSV_DEV Ext ext_from_niels(const Niels& n) {
   r.t2 = cv;
   return r;
 }
+// the same two with the product tt = p.t1 * p.t2 handed in: a table build needs it twice per
+// entry (once for the entry's own 2d*t, once inside the addition that produces the next entry)
+DSV_DEV Ext ext_add_aniels_t(const Ext& p, const Fe& tt, const ANiels& n) {
+  Fe a = fe_mul(fe_sub2_raw(p.v, p.u), n.vmu);
+  Fe b = fe_mul(fe_add(p.v, p.u), n.vpu);
+  Fe c = fe_mul(tt, n.t2d);
+  Fe d = fe_dbl(p.z);
+  return ext_add_tail(a, b, c, d);
+}
+DSV_DEV Niels ext_to_niels_t(const Ext& p, const Fe& tt) {
+  Niels n;
+  n.vpu = fe_carry(fe_add(p.v, p.u));
+  n.vmu = fe_sub2(p.v, p.u);
+  n.z = p.z;
+  n.t2d = fe_mul(tt, fe_const(kD2));
+  return n;
+}
 // to_niels: (v+u, v-u, z, t1*t2*2d), all brought to N / carried form for table storage
 DSV_DEV Niels ext_to_niels(const Ext& p) {
   Niels n;

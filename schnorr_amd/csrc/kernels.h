@@ -345,15 +345,17 @@ DSV_DEV Niels load_var_entry(const u32* lane_tbl, int d) {
 }
 DSV_DEV void build_var_table(u32* lane_tbl, const Fe& pu, const Fe& pv) {
   Ext p = ext_from_affine(pu, pv);
-  Niels n1 = ext_to_niels(p);
+  Fe tt = fe_mul(p.t1, p.t2);  // u*v of the current multiple: used by its entry AND by the next addition
+  Niels n1 = ext_to_niels_t(p, tt);
   if (!DSV_SHARED_IDENTITY) store_var_entry(lane_tbl, 0, niels_identity());
   store_var_entry(lane_tbl, 1, n1);
-  const ANiels a1 = {n1.vpu, n1.vmu, n1.t2d};  // P is affine: every step is a mixed addition (7M)
+  const ANiels a1 = {n1.vpu, n1.vmu, n1.t2d};  // P is affine: every step is a mixed addition
   Ext cur = p;
 #pragma unroll 1
   for (int i = 2; i < kVarEntries; i++) {
-    cur = ext_add_aniels(cur, a1);
-    store_var_entry(lane_tbl, i, ext_to_niels(cur));
+    cur = ext_add_aniels_t(cur, tt, a1);
+    tt = fe_mul(cur.t1, cur.t2);
+    store_var_entry(lane_tbl, i, ext_to_niels_t(cur, tt));
   }
 }
 // signed recoding: y = s + 0x8888..8; digit k of s is nibble k of y minus 8, in [-8, 7].
@@ -427,15 +429,17 @@ DSV_DEV int sdigit_w(const u32 (&y)[8], int k) {
 template <int N>
 DSV_DEV void build_var_table_n(u32* lane_tbl, const Fe& pu, const Fe& pv) {
   Ext p = ext_from_affine(pu, pv);
-  Niels n1 = ext_to_niels(p);
+  Fe tt = fe_mul(p.t1, p.t2);  // u*v of the current multiple: used by its entry AND by the next addition
+  Niels n1 = ext_to_niels_t(p, tt);
   if (!DSV_SHARED_IDENTITY) store_var_entry(lane_tbl, 0, niels_identity());
   store_var_entry(lane_tbl, 1, n1);
-  const ANiels a1 = {n1.vpu, n1.vmu, n1.t2d};  // P is affine: every step is a mixed addition (7M)
+  const ANiels a1 = {n1.vpu, n1.vmu, n1.t2d};  // P is affine: every step is a mixed addition
   Ext cur = p;
 #pragma unroll 1
   for (int i = 2; i < N; i++) {
-    cur = ext_add_aniels(cur, a1);
-    store_var_entry(lane_tbl, i, ext_to_niels(cur));
+    cur = ext_add_aniels_t(cur, tt, a1);
+    tt = fe_mul(cur.t1, cur.t2);
+    store_var_entry(lane_tbl, i, ext_to_niels_t(cur, tt));
   }
 }
 template <int W>
