@@ -334,7 +334,8 @@ void launch_verify_fixed(const Context& ctx, bool accumulate, const void* u, con
                          (const uint8_t*)c, op, op, (const uint8_t*)valid, n, (uint8_t*)ok, tables);
     return;
   }
-  if (DSV_FIXED_LDS_BITS && ctx.half_scalars && ctx.fixed_lds && !accumulate && which == 0) {
+#if DSV_FIXED_LDS_BITS
+  if (ctx.half_scalars && ctx.fixed_lds && !accumulate && which == 0) {
     // A/B: 8-wave workgroups, one per CU at most, table of G staged in LDS
     const ChainOperands op{(const uint8_t*)PK_uv, (const uint8_t*)R_uv, ctx.lds_table};
     unsigned g = grid_for(n, kLdsBlock);
@@ -344,6 +345,7 @@ void launch_verify_fixed(const Context& ctx, bool accumulate, const void* u, con
                        (const uint8_t*)valid, n, (uint8_t*)ok, tables);
     return;
   }
+#endif
   if (ctx.half_scalars) {
     const ChainOperands op{(const uint8_t*)PK_uv, (const uint8_t*)R_uv, ctx.table[which]};
     if (accumulate)
@@ -543,7 +545,8 @@ int dsv_init(int device) {
                        kFixedBits, kEntryWords);
     HIP_TRY(hipGetLastError());
   }
-  if (DSV_FIXED_LDS_BITS) {
+#if DSV_FIXED_LDS_BITS
+  {
     const char* lds = getenv("DSV_FIXED_LDS");
     ctx.fixed_lds = lds && strcmp(lds, "1") == 0;
     HIP_TRY(hipMalloc(&ctx.lds_table, (size_t)kLdsTableWords * 4));
@@ -555,6 +558,7 @@ int dsv_init(int device) {
         reinterpret_cast<const void*>(&k_verify_fixed_half<false, 1, kLdsBlock, true>),
         hipFuncAttributeMaxDynamicSharedMemorySize, kLdsTableWords * 4));
   }
+#endif
   HIP_TRY(hipDeviceSynchronize());
   const char* split = getenv("DSV_SPLIT");
   ctx.split = !(split && strcmp(split, "0") == 0);
