@@ -461,7 +461,7 @@ template <int TOP>
 DSV_DEV Ext var_base_mul(const u32 (&s)[8], const u32* lane_tbl) {
   u32 y[8];
   recode_signed4(y, s);
-  Ext acc = ext_add_niels(ext_identity(), load_var_entry(lane_tbl, sdigit4(y, TOP)));
+  Ext acc = ext_from_niels(load_var_entry(lane_tbl, sdigit4(y, TOP)));
 #pragma unroll 1
   for (int k = TOP - 1; k >= 0; k--) {
     acc = ext_mul16(acc);
@@ -474,7 +474,7 @@ DSV_DEV Ext var_base_mul2(const u32 (&a)[8], const u32* tp, const u32 (&b)[8], c
   u32 ya[8], yb[8];
   recode_signed4(ya, a);
   recode_signed4(yb, b);
-  Ext acc = ext_add_niels(ext_identity(), load_var_entry(tp, sdigit4(ya, 63)));
+  Ext acc = ext_from_niels(load_var_entry(tp, sdigit4(ya, 63)));
   acc = ext_add_niels(acc, load_var_entry(tq, sdigit4(yb, 63)));
 #pragma unroll 1
   for (int k = 62; k >= 0; k--) {

@@ -98,7 +98,10 @@ class MixedShardedVerifier:
     Per call (everything on the GPU, nothing synchronises with the host):
       1. split the local kind vector on the device (stable index compaction, libdsv k_kind_*),
       2. gather the rows of each kind into compact arrays (k_gather_rows),
-      3. run each kind through its own entry point (dsv_verify_single_dev / _double_dev),
+      3. run each kind through its own entry point (dsv_verify_single_dev / _double_dev), one
+         after the other on the current stream (running the two kinds on two side streams at
+         once was measured 5 % SLOWER: 42.3 against 44.6 M items/s — four sub-batch streams
+         compete for the same SIMDs),
       4. all_gather the two per-kind verdict vectors (RCCL when the backend is "nccl"),
       5. scatter them back into GLOBAL batch order with the index vectors obtained by splitting
          the global kind vector (every rank ends up with all world*n_local verdicts).
