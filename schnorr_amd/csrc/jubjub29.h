@@ -94,7 +94,7 @@ DSV_DEV void ext_double_uvz(Fe& u, Fe& v, Fe& z) {
 DSV_DEV Ext ext_add_tail(const Fe& a, const Fe& b, const Fe& c, const Fe& d) {
   Fe cu = fe_sub2_raw(b, a);                // < 3.2, limbs < 1.5 * 2^30 (partners cz, ct, t2 < 2^30)
   Fe cv = fe_add(b, a);                     // < 2.4, limbs < 2^30
-  Fe cz = fe_carry(fe_add(d, c));           // < 4.2, carried
+  Fe cz = fe_add(d, c);                     // < 4.2, limbs < 1.5 * 2^30 (r02: no carry pass, proved)
   Fe ct = fe_sub2(d, c);                    // < 5.0
   Ext r;
   r.u = fe_mul(cu, ct);                     // < 1.23

@@ -82,7 +82,7 @@ DSV_DEV void qext_double(QExt& p, int q) {
 DSV_DEV void qext_add_tail(QExt& p, int q, const Fe& a, const Fe& b, const Fe& c, const Fe& d) {
   const Fe cu = fe_sub2_raw(b, a);
   const Fe cv = fe_add(b, a);
-  const Fe cz = fe_carry(fe_add(d, c));
+  const Fe cz = fe_add(d, c);
   const Fe ct = fe_sub2(d, c);
   const Fe x = quad_pick(q, cu, cv, cz, cu);
   const Fe y = quad_pick(q, ct, cz, ct, cv);

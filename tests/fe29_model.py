@@ -268,7 +268,7 @@ def ext_double(p):
 def _add_tail(a, b, c, d):
     cu = sub_raw(b, a, 2)
     cv = add(b, a)
-    cz = carry(add(d, c))
+    cz = add(d, c)
     ct = sub(d, c, 2)
     return {"u": mul(cu, ct), "v": mul(cv, cz), "z": mul(cz, ct), "t1": cu, "t2": cv}
 
