@@ -176,6 +176,11 @@ k_challenge(const uint8_t* __restrict__ R_uv, const uint8_t* __restrict__ Rp_uv,
 // acc += u * Gen from the signed kFixedBits-bit-window table: kFixedWindows (23 for 11 bits) mixed
 // additions, no doubling.  The running accumulator is passed in so that u*G + c*PK needs no
 // separate final addition (and no second live point).
+// -DDSV_FIXED_PREFETCH=1: the same pipelining for the fixed-base lookups (L2 hits, 23 per chain):
+// measured equal (profiles/r02/ab_table_prefetch.txt), so the plain loop ships.
+#ifndef DSV_FIXED_PREFETCH
+#define DSV_FIXED_PREFETCH 0
+#endif
 DSV_DEV Ext fixed_base_accumulate(Ext acc, const u32 (&s)[8], const u32* __restrict__ table) {
   // signed recoding: add 2^(bits-1) to every window; digit = window value - 2^(bits-1).
   // s < 2^252, so the top window cannot overflow.  Windows are consumed LSB first (the order of
@@ -197,6 +202,29 @@ DSV_DEV Ext fixed_base_accumulate(Ext acc, const u32 (&s)[8], const u32* __restr
       carry = (u32)(t >> 32);
     }
   }
+#if DSV_FIXED_PREFETCH
+  // Software pipelining: the entry of window w+1 is loaded before the addition of window w.  Two
+  // windows per round with the two entries in their own registers (a rolled one-window loop would
+  // have to copy `next` into `current`, and the copy waits for the load).
+  auto next_digit = [&y]() {
+    const int d = (int)(y[0] & ((1u << kFixedBits) - 1)) - kFixedHalf;
+#pragma unroll
+    for (int i = 0; i < 8; i++) y[i] = __funnelshift_r(y[i], y[i + 1], kFixedBits);
+    y[8] >>= kFixedBits;
+    return d;
+  };
+  ANiels e0 = load_aniels(table, 0, next_digit());
+#pragma unroll 1
+  for (int w = 0; w + 1 < kFixedWindows; w += 2) {
+    const ANiels e1 = load_aniels(table, w + 1, next_digit());
+    acc = ext_add_aniels(acc, e0);
+    const bool more = w + 2 < kFixedWindows;  // even window count: the last load is a dummy
+    const int d2 = next_digit();
+    e0 = load_aniels(table, more ? w + 2 : w + 1, more ? d2 : 0);
+    acc = ext_add_aniels(acc, e1);
+  }
+  if (kFixedWindows & 1) acc = ext_add_aniels(acc, e0);
+#else
 #pragma unroll 1
   for (int w = 0; w < kFixedWindows; w++) {
     const int d = (int)(y[0] & ((1u << kFixedBits) - 1)) - kFixedHalf;
@@ -206,6 +234,7 @@ DSV_DEV Ext fixed_base_accumulate(Ext acc, const u32 (&s)[8], const u32* __restr
     ANiels e = load_aniels(table, w, d);
     acc = ext_add_aniels(acc, e);
   }
+#endif
   return acc;
 }
 
@@ -343,6 +372,36 @@ DSV_DEV Niels load_var_entry(const u32* lane_tbl, int d) {
   }
   return n;
 }
+// Software-pipelined form of load_var_entry (-DDSV_VAR_PREFETCH, A/B in DESIGN.md §3): the loads
+// of the entry for the NEXT window are issued one group operation ahead and stay in flight while
+// the chain works; the sign fix-up waits until the entry is consumed, so nothing forces an
+// s_waitcnt right behind the loads.
+#ifndef DSV_VAR_PREFETCH
+#define DSV_VAR_PREFETCH 1
+#endif
+struct RawNiels {
+  Fe a, b, z, t;  // vpu / vmu already swapped by address for a negative digit; t = 2d*t of +entry
+  bool neg;
+};
+DSV_DEV RawNiels load_var_entry_raw(const u32* lane_tbl, int d) {
+  RawNiels r;
+  r.neg = d < 0;
+  const int mag = r.neg ? -d : d;
+  const u32* p = (DSV_SHARED_IDENTITY && mag == 0) ? kIdentityEntry : lane_tbl + mag * kVarEntryWords;
+  r.a = load_fe_words(p + (r.neg ? NL : 0));
+  r.b = load_fe_words(p + (r.neg ? 0 : NL));
+  r.z = load_fe_words(p + 2 * NL);
+  r.t = load_fe_words(p + 3 * NL);
+  return r;
+}
+DSV_DEV Niels finish_var_entry(const RawNiels& r) {
+  Niels n;
+  n.vpu = r.a;
+  n.vmu = r.b;
+  n.z = r.z;
+  n.t2d = fe_select(r.neg, fe_neg2(r.t), r.t);
+  return n;
+}
 DSV_DEV void build_var_table(u32* lane_tbl, const Fe& pu, const Fe& pv) {
   Ext p = ext_from_affine(pu, pv);
   Fe tt = fe_mul(p.t1, p.t2);  // u*v of the current multiple: used by its entry AND by the next addition
@@ -476,12 +535,26 @@ DSV_DEV Ext var_base_mul2(const u32 (&a)[8], const u32* tp, const u32 (&b)[8], c
   recode_signed4(yb, b);
   Ext acc = ext_from_niels(load_var_entry(tp, sdigit4(ya, 63)));
   acc = ext_add_niels(acc, load_var_entry(tq, sdigit4(yb, 63)));
+#if DSV_VAR_PREFETCH && !DSV_VAR_NEG_T2D
+  RawNiels ea = load_var_entry_raw(tp, sdigit4(ya, 62));
+  RawNiels eb = load_var_entry_raw(tq, sdigit4(yb, 62));
+#pragma unroll 1
+  for (int k = 62; k >= 0; k--) {
+    acc = ext_mul16(acc);
+    const int kn = k > 0 ? k - 1 : 0;  // last round: reloads its own entries, unused
+    acc = ext_add_niels(acc, finish_var_entry(ea));
+    ea = load_var_entry_raw(tp, sdigit4(ya, kn));
+    acc = ext_add_niels(acc, finish_var_entry(eb));
+    eb = load_var_entry_raw(tq, sdigit4(yb, kn));
+  }
+#else
 #pragma unroll 1
   for (int k = 62; k >= 0; k--) {
     acc = ext_mul16(acc);
     acc = ext_add_niels(acc, load_var_entry(tp, sdigit4(ya, k)));
     acc = ext_add_niels(acc, load_var_entry(tq, sdigit4(yb, k)));
   }
+#endif
   return acc;
 }
 
@@ -617,12 +690,29 @@ k_verify_fixed_half(const uint8_t* __restrict__ u, const uint8_t* __restrict__ c
       // T = a*PK + (b_neg ? +|b| : -|b|) * R  (+ w*G below)
       Ext acc = ext_from_niels(load_var_entry(tpk, sdigit_w<kHalfW>(ya, top)));
       acc = ext_add_niels(acc, load_var_entry(tr, rsign * sdigit_w<kHalfW>(yb, top)));
+#if DSV_VAR_PREFETCH && !DSV_VAR_NEG_T2D
+      {
+        const int k0 = top > 0 ? top - 1 : 0;
+        RawNiels ea = load_var_entry_raw(tpk, sdigit_w<kHalfW>(ya, k0));
+        RawNiels eb = load_var_entry_raw(tr, rsign * sdigit_w<kHalfW>(yb, k0));
+#pragma unroll 1
+        for (int k = top - 1; k >= 0; k--) {
+          acc = ext_mul_pow2<kHalfW>(acc);
+          const int kn = k > 0 ? k - 1 : 0;  // last round: reloads its own entries, unused
+          acc = ext_add_niels(acc, finish_var_entry(ea));
+          ea = load_var_entry_raw(tpk, sdigit_w<kHalfW>(ya, kn));
+          acc = ext_add_niels(acc, finish_var_entry(eb));
+          eb = load_var_entry_raw(tr, rsign * sdigit_w<kHalfW>(yb, kn));
+        }
+      }
+#else
 #pragma unroll 1
       for (int k = top - 1; k >= 0; k--) {
         acc = ext_mul_pow2<kHalfW>(acc);
         acc = ext_add_niels(acc, load_var_entry(tpk, sdigit_w<kHalfW>(ya, k)));
         acc = ext_add_niels(acc, load_var_entry(tr, rsign * sdigit_w<kHalfW>(yb, k)));
       }
+#endif
       acc = LDS ? fixed_base_accumulate_lds(acc, w, lds_table) : fixed_base_accumulate(acc, w, op.table);
       // T == O  <=>  u == 0 and v == z
       good &= (bool)((int)fe_is_zero_canon(fe_canon(acc.u)) & (int)fe_equal(acc.v, acc.z));
