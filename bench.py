@@ -66,32 +66,37 @@ def _verify_counts(chains=1):
 
 
 def _hash_counts(double):
-    """(multiplications, squarings, dot-product limb products, reductions of dots) of k_challenge"""
+    """(multiplications, squarings, VALU dot-product terms, reductions of all dots, MFMA dots,
+    MFMA wave-instructions per wave) of k_challenge.  Since r02's matrix-core form
+    (schnorr_amd/csrc/hades_mfma.h) the recurrence rounds and the dense layers of the full rounds
+    multiply by their constants with v_mfma_i32_32x32x32_i8; only the start-up rows of the
+    recurrence and the state rebuild keep 81-MAD limb products."""
     def perm(first_const, word1_only):
         sbox = 5 * 8 + 59 - first_const
-        dots5 = 5 * 8 - (4 if word1_only else 0)
-        # partial rounds as one scalar recurrence: 4 start-up rows (7, 9, 11, 13 terms), 54 rounds of
-        # 10 terms, 5 rows of 10 to rebuild the state
-        terms = 5 * dots5 + (7 + 9 + 11 + 13) + 54 * 10 + 5 * 10
+        dots5 = 5 * 8 - (4 if word1_only else 0)            # rows of the dense layer: MFMA, 5 terms
+        valu_terms = (7 + 9 + 11 + 13) + 5 * 10             # recurrence start-up + state rebuild
+        mfma_dots = dots5 + 54
         ndots = dots5 + 4 + 54 + 5
-        return sbox, terms, ndots
+        mfma_instr = 4 * (5 * dots5 + 10 * 54 + 9)          # 4 per term (2 row x 2 hash tiles) + prologue
+        return sbox, valu_terms, ndots, mfma_dots, mfma_instr
     if double:
         a, b = perm(1, False), perm(0, True)
-        sbox, terms, ndots = a[0] + b[0], a[1] + b[1], a[2] + b[2]
+        sbox, terms, ndots, mdots, minstr = (a[i] + b[i] for i in range(5))
         conv = 5
     else:
-        sbox, terms, ndots = perm(2, True)
+        sbox, terms, ndots, mdots, minstr = perm(2, True)
         conv = 3
-    return conv + 1 + sbox, 2 * sbox, terms, ndots     # +1: out of Montgomery form
+    return conv + 1 + sbox, 2 * sbox, terms, ndots, mdots, minstr     # +1: out of Montgomery form
 
 
 def _mads(m, s, dot_terms=0, dot_reds=0):
     return m * MUL_MAD + s * SQR_MAD + dot_terms * 81 + dot_reds * 72
 
 
-def _valu(m, s, dot_terms=0, dot_reds=0, other=0):
-    # a dot product: 81 MADs per term + one operand-scanning reduction (72 MADs + 58 others)
-    return m * MUL_ALL + s * SQR_ALL + dot_terms * 81 + dot_reds * 130 + other
+def _valu(m, s, dot_terms=0, dot_reds=0, other=0, mfma_dots=0):
+    # a dot product: 81 MADs per term + one operand-scanning reduction (72 MADs + 58 others); one
+    # on the matrix cores: the same reduction + ~235 cheap instructions of digit packing / recombination
+    return m * MUL_ALL + s * SQR_ALL + dot_terms * 81 + dot_reds * 130 + mfma_dots * 235 + other
 
 
 # lane-instructions outside multiplications: limb-wise add / biased subtract / carry passes of the
@@ -324,13 +329,17 @@ def main():
 
     kernels = {}
 
-    def kernel_block(name, ms, items, m, s, dt_=0, dr=0, other=0, algo_bytes=None):
-        mads, valu = _mads(m, s, dt_, dr), _valu(m, s, dt_, dr, other)
+    def kernel_block(name, ms, items, m, s, dt_=0, dr=0, other=0, algo_bytes=None, mfma_dots=0, mfma_instr=0):
+        mads, valu = _mads(m, s, dt_, dr), _valu(m, s, dt_, dr, other, mfma_dots)
         sec = ms * 1e-3
         blk = {"ms_per_launch": ms, "items": items, "mad_lane_ops_per_item": round(mads),
                "valu_lane_instr_per_item": round(valu),
                "mad_frac": mads * items / sec / MAD_PEAK,
                "valu_issue_frac": valu * items / sec / (MAD_PEAK * MAD_CYCLES / 4.05)}
+        if mfma_instr:
+            # v_mfma_i32_32x32x32_i8: 8 passes = 32 cycles of one SIMD's matrix core per wave instruction
+            blk["mfma_wave_instr_per_wave"] = mfma_instr
+            blk["mfma_pipe_frac"] = mfma_instr * (items / 64.0) * 32 / (sec * N_CU * SIMD_PER_CU * CLOCK_HZ)
         if algo_bytes:
             blk["algorithmic_GBps"] = algo_bytes * items / sec / 1e9
         kernels[name] = blk
@@ -340,8 +349,8 @@ def main():
         vm, vs = _verify_counts(1)
         dom = kernel_block("k_verify_fixed_half<false,1>", core_ms, n, vm, vs, other=VERIFY_OTHER,
                            algo_bytes=ALGO_BYTES["single"])
-        hm, hs, ht, hr = _hash_counts(False)
-        kernel_block("k_challenge<false>", hash_ms, n, hm, hs, ht, hr, other=600)
+        hm, hs, ht, hr, hmd, hmi = _hash_counts(False)
+        kernel_block("k_challenge<false>", hash_ms, n, hm, hs, ht, hr, other=600, mfma_dots=hmd, mfma_instr=hmi)
         pmc = _pmc()
         traffic = clock = valu_busy = None
         if pmc:
@@ -399,8 +408,8 @@ def main():
         vm2, vs2 = _verify_counts(2)
         kernel_block("k_verify_fixed_half<false,2>", cd_ms, n, vm2, vs2, other=2 * VERIFY_OTHER - 9500,
                      algo_bytes=ALGO_BYTES["double"])
-        hm2, hs2, ht2, hr2 = _hash_counts(True)
-        kernel_block("k_challenge<true>", hd_ms, n, hm2, hs2, ht2, hr2, other=900)
+        hm2, hs2, ht2, hr2, hmd2, hmi2 = _hash_counts(True)
+        kernel_block("k_challenge<true>", hd_ms, n, hm2, hs2, ht2, hr2, other=900, mfma_dots=hmd2, mfma_instr=hmi2)
         sample_checks["double"] = (bd, okd.clone())
 
         nv = min(n, 1 << 18)

@@ -222,6 +222,147 @@ def arma_partial_rounds(rc, m):
     return out
 
 
+# ---- the recurrence of arma_partial_rounds on the matrix cores (hades_mfma.h) -------------------
+# a_{r+5} = sum_j k_j x_j + gamma_r is a CONSTANT row vector times the per-hash vector (x_j): over a
+# wave that is a (byte-Toeplitz of the k_j) x (bytes of the x_j) integer matrix product, which
+# v_mfma_i32_32x32x32_i8 evaluates exactly.  This block builds the operand table and the start
+# values, and re-derives every intermediate of hades_mfma_step() in plain integers.
+MFMA_TERMS = 10
+MFMA_DELTA = 128 * sum(1 << (8 * k) for k in range(32))          # x = signed-digit value + DELTA
+MFMA_WBIAS = (1 << 31) + (1 << 47)                                # bias of one 4-row group W'
+MFMA_KTOP = (1 << 527) + (1 << 511) - (1 << 515)                  # taken off the top words again
+MFMA_BNET = sum(MFMA_WBIAS << (32 * i) for i in range(16)) - MFMA_KTOP
+
+
+def balanced_digits(x):
+    """32 digits in [-128, 127], sum d_k 2^(8k) = x  (x < 2^255: the top digit needs no carry)"""
+    out, carry = [], 0
+    for k in range(32):
+        d = ((x >> (8 * k)) & 255) + carry
+        carry = 0
+        if d >= 128:
+            d -= 256
+            carry = 1
+        out.append(d)
+    assert carry == 0 and sum(d << (8 * k) for k, d in enumerate(out)) == x
+    return out
+
+
+def mfma_a_table(ks):
+    """A operands: [term][m-tile][lane][16 bytes]; row m = 32*mt + lane%32, k = 16*(lane/32) + byte,
+    A[m][k] = digit (m - k) of the term's multiplier (operand layout: tools/microbench/mfma_layout.hip)"""
+    tab = []
+    for kj in ks:
+        dg = balanced_digits(kj)
+        for mt in range(2):
+            for lane in range(64):
+                m = 32 * mt + lane % 32
+                for byte in range(16):
+                    k = 16 * (lane // 32) + byte
+                    tab.append(dg[m - k] & 255 if 0 <= m - k < 32 else 0)
+    return tab
+
+
+def reduce_cols_model(c):
+    """fe29.h: fe_reduce_cols on 17 integer columns (columns 0..8 carry the +M29 bias)"""
+    c = list(c) + [0]
+    qq = limbs(Q)
+    k = 0
+    for i in range(NLIMBS):
+        s_ = c[i] + k
+        assert s_ < (1 << 64)
+        m_ = (~s_) & MASK
+        k = s_ >> LIMB_BITS
+        for j in range(1, NLIMBS):
+            c[i + j] += m_ * qq[j]
+            assert c[i + j] < (1 << 64)
+    out = []
+    for i in range(NLIMBS - 1):
+        s_ = c[NLIMBS + i] + k
+        assert s_ < (1 << 64)
+        out.append(s_ & MASK)
+        k = s_ >> LIMB_BITS
+    out.append(k)
+    return out
+
+
+def mfma_step_model(ks, xs, start):
+    """hades_mfma_step in integers: xs = the ten window values as stored (z entries one below the
+    multiplication result), start = start limbs incl. the reduction bias.  Returns the 9 limbs."""
+    cd = [balanced_digits(kj) for kj in ks]
+    xd = [[((x >> (8 * k)) & 255) - 128 for k in range(32)] for x in xs]
+    W = []
+    for idx in range(16):
+        cp = []
+        for jj in range(4):
+            m = 4 * idx + jj
+            cm = sum(cd[j][m - k] * xd[j][k] for j in range(len(ks)) for k in range(32) if 0 <= m - k < 32)
+            assert abs(cm) < 5300000                               # <= 10 terms: 320 * 2^14 = 5 242 880
+            cp.append(cm)
+        t0 = cp[0] + (cp[1] << 8) + (1 << 31)                       # sign bit flipped: signed -> biased
+        t1 = cp[2] + (cp[3] << 8) + (1 << 31)
+        assert 0 <= t0 < (1 << 32) and 0 <= t1 < (1 << 32)
+        W.append(t0 + (t1 << 16))
+    z = sum(w_ << (32 * i) for i, w_ in enumerate(W))
+    assert z >> 512 < (1 << 32) and ((z >> 480) & ((1 << 64) - 1)) >= ((0x8000 - 8) << 32 | 0x80000000)
+    z -= MFMA_KTOP
+    assert 0 < z < (1 << 516)
+    cols = [(z >> (LIMB_BITS * k)) & MASK for k in range(16)] + [z >> (LIMB_BITS * 16)]
+    cols = [c_ + (start[k] if k < NLIMBS else 0) for k, c_ in enumerate(cols)]
+    return reduce_cols_model(cols)
+
+
+def mfma_linear(coefs, inc, consts):
+    """One output row sum_j coefs[j] * x_j + const on the matrix cores, for every const in `consts`
+    (field elements; plain).  inc[j] = 1 where the stored operand is one below its value.
+    Returns (A operand bytes, [start limbs per const]); self-tested against the field arithmetic."""
+    assert len(coefs) <= MFMA_TERMS
+    ks = [c_ * RMONT % Q for c_ in coefs]
+    RR = RMONT * RMONT % Q
+    corr = (sum(k_ * i_ for k_, i_ in zip(ks, inc)) + MFMA_DELTA * sum(ks) - MFMA_BNET) % Q
+    starts = [[x + MASK for x in limbs((g * RR + corr) % Q)] for g in consts]
+    import random as _random
+    rnd = _random.Random(11)
+    rinv = pow(RMONT, -1, Q)
+    n = len(ks)
+    cases = [[rnd.randrange(1 << 256) for _ in range(n)] for _ in range(4)]
+    cases += [[0] * n, [(1 << 256) - 1] * n]
+    if n == MFMA_TERMS:
+        cases += [[0] * 5 + [(1 << 256) - 1] * 5, [(1 << 256) - 1] * 5 + [0] * 5]
+    for sgn in (127, -128):                                          # push every byte column to its extreme
+        xs = []
+        for kj in ks:
+            dg = balanced_digits(kj)
+            xs.append(sum((((sgn if d >= 0 else -1 - sgn) + 128) & 255) << (8 * k) for k, d in enumerate(dg[::-1])))
+        cases.append(xs)
+    for xs in cases:
+        for gi in (0, len(consts) - 1):
+            out = mfma_step_model(ks, xs, starts[gi])
+            v = sum(l_ << (LIMB_BITS * i) for i, l_ in enumerate(out))
+            want = (sum(k_ * (x + i_) for k_, x, i_ in zip(ks, xs, inc)) + consts[gi] * RR) * rinv % Q
+            assert v % Q == want, "MFMA linear-layer model disagrees with the field arithmetic"
+            assert v < (1 << 256) and all(l_ <= MASK for l_ in out[:-1])
+    return mfma_a_table(ks), starts
+
+
+def mfma_recurrence(rec, gamma):
+    """A table + per-round start limbs for the recurrence; rec = ca + cz (plain field elements);
+    the five z operands are stored one below their value (fe_mul's limb 0 is in [1, 2^29])"""
+    return mfma_linear(rec, [0] * 5 + [1] * 5, gamma)
+
+
+def mfma_mds(m):
+    """The dense 5 x 5 layer of a full round, one output row at a time: operands are the five
+    S-box outputs (stored one below their value), no constant.  Returns (A bytes of the 5 rows, 5
+    start-limb rows)."""
+    tab, starts = [], []
+    for row in m:
+        t_, s_ = mfma_linear(list(row), [1] * WIDTH, [0])
+        tab += t_
+        starts.append(s_[0])
+    return tab, starts
+
+
 def arr(v):
     return "{" + ", ".join("0x%08xu" % x for x in v) + "}"
 
@@ -314,6 +455,10 @@ def main():
         w("// (0 + rc[0])^5 and (1 + rc[4])^5: S-box outputs of the constant words in round 0\n")
         w("#define DSV_HADES_SBOX0_CAP %s\n" % arr(mont(pow(rc[0], 5, Q))))
         w("#define DSV_HADES_SBOX0_PAD %s\n" % arr(mont(pow(1 + rc[4], 5, Q))))
+        # the same two constants one below their Montgomery integer (operand convention of hades_mfma.h)
+        m1 = lambda x: limbs((x * RMONT % Q or Q) - 1)
+        w("#define DSV_HADES_SBOX0_CAP_M1 %s\n" % arr(m1(pow(rc[0], 5, Q))))
+        w("#define DSV_HADES_SBOX0_PAD_M1 %s\n" % arr(m1(pow(1 + rc[4], 5, Q))))
         w("static const uint32_t DSV_HADES_MDS_HOST[%d][9] = {\n" % (WIDTH * WIDTH))
         for row in m:
             for x in row:
@@ -416,6 +561,28 @@ def main():
         for r_ in rows:
             w("  %s,\n" % arr(r_))
         w("};\n")
+        # ---- the same recurrence on the matrix cores (hades_mfma.h)
+        atab, starts = mfma_recurrence(rec, A["gamma"])
+        words_ = [atab[i] | atab[i + 1] << 8 | atab[i + 2] << 16 | atab[i + 3] << 24 for i in range(0, len(atab), 4)]
+        w("// recurrence on the matrix cores (generator: mfma_recurrence): A operands [term][m-tile][lane][4 words]\n")
+        w("#define DSV_HADES_MFMA_A_WORDS %d\n" % len(words_))
+        w("#define DSV_HADES_MFMA_A_LIST \\\n")
+        for i in range(0, len(words_), 8):
+            w("  " + ", ".join("0x%08xu" % x for x in words_[i:i + 8]) + (", \\\n" if i + 8 < len(words_) else "\n"))
+        w("#define DSV_HADES_MFMA_ROUNDS %d\n" % len(starts))
+        w("#define DSV_HADES_MFMA_START_LIST \\\n")
+        for i, st in enumerate(starts):
+            w("  " + arr(st) + (", \\\n" if i + 1 < len(starts) else "\n"))
+        # ---- the dense layer of the full rounds, same machinery: [row][term][m-tile][lane][4 words]
+        mtab, mstarts = mfma_mds(m)
+        words_ = [mtab[i] | mtab[i + 1] << 8 | mtab[i + 2] << 16 | mtab[i + 3] << 24 for i in range(0, len(mtab), 4)]
+        w("#define DSV_HADES_MFMA_MDS_WORDS %d\n" % len(words_))
+        w("#define DSV_HADES_MFMA_MDS_LIST \\\n")
+        for i in range(0, len(words_), 8):
+            w("  " + ", ".join("0x%08xu" % x for x in words_[i:i + 8]) + (", \\\n" if i + 8 < len(words_) else "\n"))
+        w("#define DSV_HADES_MFMA_MDS_START_LIST \\\n")
+        for i, st in enumerate(mstarts):
+            w("  " + arr(st) + (", \\\n" if i + 1 < len(mstarts) else "\n"))
     print("wrote", path)
 
 

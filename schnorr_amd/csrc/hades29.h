@@ -13,6 +13,19 @@
 // round is ~1.2k instructions of code instead of ~6k (the instruction cache is shared by two CUs).
 #pragma once
 #include "fe29.h"
+// DSV_HADES_MFMA (shipped: 1): the recurrence of the partial rounds runs on the matrix cores
+// (hades_mfma.h).  The hashes of a wave then cooperate: every lane of the wave has to run the
+// permutation (callers clamp the index instead of leaving) and the workgroup calls
+// hades_mfma_load_table() first.  -DDSV_HADES_MFMA=0: all-VALU form (A/B).
+#ifndef DSV_HADES_MFMA
+#define DSV_HADES_MFMA 1
+#endif
+#ifndef DSV_HADES_MFMA_UNROLL5
+#define DSV_HADES_MFMA_UNROLL5 1  /* rotating window slots, five rounds per loop iteration */
+#endif
+#if DSV_HADES_MFMA
+#include "hades_mfma.h"
+#endif
 
 namespace dsv {
 
@@ -63,6 +76,33 @@ DSV_DEV void hades_mds(Fe (&s)[5], const u32 (*mat)[NL]) {
   for (int k = 0; k < 5; k++) s[k] = out[k];
 }
 
+#if DSV_HADES_MFMA && DSV_HADES_MFMA_MDS
+// state' = MDS * state on the matrix cores.  s[j] = S-box outputs as fe_mul returns them (limb 0
+// in [1, 2^29], limbs 1..7 < 2^29), or constants given one below their value (ONE_BELOW).
+DSV_DEV void hades_mds_mfma(Fe (&s)[5], int first_row, int rows, unsigned one_below_mask = 0) {
+  const MfmaTable tab = hades_mfma_table();
+  Dig d[5];
+#pragma unroll
+  for (int j = 0; j < 5; j++) {
+    Fe t = s[j];
+    if (!((one_below_mask >> j) & 1)) t.l[0] -= 1;
+    d[j] = mfma_digits(t);
+  }
+  Fe out[5] = {fe_zero(), fe_zero(), fe_zero(), fe_zero(), fe_zero()};
+#pragma unroll 1
+  for (int k = first_row; k < first_row + rows; k++) {
+    const Fe r = hades_mfma_mds_row(d, k, tab);
+    out[0] = out[1];
+    out[1] = out[2];
+    out[2] = out[3];
+    out[3] = out[4];
+    out[4] = r;
+  }
+#pragma unroll
+  for (int k = 0; k < 5; k++) s[k] = out[k];
+}
+#endif
+
 // one full round: add constants, x^5 on every word, dense matrix
 DSV_DEV void hades_full_round(Fe (&s)[5], const u32 (*rc)[NL], const u32 (*mat)[NL]) {
 #pragma unroll
@@ -77,11 +117,21 @@ DSV_DEV void hades_full_round(Fe (&s)[5], const u32 (*rc)[NL], const u32 (*mat)[
     s[3] = s[4];
     s[4] = t;
   }
+#if DSV_HADES_MFMA && DSV_HADES_MFMA_MDS
+  (void)mat;
+  hades_mds_mfma(s, 0, 5);
+#else
   hades_mds(s, mat);
+#endif
 }
 
+#if DSV_HADES_MFMA && DSV_HADES_MFMA_MDS
+__device__ constexpr u32 kSbox0Cap[NL] = DSV_HADES_SBOX0_CAP_M1;  // one below: operand convention
+__device__ constexpr u32 kSbox0Pad[NL] = DSV_HADES_SBOX0_PAD_M1;
+#else
 __device__ constexpr u32 kSbox0Cap[NL] = DSV_HADES_SBOX0_CAP;
 __device__ constexpr u32 kSbox0Pad[NL] = DSV_HADES_SBOX0_PAD;
+#endif
 
 // round 0 of a permutation whose word 0 (and, with PAD, word 4) enters as the constant 0 (1): the
 // S-boxes of those words are compile-time constants — x^5 runs on words 1..3 (1..4) only
@@ -99,7 +149,12 @@ DSV_DEV void hades_first_round_const(Fe (&s)[5], const u32 (*rc)[NL], const u32 
   }
   s[0] = fe_const(kSbox0Cap);
   if (PAD) s[4] = fe_const(kSbox0Pad);
+#if DSV_HADES_MFMA && DSV_HADES_MFMA_MDS
+  (void)mat;
+  hades_mds_mfma(s, 0, 5, PAD ? 0x11u : 0x01u);
+#else
   hades_mds(s, mat);
+#endif
 }
 // last round of a permutation of which only word 1 is read (the sponge's output): one matrix row
 DSV_DEV void hades_last_round_word1(Fe (&s)[5], const u32 (*rc)[NL], const u32 (*mat)[NL]) {
@@ -114,10 +169,16 @@ DSV_DEV void hades_last_round_word1(Fe (&s)[5], const u32 (*rc)[NL], const u32 (
     s[3] = s[4];
     s[4] = t;
   }
+#if DSV_HADES_MFMA && DSV_HADES_MFMA_MDS
+  (void)mat;
+  hades_mds_mfma(s, 1, 1);  // row 1 lands in s[4]
+  s[1] = s[4];
+#else
   Fe m[5];
 #pragma unroll
   for (int j = 0; j < 5; j++) m[j] = fe_load_const(mat[5 + j]);
   s[1] = fe_dot5(s, m);
+#endif
 }
 
 // The 59 partial rounds as ONE scalar recurrence.  Only the S-box inputs a_r and outputs
@@ -142,6 +203,102 @@ DSV_DEV void hades_partial_rounds_arma(Fe (&s)[5]) {
     A[3] = fe_dot_const_plus<11>(t, k, k[11]); k += 12; asm volatile("" : "+s"(k)); Z[3] = hades_sbox(A[3]); }
   { const Fe t[13] = {s[0], s[1], s[2], s[3], s[4], A[0], Z[0], A[1], Z[1], A[2], Z[2], A[3], Z[3]};
     A[4] = fe_dot_const_plus<13>(t, k, k[13]); Z[4] = hades_sbox(A[4]); }
+#if DSV_HADES_MFMA
+  {
+    static_assert(DSV_HADES_MFMA_ROUNDS == DSV_HADES_PARTIAL - 5, "one start row per recurrence round");
+    const MfmaTable tab = hades_mfma_table();
+    const v4i* rbase = tab.a + tab.lane;
+    // window as MFMA operands; a z entry is stored one below its value (fe_mul returns limb 0 in
+    // [1, 2^29]; the generator folds the missing 1 x multiplier into the start limbs)
+    Dig win[kMfmaTerms];
+    // A[0] = s[4] + k0 is the one operand that is not the output of a reduction: s[4] < 2^255.6
+    // (dense layer on the matrix cores: 2^254 of residual bias + q), k0 < q, so the sum can pass
+    // 2^256 — one conditional subtraction of q brings it back under 2^256 (32 digits)
+    A[0] = fe_cond_sub(fe_ripple(A[0]), kQx1);
+#pragma unroll
+    for (int i = 0; i < 5; i++) {
+      win[i] = mfma_digits(A[i]);
+      Fe zd = Z[i];
+      zd.l[0] -= 1;
+      win[5 + i] = mfma_digits(zd);
+    }
+    // Software pipeline: of the ten terms of round r+1 eight are known before round r has produced
+    // anything, so their 32 MFMAs are issued as soon as round r's accumulators have been read out
+    // and run under the reduction and the S-box of round r; a_r adds its term before the S-box,
+    // z_r at the top of the next round — only those 4 MFMAs are ever waited for.
+    // OLD(t) / NEW: window slot of the pair that is t rounds from the oldest / that is replaced.
+#define DSV_MFMA_ROUND(OLD, NEW, START)                                                        \
+  {                                                                                            \
+    mfma_term(acc, 9, win[5 + OLD(4)], rbase); /* z_{r-1} */                                     \
+    const MfmaGroups grp = mfma_collect(acc);                                                  \
+    mfma_clear(acc); /* round r+1: terms 0..3 = a_{r-4..r-1}, 5..8 = z_{r-4..r-1} */           \
+    mfma_term(acc, 0, win[OLD(1)], rbase);                                                       \
+    mfma_term(acc, 5, win[5 + OLD(1)], rbase);                                                   \
+    mfma_term(acc, 1, win[OLD(2)], rbase);                                                       \
+    mfma_term(acc, 6, win[5 + OLD(2)], rbase);                                                   \
+    mfma_term(acc, 2, win[OLD(3)], rbase);                                                       \
+    mfma_term(acc, 7, win[5 + OLD(3)], rbase);                                                   \
+    mfma_term(acc, 3, win[OLD(4)], rbase);                                                       \
+    mfma_term(acc, 8, win[5 + OLD(4)], rbase);                                                   \
+    const Fe an = mfma_finish(grp, START);                                                     \
+    const Dig da = mfma_digits(an);                                                            \
+    mfma_term(acc, 4, da, rbase); /* a_r */                                                      \
+    Fe zn = hades_sbox(an);                                                                    \
+    zn.l[0] -= 1;                                                                              \
+    NEW(da, mfma_digits(zn))                                                                   \
+  }
+#define DSV_ROT0(t) (t)
+    MfmaAcc acc;
+    mfma_clear(acc);
+#pragma unroll
+    for (int j = 0; j < kMfmaTerms - 1; j++) mfma_term(acc, j, win[j], rbase);
+    constexpr int kBlocks = DSV_HADES_MFMA_UNROLL5 ? (DSV_HADES_PARTIAL - 5) / 5 : 0;
+#if DSV_HADES_MFMA_UNROLL5
+    // five rounds per iteration, the window slots rotating by NAME: slot i holds the oldest pair in
+    // round i of a block and takes the new one, so nothing is moved
+#define DSV_ROT1(t) ((1 + (t)) % 5)
+#define DSV_ROT2(t) ((2 + (t)) % 5)
+#define DSV_ROT3(t) ((3 + (t)) % 5)
+#define DSV_ROT4(t) ((4 + (t)) % 5)
+#define DSV_PUT0(a, z) { win[0] = a; win[5] = z; }
+#define DSV_PUT1(a, z) { win[1] = a; win[6] = z; }
+#define DSV_PUT2(a, z) { win[2] = a; win[7] = z; }
+#define DSV_PUT3(a, z) { win[3] = a; win[8] = z; }
+#define DSV_PUT4(a, z) { win[4] = a; win[9] = z; }
+#pragma unroll 1
+    for (int blk = 0; blk < kBlocks; blk++) {
+      const u32(*st)[NL] = g_hades_mfma_start + 5 * blk;
+      DSV_MFMA_ROUND(DSV_ROT0, DSV_PUT0, st[0])
+      DSV_MFMA_ROUND(DSV_ROT1, DSV_PUT1, st[1])
+      DSV_MFMA_ROUND(DSV_ROT2, DSV_PUT2, st[2])
+      DSV_MFMA_ROUND(DSV_ROT3, DSV_PUT3, st[3])
+      DSV_MFMA_ROUND(DSV_ROT4, DSV_PUT4, st[4])
+    }
+#endif
+    // rolled copy (all 54 rounds, or the last four after the blocks: 54 = 10 * 5 + 4): the window
+    // is shifted by register moves
+#define DSV_SHIFT_PUT(a, z)           \
+  {                                   \
+    _Pragma("unroll") for (int i_ = 0; i_ < 4; i_++) { \
+      win[i_] = win[i_ + 1];          \
+      win[5 + i_] = win[6 + i_];      \
+    }                                 \
+    win[4] = a;                       \
+    win[9] = z;                       \
+  }
+#pragma unroll 1
+    for (int r = 5 + 5 * kBlocks; r < DSV_HADES_PARTIAL; r++) {
+      DSV_MFMA_ROUND(DSV_ROT0, DSV_SHIFT_PUT, g_hades_mfma_start[r - 5])
+    }
+#undef DSV_MFMA_ROUND
+#pragma unroll
+    for (int i = 0; i < 5; i++) {
+      A[i] = mfma_undigits(win[i]);
+      Z[i] = mfma_undigits(win[5 + i]);
+      Z[i].l[0] += 1;
+    }
+  }
+#else
   const u32(*rec)[NL] = c_hades_arma + DSV_HADES_ARMA_REC;
   const u32(*gam)[NL] = c_hades_arma + DSV_HADES_ARMA_GAMMA;
   // One round per loop iteration, the window (oldest -> newest) shifted by register moves (72
@@ -166,6 +323,7 @@ DSV_DEV void hades_partial_rounds_arma(Fe (&s)[5]) {
     A[4] = an;
     Z[4] = zn;
   }
+#endif
   const u32(*fin)[NL] = c_hades_arma + DSV_HADES_ARMA_FINAL;
   const Fe t[10] = {A[0], A[1], A[2], A[3], A[4], Z[0], Z[1], Z[2], Z[3], Z[4]};
 #pragma unroll 1

@@ -149,8 +149,18 @@ __global__ void __launch_bounds__(256, DSV_WAVES_HASH)
 k_challenge(const uint8_t* __restrict__ R_uv, const uint8_t* __restrict__ Rp_uv,
             const uint8_t* __restrict__ m, size_t n, uint8_t* __restrict__ c_out,
             uint8_t* __restrict__ valid) {
+#if DSV_HADES_MFMA
+  // the hashes of a wave cooperate through the matrix cores: every lane runs, spare lanes redo
+  // the last item and skip the stores
+  hades_mfma_load_table();
+  const size_t i_raw = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const bool live = i_raw < n;
+  const size_t i = live ? i_raw : n - 1;
+#else
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
+  constexpr bool live = true;
+#endif
   Fe ru, rv, mm;
   bool ok = load_fq(ru, R_uv, 2 * i);
   ok &= load_fq(rv, R_uv, 2 * i + 1);
@@ -166,6 +176,7 @@ k_challenge(const uint8_t* __restrict__ R_uv, const uint8_t* __restrict__ Rp_uv,
   }
   u32 c[8];
   poseidon_truncate(c, h);
+  if (!live) return;
   store_words8(c_out, i, c);
   if (valid) valid[i] = ok ? 1 : 0;
 }

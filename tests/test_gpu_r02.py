@@ -469,3 +469,24 @@ def test_sharded_entry_points_with_the_hip_engine_in_two_ranks():
         p.join(timeout=120)
         assert p.exitcode == 0
     assert res == [(0, True, True), (1, True, True)]
+
+
+def test_challenge_hash_ragged_waves_and_extreme_inputs(engine):
+    """The hashes of a wave cooperate through the matrix cores (hades_mfma.h): batch sizes that
+    leave a wave / a workgroup partly empty, and field elements at the ends of the range, must give
+    the oracle's challenges bit for bit (single and double hash)."""
+    rng = np.random.default_rng(99)
+
+    def felts(n):
+        vals = [int.from_bytes(rng.bytes(40), "little") % M.Q for _ in range(n)]
+        for k, v in enumerate([0, 1, M.Q - 1, M.Q - 2, (1 << 254) - 1, 1 << 254, (1 << 128) - 1]):
+            if k < n:
+                vals[(5 * k) % n] = v
+        return np.frombuffer(b"".join(v.to_bytes(32, "little") for v in vals), dtype=np.uint8).reshape(n, 32)
+
+    for n in (1, 2, 31, 33, 63, 64, 65, 127, 255, 256, 257, 300):
+        R = np.concatenate([felts(n), felts(n)], axis=1)
+        Rp = np.concatenate([felts(n), felts(n)], axis=1)
+        m = felts(n)
+        assert np.array_equal(engine.challenge_single(R, m), O.challenge_single(R, m)), n
+        assert np.array_equal(engine.challenge_double(R, Rp, m), O.challenge_double(R, Rp, m)), n
