@@ -69,15 +69,16 @@ def _hash_counts(double):
     """(multiplications, squarings, VALU dot-product terms, reductions of all dots, MFMA dots,
     MFMA wave-instructions per wave) of k_challenge.  Since r02's matrix-core form
     (schnorr_amd/csrc/hades_mfma.h) the recurrence rounds and the dense layers of the full rounds
-    multiply by their constants with v_mfma_i32_32x32x32_i8; only the start-up rows of the
-    recurrence and the state rebuild keep 81-MAD limb products."""
+    multiply by their constants with v_mfma_i32_32x32x32_i8, and so do the start-up rows of the
+    recurrence and the state rebuild: no 81-MAD limb product against a constant is left."""
     def perm(first_const, word1_only):
         sbox = 5 * 8 + 59 - first_const
-        dots5 = 5 * 8 - (4 if word1_only else 0)            # rows of the dense layer: MFMA, 5 terms
-        valu_terms = (7 + 9 + 11 + 13) + 5 * 10             # recurrence start-up + state rebuild
-        mfma_dots = dots5 + 54
+        dots5 = 5 * 8 - (4 if word1_only else 0)            # rows of the dense layer: 5 terms
+        valu_terms = 0
+        edge_terms = (7 + 9 + 11 + 13) + 5 * 10             # recurrence start-up + state rebuild
         ndots = dots5 + 4 + 54 + 5
-        mfma_instr = 4 * (5 * dots5 + 10 * 54 + 9)          # 4 per term (2 row x 2 hash tiles) + prologue
+        mfma_dots = ndots
+        mfma_instr = 4 * (5 * dots5 + 10 * 54 + 9 + edge_terms)   # 4 per term (2 row x 2 hash tiles)
         return sbox, valu_terms, ndots, mfma_dots, mfma_instr
     if double:
         a, b = perm(1, False), perm(0, True)

@@ -297,7 +297,7 @@ def mfma_step_model(ks, xs, start):
         for jj in range(4):
             m = 4 * idx + jj
             cm = sum(cd[j][m - k] * xd[j][k] for j in range(len(ks)) for k in range(32) if 0 <= m - k < 32)
-            assert abs(cm) < 5300000                               # <= 10 terms: 320 * 2^14 = 5 242 880
+            assert abs(cm) < 6900000                               # <= 13 terms: 416 * 2^14 = 6 815 744 < 2^23
             cp.append(cm)
         t0 = cp[0] + (cp[1] << 8) + (1 << 31)                       # sign bit flipped: signed -> biased
         t1 = cp[2] + (cp[3] << 8) + (1 << 31)
@@ -316,7 +316,7 @@ def mfma_linear(coefs, inc, consts):
     """One output row sum_j coefs[j] * x_j + const on the matrix cores, for every const in `consts`
     (field elements; plain).  inc[j] = 1 where the stored operand is one below its value.
     Returns (A operand bytes, [start limbs per const]); self-tested against the field arithmetic."""
-    assert len(coefs) <= MFMA_TERMS
+    assert len(coefs) <= 13                                          # digit-sum bound of mfma_step_model
     ks = [c_ * RMONT % Q for c_ in coefs]
     RR = RMONT * RMONT % Q
     corr = (sum(k_ * i_ for k_, i_ in zip(ks, inc)) + MFMA_DELTA * sum(ks) - MFMA_BNET) % Q
@@ -583,6 +583,27 @@ def main():
         w("#define DSV_HADES_MFMA_MDS_START_LIST \\\n")
         for i, st in enumerate(mstarts):
             w("  " + arr(st) + (", \\\n" if i + 1 < len(mstarts) else "\n"))
+        # ---- start-up rows (a_1..a_4) and state rebuild (5 rows) of the recurrence, same machinery;
+        # operand order as in hades_partial_rounds_arma: x_0 (5), then (a_s, z_s) pairs / a (5), z (5)
+        etab, estarts = [], []
+        for r_, it in enumerate(A["init"], start=1):
+            cs = it["x"] + [v for pair in it["az"] for v in pair]
+            t_, s_ = mfma_linear(cs, [0] * 5 + [0, 1] * r_, [it["const"]])
+            etab += t_
+            estarts.append(s_[0])
+        for j in range(WIDTH):
+            t_, s_ = mfma_linear(A["Fa"][j] + A["Fz"][j], [0] * 5 + [1] * 5, [A["fconst"][j]])
+            etab += t_
+            estarts.append(s_[0])
+        words_ = [etab[i] | etab[i + 1] << 8 | etab[i + 2] << 16 | etab[i + 3] << 24 for i in range(0, len(etab), 4)]
+        w("// start-up rows (7, 9, 11, 13 terms) then the five 10-term rows of the state rebuild\n")
+        w("#define DSV_HADES_MFMA_EDGE_WORDS %d\n" % len(words_))
+        w("#define DSV_HADES_MFMA_EDGE_LIST \\\n")
+        for i in range(0, len(words_), 8):
+            w("  " + ", ".join("0x%08xu" % x for x in words_[i:i + 8]) + (", \\\n" if i + 8 < len(words_) else "\n"))
+        w("#define DSV_HADES_MFMA_EDGE_START_LIST \\\n")
+        for i, st in enumerate(estarts):
+            w("  " + arr(st) + (", \\\n" if i + 1 < len(estarts) else "\n"))
     print("wrote", path)
 
 

@@ -191,6 +191,38 @@ DSV_DEV void hades_partial_rounds_arma(Fe (&s)[5]) {
   static_assert(DSV_HADES_PARTIAL == 59, "window bookkeeping below is written for 59 rounds");
   const u32(*k)[NL] = c_hades_arma;
   Fe A[5], Z[5];
+#if DSV_HADES_MFMA && DSV_HADES_MFMA_EDGE
+  // start-up rows on the matrix cores as well: operands are the entering state and the (a, z)
+  // pairs so far, as MFMA digits (a z entry is stored one below its value, see below)
+  Dig win[kMfmaTerms];
+  const MfmaTable tab = hades_mfma_table();
+  {
+    const v4i* edge = reinterpret_cast<const v4i*>(g_hades_mfma_edge) + tab.lane;
+    Dig ds[5];
+#pragma unroll
+    for (int i = 0; i < 5; i++) ds[i] = mfma_digits(s[i]);
+    // A[0] = s[4] + k0 is the one operand that is not the output of a reduction: s[4] < 2^255.6
+    // (dense layer on the matrix cores: 2^254 of residual bias + q), k0 < q, so the sum can pass
+    // 2^256 — one conditional subtraction of q brings it back under 2^256 (32 digits)
+    A[0] = fe_cond_sub(fe_ripple(fe_add(s[4], fe_load_const(k[0]))), kQx1);
+    auto push = [&](int i) {  // S-box of a_i, both into the window
+      Fe z = hades_sbox(A[i]);
+      z.l[0] -= 1;
+      win[i] = mfma_digits(A[i]);
+      win[5 + i] = mfma_digits(z);
+    };
+    push(0);
+    { const Dig t[7] = {ds[0], ds[1], ds[2], ds[3], ds[4], win[0], win[5]};
+      A[1] = mfma_dot<7>(t, edge + kMfmaEdgeInitOff[0], g_hades_mfma_edge_start[0]); push(1); }
+    { const Dig t[9] = {ds[0], ds[1], ds[2], ds[3], ds[4], win[0], win[5], win[1], win[6]};
+      A[2] = mfma_dot<9>(t, edge + kMfmaEdgeInitOff[1], g_hades_mfma_edge_start[1]); push(2); }
+    { const Dig t[11] = {ds[0], ds[1], ds[2], ds[3], ds[4], win[0], win[5], win[1], win[6], win[2], win[7]};
+      A[3] = mfma_dot<11>(t, edge + kMfmaEdgeInitOff[2], g_hades_mfma_edge_start[2]); push(3); }
+    { const Dig t[13] = {ds[0], ds[1], ds[2], ds[3], ds[4], win[0], win[5], win[1], win[6], win[2], win[7],
+                         win[3], win[8]};
+      A[4] = mfma_dot<13>(t, edge + kMfmaEdgeInitOff[3], g_hades_mfma_edge_start[3]); push(4); }
+  }
+#else
   A[0] = fe_carry(fe_add(s[4], fe_load_const(k[0])));
   k += 1;
   asm volatile("" : "+s"(k));  // (see the loop below: keeps the scalar loads of each dot product local)
@@ -203,18 +235,16 @@ DSV_DEV void hades_partial_rounds_arma(Fe (&s)[5]) {
     A[3] = fe_dot_const_plus<11>(t, k, k[11]); k += 12; asm volatile("" : "+s"(k)); Z[3] = hades_sbox(A[3]); }
   { const Fe t[13] = {s[0], s[1], s[2], s[3], s[4], A[0], Z[0], A[1], Z[1], A[2], Z[2], A[3], Z[3]};
     A[4] = fe_dot_const_plus<13>(t, k, k[13]); Z[4] = hades_sbox(A[4]); }
+#endif
 #if DSV_HADES_MFMA
   {
     static_assert(DSV_HADES_MFMA_ROUNDS == DSV_HADES_PARTIAL - 5, "one start row per recurrence round");
-    const MfmaTable tab = hades_mfma_table();
-    const v4i* rbase = tab.a + tab.lane;
     // window as MFMA operands; a z entry is stored one below its value (fe_mul returns limb 0 in
     // [1, 2^29]; the generator folds the missing 1 x multiplier into the start limbs)
+#if !DSV_HADES_MFMA_EDGE
+    const MfmaTable tab = hades_mfma_table();
     Dig win[kMfmaTerms];
-    // A[0] = s[4] + k0 is the one operand that is not the output of a reduction: s[4] < 2^255.6
-    // (dense layer on the matrix cores: 2^254 of residual bias + q), k0 < q, so the sum can pass
-    // 2^256 — one conditional subtraction of q brings it back under 2^256 (32 digits)
-    A[0] = fe_cond_sub(fe_ripple(A[0]), kQx1);
+    A[0] = fe_cond_sub(fe_ripple(A[0]), kQx1);  // (s[4] + k0 can pass 2^256, see above)
 #pragma unroll
     for (int i = 0; i < 5; i++) {
       win[i] = mfma_digits(A[i]);
@@ -222,6 +252,8 @@ DSV_DEV void hades_partial_rounds_arma(Fe (&s)[5]) {
       zd.l[0] -= 1;
       win[5 + i] = mfma_digits(zd);
     }
+#endif
+    const v4i* rbase = tab.a + tab.lane;
     // Software pipeline: of the ten terms of round r+1 eight are known before round r has produced
     // anything, so their 32 MFMAs are issued as soon as round r's accumulators have been read out
     // and run under the reduction and the S-box of round r; a_r adds its term before the S-box,
@@ -291,12 +323,27 @@ DSV_DEV void hades_partial_rounds_arma(Fe (&s)[5]) {
       DSV_MFMA_ROUND(DSV_ROT0, DSV_SHIFT_PUT, g_hades_mfma_start[r - 5])
     }
 #undef DSV_MFMA_ROUND
+#if DSV_HADES_MFMA_EDGE
+    // state rebuild: five 10-term rows straight from the window
+    const v4i* fin = reinterpret_cast<const v4i*>(g_hades_mfma_edge) + kMfmaEdgeFinalOff + tab.lane;
+#pragma unroll 1
+    for (int j = 0; j < 5; j++) {  // one inlined copy: rotate the output through s[]
+      const Fe r = mfma_dot<kMfmaTerms>(win, fin + j * (kMfmaTerms * 128), g_hades_mfma_edge_start[4 + j]);
+      s[0] = s[1];
+      s[1] = s[2];
+      s[2] = s[3];
+      s[3] = s[4];
+      s[4] = r;
+    }
+    return;
+#else
 #pragma unroll
     for (int i = 0; i < 5; i++) {
       A[i] = mfma_undigits(win[i]);
       Z[i] = mfma_undigits(win[5 + i]);
       Z[i].l[0] += 1;
     }
+#endif
   }
 #else
   const u32(*rec)[NL] = c_hades_arma + DSV_HADES_ARMA_REC;

@@ -100,6 +100,21 @@ DSV_DEV Fe mfma_undigits(const Dig& d) {
   return r;
 }
 
+// start-up rows and state rebuild of the recurrence (DSV_HADES_MFMA_EDGE, shipped 1; 0 keeps the
+// limb products for A/B): used once per permutation, so their 180 KB of operands stay in global
+// memory (L2) instead of LDS.  Row offsets in 16-byte operands: rows of 7, 9, 11, 13 terms, then
+// five rows of 10.
+#ifndef DSV_HADES_MFMA_EDGE
+#define DSV_HADES_MFMA_EDGE 1
+#endif
+#if DSV_HADES_MFMA_EDGE
+__device__ const u32 g_hades_mfma_edge[DSV_HADES_MFMA_EDGE_WORDS] = {DSV_HADES_MFMA_EDGE_LIST};
+__device__ const u32 g_hades_mfma_edge_start[9][NL] = {DSV_HADES_MFMA_EDGE_START_LIST};
+static_assert(DSV_HADES_MFMA_EDGE_WORDS / 4 == (7 + 9 + 11 + 13 + 5 * 10) * 2 * 64, "operand table shape");
+constexpr int kMfmaEdgeInitOff[4] = {0, 7 * 128, (7 + 9) * 128, (7 + 9 + 11) * 128};
+constexpr int kMfmaEdgeFinalOff = (7 + 9 + 11 + 13) * 128;
+#endif
+
 // The operand tables live in LDS (20 KB recurrence + 50 KB dense layer per workgroup of four waves,
 // two workgroups per CU): every lane re-reads its 16 bytes of each A operand every time.
 struct MfmaTable {
@@ -218,6 +233,16 @@ DSV_DEV Fe hades_mfma_step(const Dig (&win)[kMfmaTerms], const u32* start, const
   mfma_clear(acc);
 #pragma unroll
   for (int j = 0; j < kMfmaTerms; j++) mfma_term(acc, j, win[j], tab.a + tab.lane);
+  return mfma_finish(mfma_collect(acc), start);
+}
+// one row of NT terms: operands d[], A operands at base[(term * 2 + row tile) * 64] (lane offset
+// already applied; LDS or global), start limbs of the row
+template <int NT>
+DSV_DEV Fe mfma_dot(const Dig (&d)[NT], const v4i* base, const u32* start) {
+  MfmaAcc acc;
+  mfma_clear(acc);
+#pragma unroll
+  for (int j = 0; j < NT; j++) mfma_term(acc, j, d[j], base);
   return mfma_finish(mfma_collect(acc), start);
 }
 // one output row of the dense layer: sum_j M[row][j] * s_j, operands = the five S-box outputs
