@@ -2,11 +2,13 @@
 // The kernels are in kernels.h; this file owns the per-device contexts, the sub-batch / pipeline
 // scheduling and every extern "C" entry point.
 //
-// Pipeline per batch (one lane = one signature, 64 signatures per wavefront, no cross-lane
-// traffic, no LDS, no MFMA — integer modular arithmetic on 29-bit limbs, see fe29.h):
+// Pipeline per batch (one lane = one signature, 64 signatures per wavefront; integer modular
+// arithmetic on 29-bit limbs, see fe29.h.  The scalar multiplications use no cross-lane traffic,
+// no LDS and no MFMA; the hash runs its constant linear layers as int8 products on the matrix
+// cores, the 64 hashes of a wave cooperating — hades_mfma.h):
 //
-//   k_challenge          c = trunc250(Poseidon(R.u, R.v[, R'.u, R'.v], m))          (~27 % of the work)
-//   k_verify_fixed_half  ok &= [ u*G + c*PK == R ], evaluated as                      (~73 %)
+//   k_challenge          c = trunc250(Poseidon(R.u, R.v[, R'.u, R'.v], m))          (~23 % of the work)
+//   k_verify_fixed_half  ok &= [ u*G + c*PK == R ], evaluated as                      (~77 %)
 //                        (b*u mod r)*G + a*PK - b*R == O  with (a, b) ~ 128 bits, a = b*c mod 8r,
 //                        b odd (halfgcd.h: same verdict on the whole curve group):
 //                          a*PK - b*R : two per-lane signed 4-bit window tables (lane-major in a
