@@ -321,6 +321,22 @@ def mfma_linear(coefs, inc, consts):
     RR = RMONT * RMONT % Q
     corr = (sum(k_ * i_ for k_, i_ in zip(ks, inc)) + MFMA_DELTA * sum(ks) - MFMA_BNET) % Q
     starts = [[x + MASK for x in limbs((g * RR + corr) % Q)] for g in consts]
+    # ---- bounds for ALL operand values (operands: integers in [0, 2^256), digits d = byte - 128 in
+    # [-128, 127]), from the actual multiplier digits:
+    cd = [balanced_digits(kj) for kj in ks]
+    cmax = [sum(abs(cd[j][m - k]) for j in range(len(ks)) for k in range(32) if 0 <= m - k < 32) * 128
+            for m in range(64)]
+    for idx in range(16):
+        # the two halves of a group are signed 32-bit values (so the sign-bit flip makes them unsigned)
+        assert cmax[4 * idx] + 256 * cmax[4 * idx + 1] < (1 << 31)
+        assert cmax[4 * idx + 2] + 256 * cmax[4 * idx + 3] < (1 << 31)
+    assert max(cmax) < (1 << 31)                                    # int32 accumulators, with room
+    xmax = max(MFMA_DELTA, (1 << 256) - 1 - MFMA_DELTA)              # |signed-digit value of an operand|
+    spread = sum(ks) * xmax
+    assert MFMA_BNET - spread > 0                                    # z - KTOP stays positive ...
+    tmax = MFMA_BNET + spread + Q + (1 << 38)                        # ... and, with the start limbs (+ bias), small:
+    assert tmax < (1 << 516)
+    assert tmax // (1 << RBITS) + Q < (1 << 256)                     # result of the reduction: 32 digits again
     import random as _random
     rnd = _random.Random(11)
     rinv = pow(RMONT, -1, Q)
