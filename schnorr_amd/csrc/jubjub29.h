@@ -59,12 +59,25 @@ DSV_DEV Niels niels_identity() {
 
 // in : u, v, z  N (< 1.5q)            (t1, t2 unused)
 // out: u, v, z  N;  t1 < 2.1q, t2 < 2.1q (both limbs < 2^30)
+// 2uv: as a multiplication (153 MADs), or as (u+v)^2 - (u^2 + v^2) (117 MADs + an addition and a
+// biased subtraction; -DDSV_DBL_SQR=1, A/B in DESIGN.md §3)
+#ifndef DSV_DBL_SQR
+#define DSV_DBL_SQR 0
+#endif
+DSV_DEV Fe ext_two_uv(const Fe& u, const Fe& v, const Fe& vpu) {
+#if DSV_DBL_SQR
+  return fe_sub4w(fe_sqr(fe_add(u, v)), vpu);  // < 5.1, carried
+#else
+  (void)vpu;
+  return fe_dbl(fe_mul(u, v));                 // < 2.1, limbs < 2^30
+#endif
+}
 DSV_DEV Ext ext_double(const Ext& p) {
   Fe uu = fe_sqr(p.u);                      // < 1.04
   Fe vv = fe_sqr(p.v);                      // < 1.04
   Fe zz2 = fe_dbl(fe_sqr(p.z));             // < 2.1, limbs < 2^30
-  Fe cu = fe_dbl(fe_mul(p.u, p.v));         // 2uv = (u+v)^2 - u^2 - v^2 without the subtraction; < 2.1
   Fe vpu = fe_add(vv, uu);                  // < 2.1, limbs < 2^30
+  Fe cu = ext_two_uv(p.u, p.v, vpu);        // 2uv
   Fe vmu = fe_sub2_raw(vv, uu);             // < 3.1, limbs < 2^31 (partners vpu < 2^30, ct carried)
   Fe ct = fe_sub4w(zz2, vmu);               // < 6.1, carried
   Ext r;
@@ -81,8 +94,8 @@ DSV_DEV void ext_double_uvz(Fe& u, Fe& v, Fe& z) {
   Fe uu = fe_sqr(u);
   Fe vv = fe_sqr(v);
   Fe zz2 = fe_dbl(fe_sqr(z));
-  Fe cu = fe_dbl(fe_mul(u, v));
   Fe vpu = fe_add(vv, uu);
+  Fe cu = ext_two_uv(u, v, vpu);
   Fe vmu = fe_sub2_raw(vv, uu);
   Fe ct = fe_sub4w(zz2, vmu);
   u = fe_mul(cu, ct);

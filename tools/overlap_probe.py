@@ -27,6 +27,6 @@ def run(parts):
     assert bool(ok.all())
     return dt * 1e3
 for NS in (2, 3, 4):
-    for parts in (1, 8, 16, 32, 8, 16):
+    for parts in (1, 8, 16, 32, 64, 16):
         t = run(parts)
         print("streams %d parts %2d: %.3f ms per 2^20 -> %.2f M/s" % (NS, parts, t, n / t / 1e3))
