@@ -66,38 +66,40 @@ def _verify_counts(chains=1):
 
 
 def _hash_counts(double):
-    """(multiplications, squarings, VALU dot-product terms, reductions of all dots, MFMA dots,
-    MFMA wave-instructions per wave) of k_challenge.  Since r02's matrix-core form
-    (schnorr_amd/csrc/hades_mfma.h) the recurrence rounds and the dense layers of the full rounds
-    multiply by their constants with v_mfma_i32_32x32x32_i8, and so do the start-up rows of the
-    recurrence and the state rebuild: no 81-MAD limb product against a constant is left."""
+    """(multiplications, squarings, rows on the matrix cores, MFMA wave-instructions per wave) of
+    k_challenge.  Since r02's matrix-core form (schnorr_amd/csrc/hades_mfma.h) every product with a
+    constant field element — recurrence rounds, dense layers of the full rounds, start-up rows and
+    state rebuild — is an int8 MFMA product; the VALU keeps the S-boxes, and per row one Barrett
+    step (8 MADs + one v_mul_hi) and ~205 cheap instructions of digit packing / recombination."""
     def perm(first_const, word1_only):
         sbox = 5 * 8 + 59 - first_const
         dots5 = 5 * 8 - (4 if word1_only else 0)            # rows of the dense layer: 5 terms
-        valu_terms = 0
         edge_terms = (7 + 9 + 11 + 13) + 5 * 10             # recurrence start-up + state rebuild
-        ndots = dots5 + 4 + 54 + 5
-        mfma_dots = ndots
-        mfma_instr = 4 * (5 * dots5 + 10 * 54 + 9 + edge_terms)   # 4 per term (2 row x 2 hash tiles)
-        return sbox, valu_terms, ndots, mfma_dots, mfma_instr
+        rows = dots5 + 4 + 54 + 5
+        mfma_instr = 2 * (5 * dots5 + 10 * 54 + 9 + edge_terms)   # 2 per term (one per hash tile)
+        return sbox, rows, mfma_instr
     if double:
         a, b = perm(1, False), perm(0, True)
-        sbox, terms, ndots, mdots, minstr = (a[i] + b[i] for i in range(5))
+        sbox, rows, minstr = (a[i] + b[i] for i in range(3))
         conv = 5
     else:
-        sbox, terms, ndots, mdots, minstr = perm(2, True)
+        sbox, rows, minstr = perm(2, True)
         conv = 3
-    return conv + 1 + sbox, 2 * sbox, terms, ndots, mdots, minstr     # +1: out of Montgomery form
+    return conv + 1 + sbox, 2 * sbox, rows, minstr           # +1: out of Montgomery form
 
 
-def _mads(m, s, dot_terms=0, dot_reds=0):
-    return m * MUL_MAD + s * SQR_MAD + dot_terms * 81 + dot_reds * 72
+MFMA_ROW_MAD, MFMA_ROW_OTHER = 9, 205
 
 
-def _valu(m, s, dot_terms=0, dot_reds=0, other=0, mfma_dots=0):
-    # a dot product: 81 MADs per term + one operand-scanning reduction (72 MADs + 58 others); one
-    # on the matrix cores: the same reduction + ~235 cheap instructions of digit packing / recombination
-    return m * MUL_ALL + s * SQR_ALL + dot_terms * 81 + dot_reds * 130 + mfma_dots * 235 + other
+def _mads(m, s, dot_terms=0, dot_reds=0, mfma_rows=0):
+    return m * MUL_MAD + s * SQR_MAD + dot_terms * 81 + dot_reds * 72 + mfma_rows * MFMA_ROW_MAD
+
+
+def _valu(m, s, dot_terms=0, dot_reds=0, other=0, mfma_rows=0):
+    # a limb dot product: 81 MADs per term + one operand-scanning reduction (72 MADs + 58 others); a
+    # row on the matrix cores: Barrett step + digit packing / recombination
+    return (m * MUL_ALL + s * SQR_ALL + dot_terms * 81 + dot_reds * 130
+            + mfma_rows * (MFMA_ROW_MAD + MFMA_ROW_OTHER) + other)
 
 
 # lane-instructions outside multiplications: limb-wise add / biased subtract / carry passes of the
@@ -330,8 +332,8 @@ def main():
 
     kernels = {}
 
-    def kernel_block(name, ms, items, m, s, dt_=0, dr=0, other=0, algo_bytes=None, mfma_dots=0, mfma_instr=0):
-        mads, valu = _mads(m, s, dt_, dr), _valu(m, s, dt_, dr, other, mfma_dots)
+    def kernel_block(name, ms, items, m, s, dt_=0, dr=0, other=0, algo_bytes=None, mfma_rows=0, mfma_instr=0):
+        mads, valu = _mads(m, s, dt_, dr, mfma_rows), _valu(m, s, dt_, dr, other, mfma_rows)
         sec = ms * 1e-3
         blk = {"ms_per_launch": ms, "items": items, "mad_lane_ops_per_item": round(mads),
                "valu_lane_instr_per_item": round(valu),
@@ -350,8 +352,8 @@ def main():
         vm, vs = _verify_counts(1)
         dom = kernel_block("k_verify_fixed_half<false,1>", core_ms, n, vm, vs, other=VERIFY_OTHER,
                            algo_bytes=ALGO_BYTES["single"])
-        hm, hs, ht, hr, hmd, hmi = _hash_counts(False)
-        kernel_block("k_challenge<false>", hash_ms, n, hm, hs, ht, hr, other=600, mfma_dots=hmd, mfma_instr=hmi)
+        hm, hs, hrows, hmi = _hash_counts(False)
+        kernel_block("k_challenge<false>", hash_ms, n, hm, hs, other=600, mfma_rows=hrows, mfma_instr=hmi)
         pmc = _pmc()
         traffic = clock = valu_busy = None
         if pmc:
@@ -377,7 +379,7 @@ def main():
             "valu_busy_from_pmc": valu_busy,
             "traffic": traffic,
             "traffic_ratio": traffic / algo if traffic else None,
-            "step_mad_frac": (_mads(vm, vs) + _mads(hm, hs, ht, hr)) * n / (dt / args.steps) / MAD_PEAK,
+            "step_mad_frac": (_mads(vm, vs) + _mads(hm, hs, mfma_rows=hrows)) * n / (dt / args.steps) / MAD_PEAK,
             "model": {"mad_cycles_per_wave_instr": MAD_CYCLES, "windows": WINDOWS,
                       "mul_sqr_per_verdict": [round(vm), round(vs)], "kernel_ms": core_ms,
                       "hash_kernel_ms": hash_ms,
@@ -409,8 +411,8 @@ def main():
         vm2, vs2 = _verify_counts(2)
         kernel_block("k_verify_fixed_half<false,2>", cd_ms, n, vm2, vs2, other=2 * VERIFY_OTHER - 9500,
                      algo_bytes=ALGO_BYTES["double"])
-        hm2, hs2, ht2, hr2, hmd2, hmi2 = _hash_counts(True)
-        kernel_block("k_challenge<true>", hd_ms, n, hm2, hs2, ht2, hr2, other=900, mfma_dots=hmd2, mfma_instr=hmi2)
+        hm2, hs2, hrows2, hmi2 = _hash_counts(True)
+        kernel_block("k_challenge<true>", hd_ms, n, hm2, hs2, other=900, mfma_rows=hrows2, mfma_instr=hmi2)
         sample_checks["double"] = (bd, okd.clone())
 
         nv = min(n, 1 << 18)

@@ -222,16 +222,20 @@ def arma_partial_rounds(rc, m):
     return out
 
 
-# ---- the recurrence of arma_partial_rounds on the matrix cores (hades_mfma.h) -------------------
-# a_{r+5} = sum_j k_j x_j + gamma_r is a CONSTANT row vector times the per-hash vector (x_j): over a
-# wave that is a (byte-Toeplitz of the k_j) x (bytes of the x_j) integer matrix product, which
-# v_mfma_i32_32x32x32_i8 evaluates exactly.  This block builds the operand table and the start
-# values, and re-derives every intermediate of hades_mfma_step() in plain integers.
+# ---- the linear layers of Hades on the matrix cores (hades_mfma.h) --------------------------------
+# A row  y = sum_j c_j x_j + const  multiplies per-hash values x_j by CONSTANT field elements c_j:
+# over a wave that is a constant matrix times a matrix of per-hash columns, which
+# v_mfma_i32_32x32x32_i8 evaluates exactly.  Byte k of x_j is multiplied by the constant
+# K_jk = c_j * 2^(8k) mod q — the position of the byte is folded into the constant modulo q, so
+# every product lands in the SAME 32 byte rows (no Toeplitz band, no empty half tiles):
+#     sum_j c_j x_j  ==  sum_m 2^(8m) C_m  (mod q),   C_m = sum_j sum_k digit_m(K_jk) * byte_jk,
+# one 32 x 32 tile per term, a 271-bit result, and one Barrett step brings it under 2^256.
+# This block builds the operand tables and the start words, proves the ranges for ALL operand
+# values from the actual digits, and re-derives every intermediate of the device code in integers.
 MFMA_TERMS = 10
-MFMA_DELTA = 128 * sum(1 << (8 * k) for k in range(32))          # x = signed-digit value + DELTA
-MFMA_WBIAS = (1 << 31) + (1 << 47)                                # bias of one 4-row group W'
-MFMA_KTOP = (1 << 527) + (1 << 511) - (1 << 515)                  # taken off the top words again
-MFMA_BNET = sum(MFMA_WBIAS << (32 * i) for i in range(16)) - MFMA_KTOP
+MFMA_WBIAS = (1 << 31) + (1 << 47)                                # bias of one 4-row group (two halves)
+MFMA_BNET = sum(MFMA_WBIAS << (32 * i) for i in range(8))
+MFMA_MU = (1 << 272) // Q                                         # Barrett multiplier for z >> 240
 
 
 def balanced_digits(x):
@@ -248,129 +252,91 @@ def balanced_digits(x):
     return out
 
 
-def mfma_a_table(ks):
-    """A operands: [term][m-tile][lane][16 bytes]; row m = 32*mt + lane%32, k = 16*(lane/32) + byte,
-    A[m][k] = digit (m - k) of the term's multiplier (operand layout: tools/microbench/mfma_layout.hip)"""
+def mfma_consts(coefs):
+    """K[j][k] = c_j * 2^(8k) mod q as balanced digits"""
+    return [[balanced_digits(c_ * (1 << (8 * k)) % Q) for k in range(32)] for c_ in coefs]
+
+
+def mfma_a_table(coefs):
+    """A operands: [term][lane][16 bytes]; row m = lane%32, k = 16*(lane/32) + byte,
+    A[m][k] = digit m of K_jk (operand layout: tools/microbench/mfma_layout.hip)"""
     tab = []
-    for kj in ks:
-        dg = balanced_digits(kj)
-        for mt in range(2):
-            for lane in range(64):
-                m = 32 * mt + lane % 32
-                for byte in range(16):
-                    k = 16 * (lane // 32) + byte
-                    tab.append(dg[m - k] & 255 if 0 <= m - k < 32 else 0)
+    for Kj in mfma_consts(coefs):
+        for lane in range(64):
+            m = lane % 32
+            for byte in range(16):
+                tab.append(Kj[16 * (lane // 32) + byte][m] & 255)
     return tab
 
 
-def reduce_cols_model(c):
-    """fe29.h: fe_reduce_cols on 17 integer columns (columns 0..8 carry the +M29 bias)"""
-    c = list(c) + [0]
-    qq = limbs(Q)
-    k = 0
-    for i in range(NLIMBS):
-        s_ = c[i] + k
-        assert s_ < (1 << 64)
-        m_ = (~s_) & MASK
-        k = s_ >> LIMB_BITS
-        for j in range(1, NLIMBS):
-            c[i + j] += m_ * qq[j]
-            assert c[i + j] < (1 << 64)
-    out = []
-    for i in range(NLIMBS - 1):
-        s_ = c[NLIMBS + i] + k
-        assert s_ < (1 << 64)
-        out.append(s_ & MASK)
-        k = s_ >> LIMB_BITS
-    out.append(k)
-    return out
-
-
-def mfma_step_model(ks, xs, start):
-    """hades_mfma_step in integers: xs = the ten window values as stored (z entries one below the
-    multiplication result), start = start limbs incl. the reduction bias.  Returns the 9 limbs."""
-    cd = [balanced_digits(kj) for kj in ks]
+def mfma_step_model(coefs, xs, start):
+    """mfma_row in integers: xs = the operands as stored (32-byte integers), start = the row's start
+    value.  Returns the 256-bit result (8 words on the device)."""
+    K = mfma_consts(coefs)
     xd = [[((x >> (8 * k)) & 255) - 128 for k in range(32)] for x in xs]
-    W = []
-    for idx in range(16):
-        cp = []
-        for jj in range(4):
-            m = 4 * idx + jj
-            cm = sum(cd[j][m - k] * xd[j][k] for j in range(len(ks)) for k in range(32) if 0 <= m - k < 32)
-            assert abs(cm) < 6900000                               # <= 13 terms: 416 * 2^14 = 6 815 744 < 2^23
-            cp.append(cm)
+    z = 0
+    for idx in range(8):
+        cp = [sum(K[j][k][4 * idx + jj] * xd[j][k] for j in range(len(xs)) for k in range(32)) for jj in range(4)]
         t0 = cp[0] + (cp[1] << 8) + (1 << 31)                       # sign bit flipped: signed -> biased
         t1 = cp[2] + (cp[3] << 8) + (1 << 31)
         assert 0 <= t0 < (1 << 32) and 0 <= t1 < (1 << 32)
-        W.append(t0 + (t1 << 16))
-    z = sum(w_ << (32 * i) for i, w_ in enumerate(W))
-    assert z >> 512 < (1 << 32) and ((z >> 480) & ((1 << 64) - 1)) >= ((0x8000 - 8) << 32 | 0x80000000)
-    z -= MFMA_KTOP
-    assert 0 < z < (1 << 516)
-    cols = [(z >> (LIMB_BITS * k)) & MASK for k in range(16)] + [z >> (LIMB_BITS * 16)]
-    cols = [c_ + (start[k] if k < NLIMBS else 0) for k, c_ in enumerate(cols)]
-    return reduce_cols_model(cols)
+        z += (t0 + (t1 << 16)) << (32 * idx)
+    z += start
+    assert 0 < z < (1 << 272)
+    qhat = ((z >> 240) * MFMA_MU) >> 32
+    r = z - qhat * Q
+    assert 0 <= r < (1 << 256)
+    return r
 
 
 def mfma_linear(coefs, inc, consts):
     """One output row sum_j coefs[j] * x_j + const on the matrix cores, for every const in `consts`
-    (field elements; plain).  inc[j] = 1 where the stored operand is one below its value.
-    Returns (A operand bytes, [start limbs per const]); self-tested against the field arithmetic."""
-    assert len(coefs) <= 13                                          # digit-sum bound of mfma_step_model
-    ks = [c_ * RMONT % Q for c_ in coefs]
-    RR = RMONT * RMONT % Q
-    corr = (sum(k_ * i_ for k_, i_ in zip(ks, inc)) + MFMA_DELTA * sum(ks) - MFMA_BNET) % Q
-    starts = [[x + MASK for x in limbs((g * RR + corr) % Q)] for g in consts]
-    # ---- bounds for ALL operand values (operands: integers in [0, 2^256), digits d = byte - 128 in
-    # [-128, 127]), from the actual multiplier digits:
-    cd = [balanced_digits(kj) for kj in ks]
-    cmax = [sum(abs(cd[j][m - k]) for j in range(len(ks)) for k in range(32) if 0 <= m - k < 32) * 128
-            for m in range(64)]
-    for idx in range(16):
-        # the two halves of a group are signed 32-bit values (so the sign-bit flip makes them unsigned)
+    (plain field elements; the x_j and the result are Montgomery integers).  inc[j] = 1 where the
+    stored operand is one below its value.  Returns (A operand bytes, [start value per const])."""
+    assert len(coefs) <= 13
+    K = mfma_consts(coefs)
+    ksum = sum(sum(d << (8 * m) for m, d in enumerate(K[j][k])) for j in range(len(coefs)) for k in range(32))
+    corr = (sum(c_ * i_ for c_, i_ in zip(coefs, inc)) + 128 * ksum - MFMA_BNET) % Q
+    starts = [(g * RMONT + corr) % Q for g in consts]
+    # ---- ranges for ALL operand values (digits in [-128, 127]) from the actual constant digits
+    cmax = [sum(abs(K[j][k][m]) for j in range(len(coefs)) for k in range(32)) * 128 for m in range(32)]
+    assert max(cmax) < (1 << 23)                                    # int32 accumulators, with room
+    for idx in range(8):                                            # halves are signed 32-bit values
         assert cmax[4 * idx] + 256 * cmax[4 * idx + 1] < (1 << 31)
         assert cmax[4 * idx + 2] + 256 * cmax[4 * idx + 3] < (1 << 31)
-    assert max(cmax) < (1 << 31)                                    # int32 accumulators, with room
-    xmax = max(MFMA_DELTA, (1 << 256) - 1 - MFMA_DELTA)              # |signed-digit value of an operand|
-    spread = sum(ks) * xmax
-    assert MFMA_BNET - spread > 0                                    # z - KTOP stays positive ...
-    tmax = MFMA_BNET + spread + Q + (1 << 38)                        # ... and, with the start limbs (+ bias), small:
-    assert tmax < (1 << 516)
-    assert tmax // (1 << RBITS) + Q < (1 << 256)                     # result of the reduction: 32 digits again
+    spread = sum(c_ << (8 * m) for m, c_ in enumerate(cmax))
+    assert MFMA_BNET - spread > 0 and MFMA_BNET + spread + Q < (1 << 272)
+    # Barrett step, any z < 2^272: t = z >> 240 < 2^32, qhat = (t * MU) >> 32 with MU = floor(2^272 / q):
+    # z/q - 2 - 2^-14.8 < qhat <= z/q, so 0 <= z - qhat * q < (2 + 2^-14) q < 2^256
+    assert MFMA_MU < (1 << 18) and 2 * Q + (Q >> 14) < (1 << 256)
     import random as _random
     rnd = _random.Random(11)
-    rinv = pow(RMONT, -1, Q)
-    n = len(ks)
+    n = len(coefs)
     cases = [[rnd.randrange(1 << 256) for _ in range(n)] for _ in range(4)]
     cases += [[0] * n, [(1 << 256) - 1] * n]
-    if n == MFMA_TERMS:
-        cases += [[0] * 5 + [(1 << 256) - 1] * 5, [(1 << 256) - 1] * 5 + [0] * 5]
-    for sgn in (127, -128):                                          # push every byte column to its extreme
+    for sgn in (127, -128):                                          # push the byte rows to their extremes
         xs = []
-        for kj in ks:
-            dg = balanced_digits(kj)
-            xs.append(sum((((sgn if d >= 0 else -1 - sgn) + 128) & 255) << (8 * k) for k, d in enumerate(dg[::-1])))
+        for j in range(n):
+            # the sign of the top row's digit decides the byte: all rows cannot be extreme at once
+            xs.append(sum((((sgn if K[j][k][31] >= 0 else -1 - sgn) + 128) & 255) << (8 * k) for k in range(32)))
         cases.append(xs)
     for xs in cases:
         for gi in (0, len(consts) - 1):
-            out = mfma_step_model(ks, xs, starts[gi])
-            v = sum(l_ << (LIMB_BITS * i) for i, l_ in enumerate(out))
-            want = (sum(k_ * (x + i_) for k_, x, i_ in zip(ks, xs, inc)) + consts[gi] * RR) * rinv % Q
-            assert v % Q == want, "MFMA linear-layer model disagrees with the field arithmetic"
-            assert v < (1 << 256) and all(l_ <= MASK for l_ in out[:-1])
-    return mfma_a_table(ks), starts
+            r = mfma_step_model(coefs, xs, starts[gi])
+            want = (sum(c_ * (x + i_) for c_, x, i_ in zip(coefs, xs, inc)) + consts[gi] * RMONT) % Q
+            assert r % Q == want, "matrix-core linear-layer model disagrees with the field arithmetic"
+    return mfma_a_table(coefs), starts
 
 
 def mfma_recurrence(rec, gamma):
-    """A table + per-round start limbs for the recurrence; rec = ca + cz (plain field elements);
+    """A table + per-round start values for the recurrence; rec = ca + cz (plain field elements);
     the five z operands are stored one below their value (fe_mul's limb 0 is in [1, 2^29])"""
     return mfma_linear(rec, [0] * 5 + [1] * 5, gamma)
 
 
 def mfma_mds(m):
     """The dense 5 x 5 layer of a full round, one output row at a time: operands are the five
-    S-box outputs (stored one below their value), no constant.  Returns (A bytes of the 5 rows, 5
-    start-limb rows)."""
+    S-box outputs (stored one below their value), no constant."""
     tab, starts = [], []
     for row in m:
         t_, s_ = mfma_linear(list(row), [1] * WIDTH, [0])
@@ -580,7 +546,7 @@ def main():
         # ---- the same recurrence on the matrix cores (hades_mfma.h)
         atab, starts = mfma_recurrence(rec, A["gamma"])
         words_ = [atab[i] | atab[i + 1] << 8 | atab[i + 2] << 16 | atab[i + 3] << 24 for i in range(0, len(atab), 4)]
-        w("// recurrence on the matrix cores (generator: mfma_recurrence): A operands [term][m-tile][lane][4 words]\n")
+        w("// recurrence on the matrix cores (generator: mfma_recurrence): A operands [term][lane][4 words]\n")
         w("#define DSV_HADES_MFMA_A_WORDS %d\n" % len(words_))
         w("#define DSV_HADES_MFMA_A_LIST \\\n")
         for i in range(0, len(words_), 8):
@@ -588,8 +554,9 @@ def main():
         w("#define DSV_HADES_MFMA_ROUNDS %d\n" % len(starts))
         w("#define DSV_HADES_MFMA_START_LIST \\\n")
         for i, st in enumerate(starts):
-            w("  " + arr(st) + (", \\\n" if i + 1 < len(starts) else "\n"))
-        # ---- the dense layer of the full rounds, same machinery: [row][term][m-tile][lane][4 words]
+            w("  " + arr(words32(st)) + (", \\\n" if i + 1 < len(starts) else "\n"))
+        w("#define DSV_HADES_MFMA_MU 0x%xu\n" % MFMA_MU)
+        # ---- the dense layer of the full rounds, same machinery: [row][term][lane][4 words]
         mtab, mstarts = mfma_mds(m)
         words_ = [mtab[i] | mtab[i + 1] << 8 | mtab[i + 2] << 16 | mtab[i + 3] << 24 for i in range(0, len(mtab), 4)]
         w("#define DSV_HADES_MFMA_MDS_WORDS %d\n" % len(words_))
@@ -598,7 +565,7 @@ def main():
             w("  " + ", ".join("0x%08xu" % x for x in words_[i:i + 8]) + (", \\\n" if i + 8 < len(words_) else "\n"))
         w("#define DSV_HADES_MFMA_MDS_START_LIST \\\n")
         for i, st in enumerate(mstarts):
-            w("  " + arr(st) + (", \\\n" if i + 1 < len(mstarts) else "\n"))
+            w("  " + arr(words32(st)) + (", \\\n" if i + 1 < len(mstarts) else "\n"))
         # ---- start-up rows (a_1..a_4) and state rebuild (5 rows) of the recurrence, same machinery;
         # operand order as in hades_partial_rounds_arma: x_0 (5), then (a_s, z_s) pairs / a (5), z (5)
         etab, estarts = [], []
@@ -619,7 +586,7 @@ def main():
             w("  " + ", ".join("0x%08xu" % x for x in words_[i:i + 8]) + (", \\\n" if i + 8 < len(words_) else "\n"))
         w("#define DSV_HADES_MFMA_EDGE_START_LIST \\\n")
         for i, st in enumerate(estarts):
-            w("  " + arr(st) + (", \\\n" if i + 1 < len(estarts) else "\n"))
+            w("  " + arr(words32(st)) + (", \\\n" if i + 1 < len(estarts) else "\n"))
     print("wrote", path)
 
 

@@ -201,9 +201,9 @@ DSV_DEV void hades_partial_rounds_arma(Fe (&s)[5]) {
     Dig ds[5];
 #pragma unroll
     for (int i = 0; i < 5; i++) ds[i] = mfma_digits(s[i]);
-    // A[0] = s[4] + k0 is the one operand that is not the output of a reduction: s[4] < 2^255.6
-    // (dense layer on the matrix cores: 2^254 of residual bias + q), k0 < q, so the sum can pass
-    // 2^256 — one conditional subtraction of q brings it back under 2^256 (32 digits)
+    // A[0] = s[4] + k0 is the one operand that is not the output of a row: s[4] < 2.0001 q (dense
+    // layer on the matrix cores), k0 < q, so the sum can pass 2^256 = 2.2 q — one conditional
+    // subtraction of q brings it back under 2.0001 q (32 digits)
     A[0] = fe_cond_sub(fe_ripple(fe_add(s[4], fe_load_const(k[0]))), kQx1);
     auto push = [&](int i) {  // S-box of a_i, both into the window
       Fe z = hades_sbox(A[i]);
@@ -272,8 +272,10 @@ DSV_DEV void hades_partial_rounds_arma(Fe (&s)[5]) {
     mfma_term(acc, 7, win[5 + OLD(3)], rbase);                                                   \
     mfma_term(acc, 3, win[OLD(4)], rbase);                                                       \
     mfma_term(acc, 8, win[5 + OLD(4)], rbase);                                                   \
-    const Fe an = mfma_finish(grp, START);                                                     \
-    const Dig da = mfma_digits(an);                                                            \
+    u32 aw[8];                                                                                 \
+    mfma_finish(aw, grp, START);                                                               \
+    const Fe an = fe_from_words_plain(aw);                                                     \
+    const Dig da = mfma_digits_words(aw);                                                      \
     mfma_term(acc, 4, da, rbase); /* a_r */                                                      \
     Fe zn = hades_sbox(an);                                                                    \
     zn.l[0] -= 1;                                                                              \
@@ -299,7 +301,7 @@ DSV_DEV void hades_partial_rounds_arma(Fe (&s)[5]) {
 #define DSV_PUT4(a, z) { win[4] = a; win[9] = z; }
 #pragma unroll 1
     for (int blk = 0; blk < kBlocks; blk++) {
-      const u32(*st)[NL] = g_hades_mfma_start + 5 * blk;
+      const u32(*st)[8] = g_hades_mfma_start + 5 * blk;
       DSV_MFMA_ROUND(DSV_ROT0, DSV_PUT0, st[0])
       DSV_MFMA_ROUND(DSV_ROT1, DSV_PUT1, st[1])
       DSV_MFMA_ROUND(DSV_ROT2, DSV_PUT2, st[2])
@@ -328,7 +330,7 @@ DSV_DEV void hades_partial_rounds_arma(Fe (&s)[5]) {
     const v4i* fin = reinterpret_cast<const v4i*>(g_hades_mfma_edge) + kMfmaEdgeFinalOff + tab.lane;
 #pragma unroll 1
     for (int j = 0; j < 5; j++) {  // one inlined copy: rotate the output through s[]
-      const Fe r = mfma_dot<kMfmaTerms>(win, fin + j * (kMfmaTerms * 128), g_hades_mfma_edge_start[4 + j]);
+      const Fe r = mfma_dot<kMfmaTerms>(win, fin + j * (kMfmaTerms * 64), g_hades_mfma_edge_start[4 + j]);
       s[0] = s[1];
       s[1] = s[2];
       s[2] = s[3];

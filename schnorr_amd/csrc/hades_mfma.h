@@ -1,28 +1,35 @@
-// hades_mfma.h — the partial-round recurrence of hades29.h on the matrix cores.
+// hades_mfma.h — the linear layers of Hades (hades29.h) on the matrix cores.
 //
-// hades_partial_rounds_arma() spends 810 of its ~1270 v_mad_u64_u32 per round on ten products of a
-// per-hash value with a CONSTANT field element.  Over the 64 hashes of a wave that is a constant
-// matrix times a matrix of per-hash columns — the one place in this engine where the work has the
-// shape the matrix cores want (every other product has two per-lane operands).  In bytes:
-//   x_j = sum_k d_jk 2^(8k)          (32 signed digits per window value, d = byte - 128)
-//   k_j = sum_c e_jc 2^(8c)          (32 balanced digits per multiplier, generator)
-//   sum_j k_j x_j = sum_m 2^(8m) C_m,   C_m = sum_j sum_k e_j(m-k) d_jk     (|C_m| < 2^22.4)
-// i.e. C (64 byte columns x 64 hashes) = A (64 x 320, Toeplitz blocks of the e_j) * B (320 x 64):
-// 2 row tiles x 2 hash tiles x 10 terms = 40 v_mfma_i32_32x32x32_i8 per wave and round, exact in
-// int32.  The VALU keeps what only it can do: the S-box (x^5), the Montgomery reduction of the
-// recombined column sums, and ~250 cheap instructions per round of digit packing / recombination.
-// Measured co-issue (tools/microbench/mfma_mix.hip): one such MFMA costs a 2-wave SIMD ~14 cycles
-// of VALU issue, so the 810 MADs (~3 300 cycles) become ~560 + ~650 cycles.
-//
+// After the scalar recurrence of the partial rounds, 64 % of k_challenge's MADs were products of a
+// per-hash value with a CONSTANT field element: ten per recurrence round, five per row of the dense
+// layer of a full round.  Over the 64 hashes of a wave such a row is a constant matrix times a
+// matrix of per-hash columns — the one place in this engine where the work has the shape the matrix
+// cores want (every other product has two per-lane operands).  In bytes, with the POSITION of a
+// byte folded into the constant modulo q:
+//   x_j = sum_k b_jk 2^(8k),   K_jk = c_j * 2^(8k) mod q = sum_m e_jkm 2^(8m)   (generator)
+//   sum_j c_j x_j == sum_m 2^(8m) C_m (mod q),   C_m = sum_j sum_k e_jkm (b_jk - 128) + constant
+// i.e. C (32 byte rows x 64 hashes) = A (32 x 32*terms, dense) * B (32*terms x 64): one
+// v_mfma_i32_32x32x32_i8 per term and hash tile (2 per term and wave), exact in int32
+// (|C_m| < 2^23).  The result is a 271-bit integer congruent to the row; one Barrett step (a
+// 32 x 18-bit product for the quotient, 8 MADs for quotient * q) brings it under 2^256 — no
+// Montgomery reduction, because the operands carry their Montgomery factor through a linear map
+// unchanged.  (r02's first version kept c_j as ONE constant: a Toeplitz band, 64 rows, two half-empty
+// tiles per term and a 17-column Montgomery reduction — twice the MFMAs; profiles/r02/ab_hades_mfma.txt.)
+// The VALU keeps what only it can do — the S-box — plus the glue around the MFMAs:
+//  * operands: 8 words -> XOR 0x80808080 (signed digits b - 128, no carry chain) -> one
+//    v_permlane32_swap per register, because a hash tile is 32 hashes wide and its K range is split
+//    over the two halves of the wave; kept as the 4-register tuples the MFMA reads;
+//  * result: each lane holds four 4-row groups of BOTH hash tiles; two v_lshl_add_u32 and a sign-bit
+//    flip turn a group into two unsigned halves, the same swap brings the partner's groups home, one
+//    9-word carry chain z = P + 2^16 Q + start, the Barrett step, 8 result words.
 // Layout (tools/microbench/mfma_layout.hip): A and B hold k = 16*(lane/32) + byte of 4 VGPRs, row /
-// column = lane%32; D register i of lane l is row 8*(i/4) + 4*(l/32) + i%4, column l%32.  Hash tile
-// t = hashes 32t .. 32t+31 of the wave, so the digits of a hash have to sit in ITS lane (half of
-// the k range) and in the partner lane l ^ 32 (other half): one v_permlane32_swap per register.
-// The same swap brings the two halves of a result column back into the hash's own lane.
+// column = lane%32; D register i of lane l is row 8*(i/4) + 4*(l/32) + i%4, column l%32.
 //
-// Every intermediate (digit ranges, biases, the constant folded into the start limbs, the bound of
-// the value handed to fe_reduce_cols) is re-derived in plain integers by gen_constants.py:
-// mfma_step_model, which also emits the operand table and the start limbs used here.
+// Every constant of that arithmetic (the -128 offsets, the 2^31 biases of the halves, the +1 of an
+// operand stored one below its value, the round constant) is ONE field element per row, folded by
+// the generator into the row's start words; gen_constants.py: mfma_linear proves the ranges for all
+// operand values from the actual digits and re-derives every intermediate in plain integers
+// (mfma_step_model) against the field arithmetic.
 #pragma once
 #include "fe29.h"
 
@@ -33,20 +40,35 @@ typedef int v16i __attribute__((ext_vector_type(16)));
 typedef unsigned v2u __attribute__((ext_vector_type(2)));
 
 __device__ const u32 g_hades_mfma_a[DSV_HADES_MFMA_A_WORDS] = {DSV_HADES_MFMA_A_LIST};
-__device__ const u32 g_hades_mfma_start[DSV_HADES_MFMA_ROUNDS][NL] = {DSV_HADES_MFMA_START_LIST};
+__device__ const u32 g_hades_mfma_start[DSV_HADES_MFMA_ROUNDS][8] = {DSV_HADES_MFMA_START_LIST};
 constexpr int kMfmaTerms = 10;
-constexpr int kMfmaAVecs = DSV_HADES_MFMA_A_WORDS / 4;  // 16-byte operands: [term][row tile][lane]
-static_assert(kMfmaAVecs == kMfmaTerms * 2 * 64, "operand table shape");
+constexpr int kMfmaAVecs = DSV_HADES_MFMA_A_WORDS / 4;  // 16-byte operands: [term][lane]
+static_assert(kMfmaAVecs == kMfmaTerms * 64, "operand table shape");
 // the dense 5 x 5 layer of the full rounds, one output row = one 5-term product of the same kind
 // (DSV_HADES_MFMA_MDS, shipped 1; 0 keeps fe_dot5 for A/B)
 #ifndef DSV_HADES_MFMA_MDS
 #define DSV_HADES_MFMA_MDS 1
 #endif
 __device__ const u32 g_hades_mfma_mds[DSV_HADES_MFMA_MDS_WORDS] = {DSV_HADES_MFMA_MDS_LIST};
-__device__ const u32 g_hades_mfma_mds_start[DSV_HADES_WIDTH][NL] = {DSV_HADES_MFMA_MDS_START_LIST};
-constexpr int kMfmaMdsRowVecs = DSV_HADES_WIDTH * 2 * 64;  // one output row: [term][row tile][lane]
+__device__ const u32 g_hades_mfma_mds_start[DSV_HADES_WIDTH][8] = {DSV_HADES_MFMA_MDS_START_LIST};
+constexpr int kMfmaMdsRowVecs = DSV_HADES_WIDTH * 64;  // one output row: [term][lane]
 constexpr int kMfmaMdsVecs = DSV_HADES_MFMA_MDS ? DSV_HADES_MFMA_MDS_WORDS / 4 : 0;
 static_assert(DSV_HADES_MFMA_MDS_WORDS / 4 == DSV_HADES_WIDTH * kMfmaMdsRowVecs, "operand table shape");
+// start-up rows and state rebuild of the recurrence (DSV_HADES_MFMA_EDGE, shipped 1; 0 keeps the
+// limb products for A/B): used once per permutation, so their 90 KB of operands stay in global
+// memory (L2) instead of LDS.  Row offsets in 16-byte operands: rows of 7, 9, 11, 13 terms, then
+// five rows of 10.
+#ifndef DSV_HADES_MFMA_EDGE
+#define DSV_HADES_MFMA_EDGE 1
+#endif
+#if DSV_HADES_MFMA_EDGE
+__device__ const u32 g_hades_mfma_edge[DSV_HADES_MFMA_EDGE_WORDS] = {DSV_HADES_MFMA_EDGE_LIST};
+__device__ const u32 g_hades_mfma_edge_start[9][8] = {DSV_HADES_MFMA_EDGE_START_LIST};
+static_assert(DSV_HADES_MFMA_EDGE_WORDS / 4 == (7 + 9 + 11 + 13 + 5 * 10) * 64, "operand table shape");
+constexpr int kMfmaEdgeInitOff[4] = {0, 7 * 64, (7 + 9) * 64, (7 + 9 + 11) * 64};
+constexpr int kMfmaEdgeFinalOff = (7 + 9 + 11 + 13) * 64;
+#endif
+__device__ constexpr u32 kMfmaQ32[8] = DSV_Q32;
 
 // B operands of one window value, kept as the 4-register tuples the MFMA reads (separate words
 // would be copied into a tuple in front of every MFMA): t0 for hash tile 0, t1 for hash tile 1
@@ -61,6 +83,18 @@ DSV_DEV void half_swap(u32& a, u32& b) {
   b = r[1];
 }
 
+// 8 words -> signed digits (byte - 128) and the cross-half exchange
+DSV_DEV Dig mfma_digits_words(const u32 (&x)[8]) {
+  u32 w[8];
+#pragma unroll
+  for (int i = 0; i < 8; i++) w[i] = x[i] ^ 0x80808080u;
+#pragma unroll
+  for (int i = 0; i < 4; i++) half_swap(w[i], w[4 + i]);
+  Dig d;
+  d.t0 = v4i{(int)w[0], (int)w[1], (int)w[2], (int)w[3]};
+  d.t1 = v4i{(int)w[4], (int)w[5], (int)w[6], (int)w[7]};
+  return d;
+}
 // x: limbs < 2^29, value < 2^256.  Signed digits (byte - 128) and the cross-half exchange.
 DSV_DEV Dig mfma_digits(const Fe& x) {
   u32 w[8];
@@ -77,7 +111,7 @@ DSV_DEV Dig mfma_digits(const Fe& x) {
   d.t1 = v4i{(int)w[4], (int)w[5], (int)w[6], (int)w[7]};
   return d;
 }
-// inverse of mfma_digits
+// inverse of mfma_digits (only the -DDSV_HADES_MFMA_EDGE=0 build reads operands back)
 DSV_DEV Fe mfma_undigits(const Dig& d) {
   u32 w[8];
 #pragma unroll
@@ -89,37 +123,14 @@ DSV_DEV Fe mfma_undigits(const Dig& d) {
   for (int i = 0; i < 4; i++) half_swap(w[i], w[4 + i]);
 #pragma unroll
   for (int i = 0; i < 8; i++) w[i] ^= 0x80808080u;
-  Fe r;  // 9 x 29 bits out of 8 x 32 (fe_from_words_plain drops bit 255 and up: not here)
-#pragma unroll
-  for (int i = 0; i < NL; i++) {
-    const int bit = 29 * i, wi = bit >> 5, sh = bit & 31;
-    u32 lo = w[wi] >> sh;
-    if (sh > 3 && wi + 1 < 8) lo |= w[wi + 1] << (32 - sh);
-    r.l[i] = (i < NL - 1) ? (lo & M29) : lo;
-  }
-  return r;
+  return fe_from_words_plain(w);
 }
 
-// start-up rows and state rebuild of the recurrence (DSV_HADES_MFMA_EDGE, shipped 1; 0 keeps the
-// limb products for A/B): used once per permutation, so their 180 KB of operands stay in global
-// memory (L2) instead of LDS.  Row offsets in 16-byte operands: rows of 7, 9, 11, 13 terms, then
-// five rows of 10.
-#ifndef DSV_HADES_MFMA_EDGE
-#define DSV_HADES_MFMA_EDGE 1
-#endif
-#if DSV_HADES_MFMA_EDGE
-__device__ const u32 g_hades_mfma_edge[DSV_HADES_MFMA_EDGE_WORDS] = {DSV_HADES_MFMA_EDGE_LIST};
-__device__ const u32 g_hades_mfma_edge_start[9][NL] = {DSV_HADES_MFMA_EDGE_START_LIST};
-static_assert(DSV_HADES_MFMA_EDGE_WORDS / 4 == (7 + 9 + 11 + 13 + 5 * 10) * 2 * 64, "operand table shape");
-constexpr int kMfmaEdgeInitOff[4] = {0, 7 * 128, (7 + 9) * 128, (7 + 9 + 11) * 128};
-constexpr int kMfmaEdgeFinalOff = (7 + 9 + 11 + 13) * 128;
-#endif
-
-// The operand tables live in LDS (20 KB recurrence + 50 KB dense layer per workgroup of four waves,
+// The operand tables live in LDS (10 KB recurrence + 25 KB dense layer per workgroup of four waves,
 // two workgroups per CU): every lane re-reads its 16 bytes of each A operand every time.
 struct MfmaTable {
-  const v4i* a;    // recurrence: [term][row tile][lane]
-  const v4i* mds;  // dense layer: [row][term][row tile][lane]
+  const v4i* a;    // recurrence: [term][lane]
+  const v4i* mds;  // dense layer: [row][term][lane]
   int lane;        // lane within the wave
 };
 DSV_DEV v4i* hades_mfma_lds() {
@@ -150,109 +161,91 @@ DSV_DEV u32 mfma_half(const v16i& acc, int i) {
   return (((u32)acc[i + 1] << 8) + (u32)acc[i]) ^ 0x80000000u;
 }
 
-// ---- the step, split so that the matrix cores run under the VALU work of the SAME wave ---------
-// acc[hash tile][row tile] += (term j's Toeplitz block) x (digits of one window value)
+// ---- one row, split so that the matrix cores can run under the VALU work of the SAME wave -------
+// acc[hash tile] += (term j's 32 x 32 block) x (digits of one operand)
 struct MfmaAcc {
-  v16i t[2][2];
+  v16i t[2];
 };
 DSV_DEV void mfma_clear(MfmaAcc& acc) {
   const v16i zero = {0};  // an inline constant of the first MFMA: costs nothing
-#pragma unroll
-  for (int h = 0; h < 2; h++)
-#pragma unroll
-    for (int mt = 0; mt < 2; mt++) acc.t[h][mt] = zero;
+  acc.t[0] = zero;
+  acc.t[1] = zero;
 }
-// base: [term][row tile][lane] operands of one output row, already offset by the lane
+// base: [term][lane] operands of one output row, already offset by the lane (LDS or global)
 DSV_DEV void mfma_term(MfmaAcc& acc, int j, const Dig& d, const v4i* base) {
-#pragma unroll
-  for (int mt = 0; mt < 2; mt++) {
-    const v4i a = base[(j * 2 + mt) * 64];
-    acc.t[0][mt] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, d.t0, acc.t[0][mt], 0, 0, 0);
-    acc.t[1][mt] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, d.t1, acc.t[1][mt], 0, 0, 0);
-  }
+  const v4i a = base[j * 64];
+  acc.t[0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, d.t0, acc.t[0], 0, 0, 0);
+  acc.t[1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, d.t1, acc.t[1], 0, 0, 0);
 }
-// The sixteen 4-row groups of the lane's own hash, as halves: group idx sits at bit 32 idx, its
+// The eight 4-row groups of the lane's own hash, as halves: group idx sits at bit 32 idx, its
 // halves p (bit 32 idx) and q (bit 32 idx + 16).  Lane l (half h = l/32) holds rows
-// 32mt + 8g + 4h + (0..3) of BOTH hash tiles; after the swap every lane has, for its own hash, the
-// h = 0 groups (idx = 8mt + 2g) and the h = 1 groups (idx + 1).
+// 8g + 4h + (0..3) of BOTH hash tiles; after the swap every lane has, for its own hash, the h = 0
+// groups (idx = 2g) and the h = 1 groups (idx + 1).
 struct MfmaGroups {
-  u32 p[16], q[16];
+  u32 p[8], q[8];
 };
 DSV_DEV MfmaGroups mfma_collect(const MfmaAcc& acc) {
   MfmaGroups w;
 #pragma unroll
-  for (int mt = 0; mt < 2; mt++) {
-#pragma unroll
-    for (int g = 0; g < 4; g++) {
-      u32 xp = mfma_half(acc.t[0][mt], 4 * g), xq = mfma_half(acc.t[0][mt], 4 * g + 2);
-      u32 yp = mfma_half(acc.t[1][mt], 4 * g), yq = mfma_half(acc.t[1][mt], 4 * g + 2);
-      half_swap(xp, yp);
-      half_swap(xq, yq);
-      const int idx = 8 * mt + 2 * g;
-      w.p[idx] = xp;
-      w.q[idx] = xq;
-      w.p[idx + 1] = yp;
-      w.q[idx + 1] = yq;
-    }
+  for (int g = 0; g < 4; g++) {
+    u32 xp = mfma_half(acc.t[0], 4 * g), xq = mfma_half(acc.t[0], 4 * g + 2);
+    u32 yp = mfma_half(acc.t[1], 4 * g), yq = mfma_half(acc.t[1], 4 * g + 2);
+    half_swap(xp, yp);
+    half_swap(xq, yq);
+    w.p[2 * g] = xp;
+    w.q[2 * g] = xq;
+    w.p[2 * g + 1] = yp;
+    w.q[2 * g + 1] = yq;
   }
   return w;
 }
-// halves -> 17 words (one carry chain: z = P + 2^16 Q) -> 29-bit columns + start limbs ->
-// Montgomery reduction.  Result limbs < 2^29, value < 2^256 (generator: mfma_step_model).
-DSV_DEV Fe mfma_finish(const MfmaGroups& w, const u32* start) {
-  u32 z[17];
+// halves + start words -> z (9 words, < 2^272) -> Barrett step -> out (8 words, < 2^256), congruent
+// to the row (generator: mfma_step_model)
+DSV_DEV void mfma_finish(u32 (&out)[8], const MfmaGroups& w, const u32* start) {
+  u32 z[9];
   {
-    u32 c = 0;
-    z[0] = __builtin_addc(w.p[0], w.q[0] << 16, 0u, &c);
+    u64 s = 0;
 #pragma unroll
-    for (int i = 1; i < 16; i++)
-      z[i] = __builtin_addc(w.p[i], __funnelshift_r(w.q[i - 1], w.q[i], 16), c, &c);
-    z[16] = (w.q[15] >> 16) + c;
-    // take the bias of the top group off again, down to 2^515 (generator: MFMA_KTOP)
-    u64 top = ((u64)z[16] << 32) | z[15];
-    top -= ((u64)(0x8000u - 8u) << 32) | 0x80000000u;
-    z[15] = (u32)top;
-    z[16] = (u32)(top >> 32);
+    for (int i = 0; i < 8; i++) {
+      const u32 f = i ? __funnelshift_r(w.q[i - 1], w.q[i], 16) : (w.q[0] << 16);
+      s += (u64)w.p[i] + f + start[i];
+      z[i] = (u32)s;
+      s >>= 32;
+    }
+    z[8] = (u32)s + (w.q[7] >> 16);
   }
-  // 29-bit columns (column 16 takes everything from bit 464 up) + the start limbs
-  u64 c[18];
+  const u32 t = __funnelshift_r(z[7], z[8], 16);  // z >> 240, < 2^32
+  const u32 qhat = __umulhi(t, (u32)DSV_HADES_MFMA_MU);
+  u64 m = 0;
+  u32 borrow = 0;
 #pragma unroll
-  for (int k = 0; k < 16; k++) {
-    const int bit = 29 * k, wi = bit >> 5, sh = bit & 31;
-    const u32 v = sh ? __funnelshift_r(z[wi], z[wi + 1], sh) : z[wi];
-    c[k] = (u64)((v & M29) + (k < NL ? start[k] : 0u));
+  for (int i = 0; i < 8; i++) {
+    m += (u64)qhat * kMfmaQ32[i];
+    out[i] = __builtin_subc(z[i], (u32)m, borrow, &borrow);
+    m >>= 32;
   }
-  c[16] = (u64)__funnelshift_r(z[14], z[15], 16) | ((u64)__funnelshift_r(z[15], z[16], 16) << 32);
-  c[17] = 0;
-  return fe_reduce_cols(c);
+  // (word 8 of z - qhat * q is zero: the difference is below 2^256)
 }
 
-// a_new = sum_j k_j x_j + gamma (Montgomery form) in one go (the unpipelined form, kept for A/B)
-DSV_DEV Fe hades_mfma_step(const Dig (&win)[kMfmaTerms], const u32* start, const MfmaTable& tab) {
-  MfmaAcc acc;
-  mfma_clear(acc);
-#pragma unroll
-  for (int j = 0; j < kMfmaTerms; j++) mfma_term(acc, j, win[j], tab.a + tab.lane);
-  return mfma_finish(mfma_collect(acc), start);
-}
-// one row of NT terms: operands d[], A operands at base[(term * 2 + row tile) * 64] (lane offset
-// already applied; LDS or global), start limbs of the row
+// one row of NT terms: operands d[], A operands at base[term * 64] (lane offset already applied),
+// start words of the row; result as 8 words
 template <int NT>
-DSV_DEV Fe mfma_dot(const Dig (&d)[NT], const v4i* base, const u32* start) {
+DSV_DEV void mfma_row(u32 (&out)[8], const Dig (&d)[NT], const v4i* base, const u32* start) {
   MfmaAcc acc;
   mfma_clear(acc);
 #pragma unroll
   for (int j = 0; j < NT; j++) mfma_term(acc, j, d[j], base);
-  return mfma_finish(mfma_collect(acc), start);
+  mfma_finish(out, mfma_collect(acc), start);
+}
+template <int NT>
+DSV_DEV Fe mfma_dot(const Dig (&d)[NT], const v4i* base, const u32* start) {
+  u32 w[8];
+  mfma_row<NT>(w, d, base, start);
+  return fe_from_words_plain(w);
 }
 // one output row of the dense layer: sum_j M[row][j] * s_j, operands = the five S-box outputs
 DSV_DEV Fe hades_mfma_mds_row(const Dig (&d)[DSV_HADES_WIDTH], int row, const MfmaTable& tab) {
-  const v4i* base = tab.mds + row * kMfmaMdsRowVecs + tab.lane;
-  MfmaAcc acc;
-  mfma_clear(acc);
-#pragma unroll
-  for (int j = 0; j < DSV_HADES_WIDTH; j++) mfma_term(acc, j, d[j], base);
-  return mfma_finish(mfma_collect(acc), g_hades_mfma_mds_start[row]);
+  return mfma_dot<DSV_HADES_WIDTH>(d, tab.mds + row * kMfmaMdsRowVecs + tab.lane, g_hades_mfma_mds_start[row]);
 }
 
 }  // namespace dsv

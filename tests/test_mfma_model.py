@@ -19,17 +19,17 @@ def _tables():
 
 def test_recurrence_and_dense_layer_models_match_field_arithmetic():
     rc, m, A = _tables()
-    atab, starts = G.mfma_recurrence(A["ca"] + A["cz"], A["gamma"])   # asserts inside (self-test)
-    assert len(atab) == 10 * 2 * 64 * 16 and len(starts) == G.PARTIAL - 5
+    atab, starts = G.mfma_recurrence(A["ca"] + A["cz"], A["gamma"])   # asserts inside (self-test + ranges)
+    assert len(atab) == 10 * 64 * 16 and len(starts) == G.PARTIAL - 5
     mtab, mstarts = G.mfma_mds(m)
-    assert len(mtab) == 5 * 5 * 2 * 64 * 16 and len(mstarts) == 5
+    assert len(mtab) == 5 * 5 * 64 * 16 and len(mstarts) == 5
+    assert all(0 <= v < G.Q for v in starts + mstarts)
 
 
 def test_one_recurrence_round_equals_the_dense_partial_round():
     """a_{r+5} from the byte-matrix product == the S-box input of the dense round r+5"""
     rc, m, A = _tables()
     rec = A["ca"] + A["cz"]
-    ks = [c * G.RMONT % G.Q for c in rec]
     _, starts = G.mfma_recurrence(rec, A["gamma"])
     rnd = random.Random(5)
     x = [rnd.randrange(G.Q) for _ in range(5)]
@@ -44,23 +44,35 @@ def test_one_recurrence_round_equals_the_dense_partial_round():
         x = G._matvec(m, w)
     rinv = pow(G.RMONT, -1, G.Q)
     for r in range(5, 12):
-        # operands as the kernel stores them: Montgomery integers, z one below
-        xs = [a[r - 5 + i] * G.RMONT % G.Q for i in range(5)]
+        # operands as the kernel stores them: Montgomery integers (any representative below 2^256),
+        # z one below its value
+        xs = [a[r - 5 + i] * G.RMONT % G.Q + (G.Q if i & 1 else 0) for i in range(5)]
         xs += [(z[r - 5 + i] * G.RMONT % G.Q or G.Q) - 1 for i in range(5)]
-        out = G.mfma_step_model(ks, xs, starts[r - 5])
-        v = sum(l << (G.LIMB_BITS * i) for i, l in enumerate(out))
-        assert v * rinv % G.Q == a[r], r
+        v = G.mfma_step_model(rec, xs, starts[r - 5])
+        assert v < (1 << 256) and v * rinv % G.Q == a[r], r
 
 
 def test_operand_table_layout():
-    """A[m][k] = digit (m - k): row 32*mt + lane%32, k = 16*(lane/32) + byte"""
-    kj = 0x1234567890ABCDEF1234567890ABCDEF1234567890ABCDEF1234567890ABCDEF % G.Q
-    dg = G.balanced_digits(kj)
-    tab = G.mfma_a_table([kj])
-    assert len(tab) == 2 * 64 * 16
-    for mt in range(2):
-        for lane in (0, 1, 31, 32, 63):
-            for byte in (0, 7, 15):
-                mrow, kk = 32 * mt + lane % 32, 16 * (lane // 32) + byte
-                want = dg[mrow - kk] & 255 if 0 <= mrow - kk < 32 else 0
-                assert tab[(mt * 64 + lane) * 16 + byte] == want
+    """A[m][k] = digit m of c * 2^(8k) mod q: row lane%32, k = 16*(lane/32) + byte"""
+    c = 0x1234567890ABCDEF1234567890ABCDEF1234567890ABCDEF1234567890ABCDEF % G.Q
+    tab = G.mfma_a_table([c])
+    assert len(tab) == 64 * 16
+    for lane in (0, 1, 31, 32, 63):
+        for byte in (0, 7, 15):
+            mrow, kk = lane % 32, 16 * (lane // 32) + byte
+            dg = G.balanced_digits(c * (1 << (8 * kk)) % G.Q)
+            assert tab[lane * 16 + byte] == dg[mrow] & 255
+
+
+def test_barrett_step_bound_over_the_whole_range():
+    """z - ((z >> 240) * MU >> 32) * q lies in [0, 2^256) for z at the ends of [0, 2^272)"""
+    rnd = random.Random(9)
+    zs = [0, 1, G.Q - 1, G.Q, (1 << 272) - 1, (1 << 240) - 1, 1 << 240, (1 << 271) + 12345]
+    zs += [rnd.randrange(1 << 272) for _ in range(2000)]
+    zs += [kq * G.Q + d for kq in (1, 2, 1000, (1 << 17) - 1) for d in (-1, 0, 1)]
+    for zv in zs:
+        if not 0 <= zv < (1 << 272):
+            continue
+        qhat = ((zv >> 240) * G.MFMA_MU) >> 32
+        r = zv - qhat * G.Q
+        assert 0 <= r < (1 << 256), hex(zv)
