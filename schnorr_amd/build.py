@@ -21,7 +21,9 @@ def _stale():
     if not os.path.exists(LIB):
         return True
     t = os.path.getmtime(LIB)
-    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)]  # every source, header, generator
+    # every source, header, generator (not __pycache__ etc.: importing the generator in a test must
+    # not make the library look stale)
+    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".h", ".hip", ".py"))]
     deps.append(os.path.join(os.path.dirname(HERE), "include", "dsv.h"))
     return any(os.path.exists(d) and os.path.getmtime(d) > t for d in deps)
 
