@@ -3,10 +3,13 @@
 // `challenge_hash` / `challenge_hash_double` (/root/reference/src/signatures.rs:127-134,
 // :275-290; semantics SURVEY.md Appendix A.4).  One lane = one hash.
 //
-// Round constants and the MDS matrix are wave-uniform: they sit in __constant__ memory and are
-// fetched with scalar loads, so the MADs take them as SGPR operands (no VGPR cost).
-// The MDS layer is 5 dot products of 5 terms, each with ONE Montgomery reduction (fe_dot5):
-// 25 full multiplications become 25 x 81 MADs + 5 reductions.
+// Shipped form: every product with a CONSTANT field element — the dense layer of the full rounds,
+// the recurrence of the partial rounds, its start-up rows and the state rebuild — runs as an int8
+// product on the matrix cores over the 64 hashes of a wave (hades_mfma.h); the VALU keeps the
+// S-boxes and the additions of round constants.  The all-VALU form (-DDSV_HADES_MFMA=0, the A/B
+// baseline) is kept below: round constants and the MDS matrix are wave-uniform, sit in
+// __constant__ memory and are fetched with scalar loads, so the MADs take them as SGPR operands;
+// the MDS layer is 5 dot products of 5 terms, each with ONE Montgomery reduction (fe_dot5).
 //
 // Code-size note: the round body is kept as a rolled loop and the five S-boxes / five dot
 // products of a full round are executed by rotating the state through one inlined copy, so a
