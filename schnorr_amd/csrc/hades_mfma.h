@@ -88,19 +88,6 @@ DSV_DEV Dig mfma_digits_words(const u32 (&x)[8]) {
   u32 w[8];
 #pragma unroll
   for (int i = 0; i < 8; i++) w[i] = x[i] ^ 0x80808080u;
-#pragma unroll
-  for (int i = 0; i < 4; i++) half_swap(w[i], w[4 + i]);
-  Dig d;
-  d.t0 = v4i{(int)w[0], (int)w[1], (int)w[2], (int)w[3]};
-  d.t1 = v4i{(int)w[4], (int)w[5], (int)w[6], (int)w[7]};
-  return d;
-}
-// x: limbs < 2^29, value < 2^256.  Signed digits (byte - 128) and the cross-half exchange.
-DSV_DEV Dig mfma_digits(const Fe& x) {
-  u32 w[8];
-  fe_to_words_plain(w, x);
-#pragma unroll
-  for (int i = 0; i < 8; i++) w[i] ^= 0x80808080u;
   // before: w[0..3] = digits 0..15 (L), w[4..7] = digits 16..31 (H) of the lane's own hash.
   // after:  w[0..3] = L own (lanes < 32) | H of lane-32 (lanes >= 32)   = B of hash tile 0
   //         w[4..7] = L of lane+32 (lanes < 32) | H own (lanes >= 32)   = B of hash tile 1
@@ -110,6 +97,12 @@ DSV_DEV Dig mfma_digits(const Fe& x) {
   d.t0 = v4i{(int)w[0], (int)w[1], (int)w[2], (int)w[3]};
   d.t1 = v4i{(int)w[4], (int)w[5], (int)w[6], (int)w[7]};
   return d;
+}
+// x: limbs < 2^29, value < 2^256
+DSV_DEV Dig mfma_digits(const Fe& x) {
+  u32 w[8];
+  fe_to_words_plain(w, x);
+  return mfma_digits_words(w);
 }
 // inverse of mfma_digits (only the -DDSV_HADES_MFMA_EDGE=0 build reads operands back)
 DSV_DEV Fe mfma_undigits(const Dig& d) {
