@@ -58,11 +58,11 @@ DSV_DEV Niels niels_identity() {
 }
 
 // in : u, v, z  N (< 1.5q)            (t1, t2 unused)
-// out: u, v, z  N;  t1 < 2.1q, t2 < 2.1q (both limbs < 2^30)
-// 2uv: as a multiplication (153 MADs), or as (u+v)^2 - (u^2 + v^2) (117 MADs + an addition and a
-// biased subtraction; -DDSV_DBL_SQR=1, A/B in DESIGN.md §3)
+// out: u, v, z  N (u < 1.44q);  t1 < 5.1q carried, t2 < 2.1q (limbs < 2^30)
+// 2uv as (u+v)^2 - (u^2 + v^2): 117 MADs + an addition and a biased subtraction instead of a
+// multiplication's 153 (-DDSV_DBL_SQR=0; A/B in DESIGN.md §3; bounds: tests/fe29_bounds.py)
 #ifndef DSV_DBL_SQR
-#define DSV_DBL_SQR 0
+#define DSV_DBL_SQR 1
 #endif
 DSV_DEV Fe ext_two_uv(const Fe& u, const Fe& v, const Fe& vpu) {
 #if DSV_DBL_SQR
@@ -81,7 +81,7 @@ DSV_DEV Ext ext_double(const Ext& p) {
   Fe vmu = fe_sub2_raw(vv, uu);             // < 3.1, limbs < 2^31 (partners vpu < 2^30, ct carried)
   Fe ct = fe_sub4w(zz2, vmu);               // < 6.1, carried
   Ext r;
-  r.u = fe_mul(cu, ct);                     // 2.1*6.1*0.01414+1 = 1.2
+  r.u = fe_mul(cu, ct);                     // 5.1*6.1*0.01414+1 = 1.44
   r.v = fe_mul(vpu, vmu);                   // < 1.1
   r.z = fe_mul(vmu, ct);                    // < 1.3
   r.t1 = cu;

@@ -235,11 +235,14 @@ def equal_ok(a, b):
 
 
 # ---- jubjub29.h -----------------------------------------------------------------------------
+DBL_SQR = True    # jubjub29.h: DSV_DBL_SQR (2uv as (u+v)^2 - (u^2 + v^2)); False = the multiplication
+
+
 def ext_double(p):
     uu, vv = sqr(p["u"]), sqr(p["v"])
     zz2 = dbl(sqr(p["z"]))
-    cu = dbl(mul(p["u"], p["v"]))
     vpu = add(vv, uu)
+    cu = sub(sqr(add(p["u"], p["v"])), vpu, "4w") if DBL_SQR else dbl(mul(p["u"], p["v"]))
     vmu = sub_raw(vv, uu, 2)
     ct = sub(zz2, vmu, "4w")
     return {"u": mul(cu, ct), "v": mul(vpu, vmu), "z": mul(vmu, ct), "t1": cu, "t2": vpu}
