@@ -56,7 +56,7 @@ FIXED_ADDS = 23                        # signed 11-bit windows over 253 bits
 def _verify_counts(chains=1):
     """(multiplications, squarings) per verdict of k_verify_fixed_half<., chains>"""
     table = 1 + 7 * 7 + 8                              # u*v; |d|P, d = 2..8: 7 mixed additions sharing t1*t2; 8 x (*2d)
-    dbl_m, dbl_s, add_m = 4, 3, 8
+    dbl_m, dbl_s, add_m = 3, 4, 8                       # doubling: 2uv as (u+v)^2 - (u^2+v^2)
     per_chain_m = (4 + 2 * table                       # PK, R to Montgomery form; two tables
                    + 2 + add_m                         # top window: O + entry (2M + 1S), one addition
                    + (WINDOWS - 1) * (4 * dbl_m + 2 * add_m)
