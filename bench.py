@@ -50,7 +50,7 @@ METRIC = "Schnorr verifies/sec (single + double) at batch=2^20; 1/2/4/8 MI355X" 
 MUL_MAD, MUL_ALL = 153, 189            # 81 + 72 MADs; + 36 digit / shift instructions
 SQR_MAD, SQR_ALL = 117, 161            # 45 + 72 MADs; + 8 doublings + 36
 WINDOWS = 33.1                         # mean over waves of the longest lane's window count
-FIXED_ADDS = 23                        # signed 11-bit windows over 253 bits
+FIXED_ADDS = 16                        # signed 16-bit windows over 253 bits
 
 
 def _verify_counts(chains=1):

@@ -13,8 +13,8 @@
 //                        b odd (halfgcd.h: same verdict on the whole curve group):
 //                          a*PK - b*R : two per-lane signed 4-bit window tables (lane-major in a
 //                                       global workspace), one Straus chain of ~33 windows
-//                          (b*u)*G    : 23 mixed additions from a signed 11-bit-window table of
-//                                       G (or G'), 3.4 MB, built once on the device, L2-resident
+//                          (b*u)*G    : 16 mixed additions from a signed 16-bit-window table of
+//                                       G (or G'), 75.5 MB, built once on the device
 //                        <., 2>: both equations of a double signature in one launch
 //   k_verify_fixed       the same equation in its classic 250-bit form (DSV_VERIFY_ALGO=classic)
 //   k_verify_var         both bases variable (PublicKeyVarGen): Straus over u and c

@@ -25,9 +25,13 @@ namespace dsv {
 #ifndef DSV_WAVES_HASH
 #define DSV_WAVES_HASH 2
 #endif
-// fixed-base tables: SIGNED windows of DSV_FIXED_BITS bits over a scalar < 2^252
+// fixed-base tables: SIGNED windows of DSV_FIXED_BITS bits over a scalar < 2^252.  16 bits: 16
+// windows x 32769 entries x 144 B = 75.5 MB per generator in HBM / Infinity Cache, 16 mixed
+// additions per chain.  r01 / most of r02 ran the L2-resident 11-bit table (23 additions, 3.4 MB):
+// same-box A/B 13 bits +0.8 %, 16 bits +1.5 % (profiles/r02/ab_fixed_bits.txt) — the lookups are
+// independent of the accumulator, so their latency hides behind the additions.
 #ifndef DSV_FIXED_BITS
-#define DSV_FIXED_BITS 11
+#define DSV_FIXED_BITS 16
 #endif
 constexpr int kFixedBits = DSV_FIXED_BITS;
 constexpr int kFixedWindows = (253 + kFixedBits - 1) / kFixedBits;  // +1 bit: recoding carry
@@ -184,7 +188,7 @@ k_challenge(const uint8_t* __restrict__ R_uv, const uint8_t* __restrict__ Rp_uv,
 // ------------------------------------------------------------------------------------------
 // scalar multiplications
 // ------------------------------------------------------------------------------------------
-// acc += u * Gen from the signed kFixedBits-bit-window table: kFixedWindows (23 for 11 bits) mixed
+// acc += u * Gen from the signed kFixedBits-bit-window table: kFixedWindows (16 for 16 bits) mixed
 // additions, no doubling.  The running accumulator is passed in so that u*G + c*PK needs no
 // separate final addition (and no second live point).
 // -DDSV_FIXED_PREFETCH=1: the same pipelining for the fixed-base lookups (L2 hits, 23 per chain):
