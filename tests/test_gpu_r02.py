@@ -490,3 +490,26 @@ def test_challenge_hash_ragged_waves_and_extreme_inputs(engine):
         m = felts(n)
         assert np.array_equal(engine.challenge_single(R, m), O.challenge_single(R, m)), n
         assert np.array_equal(engine.challenge_double(R, Rp, m), O.challenge_double(R, Rp, m)), n
+
+
+def test_fixed_base_windows_at_their_extreme_digits(engine):
+    """Scalars whose signed fixed-base windows (dsv_fixed_window_bits() wide) all sit at an extreme
+    digit — +-2^(bits-1), +-(2^(bits-1) - 1), 0, 1 — through key derivation for both generators,
+    against the oracle's generic scalar multiplication."""
+    bits = engine.fixed_window_bits()
+    half = 1 << (bits - 1)
+    windows = (253 + bits - 1) // bits
+    scalars = []
+    for pat in (half, half - 1, half + 1, (1 << bits) - 1, 1, 0):
+        v = sum(pat << (bits * w) for w in range(windows)) % M.R_ORDER
+        scalars += [v, (M.R_ORDER - v) % M.R_ORDER]
+    rng = np.random.default_rng(3)
+    for _ in range(8):      # random windows drawn from the extreme set only
+        v = sum(int(rng.choice([0, 1, half - 1, half, half + 1, (1 << bits) - 1])) << (bits * w) for w in range(windows))
+        scalars.append(v % M.R_ORDER)
+    SK = np.stack([np.frombuffer(M.le32(x), np.uint8) for x in scalars])
+    for which, gen in ((0, M.GEN), (1, M.GEN_NUMS)):
+        G = np.frombuffer(M.le32(gen[0]) + M.le32(gen[1]), np.uint8)
+        want = O.scalar_mul(SK, np.broadcast_to(G, (len(scalars), 64)).copy())
+        got = engine.public_keys(SK, which)
+        assert np.array_equal(got, want), which
