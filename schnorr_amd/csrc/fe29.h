@@ -179,6 +179,68 @@ DSV_DEV Fe fe_sqr(const Fe& a) {
   });
 }
 
+// ---- two independent squarings with their MAD chains interleaved column by column (A/B:
+// -DDSV_SQR_PAIR=1).  One multiplication is ONE serial chain of dependent v_mad_u64_u32 (latency
+// ~8 cycles, issue ~4): with two waves per SIMD the chains of the two waves fill each other's
+// gaps only while both are inside a multiplication; two chains per wave need no partner.
+#ifndef DSV_SQR_PAIR
+#define DSV_SQR_PAIR 0
+#endif
+DSV_DEV void fe_sqr2(Fe& ra, Fe& rb, const Fe& a, const Fe& b) {
+  u32 da[NL], db[NL], ma[NL], mb[NL];
+#pragma unroll
+  for (int i = 0; i < NL; i++) {
+    da[i] = a.l[i] << 1;
+    db[i] = b.l[i] << 1;
+  }
+  u32 ta, tb;
+  DSV_SCHED_FENCE();
+  asm("s_mov_b32 %0, 0" : "=s"(ta));
+  asm("s_mov_b32 %0, 0" : "=s"(tb));
+  u64 xa = 0, xb = 0;
+  auto prod = [&](int k, u64& acc, u32& tok, const u32 (&d)[NL], const Fe& x) {
+#pragma unroll
+    for (int i = 0; i < NL; i++) {
+      const int j = k - i;
+      if (j > i && j < NL) mad_pin(acc, tok, d[i], x.l[j]);
+    }
+    if ((k & 1) == 0) mad_pin(acc, tok, x.l[k / 2], x.l[k / 2]);
+  };
+  prod(0, xa, ta, da, a);
+  prod(0, xb, tb, db, b);
+  ma[0] = ((~(u32)xa) & M29) + 1;
+  mb[0] = ((~(u32)xb) & M29) + 1;
+  xa >>= 29;
+  xb >>= 29;
+#pragma unroll
+  for (int k = 1; k < 2 * NL - 1; k++) {
+    prod(k, xa, ta, da, a);
+    prod(k, xb, tb, db, b);
+#pragma unroll
+    for (int i = 0; i < NL; i++) {
+      const int j = k - i;
+      if (i < k && j >= 1 && j < NL) {
+        mad_pin(xa, ta, ma[i], kQ29[j]);
+        mad_pin(xb, tb, mb[i], kQ29[j]);
+      }
+    }
+    if (k < NL) {
+      ma[k] = (~(u32)xa) & M29;
+      mb[k] = (~(u32)xb) & M29;
+    } else {
+      ra.l[k - NL] = (u32)xa & M29;
+      rb.l[k - NL] = (u32)xb & M29;
+    }
+    xa >>= 29;
+    xb >>= 29;
+  }
+  ra.l[0] += 1;
+  rb.l[0] += 1;
+  ra.l[NL - 1] = (u32)xa;
+  rb.l[NL - 1] = (u32)xb;
+  DSV_SCHED_FENCE();
+}
+
 // ---- dot products with ONE reduction (Hades linear layers) ----------------------------------
 // These keep the operand-scanning form: 17 column accumulators, one term at a time, so only the
 // nine limbs of ONE wave-uniform constant have to sit in SGPRs at any moment.  (r02 measured the

@@ -73,11 +73,20 @@ DSV_DEV Fe ext_two_uv(const Fe& u, const Fe& v, const Fe& vpu) {
 #endif
 }
 DSV_DEV Ext ext_double(const Ext& p) {
+#if DSV_SQR_PAIR && DSV_DBL_SQR
+  Fe uu, vv, zz, w2;
+  fe_sqr2(uu, vv, p.u, p.v);
+  fe_sqr2(zz, w2, p.z, fe_add(p.u, p.v));
+  Fe zz2 = fe_dbl(zz);
+  Fe vpu = fe_add(vv, uu);
+  Fe cu = fe_sub4w(w2, vpu);
+#else
   Fe uu = fe_sqr(p.u);                      // < 1.04
   Fe vv = fe_sqr(p.v);                      // < 1.04
   Fe zz2 = fe_dbl(fe_sqr(p.z));             // < 2.1, limbs < 2^30
   Fe vpu = fe_add(vv, uu);                  // < 2.1, limbs < 2^30
   Fe cu = ext_two_uv(p.u, p.v, vpu);        // 2uv
+#endif
   Fe vmu = fe_sub2_raw(vv, uu);             // < 3.1, limbs < 2^31 (partners vpu < 2^30, ct carried)
   Fe ct = fe_sub4w(zz2, vmu);               // < 6.1, carried
   Ext r;
@@ -91,11 +100,20 @@ DSV_DEV Ext ext_double(const Ext& p) {
 
 // doubling that keeps only (u, v, z): inside a run of doublings nobody reads t1/t2
 DSV_DEV void ext_double_uvz(Fe& u, Fe& v, Fe& z) {
+#if DSV_SQR_PAIR && DSV_DBL_SQR
+  Fe uu, vv, zz, w2;
+  fe_sqr2(uu, vv, u, v);
+  fe_sqr2(zz, w2, z, fe_add(u, v));
+  Fe zz2 = fe_dbl(zz);
+  Fe vpu = fe_add(vv, uu);
+  Fe cu = fe_sub4w(w2, vpu);
+#else
   Fe uu = fe_sqr(u);
   Fe vv = fe_sqr(v);
   Fe zz2 = fe_dbl(fe_sqr(z));
   Fe vpu = fe_add(vv, uu);
   Fe cu = ext_two_uv(u, v, vpu);
+#endif
   Fe vmu = fe_sub2_raw(vv, uu);
   Fe ct = fe_sub4w(zz2, vmu);
   u = fe_mul(cu, ct);
