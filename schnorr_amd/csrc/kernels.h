@@ -345,10 +345,24 @@ DSV_DEV void store_fe_words(u32* p, const Fe& a) {
     if (DSV_TABLE_NT >= 1) __builtin_nontemporal_store(a.l[i], p + i); else p[i] = a.l[i];
   }
 }
+// The table pointer is the select of a per-lane workspace slot and the shared identity entry, which
+// the compiler only knows as a generic pointer (flat_load).  -DDSV_TABLE_GLOBAL_AS=1 casts it to the
+// global address space (global_load): measured equal to slightly slower
+// (profiles/r02/ab_global_as_loads.txt), so the flat form stays.
+#ifndef DSV_TABLE_GLOBAL_AS
+#define DSV_TABLE_GLOBAL_AS 0
+#endif
+typedef const __attribute__((address_space(1))) u32* GlobalWords;
 DSV_DEV Fe load_fe_words(const u32* p) {
   Fe r;
+#if DSV_TABLE_GLOBAL_AS
+  GlobalWords g = (GlobalWords)p;
+#pragma unroll
+  for (int i = 0; i < NL; i++) r.l[i] = DSV_TABLE_NT >= 2 ? __builtin_nontemporal_load(g + i) : g[i];
+#else
 #pragma unroll
   for (int i = 0; i < NL; i++) r.l[i] = DSV_TABLE_NT >= 2 ? __builtin_nontemporal_load(p + i) : p[i];
+#endif
   return r;
 }
 DSV_DEV void store_var_entry(u32* lane_tbl, int e, const Niels& n) {
