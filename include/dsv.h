@@ -21,7 +21,10 @@
  *                                                           canonical LE BlsScalar, i.e. the pair
  *                                                           `JubJubExtended::to_hash_inputs()` returns
  *   ext point (the *_ext entry points)                     : 96 bytes = u || v || z of a
- *                                                           JubJubExtended with arbitrary z != 0
+ *                                                           JubJubExtended with arbitrary z != 0,
+ *                                                           each coordinate canonical LE (what
+ *                                                           get_u/get_v/get_z().to_bytes() yield);
+ *                                                           z = 0 or a coordinate >= q: ok[i] = 0
  *   verdict ok[i]                                          : one byte, 1 = verify() true, 0 = false
  * Verdicts are those of the reference's `verify` for every input its types can hold (any
  * on-curve point incl. identity / small order, any scalar) — bit-exact against this repository's
@@ -79,7 +82,11 @@ typedef enum {
 #define DSV_MAX_BATCH ((size_t)1 << 28)
 
 /* ---- lifecycle ---- */
-int dsv_init(int device);             /* create this GPU's context: fixed-base tables for G and G' */
+int dsv_init(int device);             /* create this GPU's context: fixed-base tables for G and G'
+                                         (2 x 75.5 MB, ~50 ms of device time) */
+int dsv_init_visible(void);           /* dsv_init for every device listed in the environment variable
+                                         DSV_DEVICES ("0,2,3"), else for every visible device;
+                                         returns how many are initialised or a negative status */
 int dsv_shutdown(void);               /* every initialised device */
 int dsv_shutdown_device(int device);
 int dsv_set_device(int device);       /* device of THIS thread's host entry points (must be initialised) */
@@ -97,10 +104,41 @@ int dsv_verify_double(const uint8_t *u, const uint8_t *R_uv, const uint8_t *Rp_u
                       uint8_t *ok);
 int dsv_verify_vargen(const uint8_t *u, const uint8_t *R_uv, const uint8_t *PK_uv,
                       const uint8_t *Gen_uv, const uint8_t *m, size_t n, uint8_t *ok);
-/* R and PK as projective (u, v, z), 96 B each: for callers holding un-normalised
- * JubJubExtended values (the device does the z inversion of to_hash_inputs) */
+/* ---- verify, projective inputs ---------------------------------------------------------------
+ * Every point as (u, v, z), 96 B: what the reference's in-memory types hold (`PublicKey::from(&sk)`
+ * = GENERATOR_EXTENDED * sk and R = GENERATOR_EXTENDED * r are JubJubExtended with z != 1,
+ * /root/reference/src/keys/public.rs:61-67, src/keys/secret.rs:159).  The device performs the
+ * `to_hash_inputs` normalisation the reference's verify starts with
+ * (/root/reference/src/signatures.rs:131, :280-281) — at most one field inversion per signature,
+ * shared by all its points and, in large batches, by eight signatures — so the caller does no
+ * field arithmetic on the host.  Same verdicts as the affine entry points on the normalised
+ * points. */
 int dsv_verify_single_ext(const uint8_t *u, const uint8_t *R_uvz, const uint8_t *PK_uvz,
                           const uint8_t *m, size_t n, uint8_t *ok);
+int dsv_verify_double_ext(const uint8_t *u, const uint8_t *R_uvz, const uint8_t *Rp_uvz,
+                          const uint8_t *PK_uvz, const uint8_t *PKp_uvz, const uint8_t *m, size_t n,
+                          uint8_t *ok);
+int dsv_verify_vargen_ext(const uint8_t *u, const uint8_t *R_uvz, const uint8_t *PK_uvz,
+                          const uint8_t *Gen_uvz, const uint8_t *m, size_t n, uint8_t *ok);
+/* ... sharded over every initialised device (what the Rust / C++ verify_batch* bind) */
+int dsv_verify_single_ext_multi(const uint8_t *u, const uint8_t *R_uvz, const uint8_t *PK_uvz,
+                                const uint8_t *m, size_t n, uint8_t *ok);
+int dsv_verify_double_ext_multi(const uint8_t *u, const uint8_t *R_uvz, const uint8_t *Rp_uvz,
+                                const uint8_t *PK_uvz, const uint8_t *PKp_uvz, const uint8_t *m,
+                                size_t n, uint8_t *ok);
+int dsv_verify_vargen_ext_multi(const uint8_t *u, const uint8_t *R_uvz, const uint8_t *PK_uvz,
+                                const uint8_t *Gen_uvz, const uint8_t *m, size_t n, uint8_t *ok);
+/* ... device buffers (enqueue only); workspace: dsv_ext_workspace_bytes(n) device bytes, 256-byte
+ * aligned */
+size_t dsv_ext_workspace_bytes(size_t n);
+int dsv_verify_single_ext_dev(const void *u, const void *R_uvz, const void *PK_uvz, const void *m,
+                              size_t n, void *ok, void *workspace, void *stream);
+int dsv_verify_double_ext_dev(const void *u, const void *R_uvz, const void *Rp_uvz,
+                              const void *PK_uvz, const void *PKp_uvz, const void *m, size_t n,
+                              void *ok, void *workspace, void *stream);
+int dsv_verify_vargen_ext_dev(const void *u, const void *R_uvz, const void *PK_uvz,
+                              const void *Gen_uvz, const void *m, size_t n, void *ok, void *workspace,
+                              void *stream);
 
 /* ---- verify, host buffers, sharded over every initialised device (see "Devices and threads") ---- */
 int dsv_verify_single_multi(const uint8_t *u, const uint8_t *R_uv, const uint8_t *PK_uv,
@@ -158,14 +196,18 @@ int dsv_verify_mixed_dev(const void *kinds, const void *u, const void *R_uv, con
  *   split : idx_single[j] / idx_double[j] = batch position (uint32) of the j-th item of that kind,
  *           at most cap_* entries written; scratch: dsv_split_scratch_bytes(n) device bytes whose
  *           last two uint32 (at offset dsv_split_scratch_bytes(n) - 256) receive the two counts
- *   gather: dst row j = src row idx[j], rows of row_bytes (multiple of 16) bytes
- *   scatter: dst[idx[j]] = src[j] (verdict bytes back into batch order) */
+ *   gather: dst row j = src row idx[j], rows of row_bytes (multiple of 16) bytes, src has src_rows rows
+ *   scatter: dst[idx[j]] = src[j] (verdict bytes back into batch order), dst has dst_len bytes
+ *   Both touch entries j < min(count, *count_limit) only (count_limit: device uint32, e.g. one of
+ *   the split's two counts; NULL = no limit) and skip an index that is out of range, so an index
+ *   vector is never dereferenced beyond what the split wrote into it. */
 size_t dsv_split_scratch_bytes(size_t n);
 int dsv_split_kinds_dev(const void *kinds, size_t n, void *idx_single, size_t cap_single,
                         void *idx_double, size_t cap_double, void *scratch, void *stream);
-int dsv_gather_rows_dev(const void *src, size_t row_bytes, const void *idx, size_t count, void *dst,
-                        void *stream);
-int dsv_scatter_verdicts_dev(const void *src, const void *idx, size_t count, void *dst, void *stream);
+int dsv_gather_rows_dev(const void *src, size_t src_rows, size_t row_bytes, const void *idx,
+                        size_t count, const void *count_limit, void *dst, void *stream);
+int dsv_scatter_verdicts_dev(const void *src, const void *idx, size_t count, const void *count_limit,
+                             void *dst, size_t dst_len, void *stream);
 
 /* ---- challenge hash only (c = trunc250(Poseidon(R.., m))), 32 B LE per item ---- */
 int dsv_challenge_single(const uint8_t *R_uv, const uint8_t *m, size_t n, uint8_t *c);
@@ -231,6 +273,15 @@ int dsv_verify_double_wire(const uint8_t *sig96, const uint8_t *pk64, const uint
                            uint8_t *ok);
 int dsv_verify_vargen_wire(const uint8_t *sig64, const uint8_t *pk64, const uint8_t *m, size_t n,
                            uint8_t *ok);
+/* the same with the serialized records already in device memory (16-byte aligned; enqueue only);
+ * workspace: dsv_wire_workspace_bytes(n) device bytes, 256-byte aligned */
+size_t dsv_wire_workspace_bytes(size_t n);
+int dsv_verify_single_wire_dev(const void *sig64, const void *pk32, const void *m, size_t n, void *ok,
+                               void *workspace, void *stream);
+int dsv_verify_double_wire_dev(const void *sig96, const void *pk64, const void *m, size_t n, void *ok,
+                               void *workspace, void *stream);
+int dsv_verify_vargen_wire_dev(const void *sig64, const void *pk64, const void *m, size_t n, void *ok,
+                               void *workspace, void *stream);
 
 /* ---- the reference harness's input generator (rand 0.8 StdRng::seed_from_u64(seed) = ChaCha12,
  * draw order per item: sk = JubJubScalar::random, m = BlsScalar::random, nonce r =

@@ -643,6 +643,42 @@ int oracle_verify_single_ext(const uint8_t *u, const uint8_t *R_ext, const uint8
   }
   return 0;
 }
+/* PublicKeyDouble::verify / PublicKeyVarGen::verify on un-normalised JubJubExtended values
+ * (/root/reference/src/keys/public.rs:222-244, :401-415): to_hash_inputs inverts each z */
+int oracle_verify_double_ext(const uint8_t *u, const uint8_t *R_ext, const uint8_t *Rp_ext,
+                             const uint8_t *PK_ext, const uint8_t *PKp_ext, const uint8_t *m,
+                             size_t n, uint8_t *ok) {
+  ensure_init();
+  for (size_t i = 0; i < n; i++) {
+    oext_t R, Rp, pk, pkp;
+    ofq_t mm;
+    ofr_t us;
+    int good = ofr_from_bytes(&us, u + 32 * i);
+    good &= load_ext(&R, R_ext + 160 * i);
+    good &= load_ext(&Rp, Rp_ext + 160 * i);
+    good &= load_ext(&pk, PK_ext + 160 * i);
+    good &= load_ext(&pkp, PKp_ext + 160 * i);
+    good &= ofq_from_bytes(&mm, m + 32 * i);
+    ok[i] = (uint8_t)(good ? verify_one_double(&pk, &pkp, u + 32 * i, &R, &Rp, &mm) : 0);
+  }
+  return 0;
+}
+int oracle_verify_vargen_ext(const uint8_t *u, const uint8_t *R_ext, const uint8_t *PK_ext,
+                             const uint8_t *Gen_ext, const uint8_t *m, size_t n, uint8_t *ok) {
+  ensure_init();
+  for (size_t i = 0; i < n; i++) {
+    oext_t R, pk, gen;
+    ofq_t mm;
+    ofr_t us;
+    int good = ofr_from_bytes(&us, u + 32 * i);
+    good &= load_ext(&R, R_ext + 160 * i);
+    good &= load_ext(&pk, PK_ext + 160 * i);
+    good &= load_ext(&gen, Gen_ext + 160 * i);
+    good &= ofq_from_bytes(&mm, m + 32 * i);
+    ok[i] = (uint8_t)(good ? verify_one_vargen(&pk, &gen, u + 32 * i, &R, &mm) : 0);
+  }
+  return 0;
+}
 int oracle_challenge_single(const uint8_t *R_uv, const uint8_t *m, size_t n, uint8_t *c) {
   ensure_init();
   for (size_t i = 0; i < n; i++) {

@@ -107,6 +107,11 @@ int oracle_verify_vargen(const uint8_t *u, const uint8_t *R_uv, const uint8_t *P
  * exercises to_hash_inputs with z != 1 (tests/keys.rs:33-59 semantics). */
 int oracle_verify_single_ext(const uint8_t *u, const uint8_t *R_ext, const uint8_t *PK_ext,
                              const uint8_t *m, size_t n, uint8_t *ok);
+int oracle_verify_double_ext(const uint8_t *u, const uint8_t *R_ext, const uint8_t *Rp_ext,
+                             const uint8_t *PK_ext, const uint8_t *PKp_ext, const uint8_t *m,
+                             size_t n, uint8_t *ok);
+int oracle_verify_vargen_ext(const uint8_t *u, const uint8_t *R_ext, const uint8_t *PK_ext,
+                             const uint8_t *Gen_ext, const uint8_t *m, size_t n, uint8_t *ok);
 
 /* challenge scalar only (for kernel-level parity of the hash stage) */
 int oracle_challenge_single(const uint8_t *R_uv, const uint8_t *m, size_t n, uint8_t *c);

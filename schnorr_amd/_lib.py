@@ -25,8 +25,18 @@ SYMBOLS = [
     "dsv_split_scratch_bytes", "dsv_split_kinds_dev", "dsv_gather_rows_dev",
     "dsv_scatter_verdicts_dev", "dsv_public_keys_vargen_dev", "dsv_sign_vargen_dev",
     "dsv_stdrng_vargen_inputs_dev",
+    # r03: projective inputs for every scheme (host / multi-device / device pointers), wire records
+    # in device memory, one-call initialisation
+    "dsv_init_visible",
+    "dsv_verify_double_ext", "dsv_verify_vargen_ext",
+    "dsv_verify_single_ext_multi", "dsv_verify_double_ext_multi", "dsv_verify_vargen_ext_multi",
+    "dsv_ext_workspace_bytes", "dsv_verify_single_ext_dev", "dsv_verify_double_ext_dev",
+    "dsv_verify_vargen_ext_dev",
+    "dsv_wire_workspace_bytes", "dsv_verify_single_wire_dev", "dsv_verify_double_wire_dev",
+    "dsv_verify_vargen_wire_dev",
 ]
-_SIZE_T_FUNCS = ("dsv_workspace_bytes", "dsv_mixed_workspace_bytes", "dsv_split_scratch_bytes")
+_SIZE_T_FUNCS = ("dsv_workspace_bytes", "dsv_mixed_workspace_bytes", "dsv_split_scratch_bytes",
+                 "dsv_ext_workspace_bytes", "dsv_wire_workspace_bytes")
 
 
 class DsvError(RuntimeError):

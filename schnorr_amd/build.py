@@ -1,35 +1,56 @@
 """Build libdsv.so (the HIP engine) in-tree with hipcc for gfx950.
 
-    python -m schnorr_amd.build [--force]
+    python -m schnorr_amd.build [--force] [-DNAME=VALUE ...]
 
-No GPU is needed to build (hipcc cross-compiles); the resulting schnorr_amd/libdsv.so is
-git-ignored but travels to the GPU box with the working tree.
+One hipcc job per translation unit (the host side dsv.hip and the kernel units k_*.hip; no
+relocatable device code), run in parallel, objects under build/obj/; only units whose sources
+changed are recompiled.  No GPU is needed to build (hipcc cross-compiles); the resulting
+schnorr_amd/libdsv.so is git-ignored but travels to the GPU box with the working tree.
 """
+import concurrent.futures
+import hashlib
 import os
 import shutil
 import subprocess
 import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libdsv.so")
-SOURCES = ["dsv.hip"]
+UNITS = ["dsv.hip", "k_hash.hip", "k_verify.hip", "k_quad.hip", "k_vargen.hip", "k_misc.hip"]
 ARCH = "gfx950"
+FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wextra"]
+
+
+def _deps():
+    # every source, header, generator (not __pycache__ etc.: importing the generator in a test must
+    # not make the library look stale)
+    deps = [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith((".h", ".hip", ".py"))]
+    deps.append(os.path.join(ROOT, "include", "dsv.h"))
+    return deps
+
+
+def _headers_stamp():
+    h = hashlib.sha256()
+    for d in _deps():
+        if d.endswith(".h"):
+            with open(d, "rb") as f:
+                h.update(f.read())
+    return h.hexdigest()[:16]
 
 
 def _stale():
     if not os.path.exists(LIB):
         return True
     t = os.path.getmtime(LIB)
-    # every source, header, generator (not __pycache__ etc.: importing the generator in a test must
-    # not make the library look stale)
-    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".h", ".hip", ".py"))]
-    deps.append(os.path.join(os.path.dirname(HERE), "include", "dsv.h"))
-    return any(os.path.exists(d) and os.path.getmtime(d) > t for d in deps)
+    return any(os.path.exists(d) and os.path.getmtime(d) > t for d in _deps())
 
 
-def build(force=False, extra_flags=(), verbose=False):
-    if not force and not _stale():
+def build(force=False, extra_flags=(), verbose=False, out=None, jobs=None):
+    """Returns the path of the library.  extra_flags / out: A/B builds (another -D set, another file)."""
+    out = out or LIB
+    if not force and not extra_flags and out == LIB and not _stale():
         return LIB
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     if not os.path.exists(hipcc):
@@ -38,14 +59,36 @@ def build(force=False, extra_flags=(), verbose=False):
     gen = os.path.join(CSRC, "gen_constants.py")
     if not os.path.exists(const_h) or os.path.getmtime(gen) > os.path.getmtime(const_h):
         subprocess.check_call([sys.executable, gen])
-    cmd = [hipcc, "--offload-arch=" + ARCH, "-O3", "-std=c++17", "-shared", "-fPIC",
-           "-Wall", "-Wextra", "-o", LIB] + [os.path.join(CSRC, s) for s in SOURCES]
-    cmd += list(extra_flags)
+    tag = hashlib.sha256(" ".join(extra_flags).encode()).hexdigest()[:8] if extra_flags else "default"
+    objdir = os.path.join(ROOT, "build", "obj", tag)
+    os.makedirs(objdir, exist_ok=True)
+    stamp = _headers_stamp()
+
+    def compile_unit(unit):
+        src = os.path.join(CSRC, unit)
+        obj = os.path.join(objdir, unit.replace(".hip", ".o"))
+        key = obj + ".key"
+        with open(src, "rb") as f:
+            want = stamp + hashlib.sha256(f.read()).hexdigest()[:16]
+        if not force and os.path.exists(obj) and os.path.exists(key) and open(key).read() == want:
+            return obj
+        cmd = [hipcc] + FLAGS + list(extra_flags) + ["-c", src, "-o", obj]
+        if verbose:
+            print(" ".join(cmd), file=sys.stderr)
+        subprocess.check_call(cmd)
+        with open(key, "w") as f:
+            f.write(want)
+        return obj
+
+    with concurrent.futures.ThreadPoolExecutor(max_workers=jobs or min(len(UNITS), os.cpu_count() or 2)) as ex:
+        objs = list(ex.map(compile_unit, UNITS))
+    cmd = [hipcc, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", out] + objs
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     subprocess.check_call(cmd)
-    return LIB
+    return out
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose=True))
+    flags = [a for a in sys.argv[1:] if a.startswith("-D")]
+    print(build(force="--force" in sys.argv, extra_flags=flags, verbose=True))

@@ -1,23 +1,25 @@
 // dsv.hip — MI355X (gfx950) batch Schnorr verification engine: host side + C ABI (include/dsv.h).
-// The kernels are in kernels.h; this file owns the per-device contexts, the sub-batch / pipeline
-// scheduling and every extern "C" entry point.
+// The kernels live in their own translation units (k_hash.hip, k_verify.hip, k_quad.hip,
+// k_vargen.hip, k_misc.hip; launchers declared in launch.h); this file owns the per-device
+// contexts, the sub-batch / pipeline scheduling and every extern "C" entry point.
 //
 // Pipeline per batch (one lane = one signature, 64 signatures per wavefront; integer modular
 // arithmetic on 29-bit limbs, see fe29.h.  The scalar multiplications use no cross-lane traffic,
 // no LDS and no MFMA; the hash runs its constant linear layers as int8 products on the matrix
 // cores, the 64 hashes of a wave cooperating — hades_mfma.h):
 //
-//   k_challenge          c = trunc250(Poseidon(R.u, R.v[, R'.u, R'.v], m))          (~23 % of the work)
-//   k_verify_fixed_half  ok &= [ u*G + c*PK == R ], evaluated as                      (~77 %)
+//   k_challenge          c = trunc250(Poseidon(R.u, R.v[, R'.u, R'.v], m))          (~20 % of the work)
+//   k_verify_fixed_half  ok &= [ u*G + c*PK == R ], evaluated as                      (~80 %)
 //                        (b*u mod r)*G + a*PK - b*R == O  with (a, b) ~ 128 bits, a = b*c mod 8r,
 //                        b odd (halfgcd.h: same verdict on the whole curve group):
 //                          a*PK - b*R : two per-lane signed 4-bit window tables (lane-major in a
 //                                       global workspace), one Straus chain of ~33 windows
 //                          (b*u)*G    : 16 mixed additions from a signed 16-bit-window table of
 //                                       G (or G'), 75.5 MB, built once on the device
-//                        <., 2>: both equations of a double signature in one launch
-//   k_verify_fixed       the same equation in its classic 250-bit form (DSV_VERIFY_ALGO=classic)
-//   k_verify_var         both bases variable (PublicKeyVarGen): Straus over u and c
+//                        <2>: both equations of a double signature in one launch
+//   k_verify_fixed_half_quad  the same with four lanes per signature (batches <= 2^14)
+//   k_verify_var         both bases variable (PublicKeyVarGen)
+//   k_normalize_uvz      to_hash_inputs for callers that hold projective points (*_ext entry points)
 //   k_decompress         wire-format points (JubJubAffine::from_bytes), decode29.h
 //   k_fixed_base_points / k_var_base_points / k_sign_finish : signing and key derivation
 //   k_kind_* / k_gather_rows / k_scatter_bytes : device-side split of a mixed batch by kind
@@ -39,7 +41,9 @@
 #include <vector>
 
 #include "../../include/dsv.h"
-#include "kernels.h"
+#define DSV_HOST_TABLES 1
+#include "dsv_constants.h"
+#include "launch.h"
 
 
 // ==========================================================================================
@@ -48,6 +52,7 @@
 namespace {
 
 using namespace dsv;
+typedef uint32_t u32;
 
 thread_local std::string g_err;
 int fail(int code, const char* fmt, ...) {
@@ -164,13 +169,10 @@ struct SplitLane {
 struct Context {
   std::atomic<bool> ready{false};
   int device = -1;
-  bool half_scalars = true;  // DSV_VERIFY_ALGO=classic selects the 250-bit chain instead
   bool split = true;         // DSV_SPLIT=0: one stream, whole batch per launch
   bool fuse_double = true;   // DSV_DOUBLE_FUSED=0: two single-equation launches per double batch (r01; A/B)
   bool quad = true;          // DSV_QUAD=0: batches of <= 2^14 items also take the one-lane-per-signature kernel
   u32* table[2] = {nullptr, nullptr};  // fixed-base tables for G, G'
-  u32* lds_table = nullptr;            // A/B (-DDSV_FIXED_LDS_BITS): narrow-window table of G, staged in LDS
-  bool fixed_lds = false;              // DSV_FIXED_LDS=1 at dsv_init (only in such a build)
   u32* ts_cancel = nullptr;            // square-root tables (decode29.h)
   uint8_t* ts_hash = nullptr;
   // host-pointer entry points of this device serialise here (they share the staging below)
@@ -251,7 +253,6 @@ int ensure_pipe_slot(Context& ctx, int slot, size_t dev_bytes, size_t host_bytes
   return DSV_OK;
 }
 
-inline unsigned grid_for(size_t n, unsigned block = 256) { return (unsigned)((n + block - 1) / block); }
 inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
 int check_n(size_t n) {
@@ -294,10 +295,6 @@ struct Workspace {
   uint8_t* valid;
   u32* tables;
 };
-unsigned verify_grid(size_t n) {
-  unsigned g = grid_for(n, kVerifyBlock);
-  return g < kMaxVerifyGrid ? g : kMaxVerifyGrid;
-}
 size_t var_table_bytes(size_t n, int tables_per_lane) {
   return (size_t)verify_grid(n) * kVerifyBlock * kVarLaneWords * 4 * (size_t)tables_per_lane;
 }
@@ -320,68 +317,32 @@ struct Stager {
   }
 };
 
-// the dominant kernel, in either formulation (same verdicts; see halfgcd.h)
+// the dominant kernel: one lane per signature, or four (small batches); same verdicts
 void launch_verify_fixed(const Context& ctx, bool accumulate, const void* u, const void* c,
                          const void* PK_uv, const void* R_uv, int which, const void* valid,
                          size_t n, void* ok, u32* tables, hipStream_t s) {
-  const dim3 grid(verify_grid(n)), block(kVerifyBlock);
-  if (ctx.half_scalars && ctx.quad && n <= kQuadMaxItems) {  // small batch: four lanes per signature
-    const ChainOperands op{(const uint8_t*)PK_uv, (const uint8_t*)R_uv, ctx.table[which]};
-    const dim3 qgrid((unsigned)((4 * n + kQuadBlock - 1) / kQuadBlock)), qblock(kQuadBlock);
-    if (accumulate)
-      hipLaunchKernelGGL((k_verify_fixed_half_quad<true, 1>), qgrid, qblock, 0, s, (const uint8_t*)u,
-                         (const uint8_t*)c, op, op, (const uint8_t*)valid, n, (uint8_t*)ok, tables);
-    else
-      hipLaunchKernelGGL((k_verify_fixed_half_quad<false, 1>), qgrid, qblock, 0, s, (const uint8_t*)u,
-                         (const uint8_t*)c, op, op, (const uint8_t*)valid, n, (uint8_t*)ok, tables);
-    return;
-  }
-#if DSV_FIXED_LDS_BITS
-  if (ctx.half_scalars && ctx.fixed_lds && !accumulate && which == 0) {
-    // A/B: 8-wave workgroups, one per CU at most, table of G staged in LDS
-    const ChainOperands op{(const uint8_t*)PK_uv, (const uint8_t*)R_uv, ctx.lds_table};
-    unsigned g = grid_for(n, kLdsBlock);
-    if (g > 256) g = 256;
-    hipLaunchKernelGGL((k_verify_fixed_half<false, 1, kLdsBlock, true>), dim3(g), dim3(kLdsBlock),
-                       kLdsTableWords * 4, s, (const uint8_t*)u, (const uint8_t*)c, op, op,
-                       (const uint8_t*)valid, n, (uint8_t*)ok, tables);
-    return;
-  }
-#endif
-  if (ctx.half_scalars) {
-    const ChainOperands op{(const uint8_t*)PK_uv, (const uint8_t*)R_uv, ctx.table[which]};
-    if (accumulate)
-      hipLaunchKernelGGL((k_verify_fixed_half<true, 1>), grid, block, 0, s, (const uint8_t*)u,
-                         (const uint8_t*)c, op, op, (const uint8_t*)valid, n, (uint8_t*)ok, tables);
-    else
-      hipLaunchKernelGGL((k_verify_fixed_half<false, 1>), grid, block, 0, s, (const uint8_t*)u,
-                         (const uint8_t*)c, op, op, (const uint8_t*)valid, n, (uint8_t*)ok, tables);
-    return;
-  }
-#define DSV_LAUNCH(K)                                                                          \
-  hipLaunchKernelGGL(K, grid, block, 0, s, (const uint8_t*)u, (const uint8_t*)c,               \
-                     (const uint8_t*)PK_uv, (const uint8_t*)R_uv, (const u32*)ctx.table[which], \
-                     (const uint8_t*)valid, n, (uint8_t*)ok, tables)
-  if (accumulate) DSV_LAUNCH(k_verify_fixed<true>); else DSV_LAUNCH(k_verify_fixed<false>);
-#undef DSV_LAUNCH
+  const ChainOperands op{(const uint8_t*)PK_uv, (const uint8_t*)R_uv, ctx.table[which]};
+  if (ctx.quad && n <= kQuadMaxItems)
+    launch_verify_half_quad(1, accumulate, (const uint8_t*)u, (const uint8_t*)c, op, op,
+                            (const uint8_t*)valid, n, (uint8_t*)ok, tables, s);
+  else
+    launch_verify_half(1, accumulate, (const uint8_t*)u, (const uint8_t*)c, op, op,
+                       (const uint8_t*)valid, n, (uint8_t*)ok, tables, s);
 }
-// both equations of a double signature: one fused launch (half-size scalars) or two (classic)
+// both equations of a double signature: one fused launch, or two single-equation ones
+// (DSV_DOUBLE_FUSED=0: the second pass ANDs into ok[])
 void launch_verify_fixed_double(const Context& ctx, const void* u, const void* c, const void* PK_uv,
                                 const void* R_uv, const void* PKp_uv, const void* Rp_uv,
                                 const void* valid, size_t n, void* ok, u32* tables, hipStream_t s) {
-  if (ctx.half_scalars && ctx.fuse_double) {
+  if (ctx.fuse_double) {
     const ChainOperands op0{(const uint8_t*)PK_uv, (const uint8_t*)R_uv, ctx.table[0]};
     const ChainOperands op1{(const uint8_t*)PKp_uv, (const uint8_t*)Rp_uv, ctx.table[1]};
-    if (ctx.quad && n <= kQuadMaxItems) {
-      hipLaunchKernelGGL((k_verify_fixed_half_quad<false, 2>),
-                         dim3((unsigned)((4 * n + kQuadBlock - 1) / kQuadBlock)), dim3(kQuadBlock), 0, s,
-                         (const uint8_t*)u, (const uint8_t*)c, op0, op1, (const uint8_t*)valid, n,
-                         (uint8_t*)ok, tables);
-      return;
-    }
-    hipLaunchKernelGGL((k_verify_fixed_half<false, 2>), dim3(verify_grid(n)), dim3(kVerifyBlock), 0,
-                       s, (const uint8_t*)u, (const uint8_t*)c, op0, op1, (const uint8_t*)valid, n,
-                       (uint8_t*)ok, tables);
+    if (ctx.quad && n <= kQuadMaxItems)
+      launch_verify_half_quad(2, false, (const uint8_t*)u, (const uint8_t*)c, op0, op1,
+                              (const uint8_t*)valid, n, (uint8_t*)ok, tables, s);
+    else
+      launch_verify_half(2, false, (const uint8_t*)u, (const uint8_t*)c, op0, op1,
+                         (const uint8_t*)valid, n, (uint8_t*)ok, tables, s);
     return;
   }
   launch_verify_fixed(ctx, false, u, c, PK_uv, R_uv, 0, valid, n, ok, tables, s);
@@ -466,8 +427,6 @@ void release_context(Context& ctx) {
     if (ctx.table[g]) (void)hipFree(ctx.table[g]);
     ctx.table[g] = nullptr;
   }
-  if (ctx.lds_table) (void)hipFree(ctx.lds_table);
-  ctx.lds_table = nullptr;
   if (ctx.ts_cancel) (void)hipFree(ctx.ts_cancel);
   if (ctx.ts_hash) (void)hipFree(ctx.ts_hash);
   ctx.ts_cancel = nullptr;
@@ -504,7 +463,7 @@ void release_context(Context& ctx) {
 
 extern "C" {
 
-const char* dsv_version(void) { return "dsv 0.2.0 (gfx950, fe29)"; }
+const char* dsv_version(void) { return "dsv 0.3.0 (gfx950, fe29)"; }
 const char* dsv_last_error(void) { return g_err.c_str(); }
 
 int dsv_device_count(void) {
@@ -524,43 +483,16 @@ int dsv_init(int device) {
   if (ctx.ready.load()) return DSV_OK;
   ctx.device = device;
   DSV_ON_DEVICE(ctx);
-  // __constant__ symbols exist once per device: these copies go to the device just selected
-  HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(c_hades_rc), DSV_HADES_RC_HOST, sizeof(DSV_HADES_RC_HOST)));
-  HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(c_hades_mds), DSV_HADES_MDS_HOST, sizeof(DSV_HADES_MDS_HOST)));
-  HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(c_hades_pre_mds), DSV_HADES_PRE_MDS_HOST,
-                            sizeof(DSV_HADES_PRE_MDS_HOST)));
-  HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(c_hades_kappa0), DSV_HADES_KAPPA0_HOST,
-                            sizeof(DSV_HADES_KAPPA0_HOST)));
-  HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(c_hades_blocks), DSV_HADES_BLOCKS_HOST,
-                            sizeof(DSV_HADES_BLOCKS_HOST)));
-  HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(c_hades_kfinal), DSV_HADES_KFINAL_HOST,
-                            sizeof(DSV_HADES_KFINAL_HOST)));
-  HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(c_hades_arma), DSV_HADES_ARMA_HOST, sizeof(DSV_HADES_ARMA_HOST)));
+  HIP_TRY(hash_upload_constants());  // this device's __constant__ round constants
   HIP_TRY(hipMalloc(&ctx.ts_cancel, sizeof(DSV_TS_CANCEL_HOST)));
   HIP_TRY(hipMemcpy(ctx.ts_cancel, DSV_TS_CANCEL_HOST, sizeof(DSV_TS_CANCEL_HOST), hipMemcpyHostToDevice));
   HIP_TRY(hipMalloc(&ctx.ts_hash, sizeof(DSV_TS_HASH_HOST)));
   HIP_TRY(hipMemcpy(ctx.ts_hash, DSV_TS_HASH_HOST, sizeof(DSV_TS_HASH_HOST), hipMemcpyHostToDevice));
   for (int g = 0; g < 2; g++) {
     HIP_TRY(hipMalloc(&ctx.table[g], kTableBytes));
-    const int total = kFixedWindows * kFixedEntries;
-    hipLaunchKernelGGL(k_build_fixed_table, dim3((total + 63) / 64), dim3(64), 0, 0, ctx.table[g], g,
-                       kFixedBits, kEntryWords);
+    launch_build_fixed_table(ctx.table[g], g, 0);
     HIP_TRY(hipGetLastError());
   }
-#if DSV_FIXED_LDS_BITS
-  {
-    const char* lds = getenv("DSV_FIXED_LDS");
-    ctx.fixed_lds = lds && strcmp(lds, "1") == 0;
-    HIP_TRY(hipMalloc(&ctx.lds_table, (size_t)kLdsTableWords * 4));
-    const int total = kLdsWindows * kLdsEntries;
-    hipLaunchKernelGGL(k_build_fixed_table, dim3((total + 63) / 64), dim3(64), 0, 0, ctx.lds_table, 0,
-                       kLdsBits, kLdsEntryWords);
-    HIP_TRY(hipGetLastError());
-    HIP_TRY(hipFuncSetAttribute(
-        reinterpret_cast<const void*>(&k_verify_fixed_half<false, 1, kLdsBlock, true>),
-        hipFuncAttributeMaxDynamicSharedMemorySize, kLdsTableWords * 4));
-  }
-#endif
   HIP_TRY(hipDeviceSynchronize());
   const char* split = getenv("DSV_SPLIT");
   ctx.split = !(split && strcmp(split, "0") == 0);
@@ -568,12 +500,40 @@ int dsv_init(int device) {
   ctx.quad = !(quad && strcmp(quad, "0") == 0);
   const char* fused = getenv("DSV_DOUBLE_FUSED");
   ctx.fuse_double = !(fused && strcmp(fused, "0") == 0);
-  const char* algo = getenv("DSV_VERIFY_ALGO");
-  ctx.half_scalars = !(algo && strcmp(algo, "classic") == 0);
   ctx.ready.store(true, std::memory_order_release);
   int none = -1;
   g_primary.compare_exchange_strong(none, device);
   return DSV_OK;
+}
+
+// Initialise the devices a process wants to use in one call: the ordinals listed in the
+// environment variable DSV_DEVICES (comma-separated, e.g. "0,2,3"), else every visible device.
+// Returns the number of initialised devices or a negative dsv_status.  What the language shims call
+// from their first verify_batch: an integrator restricts the engine's footprint (151 MB of tables
+// and ~50 ms of table construction per device) with the variable, not with code.
+int dsv_init_visible(void) {
+  int count = 0;
+  if (hipGetDeviceCount(&count) != hipSuccess || count == 0)
+    return fail(DSV_ERR_NO_DEVICE, "no HIP device visible");
+  int done = 0;
+  if (const char* e = getenv("DSV_DEVICES")) {
+    for (const char* p = e; *p;) {
+      char* end = nullptr;
+      const long d = strtol(p, &end, 10);
+      if (end == p) return fail(DSV_ERR_INVALID_ARGUMENT, "DSV_DEVICES: cannot parse '%s'", e);
+      if (int r = dsv_init((int)d)) return r;
+      done++;
+      p = *end == ',' ? end + 1 : end;
+      if (*end && *end != ',') return fail(DSV_ERR_INVALID_ARGUMENT, "DSV_DEVICES: cannot parse '%s'", e);
+    }
+    if (!done) return fail(DSV_ERR_INVALID_ARGUMENT, "DSV_DEVICES is empty");
+    return done;
+  }
+  for (int d = 0; d < count && d < kMaxDevices; d++) {
+    if (int r = dsv_init(d)) return r;
+    done++;
+  }
+  return done;
 }
 
 int dsv_shutdown_device(int device) {
@@ -646,9 +606,7 @@ int dsv_challenge_single_dev(const void* R_uv, const void* m, size_t n, void* c,
                              void* stream) {
   if (n && (!R_uv || !m || !c)) return fail(DSV_ERR_INVALID_ARGUMENT, "null pointer");
   DSV_DEV_PROLOGUE(n, c);
-  hipLaunchKernelGGL(k_challenge<false>, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream,
-                     (const uint8_t*)R_uv, (const uint8_t*)nullptr, (const uint8_t*)m, n,
-                     (uint8_t*)c, (uint8_t*)valid);
+  launch_challenge(false, (const uint8_t*)R_uv, (const uint8_t*)nullptr, (const uint8_t*)m, n, (uint8_t*)c, (uint8_t*)valid, (hipStream_t)stream);
   HIP_TRY(hipGetLastError());
   return DSV_OK;
 }
@@ -656,9 +614,7 @@ int dsv_challenge_double_dev(const void* R_uv, const void* Rp_uv, const void* m,
                              void* valid, void* stream) {
   if (n && (!R_uv || !Rp_uv || !m || !c)) return fail(DSV_ERR_INVALID_ARGUMENT, "null pointer");
   DSV_DEV_PROLOGUE(n, c);
-  hipLaunchKernelGGL(k_challenge<true>, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream,
-                     (const uint8_t*)R_uv, (const uint8_t*)Rp_uv, (const uint8_t*)m, n,
-                     (uint8_t*)c, (uint8_t*)valid);
+  launch_challenge(true, (const uint8_t*)R_uv, (const uint8_t*)Rp_uv, (const uint8_t*)m, n, (uint8_t*)c, (uint8_t*)valid, (hipStream_t)stream);
   HIP_TRY(hipGetLastError());
   return DSV_OK;
 }
@@ -673,8 +629,7 @@ int verify_single_on(Context& ctx, const void* u, const void* R_uv, const void* 
   Context* cp = &ctx;
   return run_split(ctx, n, workspace, stream,
                    [=](size_t off, size_t cnt, const Workspace& w, hipStream_t s) {
-    hipLaunchKernelGGL(k_challenge<false>, dim3(grid_for(cnt)), dim3(256), 0, s, pR + 64 * off,
-                       (const uint8_t*)nullptr, pm + 32 * off, cnt, w.c, w.valid);
+    launch_challenge(false, pR + 64 * off, (const uint8_t*)nullptr, pm + 32 * off, cnt, w.c, w.valid, s);
     launch_verify_fixed(*cp, false, pu + 32 * off, w.c, pPK + 64 * off, pR + 64 * off, 0, w.valid,
                         cnt, pok + off, w.tables, s);
   });
@@ -688,8 +643,7 @@ int verify_double_on(Context& ctx, const void* u, const void* R_uv, const void* 
   Context* cp = &ctx;
   return run_split(ctx, n, workspace, stream,
                    [=](size_t off, size_t cnt, const Workspace& w, hipStream_t s) {
-    hipLaunchKernelGGL(k_challenge<true>, dim3(grid_for(cnt)), dim3(256), 0, s, pR + 64 * off,
-                       pRp + 64 * off, pm + 32 * off, cnt, w.c, w.valid);
+    launch_challenge(true, pR + 64 * off, pRp + 64 * off, pm + 32 * off, cnt, w.c, w.valid, s);
     launch_verify_fixed_double(*cp, pu + 32 * off, w.c, pPK + 64 * off, pR + 64 * off,
                                pPKp + 64 * off, pRp + 64 * off, w.valid, cnt, pok + off, w.tables, s);
   });
@@ -702,20 +656,15 @@ int verify_vargen_on(Context& ctx, const void* u, const void* R_uv, const void* 
   uint8_t* pok = (uint8_t*)ok;
   return run_split(ctx, n, workspace, stream,
                    [=](size_t off, size_t cnt, const Workspace& w, hipStream_t s) {
-    hipLaunchKernelGGL(k_challenge<false>, dim3(grid_for(cnt)), dim3(256), 0, s, pR + 64 * off,
-                       (const uint8_t*)nullptr, pm + 32 * off, cnt, w.c, w.valid);
-    hipLaunchKernelGGL(k_verify_var, dim3(verify_grid(cnt)), dim3(kVerifyBlock), 0, s,
-                       pu + 32 * off, (const uint8_t*)w.c, pPK + 64 * off, pG + 64 * off,
-                       pR + 64 * off, (const uint8_t*)w.valid, cnt, pok + off, w.tables);
+    launch_challenge(false, pR + 64 * off, (const uint8_t*)nullptr, pm + 32 * off, cnt, w.c, w.valid, s);
+    launch_verify_var(pu + 32 * off, (const uint8_t*)w.c, pPK + 64 * off, pG + 64 * off, pR + 64 * off, (const uint8_t*)w.valid, cnt, pok + off, w.tables, s);
   });
 }
 int decompress_on(Context& ctx, const void* in, size_t in_stride, size_t n, void* out_uv, void* ok,
                   int accumulate, hipStream_t stream) {
   if (!in || !out_uv || !ok || in_stride < 32 || (in_stride & 15) || ((uintptr_t)in & 15))
     return fail(DSV_ERR_INVALID_ARGUMENT, "bad pointer / stride (need 16-byte alignment)");
-  hipLaunchKernelGGL(k_decompress, dim3(grid_for(n)), dim3(256), 0, stream, (const uint8_t*)in,
-                     in_stride, n, (uint8_t*)out_uv, (uint8_t*)ok, accumulate,
-                     TsTables{ctx.ts_cancel, ctx.ts_hash});
+  launch_decompress((const uint8_t*)in, in_stride, n, (uint8_t*)out_uv, (uint8_t*)ok, accumulate, ctx.ts_cancel, ctx.ts_hash, stream);
   HIP_TRY(hipGetLastError());
   return DSV_OK;
 }
@@ -794,25 +743,19 @@ SplitScratch carve_split(void* p, size_t n) {
 int split_on(const void* kinds, size_t n, void* idx_single, size_t cap_single, void* idx_double,
              size_t cap_double, void* scratch, hipStream_t s) {
   if ((uintptr_t)kinds & 15) return fail(DSV_ERR_INVALID_ARGUMENT, "kinds must be 16-byte aligned");
-  const size_t tiles = (n + kSplitTile - 1) / kSplitTile;
   SplitScratch sc = carve_split(scratch, n);
-  hipLaunchKernelGGL(k_kind_count, dim3((unsigned)tiles), dim3(kSplitThreads), 0, s,
-                     (const uint8_t*)kinds, n, sc.tile_counts);
-  hipLaunchKernelGGL(k_kind_scan, dim3(1), dim3(1024), 0, s, sc.tile_counts, tiles, sc.totals);
-  hipLaunchKernelGGL(k_kind_write, dim3((unsigned)tiles), dim3(kSplitThreads), 0, s,
-                     (const uint8_t*)kinds, n, (const u32*)sc.tile_counts, (u32*)idx_single,
-                     cap_single, (u32*)idx_double, cap_double);
+  launch_split_kinds((const uint8_t*)kinds, n, sc.tile_counts, sc.totals, (u32*)idx_single, cap_single,
+                     (u32*)idx_double, cap_double, s);
   HIP_TRY(hipGetLastError());
   return DSV_OK;
 }
-int gather_on(const void* src, size_t row_bytes, const void* idx, size_t count, void* dst,
-              hipStream_t s) {
+// limit (device u32, may be null): only min(count, *limit) index entries are dereferenced
+int gather_on(const void* src, size_t src_rows, size_t row_bytes, const void* idx, size_t count,
+              const void* limit, void* dst, hipStream_t s) {
   if (row_bytes == 0 || (row_bytes & 15) || ((uintptr_t)src & 15) || ((uintptr_t)dst & 15))
     return fail(DSV_ERR_INVALID_ARGUMENT, "rows must be multiples of 16 bytes, 16-byte aligned");
   if (count == 0) return DSV_OK;
-  const u32 row16 = (u32)(row_bytes / 16);
-  hipLaunchKernelGGL(k_gather_rows, dim3(grid_for(count * row16)), dim3(256), 0, s,
-                     (const uint4*)src, row16, (const u32*)idx, count, (uint4*)dst);
+  launch_gather_rows(src, src_rows, (u32)(row_bytes / 16), (const u32*)idx, count, (const u32*)limit, dst, s);
   HIP_TRY(hipGetLastError());
   return DSV_OK;
 }
@@ -827,17 +770,18 @@ int dsv_split_kinds_dev(const void* kinds, size_t n, void* idx_single, size_t ca
   DSV_DEV_PROLOGUE(n, scratch);
   return split_on(kinds, n, idx_single, cap_single, idx_double, cap_double, scratch, (hipStream_t)stream);
 }
-int dsv_gather_rows_dev(const void* src, size_t row_bytes, const void* idx, size_t count, void* dst,
-                        void* stream) {
+int dsv_gather_rows_dev(const void* src, size_t src_rows, size_t row_bytes, const void* idx,
+                        size_t count, const void* count_limit, void* dst, void* stream) {
   if (count && (!src || !idx || !dst)) return fail(DSV_ERR_INVALID_ARGUMENT, "null pointer");
   DSV_DEV_PROLOGUE(count, dst);
-  return gather_on(src, row_bytes, idx, count, dst, (hipStream_t)stream);
+  return gather_on(src, src_rows, row_bytes, idx, count, count_limit, dst, (hipStream_t)stream);
 }
-int dsv_scatter_verdicts_dev(const void* src, const void* idx, size_t count, void* dst, void* stream) {
+int dsv_scatter_verdicts_dev(const void* src, const void* idx, size_t count, const void* count_limit,
+                             void* dst, size_t dst_len, void* stream) {
   if (count && (!src || !idx || !dst)) return fail(DSV_ERR_INVALID_ARGUMENT, "null pointer");
   DSV_DEV_PROLOGUE(count, dst);
-  hipLaunchKernelGGL(k_scatter_bytes, dim3(grid_for(count)), dim3(256), 0, (hipStream_t)stream,
-                     (const uint8_t*)src, (const u32*)idx, count, (uint8_t*)dst);
+  launch_scatter_bytes((const uint8_t*)src, (const u32*)idx, count, (const u32*)count_limit, (uint8_t*)dst,
+                       dst_len, (hipStream_t)stream);
   HIP_TRY(hipGetLastError());
   return DSV_OK;
 }
@@ -872,29 +816,32 @@ int dsv_verify_mixed_dev(const void* kinds, const void* u, const void* R_uv, con
   void* vws = st.take(dsv_workspace_bytes(n));
   HIP_TRY(hipMemsetAsync(ok, 0, n, s));  // items of an invalid kind keep verdict 0
   if (int r = split_on(kinds, n, idx_s, ns, idx_d, nd, scratch, s)) return r;
+  // Only index entries the split really wrote are dereferenced: every gather / scatter is bounded
+  // on the device by the split's own totals (and skips an index >= n), whatever the caller
+  // declared.  With a wrong n_double the compacted rows are partly stale workspace bytes — the
+  // verify kernels take any bytes (out-of-contract inputs never fault) and k_mixed_check zeroes
+  // the whole verdict vector at the end.
+  const u32* totals = carve_split(scratch, n).totals;
   struct Col { const void* src; size_t bytes; uint8_t* dst; };
   const Col single_cols[4] = {{u, 32, cu}, {m, 32, cm}, {R_uv, 64, cR}, {PK_uv, 64, cPK}};
   for (const Col& c : single_cols)
-    if (int r = gather_on(c.src, c.bytes, idx_s, ns, c.dst, s)) return r;
+    if (int r = gather_on(c.src, n, c.bytes, idx_s, ns, totals, c.dst, s)) return r;
   const Col double_cols[6] = {{u, 32, cu + ns * 32},      {m, 32, cm + ns * 32},
                               {R_uv, 64, cR + ns * 64},   {PK_uv, 64, cPK + ns * 64},
                               {Rp_uv, 64, cRp},           {PKp_uv, 64, cPKp}};
   for (const Col& c : double_cols)
-    if (int r = gather_on(c.src, c.bytes, idx_d, nd, c.dst, s)) return r;
+    if (int r = gather_on(c.src, n, c.bytes, idx_d, nd, totals + 1, c.dst, s)) return r;
   if (ns) {
     if (int r = verify_single_on(ctx, cu, cR, cPK, cm, ns, oks, vws, s)) return r;
-    hipLaunchKernelGGL(k_scatter_bytes, dim3(grid_for(ns)), dim3(256), 0, s, (const uint8_t*)oks,
-                       (const u32*)idx_s, ns, (uint8_t*)ok);
+    launch_scatter_bytes(oks, idx_s, ns, totals, (uint8_t*)ok, n, s);
   }
   if (nd) {
     if (int r = verify_double_on(ctx, cu + ns * 32, cR + ns * 64, cRp, cPK + ns * 64, cPKp,
                                  cm + ns * 32, nd, okd, vws, s))
       return r;
-    hipLaunchKernelGGL(k_scatter_bytes, dim3(grid_for(nd)), dim3(256), 0, s, (const uint8_t*)okd,
-                       (const u32*)idx_d, nd, (uint8_t*)ok);
+    launch_scatter_bytes(okd, idx_d, nd, totals + 1, (uint8_t*)ok, n, s);
   }
-  hipLaunchKernelGGL(k_mixed_check, dim3(256), dim3(256), 0, s, (const u32*)carve_split(scratch, n).totals,
-                     (u32)ns, (u32)nd, (uint8_t*)ok, n);
+  launch_mixed_check(totals, (u32)ns, (u32)nd, (uint8_t*)ok, n, s);
   HIP_TRY(hipGetLastError());
   return DSV_OK;
 }
@@ -1150,24 +1097,183 @@ int dsv_verify_vargen_multi(const uint8_t* u, const uint8_t* R_uv, const uint8_t
   });
 }
 
+// ---- projective inputs: the reference's in-memory types ------------------------------------
+// `PublicKey::from(&sk)` = GENERATOR_EXTENDED * sk and R = GENERATOR_EXTENDED * r are JubJubExtended
+// values with z != 1 (/root/reference/src/keys/public.rs:61-67, src/keys/secret.rs:159), and the
+// reference's verify starts with `to_hash_inputs` (src/signatures.rs:131, :280-281): one field
+// inversion per point.  The *_ext entry points take (u, v, z) and do that step on the device —
+// Montgomery's trick over all points of an item and over the items of a lane (k_normalize_uvz) —
+// so a caller (the Rust verify_batch) does no field arithmetic on the host at all.
+extern "C++" {
+namespace {
+struct ExtWs {
+  uint8_t* pts[4];
+  uint8_t* valid;
+  u32* prefix;
+  void* vws;
+};
+size_t ext_workspace_bytes(size_t n) {
+  return 4 * align_up(n * 64, 256) + align_up(n, 256) + align_up(normalize_prefix_bytes(n, 4), 256) +
+         align_up(dsv_workspace_bytes(n), 256) + 256;
+}
+ExtWs carve_ext(void* ws, size_t n) {
+  Stager st(static_cast<uint8_t*>(ws));
+  ExtWs w;
+  for (int k = 0; k < 4; k++) w.pts[k] = st.take(n * 64);
+  w.valid = st.take(n);
+  w.prefix = reinterpret_cast<u32*>(st.take(normalize_prefix_bytes(n, 4)));
+  w.vws = st.take(dsv_workspace_bytes(n));
+  return w;
+}
+// kind 0: pts = {R, PK}; 1: {R, R', PK, PK'}; 2: {R, PK, Gen} — each n x 96 B (u || v || z)
+int verify_ext_on(Context& ctx, int kind, const void* u, const void* const* pts_uvz, const void* m,
+                  size_t n, void* ok, void* workspace, hipStream_t s) {
+  const int np = kind == 0 ? 2 : (kind == 1 ? 4 : 3);
+  const ExtWs w = carve_ext(workspace, n);
+  NormalizeArgs a = {};
+  for (int k = 0; k < np; k++) {
+    a.in[k] = (const uint8_t*)pts_uvz[k];
+    a.out[k] = w.pts[k];
+  }
+  launch_normalize_uvz(a, np, n, w.valid, w.prefix, s);
+  int rc;
+  if (kind == 0) rc = verify_single_on(ctx, u, w.pts[0], w.pts[1], m, n, ok, w.vws, s);
+  else if (kind == 1) rc = verify_double_on(ctx, u, w.pts[0], w.pts[1], w.pts[2], w.pts[3], m, n, ok, w.vws, s);
+  else rc = verify_vargen_on(ctx, u, w.pts[0], w.pts[1], w.pts[2], m, n, ok, w.vws, s);
+  if (rc) return rc;
+  launch_and_bytes((uint8_t*)ok, w.valid, n, s);
+  HIP_TRY(hipGetLastError());
+  return DSV_OK;
+}
+// host buffers: the same through the chunked pipeline; the ext workspace of a chunk sits in the
+// slot's `extra` area and the pipeline's own verify workspace is not used
+constexpr size_t kExtItemBytes = 4 * 64 + 1 + 4 * kLimbs * 4 + 1;
+template <size_t NIN>
+int verify_ext_host(Context& ctx, int kind, const HostIn (&ins)[NIN], size_t n, uint8_t* ok) {
+  Context* cp = &ctx;
+  return run_pipelined(ctx, ins, ok, n, kExtItemBytes,
+                       [cp, kind](const void* const* d, size_t cnt, void* dok, void* ws, Stager& x, hipStream_t st) {
+    // layout of d: u, points..., m
+    const int np = kind == 0 ? 2 : (kind == 1 ? 4 : 3);
+    ExtWs w;
+    for (int k = 0; k < 4; k++) w.pts[k] = x.take(cnt * 64);
+    w.valid = x.take(cnt);
+    w.prefix = reinterpret_cast<u32*>(x.take(normalize_prefix_bytes(cnt, np)));
+    NormalizeArgs a = {};
+    for (int k = 0; k < np; k++) {
+      a.in[k] = (const uint8_t*)d[1 + k];
+      a.out[k] = w.pts[k];
+    }
+    launch_normalize_uvz(a, np, cnt, w.valid, w.prefix, st);
+    const void* m = d[1 + np];
+    int rc;
+    if (kind == 0) rc = verify_single_on(*cp, d[0], w.pts[0], w.pts[1], m, cnt, dok, ws, st);
+    else if (kind == 1) rc = verify_double_on(*cp, d[0], w.pts[0], w.pts[1], w.pts[2], w.pts[3], m, cnt, dok, ws, st);
+    else rc = verify_vargen_on(*cp, d[0], w.pts[0], w.pts[1], w.pts[2], m, cnt, dok, ws, st);
+    if (rc) return rc;
+    launch_and_bytes((uint8_t*)dok, w.valid, cnt, st);
+    HIP_TRY(hipGetLastError());
+    return (int)DSV_OK;
+  });
+}
+int verify_single_ext_host(Context& ctx, const uint8_t* u, const uint8_t* R, const uint8_t* PK,
+                           const uint8_t* m, size_t n, uint8_t* ok) {
+  const HostIn ins[4] = {{u, 32}, {R, 96}, {PK, 96}, {m, 32}};
+  return verify_ext_host(ctx, 0, ins, n, ok);
+}
+int verify_double_ext_host(Context& ctx, const uint8_t* u, const uint8_t* R, const uint8_t* Rp,
+                           const uint8_t* PK, const uint8_t* PKp, const uint8_t* m, size_t n, uint8_t* ok) {
+  const HostIn ins[6] = {{u, 32}, {R, 96}, {Rp, 96}, {PK, 96}, {PKp, 96}, {m, 32}};
+  return verify_ext_host(ctx, 1, ins, n, ok);
+}
+int verify_vargen_ext_host(Context& ctx, const uint8_t* u, const uint8_t* R, const uint8_t* PK,
+                           const uint8_t* Gen, const uint8_t* m, size_t n, uint8_t* ok) {
+  const HostIn ins[5] = {{u, 32}, {R, 96}, {PK, 96}, {Gen, 96}, {m, 32}};
+  return verify_ext_host(ctx, 2, ins, n, ok);
+}
+}  // namespace
+}  // extern "C++"
+
+size_t dsv_ext_workspace_bytes(size_t n) { return ext_workspace_bytes(n); }
+
 int dsv_verify_single_ext(const uint8_t* u, const uint8_t* R_uvz, const uint8_t* PK_uvz,
                           const uint8_t* m, size_t n, uint8_t* ok) {
   if (n && (!u || !R_uvz || !PK_uvz || !m || !ok)) return fail(DSV_ERR_INVALID_ARGUMENT, "null pointer");
   DSV_HOST_PROLOGUE(n);
-  const HostIn ins[4] = {{u, 32}, {R_uvz, 96}, {PK_uvz, 96}, {m, 32}};
-  Context* cp = &ctx;
-  return run_pipelined(ctx, ins, ok, n, 64 + 64 + 1, [cp](const void* const* d, size_t cnt, void* dok, void* ws, Stager& x, hipStream_t st) {
-    uint8_t *dR = x.take(cnt * 64), *dPK = x.take(cnt * 64), *dvalid = x.take(cnt);
-    hipLaunchKernelGGL(k_normalize_uvz, dim3(grid_for(cnt)), dim3(256), 0, st, (const uint8_t*)d[1], cnt,
-                       dR, dvalid, 0);
-    hipLaunchKernelGGL(k_normalize_uvz, dim3(grid_for(cnt)), dim3(256), 0, st, (const uint8_t*)d[2], cnt,
-                       dPK, dvalid, 1);
-    if (int r = verify_single_on(*cp, d[0], dR, dPK, d[3], cnt, dok, ws, st)) return r;
-    hipLaunchKernelGGL(k_and_bytes, dim3(grid_for(cnt)), dim3(256), 0, st, (uint8_t*)dok,
-                       (const uint8_t*)dvalid, cnt);
-    HIP_TRY(hipGetLastError());
-    return (int)DSV_OK;
+  return verify_single_ext_host(ctx, u, R_uvz, PK_uvz, m, n, ok);
+}
+int dsv_verify_double_ext(const uint8_t* u, const uint8_t* R_uvz, const uint8_t* Rp_uvz,
+                          const uint8_t* PK_uvz, const uint8_t* PKp_uvz, const uint8_t* m, size_t n,
+                          uint8_t* ok) {
+  if (n && (!u || !R_uvz || !Rp_uvz || !PK_uvz || !PKp_uvz || !m || !ok))
+    return fail(DSV_ERR_INVALID_ARGUMENT, "null pointer");
+  DSV_HOST_PROLOGUE(n);
+  return verify_double_ext_host(ctx, u, R_uvz, Rp_uvz, PK_uvz, PKp_uvz, m, n, ok);
+}
+int dsv_verify_vargen_ext(const uint8_t* u, const uint8_t* R_uvz, const uint8_t* PK_uvz,
+                          const uint8_t* Gen_uvz, const uint8_t* m, size_t n, uint8_t* ok) {
+  if (n && (!u || !R_uvz || !PK_uvz || !Gen_uvz || !m || !ok))
+    return fail(DSV_ERR_INVALID_ARGUMENT, "null pointer");
+  DSV_HOST_PROLOGUE(n);
+  return verify_vargen_ext_host(ctx, u, R_uvz, PK_uvz, Gen_uvz, m, n, ok);
+}
+int dsv_verify_single_ext_multi(const uint8_t* u, const uint8_t* R_uvz, const uint8_t* PK_uvz,
+                                const uint8_t* m, size_t n, uint8_t* ok) {
+  if (int r = check_n(n)) return r;
+  if (n == 0) return DSV_OK;
+  if (!u || !R_uvz || !PK_uvz || !m || !ok) return fail(DSV_ERR_INVALID_ARGUMENT, "null pointer");
+  return run_multi(n, [=](Context& ctx, size_t off, size_t cnt) {
+    return verify_single_ext_host(ctx, u + 32 * off, R_uvz + 96 * off, PK_uvz + 96 * off, m + 32 * off,
+                                  cnt, ok + off);
   });
+}
+int dsv_verify_double_ext_multi(const uint8_t* u, const uint8_t* R_uvz, const uint8_t* Rp_uvz,
+                                const uint8_t* PK_uvz, const uint8_t* PKp_uvz, const uint8_t* m,
+                                size_t n, uint8_t* ok) {
+  if (int r = check_n(n)) return r;
+  if (n == 0) return DSV_OK;
+  if (!u || !R_uvz || !Rp_uvz || !PK_uvz || !PKp_uvz || !m || !ok)
+    return fail(DSV_ERR_INVALID_ARGUMENT, "null pointer");
+  return run_multi(n, [=](Context& ctx, size_t off, size_t cnt) {
+    return verify_double_ext_host(ctx, u + 32 * off, R_uvz + 96 * off, Rp_uvz + 96 * off,
+                                  PK_uvz + 96 * off, PKp_uvz + 96 * off, m + 32 * off, cnt, ok + off);
+  });
+}
+int dsv_verify_vargen_ext_multi(const uint8_t* u, const uint8_t* R_uvz, const uint8_t* PK_uvz,
+                                const uint8_t* Gen_uvz, const uint8_t* m, size_t n, uint8_t* ok) {
+  if (int r = check_n(n)) return r;
+  if (n == 0) return DSV_OK;
+  if (!u || !R_uvz || !PK_uvz || !Gen_uvz || !m || !ok)
+    return fail(DSV_ERR_INVALID_ARGUMENT, "null pointer");
+  return run_multi(n, [=](Context& ctx, size_t off, size_t cnt) {
+    return verify_vargen_ext_host(ctx, u + 32 * off, R_uvz + 96 * off, PK_uvz + 96 * off,
+                                  Gen_uvz + 96 * off, m + 32 * off, cnt, ok + off);
+  });
+}
+int dsv_verify_single_ext_dev(const void* u, const void* R_uvz, const void* PK_uvz, const void* m,
+                              size_t n, void* ok, void* workspace, void* stream) {
+  if (n && (!u || !R_uvz || !PK_uvz || !m || !ok || !workspace))
+    return fail(DSV_ERR_INVALID_ARGUMENT, "null pointer");
+  DSV_DEV_PROLOGUE(n, ok);
+  const void* pts[2] = {R_uvz, PK_uvz};
+  return verify_ext_on(ctx, 0, u, pts, m, n, ok, workspace, (hipStream_t)stream);
+}
+int dsv_verify_double_ext_dev(const void* u, const void* R_uvz, const void* Rp_uvz, const void* PK_uvz,
+                              const void* PKp_uvz, const void* m, size_t n, void* ok, void* workspace,
+                              void* stream) {
+  if (n && (!u || !R_uvz || !Rp_uvz || !PK_uvz || !PKp_uvz || !m || !ok || !workspace))
+    return fail(DSV_ERR_INVALID_ARGUMENT, "null pointer");
+  DSV_DEV_PROLOGUE(n, ok);
+  const void* pts[4] = {R_uvz, Rp_uvz, PK_uvz, PKp_uvz};
+  return verify_ext_on(ctx, 1, u, pts, m, n, ok, workspace, (hipStream_t)stream);
+}
+int dsv_verify_vargen_ext_dev(const void* u, const void* R_uvz, const void* PK_uvz, const void* Gen_uvz,
+                              const void* m, size_t n, void* ok, void* workspace, void* stream) {
+  if (n && (!u || !R_uvz || !PK_uvz || !Gen_uvz || !m || !ok || !workspace))
+    return fail(DSV_ERR_INVALID_ARGUMENT, "null pointer");
+  DSV_DEV_PROLOGUE(n, ok);
+  const void* pts[3] = {R_uvz, PK_uvz, Gen_uvz};
+  return verify_ext_on(ctx, 2, u, pts, m, n, ok, workspace, (hipStream_t)stream);
 }
 
 int dsv_challenge_single(const uint8_t* R_uv, const uint8_t* m, size_t n, uint8_t* c) {
@@ -1179,8 +1285,7 @@ int dsv_challenge_single(const uint8_t* R_uv, const uint8_t* m, size_t n, uint8_
   uint8_t *dR = st.take(n * 64), *dm = st.take(n * 32), *dc = st.take(n * 32);
   H2D(dR, R_uv, n * 64);
   H2D(dm, m, n * 32);
-  hipLaunchKernelGGL(k_challenge<false>, dim3(grid_for(n)), dim3(256), 0, 0, (const uint8_t*)dR,
-                     (const uint8_t*)nullptr, (const uint8_t*)dm, n, dc, (uint8_t*)nullptr);
+  launch_challenge(false, (const uint8_t*)dR, (const uint8_t*)nullptr, (const uint8_t*)dm, n, dc, (uint8_t*)nullptr, 0);
   HIP_TRY(hipGetLastError());
   D2H(c, dc, n * 32);
   HIP_TRY(hipStreamSynchronize(0));
@@ -1198,8 +1303,7 @@ int dsv_challenge_double(const uint8_t* R_uv, const uint8_t* Rp_uv, const uint8_
   H2D(dR, R_uv, n * 64);
   H2D(dRp, Rp_uv, n * 64);
   H2D(dm, m, n * 32);
-  hipLaunchKernelGGL(k_challenge<true>, dim3(grid_for(n)), dim3(256), 0, 0, (const uint8_t*)dR,
-                     (const uint8_t*)dRp, (const uint8_t*)dm, n, dc, (uint8_t*)nullptr);
+  launch_challenge(true, (const uint8_t*)dR, (const uint8_t*)dRp, (const uint8_t*)dm, n, dc, (uint8_t*)nullptr, 0);
   HIP_TRY(hipGetLastError());
   D2H(c, dc, n * 32);
   HIP_TRY(hipStreamSynchronize(0));
@@ -1214,24 +1318,17 @@ int dsv_challenge_double(const uint8_t* R_uv, const uint8_t* Rp_uv, const uint8_
 namespace {
 void launch_sign_single(Context& ctx, const void* sk, const void* m, const void* r, size_t n, void* u,
                         void* R_uv, hipStream_t s) {
-  hipLaunchKernelGGL(k_fixed_base_points, dim3(grid_for(n)), dim3(256), 0, s, (const uint8_t*)r,
-                     (const u32*)ctx.table[0], n, (uint8_t*)R_uv);
+  launch_fixed_base_points((const uint8_t*)r, (const u32*)ctx.table[0], n, (uint8_t*)R_uv, s);
   // scratch use: c is written to u (32 B per item) before k_sign_finish overwrites it in place
-  hipLaunchKernelGGL(k_challenge<false>, dim3(grid_for(n)), dim3(256), 0, s, (const uint8_t*)R_uv,
-                     (const uint8_t*)nullptr, (const uint8_t*)m, n, (uint8_t*)u, (uint8_t*)nullptr);
-  hipLaunchKernelGGL(k_sign_finish, dim3(grid_for(n)), dim3(256), 0, s, (const uint8_t*)r,
-                     (const uint8_t*)u, (const uint8_t*)sk, n, (uint8_t*)u);
+  launch_challenge(false, (const uint8_t*)R_uv, (const uint8_t*)nullptr, (const uint8_t*)m, n, (uint8_t*)u, (uint8_t*)nullptr, s);
+  launch_sign_finish((const uint8_t*)r, (const uint8_t*)u, (const uint8_t*)sk, n, (uint8_t*)u, s);
 }
 void launch_sign_double(Context& ctx, const void* sk, const void* m, const void* r, size_t n, void* u,
                         void* R_uv, void* Rp_uv, hipStream_t s) {
-  hipLaunchKernelGGL(k_fixed_base_points, dim3(grid_for(n)), dim3(256), 0, s, (const uint8_t*)r,
-                     (const u32*)ctx.table[0], n, (uint8_t*)R_uv);
-  hipLaunchKernelGGL(k_fixed_base_points, dim3(grid_for(n)), dim3(256), 0, s, (const uint8_t*)r,
-                     (const u32*)ctx.table[1], n, (uint8_t*)Rp_uv);
-  hipLaunchKernelGGL(k_challenge<true>, dim3(grid_for(n)), dim3(256), 0, s, (const uint8_t*)R_uv,
-                     (const uint8_t*)Rp_uv, (const uint8_t*)m, n, (uint8_t*)u, (uint8_t*)nullptr);
-  hipLaunchKernelGGL(k_sign_finish, dim3(grid_for(n)), dim3(256), 0, s, (const uint8_t*)r,
-                     (const uint8_t*)u, (const uint8_t*)sk, n, (uint8_t*)u);
+  launch_fixed_base_points((const uint8_t*)r, (const u32*)ctx.table[0], n, (uint8_t*)R_uv, s);
+  launch_fixed_base_points((const uint8_t*)r, (const u32*)ctx.table[1], n, (uint8_t*)Rp_uv, s);
+  launch_challenge(true, (const uint8_t*)R_uv, (const uint8_t*)Rp_uv, (const uint8_t*)m, n, (uint8_t*)u, (uint8_t*)nullptr, s);
+  launch_sign_finish((const uint8_t*)r, (const uint8_t*)u, (const uint8_t*)sk, n, (uint8_t*)u, s);
 }
 // host-side check of what the kernels would otherwise poison: scalars must be < r
 int check_canonical_scalars(const uint8_t* s, size_t n, const char* what) {
@@ -1255,8 +1352,7 @@ int check_canonical_scalars(const uint8_t* s, size_t n, const char* what) {
 int dsv_public_keys_dev(const void* sk, int which, size_t n, void* PK_uv, void* stream) {
   if (n && (!sk || !PK_uv || which < 0 || which > 1)) return fail(DSV_ERR_INVALID_ARGUMENT, "bad argument");
   DSV_DEV_PROLOGUE(n, PK_uv);
-  hipLaunchKernelGGL(k_fixed_base_points, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream,
-                     (const uint8_t*)sk, (const u32*)ctx.table[which], n, (uint8_t*)PK_uv);
+  launch_fixed_base_points((const uint8_t*)sk, (const u32*)ctx.table[which], n, (uint8_t*)PK_uv, (hipStream_t)stream);
   HIP_TRY(hipGetLastError());
   return DSV_OK;
 }
@@ -1282,9 +1378,7 @@ int dsv_public_keys_vargen_dev(const void* sk, const void* Gen_uv, size_t n, voi
                                void* workspace, void* stream) {
   if (n && (!sk || !Gen_uv || !PK_uv || !workspace)) return fail(DSV_ERR_INVALID_ARGUMENT, "null pointer");
   DSV_DEV_PROLOGUE(n, PK_uv);
-  hipLaunchKernelGGL(k_var_base_points, dim3(verify_grid(n)), dim3(kVerifyBlock), 0, (hipStream_t)stream,
-                     (const uint8_t*)sk, (const uint8_t*)Gen_uv, n, (uint8_t*)PK_uv,
-                     reinterpret_cast<u32*>(workspace));
+  launch_var_base_points((const uint8_t*)sk, (const uint8_t*)Gen_uv, n, (uint8_t*)PK_uv, reinterpret_cast<u32*>(workspace), (hipStream_t)stream);
   HIP_TRY(hipGetLastError());
   return DSV_OK;
 }
@@ -1294,12 +1388,9 @@ int dsv_sign_vargen_dev(const void* sk, const void* Gen_uv, const void* m, const
     return fail(DSV_ERR_INVALID_ARGUMENT, "null pointer");
   DSV_DEV_PROLOGUE(n, u);
   hipStream_t s = (hipStream_t)stream;
-  hipLaunchKernelGGL(k_var_base_points, dim3(verify_grid(n)), dim3(kVerifyBlock), 0, s, (const uint8_t*)r,
-                     (const uint8_t*)Gen_uv, n, (uint8_t*)R_uv, reinterpret_cast<u32*>(workspace));
-  hipLaunchKernelGGL(k_challenge<false>, dim3(grid_for(n)), dim3(256), 0, s, (const uint8_t*)R_uv,
-                     (const uint8_t*)nullptr, (const uint8_t*)m, n, (uint8_t*)u, (uint8_t*)nullptr);
-  hipLaunchKernelGGL(k_sign_finish, dim3(grid_for(n)), dim3(256), 0, s, (const uint8_t*)r,
-                     (const uint8_t*)u, (const uint8_t*)sk, n, (uint8_t*)u);
+  launch_var_base_points((const uint8_t*)r, (const uint8_t*)Gen_uv, n, (uint8_t*)R_uv, reinterpret_cast<u32*>(workspace), s);
+  launch_challenge(false, (const uint8_t*)R_uv, (const uint8_t*)nullptr, (const uint8_t*)m, n, (uint8_t*)u, (uint8_t*)nullptr, s);
+  launch_sign_finish((const uint8_t*)r, (const uint8_t*)u, (const uint8_t*)sk, n, (uint8_t*)u, s);
   HIP_TRY(hipGetLastError());
   return DSV_OK;
 }
@@ -1318,11 +1409,9 @@ int dsv_public_keys(const uint8_t* sk, int which, const uint8_t* gen_uv, size_t 
   H2D(dsk, sk, n * 32);
   if (gen_uv) {
     H2D(dg, gen_uv, n * 64);
-    hipLaunchKernelGGL(k_var_base_points, dim3(verify_grid(n)), dim3(kVerifyBlock), 0, 0, (const uint8_t*)dsk,
-                       (const uint8_t*)dg, n, dpk, reinterpret_cast<u32*>(dtab));
+    launch_var_base_points((const uint8_t*)dsk, (const uint8_t*)dg, n, dpk, reinterpret_cast<u32*>(dtab), 0);
   } else {
-    hipLaunchKernelGGL(k_fixed_base_points, dim3(grid_for(n)), dim3(256), 0, 0, (const uint8_t*)dsk,
-                       (const u32*)ctx.table[which], n, dpk);
+    launch_fixed_base_points((const uint8_t*)dsk, (const u32*)ctx.table[which], n, dpk, 0);
   }
   HIP_TRY(hipGetLastError());
   D2H(PK_uv, dpk, n * 64);
@@ -1397,12 +1486,9 @@ int dsv_sign_vargen(const uint8_t* sk, const uint8_t* Gen_uv, const uint8_t* m, 
   H2D(dm, m, n * 32);
   H2D(dr, r, n * 32);
   H2D(dG, Gen_uv, n * 64);
-  hipLaunchKernelGGL(k_var_base_points, dim3(verify_grid(n)), dim3(kVerifyBlock), 0, 0, (const uint8_t*)dr,
-                     (const uint8_t*)dG, n, dR, reinterpret_cast<u32*>(dtab));
-  hipLaunchKernelGGL(k_challenge<false>, dim3(grid_for(n)), dim3(256), 0, 0, (const uint8_t*)dR,
-                     (const uint8_t*)nullptr, (const uint8_t*)dm, n, du, (uint8_t*)nullptr);
-  hipLaunchKernelGGL(k_sign_finish, dim3(grid_for(n)), dim3(256), 0, 0, (const uint8_t*)dr,
-                     (const uint8_t*)du, (const uint8_t*)dsk, n, du);
+  launch_var_base_points((const uint8_t*)dr, (const uint8_t*)dG, n, dR, reinterpret_cast<u32*>(dtab), 0);
+  launch_challenge(false, (const uint8_t*)dR, (const uint8_t*)nullptr, (const uint8_t*)dm, n, du, (uint8_t*)nullptr, 0);
+  launch_sign_finish((const uint8_t*)dr, (const uint8_t*)du, (const uint8_t*)dsk, n, du, 0);
   HIP_TRY(hipGetLastError());
   D2H(u, du, n * 32);
   D2H(R_uv, dR, n * 64);
@@ -1450,34 +1536,81 @@ int dsv_decompress_points(const uint8_t* in32, size_t n, uint8_t* out_uv, uint8_
 namespace {
 // shared body of the *_wire entry points.  sig: n records of sig_bytes = 32 (u) + 32*n_sig_points;
 // pk: n records of 32*n_pk_points compressed points.  kind: 0 single, 1 double, 2 vargen.
+struct WireWs {
+  uint8_t *u, *R, *Rp, *P0, *P1, *valid;
+};
+constexpr size_t kWireItemBytes = 32 + 4 * 64 + 1;
+int verify_wire_on(Context& ctx, int kind, const uint8_t* dsig, const uint8_t* dpk, const void* dm,
+                   size_t cnt, void* dok, const WireWs& x, void* vws, hipStream_t st) {
+  const size_t sig_bytes = kind == 1 ? 96 : 64, pk_bytes = kind == 0 ? 32 : 64;
+  launch_gather32(dsig, sig_bytes, cnt, x.u, st);
+  if (int r = decompress_on(ctx, dsig + 32, sig_bytes, cnt, x.R, x.valid, 0, st)) return r;
+  if (kind == 1)
+    if (int r = decompress_on(ctx, dsig + 64, sig_bytes, cnt, x.Rp, x.valid, 1, st)) return r;
+  if (int r = decompress_on(ctx, dpk, pk_bytes, cnt, x.P0, x.valid, 1, st)) return r;
+  if (kind != 0)
+    if (int r = decompress_on(ctx, dpk + 32, pk_bytes, cnt, x.P1, x.valid, 1, st)) return r;
+  int rc;
+  if (kind == 0) rc = verify_single_on(ctx, x.u, x.R, x.P0, dm, cnt, dok, vws, st);
+  else if (kind == 1) rc = verify_double_on(ctx, x.u, x.R, x.Rp, x.P0, x.P1, dm, cnt, dok, vws, st);
+  else rc = verify_vargen_on(ctx, x.u, x.R, x.P0, x.P1, dm, cnt, dok, vws, st);
+  if (rc) return rc;
+  launch_and_bytes((uint8_t*)dok, x.valid, cnt, st);
+  HIP_TRY(hipGetLastError());
+  return DSV_OK;
+}
 int verify_wire(Context& ctx, int kind, const uint8_t* sig, const uint8_t* pk, const uint8_t* m,
                 size_t n, uint8_t* ok) {
   const size_t sig_bytes = kind == 1 ? 96 : 64, pk_bytes = kind == 0 ? 32 : 64;
   const HostIn ins[3] = {{sig, sig_bytes}, {pk, pk_bytes}, {m, 32}};
   Context* cp = &ctx;
-  return run_pipelined(ctx, ins, ok, n, 32 + 4 * 64 + 1, [=](const void* const* d, size_t cnt, void* dok, void* ws, Stager& x, hipStream_t st) {
-    const uint8_t *dsig = (const uint8_t*)d[0], *dpk = (const uint8_t*)d[1];
-    uint8_t *du = x.take(cnt * 32), *dR = x.take(cnt * 64), *dRp = x.take(cnt * 64),
-            *dP0 = x.take(cnt * 64), *dP1 = x.take(cnt * 64), *dvalid = x.take(cnt);
-    hipLaunchKernelGGL(k_gather32, dim3(grid_for(cnt)), dim3(256), 0, st, dsig, sig_bytes, cnt, du);
-    if (int r = decompress_on(*cp, dsig + 32, sig_bytes, cnt, dR, dvalid, 0, st)) return r;
-    if (kind == 1)
-      if (int r = decompress_on(*cp, dsig + 64, sig_bytes, cnt, dRp, dvalid, 1, st)) return r;
-    if (int r = decompress_on(*cp, dpk, pk_bytes, cnt, dP0, dvalid, 1, st)) return r;
-    if (kind != 0)
-      if (int r = decompress_on(*cp, dpk + 32, pk_bytes, cnt, dP1, dvalid, 1, st)) return r;
-    int rc;
-    if (kind == 0) rc = verify_single_on(*cp, du, dR, dP0, d[2], cnt, dok, ws, st);
-    else if (kind == 1) rc = verify_double_on(*cp, du, dR, dRp, dP0, dP1, d[2], cnt, dok, ws, st);
-    else rc = verify_vargen_on(*cp, du, dR, dP0, dP1, d[2], cnt, dok, ws, st);
-    if (rc) return rc;
-    hipLaunchKernelGGL(k_and_bytes, dim3(grid_for(cnt)), dim3(256), 0, st, (uint8_t*)dok,
-                       (const uint8_t*)dvalid, cnt);
-    HIP_TRY(hipGetLastError());
-    return (int)DSV_OK;
+  return run_pipelined(ctx, ins, ok, n, kWireItemBytes, [=](const void* const* d, size_t cnt, void* dok, void* ws, Stager& x, hipStream_t st) {
+    WireWs w;
+    w.u = x.take(cnt * 32);
+    w.R = x.take(cnt * 64);
+    w.Rp = x.take(cnt * 64);
+    w.P0 = x.take(cnt * 64);
+    w.P1 = x.take(cnt * 64);
+    w.valid = x.take(cnt);
+    return verify_wire_on(*cp, kind, (const uint8_t*)d[0], (const uint8_t*)d[1], d[2], cnt, dok, w, ws, st);
   });
 }
+// device-pointer form: serialized records already resident in HBM
+int verify_wire_dev(int kind, const void* sig, const void* pk, const void* m, size_t n, void* ok,
+                    void* workspace, void* stream) {
+  if (n && (!sig || !pk || !m || !ok || !workspace)) return fail(DSV_ERR_INVALID_ARGUMENT, "null pointer");
+  if (((uintptr_t)sig | (uintptr_t)pk) & 15) return fail(DSV_ERR_INVALID_ARGUMENT, "records must be 16-byte aligned");
+  DSV_DEV_PROLOGUE(n, ok);
+  Stager x(static_cast<uint8_t*>(workspace));
+  WireWs w;
+  w.u = x.take(n * 32);
+  w.R = x.take(n * 64);
+  w.Rp = x.take(n * 64);
+  w.P0 = x.take(n * 64);
+  w.P1 = x.take(n * 64);
+  w.valid = x.take(n);
+  void* vws = x.take(dsv_workspace_bytes(n));
+  return verify_wire_on(ctx, kind, (const uint8_t*)sig, (const uint8_t*)pk, m, n, ok, w, vws,
+                        (hipStream_t)stream);
+}
 }  // namespace
+
+size_t dsv_wire_workspace_bytes(size_t n) {
+  return align_up(n * 32, 256) + 4 * align_up(n * 64, 256) + align_up(n, 256) +
+         align_up(dsv_workspace_bytes(n), 256) + 256;
+}
+int dsv_verify_single_wire_dev(const void* sig64, const void* pk32, const void* m, size_t n, void* ok,
+                               void* workspace, void* stream) {
+  return verify_wire_dev(0, sig64, pk32, m, n, ok, workspace, stream);
+}
+int dsv_verify_double_wire_dev(const void* sig96, const void* pk64, const void* m, size_t n, void* ok,
+                               void* workspace, void* stream) {
+  return verify_wire_dev(1, sig96, pk64, m, n, ok, workspace, stream);
+}
+int dsv_verify_vargen_wire_dev(const void* sig64, const void* pk64, const void* m, size_t n, void* ok,
+                               void* workspace, void* stream) {
+  return verify_wire_dev(2, sig64, pk64, m, n, ok, workspace, stream);
+}
 
 int dsv_verify_single_wire(const uint8_t* sig64, const uint8_t* pk32, const uint8_t* m, size_t n,
                            uint8_t* ok) {
@@ -1517,8 +1650,7 @@ int dsv_stdrng_sign_inputs_dev(uint64_t seed, size_t first_item, size_t n, void*
                                void* r, void* stream) {
   if (n && (!sk || !m || !r)) return fail(DSV_ERR_INVALID_ARGUMENT, "null pointer");
   DSV_DEV_PROLOGUE(n, sk);
-  hipLaunchKernelGGL(k_stdrng_triples, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream,
-                     stdrng_key(seed), first_item, n, (uint8_t*)sk, (uint8_t*)m, (uint8_t*)r);
+  launch_stdrng_triples(stdrng_key(seed), first_item, n, (uint8_t*)sk, (uint8_t*)m, (uint8_t*)r, (hipStream_t)stream);
   HIP_TRY(hipGetLastError());
   return DSV_OK;
 }
@@ -1530,8 +1662,7 @@ int dsv_stdrng_sign_inputs(uint64_t seed, size_t first_item, size_t n, uint8_t* 
   if (int rc = ensure_stage(ctx, 3 * align_up(n * 32, 256))) return rc;
   Stager st(ctx.stage);
   uint8_t *dsk = st.take(n * 32), *dm = st.take(n * 32), *dr = st.take(n * 32);
-  hipLaunchKernelGGL(k_stdrng_triples, dim3(grid_for(n)), dim3(256), 0, 0, stdrng_key(seed),
-                     first_item, n, dsk, dm, dr);
+  launch_stdrng_triples(stdrng_key(seed), first_item, n, dsk, dm, dr, 0);
   HIP_TRY(hipGetLastError());
   D2H(sk, dsk, n * 32);
   D2H(m, dm, n * 32);
@@ -1545,9 +1676,7 @@ int dsv_stdrng_vargen_inputs_dev(uint64_t seed, size_t first_item, size_t n, voi
                                  void* m, void* r, void* stream) {
   if (n && (!sk || !g || !m || !r)) return fail(DSV_ERR_INVALID_ARGUMENT, "null pointer");
   DSV_DEV_PROLOGUE(n, sk);
-  hipLaunchKernelGGL(k_stdrng_quads, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream,
-                     stdrng_key(seed), first_item, n, (uint8_t*)sk, (uint8_t*)g, (uint8_t*)m,
-                     (uint8_t*)r);
+  launch_stdrng_quads(stdrng_key(seed), first_item, n, (uint8_t*)sk, (uint8_t*)g, (uint8_t*)m, (uint8_t*)r, (hipStream_t)stream);
   HIP_TRY(hipGetLastError());
   return DSV_OK;
 }
@@ -1570,8 +1699,8 @@ int dsv_debug_table_entry(int which, int window, int digit, uint8_t out96[96]) {
     int bits = 0, o = 0;
     uint8_t* dst = out96 + 32 * f;
     memset(dst, 0, 32);
-    for (int i = 0; i < NL; i++) {
-      acc |= (unsigned __int128)e[f * NL + i] << bits;
+    for (int i = 0; i < kLimbs; i++) {
+      acc |= (unsigned __int128)e[f * kLimbs + i] << bits;
       bits += 29;
       while (bits >= 8 && o < 32) {
         dst[o++] = (uint8_t)acc;
@@ -1598,8 +1727,7 @@ int dsv_debug_fq_mul(const uint8_t* a, const uint8_t* b, size_t n, uint8_t* out)
   uint8_t *da = st.take(n * 32), *db = st.take(n * 32), *dout = st.take(n * 32);
   H2D(da, a, n * 32);
   H2D(db, b, n * 32);
-  hipLaunchKernelGGL(k_debug_fq_mul, dim3(grid_for(n)), dim3(256), 0, 0, (const uint8_t*)da,
-                     (const uint8_t*)db, n, dout);
+  launch_debug_fq_mul((const uint8_t*)da, (const uint8_t*)db, n, dout, 0);
   HIP_TRY(hipGetLastError());
   D2H(out, dout, n * 32);
   HIP_TRY(hipStreamSynchronize(0));

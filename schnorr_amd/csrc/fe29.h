@@ -19,7 +19,6 @@
 //   fe_sub2/4/8(a, b)  : a + k*q - b with a redundant-limb k*q whose limbs dominate b's
 //                        (b limbs <= 2^30 - 2, b < (k - 0.01) q), then one parallel carry pass
 //                        -> limbs < 2^29 + 8
-// "dot5" (5-term dot product with ONE reduction) is used by the Hades MDS layer.
 //
 // Reference semantics being reproduced: dusk-bls12_381 `BlsScalar` mul/add/sub/square as used
 // by the verify path (/root/reference/src/keys/public.rs:121-130 via dusk-jubjub operators);
@@ -108,14 +107,7 @@ DSV_DEV Fe fe_one() { return fe_const(kOne); }
 // them (to hide a latency that a dependent v_mad_u64_u32 chain does not have: tools/microbench
 // mad_u64_u32_chain) keeps the live set to one accumulator and one digit vector.  The fence lets
 // scalar and memory instructions cross, vector ALU instructions not.
-#ifndef DSV_SCHED_FENCE_MASK
-#define DSV_SCHED_FENCE_MASK 0x0f4  /* SALU | all VMEM (+ read, write) | all DS */
-#endif
-#ifdef DSV_NO_SCHED_FENCE
-#define DSV_SCHED_FENCE() ((void)0)
-#else
-#define DSV_SCHED_FENCE() __builtin_amdgcn_sched_barrier(DSV_SCHED_FENCE_MASK)
-#endif
+#define DSV_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0x0f4) /* may cross: SALU | all VMEM | all DS */
 DSV_DEV void mad_pin(u64& acc, u32& tok, u32 x, u32 y) {
   acc += (u64)x * y;
   asm("s_mov_b32 %0, 0" : "+s"(tok));
@@ -177,162 +169,6 @@ DSV_DEV Fe fe_sqr(const Fe& a) {
     }
     if ((k & 1) == 0) mad_pin(acc, tok, a.l[k / 2], a.l[k / 2]);
   });
-}
-
-// ---- two independent squarings with their MAD chains interleaved column by column (A/B:
-// -DDSV_SQR_PAIR=1).  One multiplication is ONE serial chain of dependent v_mad_u64_u32 (latency
-// ~8 cycles, issue ~4): with two waves per SIMD the chains of the two waves fill each other's
-// gaps only while both are inside a multiplication; two chains per wave need no partner.
-#ifndef DSV_SQR_PAIR
-#define DSV_SQR_PAIR 0
-#endif
-DSV_DEV void fe_sqr2(Fe& ra, Fe& rb, const Fe& a, const Fe& b) {
-  u32 da[NL], db[NL], ma[NL], mb[NL];
-#pragma unroll
-  for (int i = 0; i < NL; i++) {
-    da[i] = a.l[i] << 1;
-    db[i] = b.l[i] << 1;
-  }
-  u32 ta, tb;
-  DSV_SCHED_FENCE();
-  asm("s_mov_b32 %0, 0" : "=s"(ta));
-  asm("s_mov_b32 %0, 0" : "=s"(tb));
-  u64 xa = 0, xb = 0;
-  auto prod = [&](int k, u64& acc, u32& tok, const u32 (&d)[NL], const Fe& x) {
-#pragma unroll
-    for (int i = 0; i < NL; i++) {
-      const int j = k - i;
-      if (j > i && j < NL) mad_pin(acc, tok, d[i], x.l[j]);
-    }
-    if ((k & 1) == 0) mad_pin(acc, tok, x.l[k / 2], x.l[k / 2]);
-  };
-  prod(0, xa, ta, da, a);
-  prod(0, xb, tb, db, b);
-  ma[0] = ((~(u32)xa) & M29) + 1;
-  mb[0] = ((~(u32)xb) & M29) + 1;
-  xa >>= 29;
-  xb >>= 29;
-#pragma unroll
-  for (int k = 1; k < 2 * NL - 1; k++) {
-    prod(k, xa, ta, da, a);
-    prod(k, xb, tb, db, b);
-#pragma unroll
-    for (int i = 0; i < NL; i++) {
-      const int j = k - i;
-      if (i < k && j >= 1 && j < NL) {
-        mad_pin(xa, ta, ma[i], kQ29[j]);
-        mad_pin(xb, tb, mb[i], kQ29[j]);
-      }
-    }
-    if (k < NL) {
-      ma[k] = (~(u32)xa) & M29;
-      mb[k] = (~(u32)xb) & M29;
-    } else {
-      ra.l[k - NL] = (u32)xa & M29;
-      rb.l[k - NL] = (u32)xb & M29;
-    }
-    xa >>= 29;
-    xb >>= 29;
-  }
-  ra.l[0] += 1;
-  rb.l[0] += 1;
-  ra.l[NL - 1] = (u32)xa;
-  rb.l[NL - 1] = (u32)xb;
-  DSV_SCHED_FENCE();
-}
-
-// ---- dot products with ONE reduction (Hades linear layers) ----------------------------------
-// These keep the operand-scanning form: 17 column accumulators, one term at a time, so only the
-// nine limbs of ONE wave-uniform constant have to sit in SGPRs at any moment.  (r02 measured the
-// product-scanning form above for them as well: every column then touches all NT constants,
-// the scalar loads are re-issued per column, and k_challenge ran 24 % SLOWER — 5.56 against
-// 4.47 ms per 2^20 hashes, same box.)  Cost over the product-scanning form: one 64-bit addition
-// per column, because the carry cannot start a MAD chain that was finished before it existed.
-// ---- Montgomery reduction of 17 column sums c[0..16] (c[17] scratch), R = 2^261 ----------
-// q = 1 (mod 2^29)  =>  -q^-1 = -1 (mod 2^29): the quotient digit is just the negated low limb,
-// and digit * q[0] only contributes the carry that clears that limb.
-// Callers pre-bias columns 0..8 by +M29 (the first MAD of each of those columns starts from the
-// constant instead of 0, which costs nothing): with s' = s + M29 the quotient digit is
-// m = -s mod 2^29 = ~s' & M29 and the carry (s + m) / 2^29 is simply s' >> 29 — two 64-bit and
-// two 32-bit instructions per row instead of three and two.
-DSV_DEV Fe fe_reduce_cols(u64 (&c)[18]) {
-  u64 k = 0;
-#pragma unroll
-  for (int i = 0; i < NL; i++) {
-    u64 s = c[i] + k;
-    u32 m = (~(u32)s) & M29;
-    k = s >> 29;
-#pragma unroll
-    for (int j = 1; j < NL; j++) c[i + j] += (u64)m * kQ29[j];
-  }
-  Fe r;
-#pragma unroll
-  for (int i = 0; i < NL - 1; i++) {
-    u64 s = c[NL + i] + k;
-    r.l[i] = (u32)s & M29;
-    k = s >> 29;
-  }
-  r.l[NL - 1] = (u32)k;
-  return r;
-}
-
-// sum_{t<5} a[t]*b[t] with one reduction (b limbs < 2^29: constants)
-DSV_DEV Fe fe_dot5(const Fe (&a)[5], const Fe (&b)[5]) {
-  u64 c[18];
-#pragma unroll
-  for (int k = 0; k < 17; k++) {
-    u64 s = (k < NL) ? (u64)M29 : 0;
-#pragma unroll
-    for (int t = 0; t < 5; t++) {
-#pragma unroll
-      for (int i = 0; i < NL; i++) {
-        const int j = k - i;
-        if (j >= 0 && j < NL) s += (u64)a[t].l[i] * b[t].l[j];
-      }
-    }
-    c[k] = s;
-  }
-  c[17] = 0;
-  return fe_reduce_cols(c);
-}
-
-// sum_{t<NT} a[t] * k[t] with one reduction; k: wave-uniform constants (scalar loads), limbs < 2^29.
-// The caller's generator proves the 64-bit column bound for the actual constants.
-template <int NT>
-DSV_DEV Fe fe_dot_const(const Fe (&a)[NT], const u32 (*k)[NL]) {
-  u64 c[18];
-#pragma unroll
-  for (int col = 0; col < 17; col++) c[col] = (col < NL) ? (u64)M29 : 0;
-  c[17] = 0;
-#pragma unroll
-  for (int t = 0; t < NT; t++) {
-#pragma unroll
-    for (int i = 0; i < NL; i++) {
-#pragma unroll
-      for (int j = 0; j < NL; j++) c[i + j] += (u64)a[t].l[i] * k[t][j];
-    }
-  }
-  return fe_reduce_cols(c);
-}
-
-// the same plus a constant: result = sum a[t] * k[t] + C, where start[0..8] = plain limbs of C * R^2
-// mod q, each already increased by the reduction's 2^29 - 1 bias (generator: init_limbs) — the
-// constant costs nothing: it replaces the bias the column accumulators start from anyway
-template <int NT>
-DSV_DEV Fe fe_dot_const_plus(const Fe (&a)[NT], const u32 (*k)[NL], const u32* start) {
-  u64 c[18];
-#pragma unroll
-  for (int col = 0; col < 17; col++) c[col] = (col < NL) ? (u64)start[col] : 0;
-  c[17] = 0;
-#pragma unroll
-  for (int t = 0; t < NT; t++) {
-#pragma unroll
-    for (int i = 0; i < NL; i++) {
-#pragma unroll
-      for (int j = 0; j < NL; j++) c[i + j] += (u64)a[t].l[i] * k[t][j];
-    }
-  }
-  return fe_reduce_cols(c);
 }
 
 DSV_DEV Fe fe_add(const Fe& a, const Fe& b) {

@@ -93,39 +93,6 @@ def _inv(A):
     return [row[n:] for row in A]
 
 
-def sparse_partial_rounds(rc, m):
-    """Equivalent form of the 59 partial rounds (S-box on the LAST word, constants added to all
-    words, dense MDS) in which every round multiplies by a SPARSE matrix.
-
-    With the state split as (y, z) = (words 0..3, word 4) and M_eff = [[A, b], [c^T, d]]:
-        M_eff = M'' * M',   M' = diag(A, 1),   M'' = [[I, b], [c^T A^-1, d]]
-    M' commutes with the partial S-box layer, so it is pushed into the previous round's matrix
-    (T_i below); the recursion runs from the last partial round to the first and leaves one dense
-    "pre" matrix T_0 * M that replaces M in the last of the first four full rounds.
-      w_{i+1} = M''_i * S(w_i + T_i k_i),   w_i = T_i x_i,   T_59 = I.
-    Returns (pre, kappa[60][5], b[59][4], c2[59][4], d[59]); kappa[59] = 0.
-    """
-    ident = [[1 if i == j else 0 for j in range(WIDTH)] for i in range(WIDTH)]
-    T = [None] * (PARTIAL + 1)
-    T[PARTIAL] = ident
-    bs, cs, ds = [None] * PARTIAL, [None] * PARTIAL, [None] * PARTIAL
-    for i in range(PARTIAL - 1, -1, -1):
-        me = _matmul(T[i + 1], m)
-        A = [row[:4] for row in me[:4]]
-        Ai = _inv(A)
-        bs[i] = [me[r][4] for r in range(4)]
-        cs[i] = [sum(me[4][k] * Ai[k][j] for k in range(4)) % Q for j in range(4)]
-        ds[i] = me[4][4]
-        T[i] = [A[r] + [0] for r in range(4)] + [[0, 0, 0, 0, 1]]
-    pre = _matmul(T[0], m)
-    kappa = []
-    for i in range(PARTIAL):
-        k = rc[(FULL // 2) * WIDTH + i * WIDTH:(FULL // 2) * WIDTH + (i + 1) * WIDTH]
-        kappa.append([sum(T[i][r][j] * k[j] for j in range(WIDTH)) % Q for r in range(WIDTH)])
-    kappa.append([0] * WIDTH)
-    return pre, kappa, bs, cs, ds
-
-
 def _matvec(A, v):
     return [sum(A[i][j] * v[j] for j in range(len(v))) % Q for i in range(len(A))]
 
@@ -417,6 +384,8 @@ def main():
             table[i] = d
         w("#define DSV_TS_HASH_K1 0x%08xu\n#define DSV_TS_HASH_K2 0x%08xu\n#define DSV_TS_HASH_BITS %d\n"
           % (k1, k2, HASH_BITS))
+        w("// host-side tables: only for the translation units that upload them (dsv.hip, k_hash.hip)\n")
+        w("#ifdef DSV_HOST_TABLES\n")
         w("static const uint8_t DSV_TS_HASH_HOST[%d] = {\n" % (1 << HASH_BITS))
         for i in range(0, 1 << HASH_BITS, 32):
             w("  " + ", ".join(str(x) for x in table[i:i + 32]) + ",\n")
@@ -432,117 +401,19 @@ def main():
         for c in rc:
             w("  %s,\n" % arr(mont(c)))
         w("};\n")
+        w("static const uint32_t DSV_HADES_K0_HOST[9] = %s;  // first partial round's S-box constant\n"
+          % arr(mont(arma_partial_rounds(rc, m)["k0"])))
+        w("#endif  // DSV_HOST_TABLES\n")
         # first full round of the sponge's first permutation: word 0 (capacity) starts at 0 and, in
         # the 3-input hash, word 4 is the padding 1 — their S-box outputs are constants
-        w("// (0 + rc[0])^5 and (1 + rc[4])^5: S-box outputs of the constant words in round 0\n")
-        w("#define DSV_HADES_SBOX0_CAP %s\n" % arr(mont(pow(rc[0], 5, Q))))
-        w("#define DSV_HADES_SBOX0_PAD %s\n" % arr(mont(pow(1 + rc[4], 5, Q))))
-        # the same two constants one below their Montgomery integer (operand convention of hades_mfma.h)
+        w("// (0 + rc[0])^5 and (1 + rc[4])^5: S-box outputs of the constant words in round 0, one\n")
+        w("// below their Montgomery integer (operand convention of hades_mfma.h)\n")
         m1 = lambda x: limbs((x * RMONT % Q or Q) - 1)
         w("#define DSV_HADES_SBOX0_CAP_M1 %s\n" % arr(m1(pow(rc[0], 5, Q))))
         w("#define DSV_HADES_SBOX0_PAD_M1 %s\n" % arr(m1(pow(1 + rc[4], 5, Q))))
-        w("static const uint32_t DSV_HADES_MDS_HOST[%d][9] = {\n" % (WIDTH * WIDTH))
-        for row in m:
-            for x in row:
-                w("  %s,\n" % arr(mont(x)))
-        w("};\n")
-        pre, kappa, bs, cs, ds = sparse_partial_rounds(rc, m)
-        w("// sparse form of the partial rounds (see sparse_partial_rounds in the generator)\n")
-        w("static const uint32_t DSV_HADES_PRE_MDS_HOST[%d][9] = {\n" % (WIDTH * WIDTH))
-        for row in pre:
-            for x in row:
-                w("  %s,\n" % arr(mont(x)))
-        w("};\n")
-        w("static const uint32_t DSV_HADES_KAPPA0_HOST[%d][9] = {\n" % WIDTH)
-        for x in kappa[0]:
-            w("  %s,\n" % arr(mont(x)))
-        w("};\n")
-        # constants of words 0..3 are never added inside the loop: K_i = running sum of their
-        # kappas; its contribution c_i . K_i to the last word is folded into that word's constant
-        K = list(kappa[0][:4])
-        kap4 = []
-        for i in range(PARTIAL):
-            kap4.append((kappa[i + 1][4] + sum(cs[i][j] * K[j] for j in range(4))) % Q)
-            K = [(K[j] + kappa[i + 1][j]) % Q for j in range(4)]
-        # Blocked form: inside a block of L rounds words 0..3 are NOT updated; their pending
-        # updates b_k * z_k enter the later rounds' dot products through gamma_{m,k} = c_m . b_k
-        # (one reduction per round instead of five), and one (L+1)-term dot product per word
-        # brings the block's updates in at its end:
-        #   row m of a block : [c_m[0..3], gamma_{m,0..m-1}, d_m]  applied to  (s0..s3, z_0..z_m)
-        #   update of word j : [1, b_0[j], .., b_{L-1}[j]]          applied to  (s_j, z_0..z_{L-1})
-        BLOCK = 4
-        blocks = []
-        i0 = 0
-        while i0 < PARTIAL:
-            lb = min(BLOCK, PARTIAL - i0)
-            seq = []
-            for mth in range(lb):
-                i = i0 + mth
-                gam = [sum(cs[i][j] * bs[i0 + k][j] for j in range(4)) % Q for k in range(mth)]
-                row = cs[i] + gam + [ds[i]]
-                # worst-case 64-bit column bound with every state limb at 2^29 + 8
-                for col in range(17):
-                    tot = sum(((1 << 29) + 8) * mont(c)[col - a] for c in row for a in range(9)
-                              if 0 <= col - a < 9)
-                    assert tot + 8 * (1 << 58) + (1 << 37) < (1 << 64), "column overflow"
-                seq += row + [kap4[i]]
-            for j in range(4):
-                seq += [1] + [bs[i0 + k][j] for k in range(lb)]
-            blocks.append(seq)
-            i0 += lb
-        flat = [x for blk in blocks for x in blk]
-        w("// blocked sparse partial rounds (see generator): %d blocks of %d rounds + one of %d\n"
-          % (PARTIAL // BLOCK, BLOCK, PARTIAL % BLOCK))
-        w("#define DSV_HADES_BLOCK %d\n" % BLOCK)
-        w("static const uint32_t DSV_HADES_BLOCKS_HOST[%d][9] = {\n" % len(flat))
-        for x in flat:
-            w("  %s,\n" % arr(mont(x)))
-        w("};\n")
-        w("static const uint32_t DSV_HADES_KFINAL_HOST[%d][9] = {\n" % (WIDTH - 1))
-        for x in K:
-            w("  %s,\n" % arr(mont(x)))
-        w("};\n")
         # ---- partial rounds as one scalar recurrence (arma_partial_rounds)
         A = arma_partial_rounds(rc, m)
-        RR = RMONT * RMONT % Q
-
-        def init_limbs(const):
-            """column-0..8 start values of a dot product that must come out as dot + const:
-            plain limbs of const * R^2 (the reduction divides by R, leaving const * R = its
-            Montgomery form) plus the reduction's 2^29 - 1 bias"""
-            return [x + MASK for x in limbs(const * RR % Q)]
-
-        def check_cols(consts, what):
-            # 64-bit column bound with every state limb at 2^29 + 8 and start values < 2^30
-            for col in range(17):
-                tot = sum(((1 << 29) + 8) * mont(cst)[col - a_] for cst in consts for a_ in range(9)
-                          if 0 <= col - a_ < 9)
-                assert tot + (1 << 30) + 8 * (1 << 58) + (1 << 37) < (1 << 64), "column overflow: " + what
-
-        rows = [mont(A["k0"])]
-        for it in A["init"]:
-            cs = it["x"] + [v for pair in it["az"] for v in pair]
-            check_cols(cs, "ARMA init")
-            rows += [mont(v) for v in cs] + [init_limbs(it["const"])]
-        off_rec = len(rows)
         rec = A["ca"] + A["cz"]
-        check_cols(rec, "ARMA recurrence")
-        rows += [mont(v) for v in rec]
-        off_gamma = len(rows)
-        rows += [init_limbs(g) for g in A["gamma"]]
-        off_final = len(rows)
-        for j in range(WIDTH):
-            cs = A["Fa"][j] + A["Fz"][j]
-            check_cols(cs, "ARMA final")
-            rows += [mont(v) for v in cs] + [init_limbs(A["fconst"][j])]
-        w("// partial rounds as one scalar recurrence (generator: arma_partial_rounds).  Rows: k0 | for r = 1..4:\n")
-        w("// 5 + 2r multipliers + start limbs | 10 recurrence multipliers | 54 start-limb rows | 5 x (10 + 1)\n")
-        w("#define DSV_HADES_ARMA_REC %d\n#define DSV_HADES_ARMA_GAMMA %d\n#define DSV_HADES_ARMA_FINAL %d\n"
-          % (off_rec, off_gamma, off_final))
-        w("static const uint32_t DSV_HADES_ARMA_HOST[%d][9] = {\n" % len(rows))
-        for r_ in rows:
-            w("  %s,\n" % arr(r_))
-        w("};\n")
         # ---- the same recurrence on the matrix cores (hades_mfma.h)
         atab, starts = mfma_recurrence(rec, A["gamma"])
         words_ = [atab[i] | atab[i + 1] << 8 | atab[i + 2] << 16 | atab[i + 3] << 24 for i in range(0, len(atab), 4)]

@@ -45,29 +45,19 @@ constexpr int kMfmaTerms = 10;
 constexpr int kMfmaAVecs = DSV_HADES_MFMA_A_WORDS / 4;  // 16-byte operands: [term][lane]
 static_assert(kMfmaAVecs == kMfmaTerms * 64, "operand table shape");
 // the dense 5 x 5 layer of the full rounds, one output row = one 5-term product of the same kind
-// (DSV_HADES_MFMA_MDS, shipped 1; 0 keeps fe_dot5 for A/B)
-#ifndef DSV_HADES_MFMA_MDS
-#define DSV_HADES_MFMA_MDS 1
-#endif
 __device__ const u32 g_hades_mfma_mds[DSV_HADES_MFMA_MDS_WORDS] = {DSV_HADES_MFMA_MDS_LIST};
 __device__ const u32 g_hades_mfma_mds_start[DSV_HADES_WIDTH][8] = {DSV_HADES_MFMA_MDS_START_LIST};
 constexpr int kMfmaMdsRowVecs = DSV_HADES_WIDTH * 64;  // one output row: [term][lane]
-constexpr int kMfmaMdsVecs = DSV_HADES_MFMA_MDS ? DSV_HADES_MFMA_MDS_WORDS / 4 : 0;
+constexpr int kMfmaMdsVecs = DSV_HADES_MFMA_MDS_WORDS / 4;
 static_assert(DSV_HADES_MFMA_MDS_WORDS / 4 == DSV_HADES_WIDTH * kMfmaMdsRowVecs, "operand table shape");
-// start-up rows and state rebuild of the recurrence (DSV_HADES_MFMA_EDGE, shipped 1; 0 keeps the
-// limb products for A/B): used once per permutation, so their 90 KB of operands stay in global
-// memory (L2) instead of LDS.  Row offsets in 16-byte operands: rows of 7, 9, 11, 13 terms, then
-// five rows of 10.
-#ifndef DSV_HADES_MFMA_EDGE
-#define DSV_HADES_MFMA_EDGE 1
-#endif
-#if DSV_HADES_MFMA_EDGE
+// start-up rows and state rebuild of the recurrence: used once per permutation, so their 90 KB of
+// operands stay in global memory (L2) instead of LDS.  Row offsets in 16-byte operands: rows of 7,
+// 9, 11, 13 terms, then five rows of 10.
 __device__ const u32 g_hades_mfma_edge[DSV_HADES_MFMA_EDGE_WORDS] = {DSV_HADES_MFMA_EDGE_LIST};
 __device__ const u32 g_hades_mfma_edge_start[9][8] = {DSV_HADES_MFMA_EDGE_START_LIST};
 static_assert(DSV_HADES_MFMA_EDGE_WORDS / 4 == (7 + 9 + 11 + 13 + 5 * 10) * 64, "operand table shape");
 constexpr int kMfmaEdgeInitOff[4] = {0, 7 * 64, (7 + 9) * 64, (7 + 9 + 11) * 64};
 constexpr int kMfmaEdgeFinalOff = (7 + 9 + 11 + 13) * 64;
-#endif
 __device__ constexpr u32 kMfmaQ32[8] = DSV_Q32;
 
 // B operands of one window value, kept as the 4-register tuples the MFMA reads (separate words
@@ -104,21 +94,6 @@ DSV_DEV Dig mfma_digits(const Fe& x) {
   fe_to_words_plain(w, x);
   return mfma_digits_words(w);
 }
-// inverse of mfma_digits (only the -DDSV_HADES_MFMA_EDGE=0 build reads operands back)
-DSV_DEV Fe mfma_undigits(const Dig& d) {
-  u32 w[8];
-#pragma unroll
-  for (int i = 0; i < 4; i++) {
-    w[i] = (u32)d.t0[i];
-    w[4 + i] = (u32)d.t1[i];
-  }
-#pragma unroll
-  for (int i = 0; i < 4; i++) half_swap(w[i], w[4 + i]);
-#pragma unroll
-  for (int i = 0; i < 8; i++) w[i] ^= 0x80808080u;
-  return fe_from_words_plain(w);
-}
-
 // The operand tables live in LDS (10 KB recurrence + 25 KB dense layer per workgroup of four waves,
 // two workgroups per CU): every lane re-reads its 16 bytes of each A operand every time.
 struct MfmaTable {

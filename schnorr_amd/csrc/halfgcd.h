@@ -69,7 +69,8 @@ DSV_DEV double to_double8(const u32 (&x)[8]) {
 // every iteration: 208 instructions per Euclidean step as compiled; same-box A/B +0.95 % on the
 // whole verification step, profiles/r02/ab_alternating_halfgcd.txt).  An under-estimate leaves X >= Y;
 // the following half-step then has quotient 0 and changes nothing, and the one after it finishes
-// the job, so every value that drops below the other is a true Euclidean remainder and the
+// the job (with an exact comparison when X / Y is within 2^-28 of 1, where the estimate alone
+// would say 0 again), so every value that drops below the other is a true Euclidean remainder and the
 // (remainder, cofactor) pairs are those of the exact algorithm (tests/pymodel.py: half_scalars).
 // The loop ends at the first remainder below 2^128 (its partner is still >= 2^128).  Cofactors of
 // the A side are <= 0, those of the B side >= 0 (magnitudes are stored), so the sign of the final
@@ -77,7 +78,14 @@ DSV_DEV double to_double8(const u32 (&x)[8]) {
 DSV_DEV void half_step(u32 (&X)[8], u32 (&tX)[5], const u32 (&Y)[8], const u32 (&tY)[5], double dX,
                        double dY) {
   const double qd = dX / dY * (1.0 - 0x1p-30);
-  const u32 qe = qd >= 2147483647.0 ? 2147483647u : (u32)qd;
+  u32 qe = qd >= 2147483647.0 ? 2147483647u : (u32)qd;
+  // X / Y in [1, 1 + 2^-30) rounds to quotient 0 in BOTH roles: without help the loop would spin on
+  // that pair until kHalfGcdMaxIter (r02 did: ~2^-24 per signature, correct verdict, one wave 13x
+  // slower).  When the images are too close to call, compare exactly.
+  if (qe == 0 && dX >= dY * (1.0 - 0x1p-28)) {
+    u32 d[8];
+    if (!sub8(d, X, Y)) qe = 1;
+  }
   u32 mc = 0, borrow = 0;
 #pragma unroll
   for (int i = 0; i < 8; i++) {

@@ -3,7 +3,7 @@
 // Formulas are the extended-coordinate ones dusk-jubjub's operators implement (SURVEY.md
 // Appendix A.3), i.e. what `GENERATOR_EXTENDED * u`, `pk * c`, `+` and `==` evaluate at
 // /root/reference/src/keys/public.rs:127-129, :236-243, :411-414:
-//   double : 3S + 4M (2uv as a product: one subtraction + carry pass fewer than 4S + 3M)
+//   double : 4S + 3M (2uv as (u+v)^2 - u^2 - v^2)
 //   add (extended niels) : 8M     add (affine niels, z = 1) : 7M
 // They are complete on the whole curve (a = -1 is a square, d is not), so identity, small-order
 // and repeated points need no special case — same as the reference.
@@ -60,33 +60,17 @@ DSV_DEV Niels niels_identity() {
 // in : u, v, z  N (< 1.5q)            (t1, t2 unused)
 // out: u, v, z  N (u < 1.44q);  t1 < 5.1q carried, t2 < 2.1q (limbs < 2^30)
 // 2uv as (u+v)^2 - (u^2 + v^2): 117 MADs + an addition and a biased subtraction instead of a
-// multiplication's 153 (-DDSV_DBL_SQR=0; A/B in DESIGN.md §3; bounds: tests/fe29_bounds.py)
-#ifndef DSV_DBL_SQR
-#define DSV_DBL_SQR 1
-#endif
+// multiplication's 153 (+0.26 % single, +0.9 % double, profiles/r02/ab_double_sqr.txt; bounds:
+// tests/fe29_bounds.py)
 DSV_DEV Fe ext_two_uv(const Fe& u, const Fe& v, const Fe& vpu) {
-#if DSV_DBL_SQR
   return fe_sub4w(fe_sqr(fe_add(u, v)), vpu);  // < 5.1, carried
-#else
-  (void)vpu;
-  return fe_dbl(fe_mul(u, v));                 // < 2.1, limbs < 2^30
-#endif
 }
 DSV_DEV Ext ext_double(const Ext& p) {
-#if DSV_SQR_PAIR && DSV_DBL_SQR
-  Fe uu, vv, zz, w2;
-  fe_sqr2(uu, vv, p.u, p.v);
-  fe_sqr2(zz, w2, p.z, fe_add(p.u, p.v));
-  Fe zz2 = fe_dbl(zz);
-  Fe vpu = fe_add(vv, uu);
-  Fe cu = fe_sub4w(w2, vpu);
-#else
   Fe uu = fe_sqr(p.u);                      // < 1.04
   Fe vv = fe_sqr(p.v);                      // < 1.04
   Fe zz2 = fe_dbl(fe_sqr(p.z));             // < 2.1, limbs < 2^30
   Fe vpu = fe_add(vv, uu);                  // < 2.1, limbs < 2^30
   Fe cu = ext_two_uv(p.u, p.v, vpu);        // 2uv
-#endif
   Fe vmu = fe_sub2_raw(vv, uu);             // < 3.1, limbs < 2^31 (partners vpu < 2^30, ct carried)
   Fe ct = fe_sub4w(zz2, vmu);               // < 6.1, carried
   Ext r;
@@ -100,20 +84,11 @@ DSV_DEV Ext ext_double(const Ext& p) {
 
 // doubling that keeps only (u, v, z): inside a run of doublings nobody reads t1/t2
 DSV_DEV void ext_double_uvz(Fe& u, Fe& v, Fe& z) {
-#if DSV_SQR_PAIR && DSV_DBL_SQR
-  Fe uu, vv, zz, w2;
-  fe_sqr2(uu, vv, u, v);
-  fe_sqr2(zz, w2, z, fe_add(u, v));
-  Fe zz2 = fe_dbl(zz);
-  Fe vpu = fe_add(vv, uu);
-  Fe cu = fe_sub4w(w2, vpu);
-#else
   Fe uu = fe_sqr(u);
   Fe vv = fe_sqr(v);
   Fe zz2 = fe_dbl(fe_sqr(z));
   Fe vpu = fe_add(vv, uu);
   Fe cu = ext_two_uv(u, v, vpu);
-#endif
   Fe vmu = fe_sub2_raw(vv, uu);
   Fe ct = fe_sub4w(zz2, vmu);
   u = fe_mul(cu, ct);

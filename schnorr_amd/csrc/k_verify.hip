@@ -1,0 +1,114 @@
+// k_verify.hip — the dominant kernel: ok &= [ u*Gen + c*PK == R ] for Gen = G / G' given by its
+// fixed-base table (`PublicKey::verify`, `PublicKeyDouble::verify`,
+// /root/reference/src/keys/public.rs:121-130, :222-244), evaluated with half-size scalars
+// (halfgcd.h): with (a, b), a = b*c (mod 8r), b odd,
+//   u*G + c*PK == R   <=>   (b*u mod r)*G + a*PK - b*R == O.
+// Two per-lane window tables (PK and R), one Straus chain of ~33 windows whose length is the
+// lane's own max(bitlen a, bitlen b) (lanes of a wave simply leave the loop at different times),
+// then 16 mixed additions from the fixed-base table; the verdict is an identity test.
+//
+// NCHAIN = 2 is PublicKeyDouble::verify in ONE launch: both equations share u and c, so (a, b), both
+// recodings and b*u mod r are computed once and the chain runs twice — (G, PK, R) then (G', PK', R')
+// — through the same code (a rolled loop over the two operand sets: the hot loop exists once in
+// the instruction cache) and the same two table slots.
+#include "common.h"
+#include "halfgcd.h"
+
+namespace dsv {
+
+template <int NCHAIN>
+__global__ void __launch_bounds__(kVerifyBlock, kWavesVerify)
+k_verify_fixed_half(const uint8_t* __restrict__ u, const uint8_t* __restrict__ c, ChainOperands op0,
+                    ChainOperands op1, const uint8_t* __restrict__ valid, bool accumulate, size_t n,
+                    uint8_t* __restrict__ ok, u32* __restrict__ var_tables) {
+  u32* tpk = var_tables + ((size_t)blockIdx.x * kVerifyBlock + threadIdx.x) * (2 * kVarLaneWords);
+  u32* tr = tpk + kVarLaneWords;
+#pragma unroll 1
+  for (size_t base = (size_t)blockIdx.x * kVerifyBlock; base < n;
+       base += (size_t)gridDim.x * kVerifyBlock) {
+    const size_t i = base + threadIdx.x;
+    if (i >= n) continue;
+    bool good = accumulate ? (ok[i] != 0) : (valid[i] != 0);
+    u32 ya[8], yb[8], w[8];
+    bool b_neg;
+    int top;
+    {
+      u32 cs[8], a[8], b[8];
+      load_words8(cs, c, i);
+      half_scalars(a, b, b_neg, cs);
+      recode_signed4(ya, a);
+      recode_signed4(yb, b);
+      // index of the highest non-zero signed digit of either scalar (a zero digit is nibble 8)
+      u32 nz[8];
+#pragma unroll
+      for (int k = 0; k < 8; k++) nz[k] = (ya[k] ^ 0x88888888u) | (yb[k] ^ 0x88888888u);
+      top = top_digit4(nz);
+      u32 us[8];
+      load_words8(us, u, i);
+      const bool u_ok = words_lt(us, kR32);
+      good &= u_ok;
+      if (!u_ok) us[7] &= 0x0fffffffu;  // keep fr_mul's inputs below r-ish; verdict is 0 anyway
+      fr_mul(w, b, us);                 // |b| * u mod r
+      if (b_neg) {                      // (b*u) mod r with b < 0
+        const u32 zero[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        u32 t[8];
+        fr_sub(t, zero, w);
+#pragma unroll
+        for (int k = 0; k < 8; k++) w[k] = t[k];
+      }
+    }
+    const int rsign = b_neg ? 1 : -1;
+#pragma unroll 1
+    for (int h = 0; h < NCHAIN; h++) {
+      const ChainOperands op = h ? op1 : op0;
+      {
+        Fe pku, pkv;
+        good &= load_fq(pku, op.PK_uv, 2 * i);
+        good &= load_fq(pkv, op.PK_uv, 2 * i + 1);
+        build_var_table(tpk, pku, pkv);
+      }
+      {
+        Fe ru, rv;
+        good &= load_fq(ru, op.R_uv, 2 * i);
+        good &= load_fq(rv, op.R_uv, 2 * i + 1);
+        build_var_table(tr, ru, rv);
+      }
+      // T = a*PK + (b_neg ? +|b| : -|b|) * R  (+ w*G below); entries are loaded one group
+      // operation ahead of their use
+      Ext acc = ext_from_niels(load_var_entry(tpk, sdigit4(ya, top)));
+      acc = ext_add_niels(acc, load_var_entry(tr, rsign * sdigit4(yb, top)));
+      {
+        const int k0 = top > 0 ? top - 1 : 0;
+        RawNiels ea = load_var_entry_raw(tpk, sdigit4(ya, k0));
+        RawNiels eb = load_var_entry_raw(tr, rsign * sdigit4(yb, k0));
+#pragma unroll 1
+        for (int k = top - 1; k >= 0; k--) {
+          acc = ext_mul16(acc);
+          const int kn = k > 0 ? k - 1 : 0;  // last round: reloads its own entries, unused
+          acc = ext_add_niels(acc, finish_var_entry(ea));
+          ea = load_var_entry_raw(tpk, sdigit4(ya, kn));
+          acc = ext_add_niels(acc, finish_var_entry(eb));
+          eb = load_var_entry_raw(tr, rsign * sdigit4(yb, kn));
+        }
+      }
+      acc = fixed_base_accumulate(acc, w, op.table);
+      // T == O  <=>  u == 0 and v == z
+      good &= (bool)((int)fe_is_zero_canon(fe_canon(acc.u)) & (int)fe_equal(acc.v, acc.z));
+    }
+    ok[i] = good ? 1 : 0;
+  }
+}
+
+void launch_verify_half(int nchain, bool accumulate, const uint8_t* u, const uint8_t* c,
+                        ChainOperands op0, ChainOperands op1, const uint8_t* valid, size_t n,
+                        uint8_t* ok, uint32_t* var_tables, hipStream_t s) {
+  const dim3 grid(verify_grid(n)), block(kVerifyBlock);
+  if (nchain == 2)
+    hipLaunchKernelGGL(k_verify_fixed_half<2>, grid, block, 0, s, u, c, op0, op1, valid, accumulate, n,
+                       ok, var_tables);
+  else
+    hipLaunchKernelGGL(k_verify_fixed_half<1>, grid, block, 0, s, u, c, op0, op1, valid, accumulate, n,
+                       ok, var_tables);
+}
+
+}  // namespace dsv

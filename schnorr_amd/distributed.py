@@ -120,7 +120,8 @@ class MixedShardedVerifier:
         # collective=True runs the all_gathers even for one rank (RCCL rehearsal on a one-GPU box)
         self.collective = world > 1 if collective is None else collective
         u8 = lambda *shape: torch.empty(shape, dtype=torch.uint8, device=device)
-        i32 = lambda k: torch.empty(max(k, 1), dtype=torch.int32, device=device)
+        # zero-initialised: an entry the split never writes is a valid (if meaningless) index
+        i32 = lambda k: torch.zeros(max(k, 1), dtype=torch.int32, device=device)
         self.idx_s, self.idx_d = i32(self.ns), i32(self.nd)
         self.scratch = u8(E.split_scratch_bytes(n_local))
         self.cs = {k: u8(max(self.ns, 1), w) for k, w in (("u", 32), ("R", 64), ("PK", 64), ("m", 32))}
@@ -141,10 +142,13 @@ class MixedShardedVerifier:
 
         E, ns, nd = self.E, self.ns, self.nd
         E.split_kinds_dev(batch["kinds"], self.idx_s, self.idx_d, self.scratch)
+        # every gather / scatter below is bounded ON THE DEVICE by the split's own counts: whatever
+        # (ns, nd) the caller declared, an index entry the split did not write is never read
+        cnt = E.split_counts(self.scratch)
         for k, dst in self.cs.items():
-            E.gather_rows_dev(batch[k], self.idx_s, ns, dst)
+            E.gather_rows_dev(batch[k], self.idx_s, ns, dst, limit=cnt[0:1])
         for k, dst in self.cd.items():
-            E.gather_rows_dev(batch[k], self.idx_d, nd, dst)
+            E.gather_rows_dev(batch[k], self.idx_d, nd, dst, limit=cnt[1:2])
         if ns:
             E.verify_single_dev(self.cs["u"][:ns], self.cs["R"][:ns], self.cs["PK"][:ns],
                                 self.cs["m"][:ns], self.ok_s, self.ws)
@@ -162,14 +166,20 @@ class MixedShardedVerifier:
             all_s, all_d = self.ok_s, self.ok_d
         # kind-k item number j of the global batch: rank-major, i.e. j-th in global order
         E.split_kinds_dev(global_kinds, self.gidx_s, self.gidx_d, self.gscratch)
+        gcnt = E.split_counts(self.gscratch)
         self.out.zero_()
         if ns:
-            E.scatter_verdicts_dev(all_s, self.gidx_s, self.world * ns, self.out)
+            E.scatter_verdicts_dev(all_s, self.gidx_s, self.world * ns, self.out, limit=gcnt[0:1])
         if nd:
-            E.scatter_verdicts_dev(all_d, self.gidx_d, self.world * nd, self.out)
+            E.scatter_verdicts_dev(all_d, self.gidx_d, self.world * nd, self.out, limit=gcnt[1:2])
+        # the declared per-kind counts must be what the kind vectors hold, locally and globally;
+        # otherwise the verdict mapping is meaningless: all zeros (decided on the device, no sync)
+        good = ((cnt[0] == ns) & (cnt[1] == nd) & (gcnt[0] == self.world * ns)
+                & (gcnt[1] == self.world * nd))
+        self.out.mul_(good.to(self.out.dtype))
         return self.out
 
     def local_counts(self):
         """(n_single, n_double) the device found in the LAST local split (synchronises)."""
-        t = self.scratch[-256:-248].view(self.torch.int32).cpu()
+        t = self.E.split_counts(self.scratch).cpu()
         return int(t[0]), int(t[1])

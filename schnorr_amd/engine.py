@@ -24,6 +24,17 @@ def init(device=0):
     _initialised.add(device)
 
 
+def init_visible():
+    """dsv_init_visible: every device listed in $DSV_DEVICES, else every visible one; returns the
+    list of initialised ordinals."""
+    rc = _lib.load().dsv_init_visible()
+    if rc < 0:
+        _lib.check(rc)
+    devs = initialized_devices()
+    _initialised.update(devs)
+    return devs
+
+
 def set_device(device):
     """Device of this thread's host-buffer entry points (default: the first one initialised)."""
     _lib.check(_lib.load().dsv_set_device(ctypes.c_int(device)))
@@ -129,13 +140,28 @@ def verify_vargen_multi(u, R, PK, Gen, m):
     return ok
 
 
-def verify_single_ext(u, R_uvz, PK_uvz, m):
-    u, R, PK, m = _arr(u, 32), _arr(R_uvz, 96), _arr(PK_uvz, 96), _arr(m, 32)
-    n = _same_n(u, R, PK, m)
+def _ext_call(name, widths, arrays):
+    arrs = [_arr(a, w) for a, w in zip(arrays, widths)]
+    n = _same_n(*arrs)
     ok = np.zeros(n, dtype=np.uint8)
-    _lib.check(_lib.load().dsv_verify_single_ext(_p(u), _p(R), _p(PK), _p(m), ctypes.c_size_t(n),
-                                                 _p(ok)))
+    _lib.check(getattr(_lib.load(), name)(*([_p(a) for a in arrs] + [ctypes.c_size_t(n), _p(ok)])))
     return ok
+
+
+def verify_single_ext(u, R_uvz, PK_uvz, m, multi=False):
+    """Projective points (u || v || z, 96 B): the device does to_hash_inputs."""
+    return _ext_call("dsv_verify_single_ext" + ("_multi" if multi else ""), (32, 96, 96, 32),
+                     (u, R_uvz, PK_uvz, m))
+
+
+def verify_double_ext(u, R_uvz, Rp_uvz, PK_uvz, PKp_uvz, m, multi=False):
+    return _ext_call("dsv_verify_double_ext" + ("_multi" if multi else ""), (32, 96, 96, 96, 96, 32),
+                     (u, R_uvz, Rp_uvz, PK_uvz, PKp_uvz, m))
+
+
+def verify_vargen_ext(u, R_uvz, PK_uvz, Gen_uvz, m, multi=False):
+    return _ext_call("dsv_verify_vargen_ext" + ("_multi" if multi else ""), (32, 96, 96, 96, 32),
+                     (u, R_uvz, PK_uvz, Gen_uvz, m))
 
 
 def challenge_single(R, m):
@@ -332,6 +358,14 @@ def split_scratch_bytes(n):
     return int(_lib.load().dsv_split_scratch_bytes(ctypes.c_size_t(n)))
 
 
+def ext_workspace_bytes(n):
+    return int(_lib.load().dsv_ext_workspace_bytes(ctypes.c_size_t(n)))
+
+
+def wire_workspace_bytes(n):
+    return int(_lib.load().dsv_wire_workspace_bytes(ctypes.c_size_t(n)))
+
+
 def _stream_ptr(stream, dev=None):
     import torch
 
@@ -364,6 +398,52 @@ def verify_vargen_dev(u, R, PK, Gen, m, ok, workspace, stream=None):
         _tp(u, 32), _tp(R, 64), _tp(PK, 64), _tp(Gen, 64), _tp(m, 32), ctypes.c_size_t(n),
         _bytes_out(ok, n, dev, "ok"), _bytes_out(workspace, workspace_bytes(n), dev, "workspace"),
         _stream_ptr(stream, dev)))
+
+
+def verify_single_ext_dev(u, R_uvz, PK_uvz, m, ok, workspace, stream=None):
+    n, dev = _rows((u, 32, "u"), (R_uvz, 96, "R_uvz"), (PK_uvz, 96, "PK_uvz"), (m, 32, "m"))
+    _lib.check(_lib.load().dsv_verify_single_ext_dev(
+        _tp(u, 32), _tp(R_uvz, 96), _tp(PK_uvz, 96), _tp(m, 32), ctypes.c_size_t(n),
+        _bytes_out(ok, n, dev, "ok"), _bytes_out(workspace, ext_workspace_bytes(n), dev, "workspace"),
+        _stream_ptr(stream, dev)))
+
+
+def verify_double_ext_dev(u, R_uvz, Rp_uvz, PK_uvz, PKp_uvz, m, ok, workspace, stream=None):
+    n, dev = _rows((u, 32, "u"), (R_uvz, 96, "R_uvz"), (Rp_uvz, 96, "Rp_uvz"), (PK_uvz, 96, "PK_uvz"),
+                   (PKp_uvz, 96, "PKp_uvz"), (m, 32, "m"))
+    _lib.check(_lib.load().dsv_verify_double_ext_dev(
+        _tp(u, 32), _tp(R_uvz, 96), _tp(Rp_uvz, 96), _tp(PK_uvz, 96), _tp(PKp_uvz, 96), _tp(m, 32),
+        ctypes.c_size_t(n), _bytes_out(ok, n, dev, "ok"),
+        _bytes_out(workspace, ext_workspace_bytes(n), dev, "workspace"), _stream_ptr(stream, dev)))
+
+
+def verify_vargen_ext_dev(u, R_uvz, PK_uvz, Gen_uvz, m, ok, workspace, stream=None):
+    n, dev = _rows((u, 32, "u"), (R_uvz, 96, "R_uvz"), (PK_uvz, 96, "PK_uvz"), (Gen_uvz, 96, "Gen_uvz"),
+                   (m, 32, "m"))
+    _lib.check(_lib.load().dsv_verify_vargen_ext_dev(
+        _tp(u, 32), _tp(R_uvz, 96), _tp(PK_uvz, 96), _tp(Gen_uvz, 96), _tp(m, 32), ctypes.c_size_t(n),
+        _bytes_out(ok, n, dev, "ok"), _bytes_out(workspace, ext_workspace_bytes(n), dev, "workspace"),
+        _stream_ptr(stream, dev)))
+
+
+def _wire_dev(name, sig, sig_w, pk, pk_w, m, ok, workspace, stream):
+    n, dev = _rows((sig, sig_w, "sig"), (pk, pk_w, "pk"), (m, 32, "m"))
+    _lib.check(getattr(_lib.load(), name)(
+        _tp(sig, sig_w), _tp(pk, pk_w), _tp(m, 32), ctypes.c_size_t(n), _bytes_out(ok, n, dev, "ok"),
+        _bytes_out(workspace, wire_workspace_bytes(n), dev, "workspace"), _stream_ptr(stream, dev)))
+
+
+def verify_single_wire_dev(sig64, pk32, m, ok, workspace, stream=None):
+    """Serialized records resident in HBM: Signature (64 B) / PublicKey (32 B) per item."""
+    _wire_dev("dsv_verify_single_wire_dev", sig64, 64, pk32, 32, m, ok, workspace, stream)
+
+
+def verify_double_wire_dev(sig96, pk64, m, ok, workspace, stream=None):
+    _wire_dev("dsv_verify_double_wire_dev", sig96, 96, pk64, 64, m, ok, workspace, stream)
+
+
+def verify_vargen_wire_dev(sig64, pk64, m, ok, workspace, stream=None):
+    _wire_dev("dsv_verify_vargen_wire_dev", sig64, 64, pk64, 64, m, ok, workspace, stream)
 
 
 def verify_core_dev(u, c, valid, PK, R, ok, workspace, which=0, accumulate=False, stream=None):
@@ -416,24 +496,47 @@ def split_kinds_dev(kinds, idx_single, idx_double, scratch, stream=None):
         _bytes_out(scratch, split_scratch_bytes(n), dev, "scratch"), _stream_ptr(stream, dev)))
 
 
-def gather_rows_dev(src, idx, count, dst, stream=None):
-    """dst[j] = src[idx[j]] for j < count; src/dst uint8 [*, row_bytes], row_bytes % 16 == 0."""
+def split_counts(scratch):
+    """The two device-side counts (int32 [2] view: kind 0, kind 1) the last split left in `scratch`."""
+    import torch
+
+    return scratch[-256:-248].view(torch.int32)
+
+
+def _limit_ptr(limit, dev):
+    import torch
+
+    if limit is None:
+        return ctypes.c_void_p(0)
+    if not (isinstance(limit, torch.Tensor) and limit.is_cuda and limit.device == dev
+            and limit.dtype in (torch.int32, torch.uint32) and limit.numel() >= 1):
+        raise ValueError("limit: need a 32-bit CUDA tensor of one element on %s" % dev)
+    return ctypes.c_void_p(limit.data_ptr())
+
+
+def gather_rows_dev(src, idx, count, dst, limit=None, stream=None):
+    """dst[j] = src[idx[j]] for j < min(count, limit[0]); src/dst uint8 [*, row_bytes], row_bytes %
+    16 == 0.  `limit`: one-element 32-bit device tensor (e.g. split_counts(scratch)[k:k+1]) —
+    entries of idx beyond it are never read; an index >= src.shape[0] is skipped."""
     _t(src, src.shape[1], "src")
     _t(dst, src.shape[1], "dst")
     dev = src.device
     if dst.shape[0] < count or dst.device != dev:
         raise ValueError("dst too small or on another device")
     _lib.check(_lib.load().dsv_gather_rows_dev(
-        ctypes.c_void_p(src.data_ptr()), ctypes.c_size_t(src.shape[1]), _idx(idx, count, dev, "idx"),
-        ctypes.c_size_t(count), ctypes.c_void_p(dst.data_ptr()), _stream_ptr(stream, dev)))
+        ctypes.c_void_p(src.data_ptr()), ctypes.c_size_t(src.shape[0]), ctypes.c_size_t(src.shape[1]),
+        _idx(idx, count, dev, "idx"), ctypes.c_size_t(count), _limit_ptr(limit, dev),
+        ctypes.c_void_p(dst.data_ptr()), _stream_ptr(stream, dev)))
 
 
-def scatter_verdicts_dev(src, idx, count, dst, stream=None):
-    """dst[idx[j]] = src[j] for j < count (uint8 verdicts back into batch order)."""
+def scatter_verdicts_dev(src, idx, count, dst, limit=None, stream=None):
+    """dst[idx[j]] = src[j] for j < min(count, limit[0]) (uint8 verdicts back into batch order); an
+    index >= dst.numel() is skipped."""
     dev = dst.device
     _lib.check(_lib.load().dsv_scatter_verdicts_dev(
         _bytes_out(src, count, dev, "src"), _idx(idx, count, dev, "idx"), ctypes.c_size_t(count),
-        _bytes_out(dst, 0, dev, "dst"), _stream_ptr(stream, dev)))
+        _limit_ptr(limit, dev), _bytes_out(dst, 0, dev, "dst"), ctypes.c_size_t(dst.numel()),
+        _stream_ptr(stream, dev)))
 
 
 def challenge_double_dev(R, Rp, m, c, valid=None, stream=None):

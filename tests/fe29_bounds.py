@@ -125,67 +125,6 @@ def sqr(a):
     return mul(a, a)
 
 
-def _reduce(cols, vprod):
-    """fe_reduce_cols on column maxima (without the +M29 bias, added here like the device does)"""
-    c = list(cols) + [0]
-    k = 0
-    for i in range(NL):
-        c[i] += M29
-        s = c[i] + k
-        _check(s < U64, "reduction: column %d + carry overflows 64 bits" % i)
-        k = s >> LB
-        for j in range(1, NL):
-            c[i + j] += M29 * Q29[j]
-            _check(c[i + j] < U64, "reduction: column %d overflows 64 bits" % (i + j))
-    out = []
-    for i in range(NL - 1):
-        s = c[NL + i] + k
-        _check(s < U64, "normalisation: column overflows 64 bits")
-        out.append(min(s, M29))
-        k = s >> LB
-    _check(k < U32, "top limb of a product exceeds 32 bits")
-    out.append(k)
-    # value: (a*b + m*q) / 2^261 with m < 2^261
-    v = (vprod + ((1 << RBITS) - 1) * Q) >> RBITS
-    return B(out, v)
-
-
-def dot(avec, bvec):
-    c = [0] * 17
-    vprod = 0
-    for a, b in zip(avec, bvec):
-        for x in a.l + b.l:
-            _check(x < U32, "multiplier limb exceeds 32 bits")
-        for i in range(NL):
-            for j in range(NL):
-                c[i + j] += a.l[i] * b.l[j]
-        vprod += a.v * b.v
-    for k, x in enumerate(c):
-        _check(x + M29 < U64, "dot-product column %d overflows 64 bits" % k)
-    return _reduce(c, vprod)
-
-
-def dot_plus(avec, bvec, start):
-    """fe_dot_const_plus: columns 0..8 start from `start` (< 2^30 each, bias included)"""
-    c = [0] * 17
-    vprod = 0
-    for a, b in zip(avec, bvec):
-        for x in a.l + b.l:
-            _check(x < U32, "multiplier limb exceeds 32 bits")
-        for i in range(NL):
-            for j in range(NL):
-                c[i + j] += a.l[i] * b.l[j]
-        vprod += a.v * b.v
-    for i in range(NL):
-        _check(M29 <= start.l[i] < (1 << 30), "start limb out of range")
-        c[i] += start.l[i] - M29
-    for k, x in enumerate(c):
-        _check(x + M29 < U64, "dot-product column %d overflows 64 bits" % k)
-    # the start limbs carry const * R^2 mod q < q: adds < q / R... one more q to the value bound
-    r = _reduce(c, vprod + (Q << RBITS))
-    return r
-
-
 def add(a, b):
     r = [x + y for x, y in zip(a.l, b.l)]
     for x in r:
@@ -350,93 +289,80 @@ def _load_table(name):
     return [B([int(x.strip().rstrip("u"), 16) for x in r.split(",")]) for r in rows]
 
 
+def _load_row(name):
+    text = open(_HDR).read()
+    m = re.search(r"%s\[9\] = \{([^}]*)\}" % name, text)
+    return B([int(x.strip().rstrip("u"), 16) for x in m.group(1).split(",")])
+
+
 def sbox(x):
     x2 = sqr(x)
     x4 = sqr(x2)
     return mul(x4, x)
 
 
-def hades_full_round(s, rc, mat):
+def mfma_row():
+    """hades_mfma.h: a row of a constant linear layer on the matrix cores comes back from the Barrett
+    step as 8 words < 2^256 (range proof: gen_constants.py mfma_linear, tests/test_mfma_model.py),
+    re-cut into limbs by fe_from_words_plain: limbs 0..7 < 2^29, limb 8 < 2^24"""
+    return B([M29] * (NL - 1) + [(1 << (256 - LB * (NL - 1))) - 1], (1 << 256) - 1)
+
+
+def mfma_operand_ok(x, what):
+    """mfma_digits(x): x is cut into 32 bytes by fe_to_words_plain — limbs < 2^29 (limb 0 <= 2^29 for
+    an S-box output, which is stored one below its value) and value < 2^256"""
+    _check(all(v <= M29 + (1 if i == 0 else 0) for i, v in enumerate(x.l)), what + ": limb exceeds 29 bits")
+    _check(x.v < (1 << 256), what + ": value exceeds 2^256")
+
+
+def hades_full_round(s, rc):
     s = [add(s[k], rc[k]) for k in range(5)]
     s = [sbox(x) for x in s]
-    return [dot(s, [mat[k * 5 + j] for j in range(5)]) for k in range(5)]
+    for x in s:
+        mfma_operand_ok(x, "S-box output")
+    return [mfma_row() for _ in range(5)]
 
 
-def hades_partial_rounds_arma(s):
-    """hades29.h: hades_partial_rounds_arma with the ACTUAL constants and worst-case operands"""
-    text = open(_HDR).read()
-    off = {n: int(re.search(r"#define DSV_HADES_ARMA_%s (\d+)" % n, text).group(1))
-           for n in ("REC", "GAMMA", "FINAL")}
-    k = _load_table("DSV_HADES_ARMA_HOST")
-    A, Z = [None] * 5, [None] * 5
-    A[0] = carry(add(s[4], k[0]))
-    Z[0] = sbox(A[0])
-    pos = 1
-    for r in range(1, 5):
-        t = list(s)
-        for j in range(r):
-            t += [A[j], Z[j]]
-        nt = 5 + 2 * r
-        A[r] = dot_plus(t, k[pos:pos + nt], k[pos + nt])
-        Z[r] = sbox(A[r])
-        pos += nt + 1
-    rec = k[off["REC"]:off["REC"] + 10]
-    for r in range(5, 59):
-        p = r % 5
-        t = [A[(p + i) % 5] for i in range(5)] + [Z[(p + i) % 5] for i in range(5)]
-        A[p] = dot_plus(t, rec, k[off["GAMMA"] + r - 5])
-        Z[p] = sbox(A[p])
-    t = [A[4], A[0], A[1], A[2], A[3], Z[4], Z[0], Z[1], Z[2], Z[3]]
-    f = off["FINAL"]
-    return [dot_plus(t, k[f + 11 * j:f + 11 * j + 10], k[f + 11 * j + 10]) for j in range(5)]
+def hades_partial_rounds(s):
+    """hades29.h: hades_partial_rounds — every a_r after a_0 is a row, every z_r an S-box output"""
+    for x in s:
+        mfma_operand_ok(x, "state entering the partial rounds")
+    k0 = _load_row("DSV_HADES_K0_HOST")
+    a = add(s[4], k0)
+    # fe_cond_sub(fe_ripple(.), q): ripple needs limbs < 2^31; the result is < max(q, sum - q)
+    for x in a.l:
+        _check(x < (1 << 31), "fe_ripple input limb exceeds 2^31")
+    a0 = B([M29] * (NL - 1) + [a.v >> (LB * (NL - 1))], max(Q, a.v - Q))
+    mfma_operand_ok(a0, "a_0")
+    mfma_operand_ok(sbox(a0), "z_0")
+    z = sbox(mfma_row())          # rounds 1..58: a_r is a row
+    mfma_operand_ok(z, "z_r")
+    return [mfma_row() for _ in range(5)]
 
 
-def hades_permute(s, arma=True):
-    """hades29.h: hades_permute with the ACTUAL constants (exact limbs) and worst-case state"""
-    rc, mds, pre = (_load_table("DSV_HADES_%s_HOST" % n) for n in ("RC", "MDS", "PRE_MDS"))
-    k0, blk, kf = (_load_table("DSV_HADES_%s_HOST" % n) for n in ("KAPPA0", "BLOCKS", "KFINAL"))
+def hades_permute(s):
+    """hades29.h: hades_permute with the ACTUAL round constants (exact limbs) and worst-case state"""
+    rc = _load_table("DSV_HADES_RC_HOST")
     s = list(s)
-    if arma:
-        for r in range(4):
-            s = hades_full_round(s, rc[5 * r:5 * r + 5], mds)
-        s = hades_partial_rounds_arma(s)
-        for r in range(4):
-            s = hades_full_round(s, rc[5 * (4 + 59 + r):5 * (4 + 59 + r) + 5], mds)
-        return s
     for r in range(4):
-        s = hades_full_round(s, rc[5 * r:5 * r + 5], pre if r == 3 else mds)
-    s[4] = add(s[4], k0[4])
-    pos = done = 0
-    while done < 59:
-        lb = min(4, 59 - done)
-        z = []
-        for m in range(lb):
-            z.append(sbox(s[4]))
-            a = [s[0], s[1], s[2], s[3]] + z
-            s[4] = add(dot(a, blk[pos:pos + 5 + m]), blk[pos + 5 + m])
-            pos += 6 + m
-        for j in range(4):
-            s[j] = dot([s[j]] + z, blk[pos:pos + lb + 1])
-            pos += lb + 1
-        done += lb
-    assert pos == len(blk)
-    for j in range(4):
-        s[j] = carry(add(s[j], kf[j]))
+        s = hades_full_round(s, rc[5 * r:5 * r + 5])
+    s = hades_partial_rounds(s)
     for r in range(4):
-        s = hades_full_round(s, rc[5 * (4 + 59 + r):5 * (4 + 59 + r) + 5], mds)
+        s = hades_full_round(s, rc[5 * (4 + 59 + r):5 * (4 + 59 + r) + 5])
     return s
 
 
-def prove_hades(arma=True):
-    """poseidon_hash3 / poseidon_hash5 on worst-case inputs (fe_to_mont of any canonical word),
-    then the truncation's fe_from_mont (fe_canon needs < 16 q and limbs < 2^31)."""
+def prove_hades():
+    """k_challenge (k_hash.hip): the 3-input and the 5-input sponge on worst-case inputs (fe_to_mont of
+    any canonical word; the generic first round is the worst case of the constant-folded one), then
+    the truncation's fe_from_mont (fe_canon needs < 16 q and limbs < 2^31)."""
     m = mul(canonical(), canonical())
     zero, one = B([0] * NL), canonical()
-    out3 = hades_permute([zero, m, m, m, one], arma)
-    s = hades_permute([zero, m, m, m, m], arma)
+    out3 = hades_permute([zero, m, m, m, one])
+    s = hades_permute([zero, m, m, m, m])
     s[1] = add(s[1], m)
     s[2] = add(s[2], one)
-    out5 = hades_permute(s, arma)
+    out5 = hades_permute(s)
     for o in (out3[1], out5[1]):
         h = mul(o, B([1] + [0] * (NL - 1)))
         for x in h.l:

@@ -108,64 +108,6 @@ def sqr(a):
     return mul(a, a)
 
 
-def reduce_cols(c):
-    """columns 0..8 arrive pre-biased by +M29 (see fe29.h)"""
-    k = 0
-    c = list(c) + [0]
-    for i in range(NL):
-        c[i] += M29
-        s = c[i] + k
-        assert s < U64
-        m = (~s) & M29
-        assert (s - M29 + m) & M29 == 0 and (s - M29 + m) >> LB == s >> LB
-        k = s >> LB
-        for j in range(1, NL):
-            c[i + j] += m * Q29[j]
-            assert c[i + j] < U64, "column overflow in reduction"
-            stats["max_col"] = max(stats["max_col"], c[i + j])
-    r = []
-    for i in range(NL - 1):
-        s = c[NL + i] + k
-        assert s < U64
-        r.append(s & M29)
-        k = s >> LB
-    assert k < U32
-    r.append(k)
-    return r
-
-
-def dot(avec, bvec):
-    c = [0] * 17
-    for a, b in zip(avec, bvec):
-        for l in a + b:
-            assert 0 <= l < U32
-        for i in range(NL):
-            for j in range(NL):
-                c[i + j] += a[i] * b[j]
-    for x in c:
-        assert x < U64, "column overflow in dot product"
-        stats["max_col"] = max(stats["max_col"], x)
-    return reduce_cols(c)
-
-
-def dot_plus(avec, bvec, start):
-    """fe_dot_const_plus: the column sums start from `start` (constant * R^2 limbs + the M29 bias)"""
-    c = [0] * 17
-    for a, b in zip(avec, bvec):
-        for l in a + b:
-            assert 0 <= l < U32
-        for i in range(NL):
-            for j in range(NL):
-                c[i + j] += a[i] * b[j]
-    for i in range(NL):
-        assert M29 <= start[i] < (1 << 30)
-        c[i] += start[i] - M29          # reduce_cols adds the bias itself
-    for x in c:
-        assert x < U64, "column overflow in dot product"
-        stats["max_col"] = max(stats["max_col"], x)
-    return reduce_cols(c)
-
-
 def add(a, b):
     r = [x + y for x, y in zip(a, b)]
     assert all(x < U32 for x in r)
@@ -310,106 +252,3 @@ def affine_of(p):
 
 
 # ---- Hades (hades29.h), with the generated device constants ---------------------------------
-def _load_table(name):
-    text = open(_HDR).read()
-    m = re.search(r"%s\[[^\]]*\]\[9\] = \{(.*?)\n\};" % name, text, flags=re.S)
-    rows = re.findall(r"\{([^}]*)\}", m.group(1))
-    return [[int(x.strip().rstrip("u"), 16) for x in r.split(",")] for r in rows]
-
-
-_H = {}
-
-
-def _hc():
-    if not _H:
-        _H["rc"] = _load_table("DSV_HADES_RC_HOST")
-        _H["mds"] = _load_table("DSV_HADES_MDS_HOST")
-        _H["pre"] = _load_table("DSV_HADES_PRE_MDS_HOST")
-        _H["k0"] = _load_table("DSV_HADES_KAPPA0_HOST")
-        _H["blk"] = _load_table("DSV_HADES_BLOCKS_HOST")
-        _H["kf"] = _load_table("DSV_HADES_KFINAL_HOST")
-        _H["arma"] = _load_table("DSV_HADES_ARMA_HOST")
-        text = open(_HDR).read()
-        for name in ("REC", "GAMMA", "FINAL"):
-            _H["arma_" + name.lower()] = int(re.search(r"#define DSV_HADES_ARMA_%s (\d+)" % name, text).group(1))
-    return _H
-
-
-def sbox(x):
-    x2 = sqr(x)
-    x4 = sqr(x2)
-    return mul(x4, x)
-
-
-def hades_full_round(s, rc, mat):
-    s = [add(s[k], rc[k]) for k in range(5)]
-    s = [sbox(x) for x in s]
-    return [dot(s, [mat[k * 5 + j] for j in range(5)]) for k in range(5)]
-
-
-def hades_partial_rounds_arma(s):
-    """hades29.h: hades_partial_rounds_arma, limb-exact"""
-    h = _hc()
-    k = h["arma"]
-    A, Z = [None] * 5, [None] * 5
-    A[0] = carry(add(s[4], k[0]))
-    Z[0] = sbox(A[0])
-    pos = 1
-    for r in range(1, 5):
-        t = list(s)
-        for j in range(r):
-            t += [A[j], Z[j]]
-        nt = 5 + 2 * r
-        A[r] = dot_plus(t, k[pos:pos + nt], k[pos + nt])
-        Z[r] = sbox(A[r])
-        pos += nt + 1
-    assert pos == h["arma_rec"]
-    rec = k[h["arma_rec"]:h["arma_rec"] + 10]
-    g = h["arma_gamma"]
-    for r in range(5, 59):
-        p = r % 5
-        t = [A[(p + i) % 5] for i in range(5)] + [Z[(p + i) % 5] for i in range(5)]
-        A[p] = dot_plus(t, rec, k[g])
-        Z[p] = sbox(A[p])
-        g += 1
-    assert g == h["arma_final"]
-    t = [A[4], A[0], A[1], A[2], A[3], Z[4], Z[0], Z[1], Z[2], Z[3]]
-    f = h["arma_final"]
-    return [dot_plus(t, k[f + 11 * j:f + 11 * j + 10], k[f + 11 * j + 10]) for j in range(5)]
-
-
-def hades_permute(s, arma=True):
-    h = _hc()
-    s = list(s)
-    if arma:
-        for r in range(4):
-            s = hades_full_round(s, h["rc"][5 * r:5 * r + 5], h["mds"])
-        s = hades_partial_rounds_arma(s)
-        for r in range(4):
-            s = hades_full_round(s, h["rc"][5 * (4 + 59 + r):5 * (4 + 59 + r) + 5], h["mds"])
-        return s
-    for r in range(4):
-        s = hades_full_round(s, h["rc"][5 * r:5 * r + 5], h["pre"] if r == 3 else h["mds"])
-    s[4] = add(s[4], h["k0"][4])
-    k = h["blk"]
-    pos = 0
-    done = 0
-    while done < 59:
-        lb = min(4, 59 - done)
-        z = []
-        for m in range(lb):
-            z.append(sbox(s[4]))
-            a = [s[0], s[1], s[2], s[3]] + z
-            row = k[pos:pos + 5 + m]
-            s[4] = add(dot(a, row), k[pos + 5 + m])
-            pos += 6 + m
-        for j in range(4):
-            s[j] = dot([s[j]] + z, k[pos:pos + lb + 1])
-            pos += lb + 1
-        done += lb
-    assert pos == len(k)
-    for j in range(4):
-        s[j] = carry(add(s[j], h["kf"][j]))
-    for r in range(4):
-        s = hades_full_round(s, h["rc"][5 * (4 + 59 + r):5 * (4 + 59 + r) + 5], h["mds"])
-    return s

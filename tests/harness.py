@@ -65,3 +65,25 @@ def tamper(batch, kind_single=True, period=16):
 
 def to_int_point(row):
     return (M.from_le(row[:32]), M.from_le(row[32:]))
+
+
+def projective(points, rng, zero_z=(), noncanon_z=()):
+    """Affine points [n, 64] -> (uvz [n, 96], ext [n, 160]): the same points with a random z != 1 each
+    (tests/keys.rs:33-59: equal points, all-different coordinates).  ext = (u, v, z, t1, t2) with
+    t1*t2 = uv/z, the oracle's JubJubExtended layout.  Items listed in zero_z get z = 0, items in
+    noncanon_z get z + q (same residue, not a canonical encoding): both out of contract, verdict 0."""
+    n = points.shape[0]
+    uvz = np.zeros((n, 96), np.uint8)
+    ext = np.zeros((n, 160), np.uint8)
+    for i in range(n):
+        uu, vv = to_int_point(points[i])
+        z = (int(rng.integers(2, 1 << 62)) * 0x1234567 + int(rng.integers(1, 1 << 62)) * (1 << 190)) % Q
+        U, V = uu * z % Q, vv * z % Q
+        zenc = z
+        if i in zero_z:
+            zenc = 0
+        elif i in noncanon_z and z + Q < (1 << 256):
+            zenc = z + Q
+        uvz[i] = np.frombuffer(M.le32(U) + M.le32(V) + M.le32(zenc), np.uint8)
+        ext[i] = np.frombuffer(M.le32(U) + M.le32(V) + M.le32(zenc) + M.le32(U) + M.le32(vv), np.uint8)
+    return uvz, ext

@@ -34,7 +34,8 @@ def lib():
         L.oracle_banner.restype = ctypes.c_char_p
         for name in (
             "oracle_verify_single", "oracle_verify_double", "oracle_verify_vargen",
-            "oracle_verify_single_ext", "oracle_challenge_single", "oracle_challenge_double",
+            "oracle_verify_single_ext", "oracle_verify_double_ext", "oracle_verify_vargen_ext",
+            "oracle_challenge_single", "oracle_challenge_double",
             "oracle_keygen_sign_single", "oracle_keygen_sign_double",
             "oracle_keygen_sign_vargen", "oracle_scalar_mul", "oracle_fixed_base_entry",
             "oracle_decompress", "oracle_verify_single_wire", "oracle_verify_double_wire",
@@ -87,6 +88,24 @@ def verify_single_ext(u, R_ext, PK_ext, m):
     ok = np.zeros(n, dtype=np.uint8)
     lib().oracle_verify_single_ext(_p(u), _p(R_ext), _p(PK_ext), _p(m), ctypes.c_size_t(n),
                                    _p(ok))
+    return ok
+
+
+def verify_double_ext(u, R_ext, Rp_ext, PK_ext, PKp_ext, m):
+    u, R_ext, Rp_ext, PK_ext, PKp_ext, m = map(_u8, (u, R_ext, Rp_ext, PK_ext, PKp_ext, m))
+    n = u.shape[0]
+    ok = np.zeros(n, dtype=np.uint8)
+    lib().oracle_verify_double_ext(_p(u), _p(R_ext), _p(Rp_ext), _p(PK_ext), _p(PKp_ext), _p(m),
+                                   ctypes.c_size_t(n), _p(ok))
+    return ok
+
+
+def verify_vargen_ext(u, R_ext, PK_ext, Gen_ext, m):
+    u, R_ext, PK_ext, Gen_ext, m = map(_u8, (u, R_ext, PK_ext, Gen_ext, m))
+    n = u.shape[0]
+    ok = np.zeros(n, dtype=np.uint8)
+    lib().oracle_verify_vargen_ext(_p(u), _p(R_ext), _p(PK_ext), _p(Gen_ext), _p(m),
+                                   ctypes.c_size_t(n), _p(ok))
     return ok
 
 

@@ -33,9 +33,6 @@ def test_worst_case_limbs_do_not_overflow_columns():
     F.mul(a, b)
     F.mul(b, a)
     F.sqr(a)
-    five = [[F.M29 + 8] * 8 + [1 << 25]] * 5
-    mds = [[F.M29] * 8 + [(F.Q >> 232)]] * 5
-    F.dot(five, mds)
     assert F.stats["max_col"] < (1 << 64)
 
 
@@ -101,15 +98,3 @@ def test_identity_and_torsion_through_the_formulas():
     assert F.affine_of(s) == (0, 1)
     s = F.ext_add_niels(ident, F.ext_to_niels(ident))
     assert F.affine_of(s) == (0, 1)
-
-
-def test_sparse_hades_permutation_matches_naive_model_and_keeps_bounds():
-    """hades29.h's sparse-partial-round permutation (limb-exact model, generated constants)
-    against the naive dense permutation of tests/pymodel.py, incl. extreme states."""
-    states = [[rnd.randrange(F.Q) for _ in range(5)] for _ in range(3)]
-    states += [[0] * 5, [F.Q - 1] * 5, [0, 1, 2, 3, 4]]
-    for st in states:
-        for arma in (True, False):   # the shipped scalar-recurrence form and the r01 blocked form
-            got = F.hades_permute([F.to_mont_int(x) for x in st], arma=arma)
-            assert [F.val(F.from_mont(x)) for x in got] == M.hades_permute(st), arma
-    assert F.stats["max_col"] < (1 << 64)

@@ -741,20 +741,19 @@ def test_concurrent_callers_on_their_own_streams(engine):
 
 
 def test_alternative_code_paths_in_subprocesses(engine):
-    """The library reads DSV_VERIFY_ALGO / DSV_SPLIT / DSV_QUAD / DSV_DOUBLE_FUSED once at dsv_init,
-    so the other formulations are exercised in child processes: the classic 250-bit chain
-    (k_verify_fixed), the unsplit single-stream launch, the one-lane-per-signature kernel for small
-    batches (which otherwise take the four-lane kernel) and the two-launch double path must give
-    the same verdicts on the tampering, torsion, crafted-challenge, identity and full-size cases.
-    (Children run one after the other.)"""
+    """The library reads DSV_SPLIT / DSV_QUAD / DSV_DOUBLE_FUSED once at dsv_init, so the other
+    paths are exercised in child processes: the unsplit single-stream launch, the
+    one-lane-per-signature kernel for small batches (which otherwise take the four-lane kernel) and
+    the two-launch double path (second pass ANDs into ok[]) must give the same verdicts on the
+    tampering, torsion, crafted-challenge, identity and full-size cases.  (Children run one after
+    the other.  r03 removed the classic 250-bit kernel and with it DSV_VERIFY_ALGO.)"""
     import os
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     expr = ("tampering or torsion or crafted or identity_small_order or full_size_batch_properties "
             "or golden_vectors")
-    for extra in ({"DSV_VERIFY_ALGO": "classic"}, {"DSV_SPLIT": "0"},
-                  {"DSV_QUAD": "0", "DSV_DOUBLE_FUSED": "0"}):
+    for extra in ({"DSV_SPLIT": "0"}, {"DSV_QUAD": "0", "DSV_DOUBLE_FUSED": "0"}):
         env = dict(os.environ)
         env.update(extra)
         r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_gpu_parity.py"),
