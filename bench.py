@@ -31,6 +31,10 @@ Prints ONE JSON line on rank 0.  `roofline` is SURVEY.md §8(d)'s figure for the
 k_verify_fixed_half: v_mad_u64_u32 lane-operations per verdict x verdicts / the kernel's launch
 duration (HIP events, one whole-batch launch on the current stream, right after the timed region),
 against the measured MAD issue peak.  DESIGN.md §4 has the instruction model.
+Riding along at N = 1: `double` (configs[2]), `vargen` (configs[3]), `mixed` (configs[4] shape),
+`sign`, `ext` (projective inputs, to_hash_inputs on the device), `wire` (serialized records,
+decompression on the device), `host_path` / `host_path_ext` / `wire.host` (PCIe-inclusive, never the
+headline value), `small_batch`.
 """
 import argparse
 import json
@@ -39,6 +43,8 @@ import socket
 import subprocess
 import sys
 import time
+
+import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -78,8 +84,8 @@ def _hash_counts(double):
         rows = dots5 + 4 + 54 + 5
         mfma_instr = 2 * (5 * dots5 + 10 * 54 + 9 + edge_terms)   # 2 per term (one per hash tile)
         return sbox, rows, mfma_instr
-    if double:
-        a, b = perm(1, False), perm(0, True)
+    if double:   # two trips through the generic permutation body (k_hash.hip)
+        a, b = perm(0, False), perm(0, True)
         sbox, rows, minstr = (a[i] + b[i] for i in range(3))
         conv = 5
     else:
@@ -350,7 +356,7 @@ def main():
 
     if rank == 0:
         vm, vs = _verify_counts(1)
-        dom = kernel_block("k_verify_fixed_half<false,1>", core_ms, n, vm, vs, other=VERIFY_OTHER,
+        dom = kernel_block("k_verify_fixed_half<1>", core_ms, n, vm, vs, other=VERIFY_OTHER,
                            algo_bytes=ALGO_BYTES["single"])
         hm, hs, hrows, hmi = _hash_counts(False)
         kernel_block("k_challenge<false>", hash_ms, n, hm, hs, other=600, mfma_rows=hrows, mfma_instr=hmi)
@@ -366,7 +372,7 @@ def main():
                 clock = pmc["GRBM_GUI_ACTIVE"] / 8.0 / pmc["avg_duration_ns"]
         algo = ALGO_BYTES["single"] * n
         out["roofline"] = {
-            "kernel": "k_verify_fixed_half<false,1> (dominant: %.0f %% of a step)"
+            "kernel": "k_verify_fixed_half<1> (dominant: %.0f %% of a step)"
                       % (100 * core_ms / (core_ms + hash_ms)),
             "bound": "valu",       # neither HBM nor MFMA binds: integer MAD issue
             "achieved": dom["mad_lane_ops_per_item"] * n / (core_ms * 1e-3) / 1e12,
@@ -376,6 +382,14 @@ def main():
             "mad_frac": dom["mad_frac"],
             "valu_issue_frac": dom["valu_issue_frac"],
             "clock_held_ghz": clock,
+            # what limits the kernel, in one place: the SIMDs are full
+            # (valu_busy_from_pmc), 31 % of what they issue is not a MAD (non_mad_share: digit / shift
+            # of every column, limb-wise add / sub / carry, half-gcd, recoding), and the chip holds
+            # clock_held_ghz of its 2.4 GHz at the power limit: frac_at_held_clock is the MAD
+            # fraction against the peak at the clock the kernel actually gets
+            "frac_at_held_clock": dom["mad_frac"] * (CLOCK_HZ / 1e9) / clock if clock else None,
+            "non_mad_share": 1.0 - dom["mad_lane_ops_per_item"] / float(dom["valu_lane_instr_per_item"]),
+            "limit": "power (held clock) x issue slots spent on non-MAD instructions; neither HBM nor MFMA",
             "valu_busy_from_pmc": valu_busy,
             "traffic": traffic,
             "traffic_ratio": traffic / algo if traffic else None,
@@ -409,7 +423,7 @@ def main():
         if int((okd != bd["expected"]).sum().item()):
             raise SystemExit("fused double kernel: verdicts differ from the expected pattern")
         vm2, vs2 = _verify_counts(2)
-        kernel_block("k_verify_fixed_half<false,2>", cd_ms, n, vm2, vs2, other=2 * VERIFY_OTHER - 9500,
+        kernel_block("k_verify_fixed_half<2>", cd_ms, n, vm2, vs2, other=2 * VERIFY_OTHER - 9500,
                      algo_bytes=ALGO_BYTES["double"])
         hm2, hs2, hrows2, hmi2 = _hash_counts(True)
         kernel_block("k_challenge<true>", hd_ms, n, hm2, hs2, other=900, mfma_rows=hrows2, mfma_instr=hmi2)
@@ -434,6 +448,60 @@ def main():
                      max(var_ms - hv_ms, 1e-3), nv, vvm, vvs, other=63 * (4 * 91 + 2 * 145) + 6000,
                      algo_bytes=ALGO_BYTES["vargen"])
         sample_checks["vargen"] = (bv, okv.clone())
+
+        # ---- projective inputs (what the reference's types hold): to_hash_inputs on the device
+        zr = torch.randint(0, 256, (n, 32), dtype=torch.uint8, device=dev)
+        zr[:, 31] = 0
+        zr[:, 0] |= 1                                           # canonical, non-zero
+        hz = zr.cpu().numpy()
+        hh = lambda t: t.cpu().numpy()
+
+        def projective(pt):                                     # (u z, v z, z) through the engine's own
+            a = hh(pt)                                          # field multiplier (dsv_debug_fq_mul)
+            return np.concatenate([E.debug_fq_mul(np.ascontiguousarray(a[:, :32]), hz),
+                                   E.debug_fq_mul(np.ascontiguousarray(a[:, 32:]), hz), hz], axis=1)
+
+        hR_uvz, hPK_uvz = projective(batch["R"]), projective(batch["PK"])
+        dR_uvz, dPK_uvz = torch.from_numpy(hR_uvz).to(dev), torch.from_numpy(hPK_uvz).to(dev)
+        wse = torch.empty(E.ext_workspace_bytes(n), dtype=torch.uint8, device=dev)
+        oke = torch.zeros(n, dtype=torch.uint8, device=dev)
+        fe_ = lambda: E.verify_single_ext_dev(batch["u"], dR_uvz, dPK_uvz, batch["m"], oke, wse)
+        tee = timed(fe_, reps, 1)
+        if int((oke != batch["expected"]).sum().item()):
+            raise SystemExit("projective-input verdicts differ from the expected pattern")
+        out["ext"] = {"value": n * reps / tee, "unit": "verifies/s",
+                      "workload": "2^%d single signatures, R and PK as (u, v, z) with random z: "
+                                  "dsv_verify_single_ext_dev (k_normalize_uvz: one inversion per eight "
+                                  "signatures, then the affine path)" % args.log2_batch}
+        del wse
+
+        # ---- wire records (Signature 64 B + PublicKey 32 B per item): decompression on the device
+        hsig = np.ascontiguousarray(np.concatenate([hh(batch["u"]), E.compress_points(hh(batch["R"]))], axis=1))
+        hpk = E.compress_points(hh(batch["PK"]))
+        dsig, dpk = torch.from_numpy(hsig).to(dev), torch.from_numpy(hpk).to(dev)
+        wsw = torch.empty(E.wire_workspace_bytes(n), dtype=torch.uint8, device=dev)
+        okw = torch.zeros(n, dtype=torch.uint8, device=dev)
+        fw = lambda: E.verify_single_wire_dev(dsig, dpk, batch["m"], okw, wsw)
+        tww = timed(fw, reps, 1)
+        if int((okw != batch["expected"]).sum().item()):
+            raise SystemExit("wire-format verdicts differ from the expected pattern")
+        duv = torch.empty((n, 64), dtype=torch.uint8, device=dev)
+        dec_ms = event_ms(lambda: E.decompress_points_dev(dpk, duv, valid))
+        # JubJubAffine::from_bytes per point (decode29.h): z^((t-1)/2) by 3-bit windows over a 222-bit
+        # exponent, three Tonelli-Shanks window rounds, validation — squarings / multiplications
+        dec_s, dec_m = 222 + 6 + (24 + 16 + 8) + 3 + 2, 74 + 4 + 2 + 3 * 2 + 1 + 6
+        kernel_block("k_decompress (2^%d points)" % args.log2_batch, dec_ms, n, dec_m, dec_s, other=1500,
+                     algo_bytes=32 + 65)
+        out["wire"] = {"value": n * reps / tww, "unit": "verifies/s",
+                       "workload": "2^%d single signatures as serialized records resident in HBM (64 B "
+                                   "signature + 32 B key + 32 B message = 128 B per item): "
+                                   "dsv_verify_single_wire_dev = 2 x k_decompress + the affine path"
+                                   % args.log2_batch,
+                       "k_decompress_ms_per_2^%d_points" % args.log2_batch: dec_ms,
+                       "note": "two square roots per signature (~94 k MADs) on top of the 274 k of the "
+                               "affine path: the wire path costs ~1.35x the affine one on the device"}
+        sample_checks["wire"] = (hsig, hpk, okw.clone())
+        del wsw, duv
 
         # signing (the step in front of verify): R = r*G, c = H(R, m), u = r - c*sk
         sk_ = torch.randint(0, 256, (n, 32), dtype=torch.uint8, device=dev); sk_[:, 31] &= 0x07
@@ -520,6 +588,12 @@ def main():
             if (ws_ != exp[s_]).any() or (wd_ != exp[d_]).any():
                 raise SystemExit("CPU oracle disagrees with the mixed batch's expected verdicts")
             checked.append("mixed")
+        if "wire" in sample_checks:
+            hsig_, hpk_, got = sample_checks["wire"]
+            w_ = O.verify_single_wire(hsig_[:k], hpk_[:k], h(batch["m"], k))
+            if (w_ != got[:k].cpu().numpy()).any():
+                raise SystemExit("CPU oracle disagrees with the GPU wire-format verdicts on the sample")
+            checked.append("wire")
         out["cpu_baseline"]["oracle_samples"] = "first %d items of: single (%d), %s" % (
             k, sample, ", ".join(checked))
         # host-buffer path of the C ABI (PCIe-inclusive), never the headline value
@@ -530,6 +604,27 @@ def main():
         th = time.perf_counter() - th0
         out["host_path"] = {"value": n / th, "unit": "verifies/s",
                             "note": "dsv_verify_single on %d host-resident items incl. PCIe staging" % n}
+        if "ext" in out:
+            # what the Rust / C++ verify_batch binds: projective points from host memory (256 B per
+            # item instead of 192), normalised on the device
+            E.verify_single_ext(hu, hR_uvz, hPK_uvz, hm)
+            te0 = time.perf_counter()
+            got = E.verify_single_ext(hu, hR_uvz, hPK_uvz, hm)
+            te = time.perf_counter() - te0
+            if (got != batch["expected"].cpu().numpy()).any():
+                raise SystemExit("host projective-input verdicts differ from the expected pattern")
+            out["host_path_ext"] = {"value": n / te, "unit": "verifies/s",
+                                    "note": "dsv_verify_single_ext on %d host-resident items (u, v, z "
+                                            "points: 256 B per item) incl. PCIe staging" % n}
+            E.verify_single_wire(hsig, hpk, hm)
+            tw0 = time.perf_counter()
+            got = E.verify_single_wire(hsig, hpk, hm)
+            tw = time.perf_counter() - tw0
+            if (got != batch["expected"].cpu().numpy()).any():
+                raise SystemExit("host wire-format verdicts differ from the expected pattern")
+            out["wire"]["host"] = {"value": n / tw, "unit": "verifies/s",
+                                   "note": "dsv_verify_single_wire on %d host-resident records (128 B "
+                                           "per item) incl. PCIe staging" % n}
         # BASELINE configs[0] size through the same host entry point: latency of a 1024-item call
         E.verify_single(hu[:1024], hR[:1024], hPK[:1024], hm[:1024])
         tl0 = time.perf_counter()

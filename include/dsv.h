@@ -113,6 +113,7 @@ int dsv_verify_vargen(const uint8_t *u, const uint8_t *R_uv, const uint8_t *PK_u
  * shared by all its points and, in large batches, by eight signatures — so the caller does no
  * field arithmetic on the host.  Same verdicts as the affine entry points on the normalised
  * points. */
+int dsv_to_hash_inputs(const uint8_t *in_uvz, size_t n, uint8_t *out_uv, uint8_t *ok); /* the step alone */
 int dsv_verify_single_ext(const uint8_t *u, const uint8_t *R_uvz, const uint8_t *PK_uvz,
                           const uint8_t *m, size_t n, uint8_t *ok);
 int dsv_verify_double_ext(const uint8_t *u, const uint8_t *R_uvz, const uint8_t *Rp_uvz,

@@ -22,7 +22,10 @@
 // itself (no GPU, HIP error) is not a verdict and is thrown as std::runtime_error.
 // All arithmetic happens on the GPU (libdsv.so); the only host arithmetic here is the 512-bit
 // reduction of `random()` (ff::Field::random = from_bytes_wide of 64 random bytes).
-// Points are held in affine form (u, v) — what `JubJubExtended::to_hash_inputs()` yields.
+// Keys and signatures hold JubJubExtended points (u, v, z) like the reference's types do; the
+// normalisation `to_hash_inputs` that the reference's verify starts with
+// (/root/reference/src/signatures.rs:131, :280-281) runs on the device inside the dsv_verify_*_ext
+// entry points — verify() and verify_batch*() do no field arithmetic on the host.
 #pragma once
 #include <array>
 #include <cstdint>
@@ -43,11 +46,11 @@ inline void check(int rc, const char* what) {
                              dsv_last_error());
 }
 inline void ensure_init() {
-  // every GPU of the node: verify_batch* shard over all of them (dsv_verify_*_multi)
+  // the GPUs named in $DSV_DEVICES, else every GPU of the node: verify_batch* shard over all of
+  // them (dsv_verify_*_ext_multi).  First call: two 75.5 MB window tables per device, ~50 ms each.
   static const bool once = [] {
-    const int count = dsv_device_count();
-    if (count <= 0) check(dsv_init(0), "dsv_init");  // reports DSV_ERR_NO_DEVICE
-    for (int d = 0; d < count; d++) check(dsv_init(d), "dsv_init");
+    const int rc = dsv_init_visible();
+    if (rc < 0) check(rc, "dsv_init_visible");  // e.g. DSV_ERR_NO_DEVICE
     return true;
   }();
   (void)once;
@@ -138,12 +141,48 @@ struct JubJubAffine {  // (u, v), canonical LE — the pair to_hash_inputs() ret
   }
 };
 
+// (u, v, z) with z != 0, canonical LE each: the coordinates a JubJubExtended holds.  Points that
+// come out of this library's own kernels (sign, key derivation, from_bytes) have z = 1; a caller
+// may hand in any projective representation (from_raw_unchecked): verify() treats equal points
+// alike whatever their z (/root/reference/tests/keys.rs:33-59).
+struct JubJubExtended {
+  std::array<uint8_t, 96> uvz{};
+  JubJubExtended() { uvz[32] = 1; uvz[64] = 1; }  // identity (0, 1, 1), like Default in the reference
+  static JubJubExtended from(const JubJubAffine& a) {
+    JubJubExtended p;
+    std::memcpy(p.uvz.data(), a.uv.data(), 64);
+    std::memset(p.uvz.data() + 64, 0, 32);
+    p.uvz[64] = 1;
+    return p;
+  }
+  // JubJubExtended::to_hash_inputs / JubJubAffine::from(ext): (u/z, v/z), computed on the GPU
+  JubJubAffine to_affine() const {
+    ensure_init_();
+    JubJubAffine a;
+    uint8_t ok = 0;
+    detail::check(dsv_to_hash_inputs(uvz.data(), 1, a.uv.data(), &ok), "dsv_to_hash_inputs");
+    if (!ok) throw std::domain_error("JubJubExtended with z = 0 (the reference panics here)");
+    return a;
+  }
+  std::array<uint8_t, 32> to_bytes() const { return to_affine().to_bytes(); }
+  static std::optional<JubJubExtended> from_bytes(const uint8_t b[32]) {
+    auto a = JubJubAffine::from_bytes(b);
+    if (!a) return std::nullopt;
+    return from(*a);
+  }
+  // PartialEq of the reference: projective equality (u1 z2 == u2 z1 and v1 z2 == v2 z1)
+  bool operator==(const JubJubExtended& o) const { return uvz == o.uvz || to_affine() == o.to_affine(); }
+
+ private:
+  static void ensure_init_() { detail::ensure_init(); }
+};
+
 struct Signature {
   static constexpr size_t SIZE = 64;  // u || compressed R
   JubJubScalar u_;
-  JubJubAffine R_;
+  JubJubExtended R_;
   const JubJubScalar& u() const { return u_; }
-  const JubJubAffine& R() const { return R_; }
+  const JubJubExtended& R() const { return R_; }
   bool operator==(const Signature& o) const { return u_ == o.u_ && R_ == o.R_; }
   std::array<uint8_t, SIZE> to_bytes() const {
     std::array<uint8_t, SIZE> b;
@@ -153,7 +192,7 @@ struct Signature {
   }
   static std::optional<Signature> from_bytes(const std::array<uint8_t, SIZE>& b) {
     auto u = JubJubScalar::from_bytes(b.data());
-    auto R = JubJubAffine::from_bytes(b.data() + 32);
+    auto R = JubJubExtended::from_bytes(b.data() + 32);
     if (!u || !R) return std::nullopt;
     return Signature{*u, *R};
   }
@@ -161,10 +200,10 @@ struct Signature {
 struct SignatureDouble {
   static constexpr size_t SIZE = 96;  // u || compressed R || compressed R'
   JubJubScalar u_;
-  JubJubAffine R_, R_prime_;
+  JubJubExtended R_, R_prime_;
   const JubJubScalar& u() const { return u_; }
-  const JubJubAffine& R() const { return R_; }
-  const JubJubAffine& R_prime() const { return R_prime_; }
+  const JubJubExtended& R() const { return R_; }
+  const JubJubExtended& R_prime() const { return R_prime_; }
   bool operator==(const SignatureDouble& o) const {
     return u_ == o.u_ && R_ == o.R_ && R_prime_ == o.R_prime_;
   }
@@ -177,8 +216,8 @@ struct SignatureDouble {
   }
   static std::optional<SignatureDouble> from_bytes(const std::array<uint8_t, SIZE>& b) {
     auto u = JubJubScalar::from_bytes(b.data());
-    auto R = JubJubAffine::from_bytes(b.data() + 32);
-    auto Rp = JubJubAffine::from_bytes(b.data() + 64);
+    auto R = JubJubExtended::from_bytes(b.data() + 32);
+    auto Rp = JubJubExtended::from_bytes(b.data() + 64);
     if (!u || !R || !Rp) return std::nullopt;
     return SignatureDouble{*u, *R, *Rp};
   }
@@ -186,9 +225,9 @@ struct SignatureDouble {
 struct SignatureVarGen {
   static constexpr size_t SIZE = 64;
   JubJubScalar u_;
-  JubJubAffine R_;
+  JubJubExtended R_;
   const JubJubScalar& u() const { return u_; }
-  const JubJubAffine& R() const { return R_; }
+  const JubJubExtended& R() const { return R_; }
   bool operator==(const SignatureVarGen& o) const { return u_ == o.u_ && R_ == o.R_; }
   std::array<uint8_t, SIZE> to_bytes() const {
     std::array<uint8_t, SIZE> b;
@@ -198,7 +237,7 @@ struct SignatureVarGen {
   }
   static std::optional<SignatureVarGen> from_bytes(const std::array<uint8_t, SIZE>& b) {
     auto u = JubJubScalar::from_bytes(b.data());
-    auto R = JubJubAffine::from_bytes(b.data() + 32);
+    auto R = JubJubExtended::from_bytes(b.data() + 32);
     if (!u || !R) return std::nullopt;
     return SignatureVarGen{*u, *R};
   }
@@ -221,8 +260,10 @@ struct SecretKey {
     detail::ensure_init();
     const JubJubScalar r = JubJubScalar::random(rng);
     Signature s;
+    JubJubAffine R;
     detail::check(dsv_sign_single(sk.bytes.data(), message.bytes.data(), r.bytes.data(), 1,
-                                  s.u_.bytes.data(), s.R_.uv.data()), "dsv_sign_single");
+                                  s.u_.bytes.data(), R.uv.data()), "dsv_sign_single");
+    s.R_ = JubJubExtended::from(R);
     return s;
   }
   template <class Rng>
@@ -230,28 +271,34 @@ struct SecretKey {
     detail::ensure_init();
     const JubJubScalar r = JubJubScalar::random(rng);
     SignatureDouble s;
+    JubJubAffine R, Rp;
     detail::check(dsv_sign_double(sk.bytes.data(), message.bytes.data(), r.bytes.data(), 1,
-                                  s.u_.bytes.data(), s.R_.uv.data(), s.R_prime_.uv.data()),
+                                  s.u_.bytes.data(), R.uv.data(), Rp.uv.data()),
                   "dsv_sign_double");
+    s.R_ = JubJubExtended::from(R);
+    s.R_prime_ = JubJubExtended::from(Rp);
     return s;
   }
 };
 
+namespace detail {
+inline JubJubExtended derive(const JubJubScalar& sk, int which, const uint8_t* gen_uv, const char* what) {
+  ensure_init();
+  JubJubAffine a;
+  check(dsv_public_keys(sk.bytes.data(), which, gen_uv, 1, a.uv.data()), what);
+  return JubJubExtended::from(a);
+}
+}  // namespace detail
+
 struct PublicKey {
-  JubJubAffine pk;
-  static PublicKey from(const SecretKey& sk) {
-    detail::ensure_init();
-    PublicKey p;
-    detail::check(dsv_public_keys(sk.sk.bytes.data(), 0, nullptr, 1, p.pk.uv.data()),
-                  "dsv_public_keys");
-    return p;
-  }
-  const JubJubAffine& as_ref() const { return pk; }
+  JubJubExtended pk;
+  static PublicKey from(const SecretKey& sk) { return PublicKey{detail::derive(sk.sk, 0, nullptr, "dsv_public_keys")}; }
+  const JubJubExtended& as_ref() const { return pk; }
   // public.rs:142 from_raw_unchecked: any coordinates, no validation
-  static PublicKey from_raw_unchecked(const JubJubAffine& p) { return PublicKey{p}; }
+  static PublicKey from_raw_unchecked(const JubJubExtended& p) { return PublicKey{p}; }
   std::array<uint8_t, 32> to_bytes() const { return pk.to_bytes(); }
   static std::optional<PublicKey> from_bytes(const std::array<uint8_t, 32>& b) {
-    auto p = JubJubAffine::from_bytes(b.data());
+    auto p = JubJubExtended::from_bytes(b.data());
     if (!p) return std::nullopt;
     return PublicKey{*p};
   }
@@ -259,24 +306,23 @@ struct PublicKey {
   bool verify(const Signature& sig, const BlsScalar& message) const {
     detail::ensure_init();
     uint8_t ok = 0;
-    detail::check(dsv_verify_single(sig.u_.bytes.data(), sig.R_.uv.data(), pk.uv.data(),
-                                    message.bytes.data(), 1, &ok), "dsv_verify_single");
+    detail::check(dsv_verify_single_ext(sig.u_.bytes.data(), sig.R_.uvz.data(), pk.uvz.data(),
+                                        message.bytes.data(), 1, &ok), "dsv_verify_single_ext");
     return ok == 1;
   }
   bool operator==(const PublicKey& o) const { return pk == o.pk; }
 };
 
 struct PublicKeyDouble {
-  JubJubAffine pk_, pk_prime_;
+  JubJubExtended pk_, pk_prime_;
   static PublicKeyDouble from(const SecretKey& sk) {
-    detail::ensure_init();
-    PublicKeyDouble p;
-    detail::check(dsv_public_keys(sk.sk.bytes.data(), 0, nullptr, 1, p.pk_.uv.data()), "pk");
-    detail::check(dsv_public_keys(sk.sk.bytes.data(), 1, nullptr, 1, p.pk_prime_.uv.data()), "pk'");
-    return p;
+    return PublicKeyDouble{detail::derive(sk.sk, 0, nullptr, "pk"), detail::derive(sk.sk, 1, nullptr, "pk'")};
   }
-  const JubJubAffine& pk() const { return pk_; }
-  const JubJubAffine& pk_prime() const { return pk_prime_; }
+  static PublicKeyDouble from_raw_unchecked(const JubJubExtended& p, const JubJubExtended& pp) {
+    return PublicKeyDouble{p, pp};
+  }
+  const JubJubExtended& pk() const { return pk_; }
+  const JubJubExtended& pk_prime() const { return pk_prime_; }
   bool operator==(const PublicKeyDouble& o) const { return pk_ == o.pk_ && pk_prime_ == o.pk_prime_; }
   std::array<uint8_t, 64> to_bytes() const {  // pk || pk'
     std::array<uint8_t, 64> b;
@@ -285,25 +331,25 @@ struct PublicKeyDouble {
     return b;
   }
   static std::optional<PublicKeyDouble> from_bytes(const std::array<uint8_t, 64>& b) {
-    auto p = JubJubAffine::from_bytes(b.data());
-    auto pp = JubJubAffine::from_bytes(b.data() + 32);
+    auto p = JubJubExtended::from_bytes(b.data());
+    auto pp = JubJubExtended::from_bytes(b.data() + 32);
     if (!p || !pp) return std::nullopt;
     return PublicKeyDouble{*p, *pp};
   }
   bool verify(const SignatureDouble& sig, const BlsScalar& message) const {
     detail::ensure_init();
     uint8_t ok = 0;
-    detail::check(dsv_verify_double(sig.u_.bytes.data(), sig.R_.uv.data(), sig.R_prime_.uv.data(),
-                                    pk_.uv.data(), pk_prime_.uv.data(), message.bytes.data(), 1,
-                                    &ok), "dsv_verify_double");
+    detail::check(dsv_verify_double_ext(sig.u_.bytes.data(), sig.R_.uvz.data(), sig.R_prime_.uvz.data(),
+                                        pk_.uvz.data(), pk_prime_.uvz.data(), message.bytes.data(), 1,
+                                        &ok), "dsv_verify_double_ext");
     return ok == 1;
   }
 };
 
 struct SecretKeyVarGen {
   JubJubScalar sk;
-  JubJubAffine generator_;
-  static SecretKeyVarGen make(const JubJubScalar& sk, const JubJubAffine& generator) {
+  JubJubExtended generator_;
+  static SecretKeyVarGen make(const JubJubScalar& sk, const JubJubExtended& generator) {
     return SecretKeyVarGen{sk, generator};
   }
   // random: sk, then a generator scalar g; generator = g * G   (secret.rs:367-376)
@@ -313,10 +359,10 @@ struct SecretKeyVarGen {
     SecretKeyVarGen k;
     k.sk = JubJubScalar::random(rng);
     const JubJubScalar g = JubJubScalar::random(rng);
-    detail::check(dsv_public_keys(g.bytes.data(), 0, nullptr, 1, k.generator_.uv.data()), "gen");
+    k.generator_ = detail::derive(g, 0, nullptr, "gen");
     return k;
   }
-  const JubJubAffine& generator() const { return generator_; }
+  const JubJubExtended& generator() const { return generator_; }
   bool operator==(const SecretKeyVarGen& o) const { return sk == o.sk && generator_ == o.generator_; }
   std::array<uint8_t, 64> to_bytes() const {  // sk || compressed generator
     std::array<uint8_t, 64> b;
@@ -326,7 +372,7 @@ struct SecretKeyVarGen {
   }
   static std::optional<SecretKeyVarGen> from_bytes(const std::array<uint8_t, 64>& b) {
     auto s = JubJubScalar::from_bytes(b.data());
-    auto g = JubJubAffine::from_bytes(b.data() + 32);
+    auto g = JubJubExtended::from_bytes(b.data() + 32);
     if (!s || !g) return std::nullopt;
     return SecretKeyVarGen{*s, *g};
   }
@@ -335,25 +381,27 @@ struct SecretKeyVarGen {
     detail::ensure_init();
     const JubJubScalar r = JubJubScalar::random(rng);
     SignatureVarGen s;
-    detail::check(dsv_sign_vargen(sk.bytes.data(), generator_.uv.data(), message.bytes.data(),
-                                  r.bytes.data(), 1, s.u_.bytes.data(), s.R_.uv.data()),
+    const JubJubAffine gen = generator_.to_affine();  // the signing kernels take affine bases
+    JubJubAffine R;
+    detail::check(dsv_sign_vargen(sk.bytes.data(), gen.uv.data(), message.bytes.data(),
+                                  r.bytes.data(), 1, s.u_.bytes.data(), R.uv.data()),
                   "dsv_sign_vargen");
+    s.R_ = JubJubExtended::from(R);
     return s;
   }
 };
 
 struct PublicKeyVarGen {
-  JubJubAffine pk_, generator_;
+  JubJubExtended pk_, generator_;
   static PublicKeyVarGen from(const SecretKeyVarGen& sk) {
-    detail::ensure_init();
-    PublicKeyVarGen p;
-    p.generator_ = sk.generator_;
-    detail::check(dsv_public_keys(sk.sk.bytes.data(), 0, sk.generator_.uv.data(), 1,
-                                  p.pk_.uv.data()), "dsv_public_keys(gen)");
-    return p;
+    const JubJubAffine gen = sk.generator_.to_affine();
+    return PublicKeyVarGen{detail::derive(sk.sk, 0, gen.uv.data(), "dsv_public_keys(gen)"), sk.generator_};
   }
-  const JubJubAffine& public_key() const { return pk_; }
-  const JubJubAffine& generator() const { return generator_; }
+  static PublicKeyVarGen from_raw_unchecked(const JubJubExtended& pk, const JubJubExtended& gen) {
+    return PublicKeyVarGen{pk, gen};
+  }
+  const JubJubExtended& public_key() const { return pk_; }
+  const JubJubExtended& generator() const { return generator_; }
   bool operator==(const PublicKeyVarGen& o) const { return pk_ == o.pk_ && generator_ == o.generator_; }
   std::array<uint8_t, 64> to_bytes() const {  // compressed pk || compressed generator
     std::array<uint8_t, 64> b;
@@ -362,17 +410,17 @@ struct PublicKeyVarGen {
     return b;
   }
   static std::optional<PublicKeyVarGen> from_bytes(const std::array<uint8_t, 64>& b) {
-    auto p = JubJubAffine::from_bytes(b.data());
-    auto g = JubJubAffine::from_bytes(b.data() + 32);
+    auto p = JubJubExtended::from_bytes(b.data());
+    auto g = JubJubExtended::from_bytes(b.data() + 32);
     if (!p || !g) return std::nullopt;
     return PublicKeyVarGen{*p, *g};
   }
   bool verify(const SignatureVarGen& sig, const BlsScalar& message) const {
     detail::ensure_init();
     uint8_t ok = 0;
-    detail::check(dsv_verify_vargen(sig.u_.bytes.data(), sig.R_.uv.data(), pk_.uv.data(),
-                                    generator_.uv.data(), message.bytes.data(), 1, &ok),
-                  "dsv_verify_vargen");
+    detail::check(dsv_verify_vargen_ext(sig.u_.bytes.data(), sig.R_.uvz.data(), pk_.uvz.data(),
+                                        generator_.uvz.data(), message.bytes.data(), 1, &ok),
+                  "dsv_verify_vargen_ext");
     return ok == 1;
   }
 };
@@ -385,15 +433,15 @@ inline std::vector<bool> verify_batch(const std::vector<Signature>& sigs,
     throw std::invalid_argument("verify_batch: slice lengths differ");
   detail::ensure_init();
   const size_t n = sigs.size();
-  std::vector<uint8_t> u(32 * n), r(64 * n), pk(64 * n), m(32 * n), ok(n);
-  for (size_t i = 0; i < n; i++) {
+  std::vector<uint8_t> u(32 * n), r(96 * n), pk(96 * n), m(32 * n), ok(n);
+  for (size_t i = 0; i < n; i++) {  // byte copies only: no to_hash_inputs on the host
     std::memcpy(&u[32 * i], sigs[i].u_.bytes.data(), 32);
-    std::memcpy(&r[64 * i], sigs[i].R_.uv.data(), 64);
-    std::memcpy(&pk[64 * i], pks[i].pk.uv.data(), 64);
+    std::memcpy(&r[96 * i], sigs[i].R_.uvz.data(), 96);
+    std::memcpy(&pk[96 * i], pks[i].pk.uvz.data(), 96);
     std::memcpy(&m[32 * i], msgs[i].bytes.data(), 32);
   }
-  detail::check(dsv_verify_single_multi(u.data(), r.data(), pk.data(), m.data(), n, ok.data()),
-                "dsv_verify_single_multi");
+  detail::check(dsv_verify_single_ext_multi(u.data(), r.data(), pk.data(), m.data(), n, ok.data()),
+                "dsv_verify_single_ext_multi");
   std::vector<bool> out(n);
   for (size_t i = 0; i < n; i++) out[i] = ok[i] == 1;
   return out;
@@ -405,17 +453,17 @@ inline std::vector<bool> verify_batch_double(const std::vector<SignatureDouble>&
     throw std::invalid_argument("verify_batch_double: slice lengths differ");
   detail::ensure_init();
   const size_t n = sigs.size();
-  std::vector<uint8_t> u(32 * n), r(64 * n), rp(64 * n), pk(64 * n), pkp(64 * n), m(32 * n), ok(n);
+  std::vector<uint8_t> u(32 * n), r(96 * n), rp(96 * n), pk(96 * n), pkp(96 * n), m(32 * n), ok(n);
   for (size_t i = 0; i < n; i++) {
     std::memcpy(&u[32 * i], sigs[i].u_.bytes.data(), 32);
-    std::memcpy(&r[64 * i], sigs[i].R_.uv.data(), 64);
-    std::memcpy(&rp[64 * i], sigs[i].R_prime_.uv.data(), 64);
-    std::memcpy(&pk[64 * i], pks[i].pk_.uv.data(), 64);
-    std::memcpy(&pkp[64 * i], pks[i].pk_prime_.uv.data(), 64);
+    std::memcpy(&r[96 * i], sigs[i].R_.uvz.data(), 96);
+    std::memcpy(&rp[96 * i], sigs[i].R_prime_.uvz.data(), 96);
+    std::memcpy(&pk[96 * i], pks[i].pk_.uvz.data(), 96);
+    std::memcpy(&pkp[96 * i], pks[i].pk_prime_.uvz.data(), 96);
     std::memcpy(&m[32 * i], msgs[i].bytes.data(), 32);
   }
-  detail::check(dsv_verify_double_multi(u.data(), r.data(), rp.data(), pk.data(), pkp.data(),
-                                        m.data(), n, ok.data()), "dsv_verify_double_multi");
+  detail::check(dsv_verify_double_ext_multi(u.data(), r.data(), rp.data(), pk.data(), pkp.data(),
+                                            m.data(), n, ok.data()), "dsv_verify_double_ext_multi");
   std::vector<bool> out(n);
   for (size_t i = 0; i < n; i++) out[i] = ok[i] == 1;
   return out;
@@ -427,16 +475,16 @@ inline std::vector<bool> verify_batch_var_gen(const std::vector<SignatureVarGen>
     throw std::invalid_argument("verify_batch_var_gen: slice lengths differ");
   detail::ensure_init();
   const size_t n = sigs.size();
-  std::vector<uint8_t> u(32 * n), r(64 * n), pk(64 * n), g(64 * n), m(32 * n), ok(n);
+  std::vector<uint8_t> u(32 * n), r(96 * n), pk(96 * n), g(96 * n), m(32 * n), ok(n);
   for (size_t i = 0; i < n; i++) {
     std::memcpy(&u[32 * i], sigs[i].u_.bytes.data(), 32);
-    std::memcpy(&r[64 * i], sigs[i].R_.uv.data(), 64);
-    std::memcpy(&pk[64 * i], pks[i].pk_.uv.data(), 64);
-    std::memcpy(&g[64 * i], pks[i].generator_.uv.data(), 64);
+    std::memcpy(&r[96 * i], sigs[i].R_.uvz.data(), 96);
+    std::memcpy(&pk[96 * i], pks[i].pk_.uvz.data(), 96);
+    std::memcpy(&g[96 * i], pks[i].generator_.uvz.data(), 96);
     std::memcpy(&m[32 * i], msgs[i].bytes.data(), 32);
   }
-  detail::check(dsv_verify_vargen_multi(u.data(), r.data(), pk.data(), g.data(), m.data(), n,
-                                        ok.data()), "dsv_verify_vargen_multi");
+  detail::check(dsv_verify_vargen_ext_multi(u.data(), r.data(), pk.data(), g.data(), m.data(), n,
+                                            ok.data()), "dsv_verify_vargen_ext_multi");
   std::vector<bool> out(n);
   for (size_t i = 0; i < n; i++) out[i] = ok[i] == 1;
   return out;

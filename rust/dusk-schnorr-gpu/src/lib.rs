@@ -18,17 +18,19 @@ use dusk_schnorr::{
 #[allow(non_snake_case)]
 extern "C" {
     fn dsv_init(device: c_int) -> c_int;
-    fn dsv_device_count() -> c_int;
+    fn dsv_init_visible() -> c_int;
     fn dsv_last_error() -> *const c_char;
-    // the *_multi entry points shard one host batch over EVERY initialised device (contiguous
-    // shards, one host thread per device, no collective); with one device they are the plain
-    // dsv_verify_single / _double / _vargen
-    fn dsv_verify_single_multi(u: *const u8, R_uv: *const u8, PK_uv: *const u8, m: *const u8,
-                               n: usize, ok: *mut u8) -> c_int;
-    fn dsv_verify_double_multi(u: *const u8, R_uv: *const u8, Rp_uv: *const u8, PK_uv: *const u8,
-                               PKp_uv: *const u8, m: *const u8, n: usize, ok: *mut u8) -> c_int;
-    fn dsv_verify_vargen_multi(u: *const u8, R_uv: *const u8, PK_uv: *const u8, Gen_uv: *const u8,
-                               m: *const u8, n: usize, ok: *mut u8) -> c_int;
+    // Points go over as (u, v, z), 96 bytes: the coordinates the JubJubExtended values hold, with
+    // NO normalisation on the host — the device performs `to_hash_inputs` (one field inversion per
+    // signature at most).  The *_multi entry points shard one host batch over EVERY initialised
+    // device (contiguous shards, one host thread per device, no collective).
+    fn dsv_verify_single_ext_multi(u: *const u8, R_uvz: *const u8, PK_uvz: *const u8, m: *const u8,
+                                   n: usize, ok: *mut u8) -> c_int;
+    fn dsv_verify_double_ext_multi(u: *const u8, R_uvz: *const u8, Rp_uvz: *const u8,
+                                   PK_uvz: *const u8, PKp_uvz: *const u8, m: *const u8, n: usize,
+                                   ok: *mut u8) -> c_int;
+    fn dsv_verify_vargen_ext_multi(u: *const u8, R_uvz: *const u8, PK_uvz: *const u8,
+                                   Gen_uvz: *const u8, m: *const u8, n: usize, ok: *mut u8) -> c_int;
 }
 
 /// Engine failure (no GPU, HIP error).  Never a verdict.
@@ -48,24 +50,25 @@ pub fn init(device: i32) -> Result<(), EngineError> {
     check(unsafe { dsv_init(device) })
 }
 
-/// Initialise every GPU of the node (8 on an MI355X node); `verify_batch*` then shard over all
-/// of them.  Idempotent and cheap after the first call.
+/// Initialise the GPUs this process should use: the ordinals in the environment variable
+/// `DSV_DEVICES` ("0,2,3"), else every visible one (8 on an MI355X node); `verify_batch*` then
+/// shard over all of them.  Idempotent and cheap after the first call; the first call builds two
+/// 75.5 MB window tables per device (~50 ms of device time each).
 pub fn init_all() -> Result<usize, EngineError> {
-    let n = unsafe { dsv_device_count() };
-    if n <= 0 {
-        init(0)?; // reports DSV_ERR_NO_DEVICE with its message
-    }
-    for d in 0..n {
-        init(d)?;
+    let n = unsafe { dsv_init_visible() };
+    if n < 0 {
+        check(n)?;
     }
     Ok(n as usize)
 }
 
 fn push_point(dst: &mut Vec<u8>, p: &JubJubExtended) {
-    // the same normalisation challenge_hash performs (src/signatures.rs:131)
-    let [u, v] = p.to_hash_inputs();
-    dst.extend_from_slice(&u.to_bytes());
-    dst.extend_from_slice(&v.to_bytes());
+    // three `to_bytes()` (a Montgomery reduction each, ~50 ns): no inversion, no multiplication.
+    // The reference's verify would start with `p.to_hash_inputs()` here (src/signatures.rs:131,
+    // :280-281) — that step now runs on the device.
+    dst.extend_from_slice(&p.get_u().to_bytes());
+    dst.extend_from_slice(&p.get_v().to_bytes());
+    dst.extend_from_slice(&p.get_z().to_bytes());
 }
 
 fn verdicts(ok: Vec<u8>) -> Vec<bool> {
@@ -77,7 +80,7 @@ pub fn verify_batch(sigs: &[Signature], pks: &[PublicKey], msgs: &[BlsScalar])
     assert!(sigs.len() == pks.len() && sigs.len() == msgs.len());
     let n = sigs.len();
     let (mut u, mut r, mut pk, mut m) =
-        (Vec::with_capacity(32 * n), Vec::with_capacity(64 * n), Vec::with_capacity(64 * n),
+        (Vec::with_capacity(32 * n), Vec::with_capacity(96 * n), Vec::with_capacity(96 * n),
          Vec::with_capacity(32 * n));
     for i in 0..n {
         u.extend_from_slice(&sigs[i].u().to_bytes());
@@ -88,7 +91,7 @@ pub fn verify_batch(sigs: &[Signature], pks: &[PublicKey], msgs: &[BlsScalar])
     let mut ok = vec![0u8; n];
     init_all()?;
     check(unsafe {
-        dsv_verify_single_multi(u.as_ptr(), r.as_ptr(), pk.as_ptr(), m.as_ptr(), n, ok.as_mut_ptr())
+        dsv_verify_single_ext_multi(u.as_ptr(), r.as_ptr(), pk.as_ptr(), m.as_ptr(), n, ok.as_mut_ptr())
     })?;
     Ok(verdicts(ok))
 }
@@ -110,7 +113,7 @@ pub fn verify_batch_double(sigs: &[SignatureDouble], pks: &[PublicKeyDouble], ms
     let mut ok = vec![0u8; n];
     init_all()?;
     check(unsafe {
-        dsv_verify_double_multi(u.as_ptr(), r.as_ptr(), rp.as_ptr(), pk.as_ptr(), pkp.as_ptr(),
+        dsv_verify_double_ext_multi(u.as_ptr(), r.as_ptr(), rp.as_ptr(), pk.as_ptr(), pkp.as_ptr(),
                                 m.as_ptr(), n, ok.as_mut_ptr())
     })?;
     Ok(verdicts(ok))
@@ -132,7 +135,7 @@ pub fn verify_batch_var_gen(sigs: &[SignatureVarGen], pks: &[PublicKeyVarGen], m
     let mut ok = vec![0u8; n];
     init_all()?;
     check(unsafe {
-        dsv_verify_vargen_multi(u.as_ptr(), r.as_ptr(), pk.as_ptr(), g.as_ptr(), m.as_ptr(), n,
+        dsv_verify_vargen_ext_multi(u.as_ptr(), r.as_ptr(), pk.as_ptr(), g.as_ptr(), m.as_ptr(), n,
                                 ok.as_mut_ptr())
     })?;
     Ok(verdicts(ok))

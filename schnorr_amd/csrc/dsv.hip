@@ -1196,6 +1196,31 @@ int verify_vargen_ext_host(Context& ctx, const uint8_t* u, const uint8_t* R, con
 
 size_t dsv_ext_workspace_bytes(size_t n) { return ext_workspace_bytes(n); }
 
+// JubJubExtended::to_hash_inputs for n points: (u, v, z) -> (u/z, v/z); ok[i] = 0 for z = 0 or a
+// non-canonical coordinate (the reference would panic / cannot hold such a value)
+int dsv_to_hash_inputs(const uint8_t* in_uvz, size_t n, uint8_t* out_uv, uint8_t* ok) {
+  if (n && (!in_uvz || !out_uv || !ok)) return fail(DSV_ERR_INVALID_ARGUMENT, "null pointer");
+  DSV_HOST_PROLOGUE(n);
+  DSV_HOST_LOCK();
+  const size_t pre = normalize_prefix_bytes(n, 1);
+  if (int r = ensure_stage(ctx, align_up(n * 96, 256) + align_up(n * 64, 256) + align_up(n, 256) +
+                                    align_up(pre, 256)))
+    return r;
+  Stager st(ctx.stage);
+  uint8_t *din = st.take(n * 96), *dout = st.take(n * 64), *dok = st.take(n);
+  u32* dpre = reinterpret_cast<u32*>(st.take(pre));
+  H2D(din, in_uvz, n * 96);
+  NormalizeArgs a = {};
+  a.in[0] = din;
+  a.out[0] = dout;
+  launch_normalize_uvz(a, 1, n, dok, dpre, 0);
+  HIP_TRY(hipGetLastError());
+  D2H(out_uv, dout, n * 64);
+  D2H(ok, dok, n);
+  HIP_TRY(hipStreamSynchronize(0));
+  return DSV_OK;
+}
+
 int dsv_verify_single_ext(const uint8_t* u, const uint8_t* R_uvz, const uint8_t* PK_uvz,
                           const uint8_t* m, size_t n, uint8_t* ok) {
   if (n && (!u || !R_uvz || !PK_uvz || !m || !ok)) return fail(DSV_ERR_INVALID_ARGUMENT, "null pointer");

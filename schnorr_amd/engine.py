@@ -140,6 +140,16 @@ def verify_vargen_multi(u, R, PK, Gen, m):
     return ok
 
 
+def to_hash_inputs(uvz):
+    """JubJubExtended::to_hash_inputs over [n, 96] (u || v || z) -> ([n, 64] affine, ok[n])."""
+    uvz = _arr(uvz, 96)
+    n = uvz.shape[0]
+    out = np.zeros((n, 64), dtype=np.uint8)
+    ok = np.zeros(n, dtype=np.uint8)
+    _lib.check(_lib.load().dsv_to_hash_inputs(_p(uvz), ctypes.c_size_t(n), _p(out), _p(ok)))
+    return out, ok
+
+
 def _ext_call(name, widths, arrays):
     arrs = [_arr(a, w) for a, w in zip(arrays, widths)]
     n = _same_n(*arrs)

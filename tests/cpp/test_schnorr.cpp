@@ -148,6 +148,65 @@ static void to_from_bytes() {
   r_bytes[0] -= 1;
   CHECK(SecretKey::from_bytes(r_bytes).has_value());  // r - 1
 }
+// (2x mod q) for a canonical little-endian x: enough host arithmetic to re-represent a point
+static std::array<uint8_t, 32> dbl_mod_q(const uint8_t x[32]) {
+  uint8_t wide[64] = {};
+  unsigned carry = 0;
+  for (int i = 0; i < 32; i++) {
+    const unsigned t = 2u * x[i] + carry;
+    wide[i] = (uint8_t)t;
+    carry = t >> 8;
+  }
+  wide[32] = (uint8_t)carry;
+  return BlsScalar::from_bytes_wide(wide).bytes;
+}
+// /root/reference/tests/keys.rs:17-60, :62-75, :77-127: the same point in another projective
+// representation (all coordinates different) is the same key, verifies the same signatures, and
+// serialises to the same bytes — here (2u, 2v, 2) against (u, v, 1)
+static JubJubExtended rescaled(const JubJubExtended& p) {
+  JubJubExtended q;
+  for (int k = 0; k < 3; k++) {
+    const auto d = dbl_mod_q(p.uvz.data() + 32 * k);
+    std::memcpy(q.uvz.data() + 32 * k, d.data(), 32);
+  }
+  return q;
+}
+static void partial_eq_and_projective_inputs() {
+  Rng rng(77);
+  SecretKey sk = SecretKey::random(rng);
+  BlsScalar message = BlsScalar::random(rng);
+  PublicKey pk = PublicKey::from(sk);
+  PublicKey pk2 = PublicKey::from_raw_unchecked(rescaled(rescaled(pk.as_ref())));
+  CHECK(pk.as_ref().uvz != pk2.as_ref().uvz);
+  CHECK(pk == pk2);
+  CHECK(pk.to_bytes() == pk2.to_bytes());
+  PublicKey other = PublicKey::from(SecretKey::random(rng));
+  CHECK(!(pk2 == other));
+  Signature sig = sk.sign(rng, message);
+  Signature sig2 = sig;
+  sig2.R_ = rescaled(sig.R_);
+  CHECK(pk.verify(sig2, message) && pk2.verify(sig, message) && pk2.verify(sig2, message));
+  CHECK(!other.verify(sig2, message));
+  // batch entry point on re-represented points
+  std::vector<bool> ok = verify_batch({sig, sig2, sig2}, {pk2, pk, other}, {message, message, message});
+  CHECK(ok[0] && ok[1] && !ok[2]);
+  // double and var-generator keys
+  PublicKeyDouble pkd = PublicKeyDouble::from(sk);
+  PublicKeyDouble pkd2 = PublicKeyDouble::from_raw_unchecked(rescaled(pkd.pk()), rescaled(rescaled(pkd.pk_prime())));
+  CHECK(pkd == pkd2);
+  SignatureDouble sigd = sk.sign_double(rng, message);
+  sigd.R_prime_ = rescaled(sigd.R_prime_);
+  CHECK(pkd2.verify(sigd, message) && verify_batch_double({sigd}, {pkd2}, {message})[0]);
+  SecretKeyVarGen skv = SecretKeyVarGen::random(rng);
+  PublicKeyVarGen pkv = PublicKeyVarGen::from(skv);
+  PublicKeyVarGen pkv2 = PublicKeyVarGen::from_raw_unchecked(rescaled(pkv.public_key()), rescaled(pkv.generator()));
+  CHECK(pkv == pkv2);
+  SignatureVarGen sigv = skv.sign(rng, message);
+  CHECK(pkv2.verify(sigv, message) && verify_batch_var_gen({sigv}, {pkv2}, {message})[0]);
+  // a signing key whose generator is held un-normalised signs the same way
+  SecretKeyVarGen skv2 = SecretKeyVarGen::make(skv.sk, rescaled(skv.generator()));
+  CHECK(pkv.verify(skv2.sign(rng, message), message));
+}
 static void random_is_reduced() {
   uint8_t wide[64];
   for (int i = 0; i < 64; i++) wide[i] = 0xff;
@@ -162,6 +221,7 @@ static void random_is_reduced() {
 int main() {
   to_from_bytes();
   random_is_reduced();
+  partial_eq_and_projective_inputs();
   sign_verify();
   test_wrong_keys();
   sign_verify_double();

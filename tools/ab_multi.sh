@@ -9,7 +9,10 @@ for i in $(seq $ROUNDS); do
     python3 bench.py --steps 20 --warmup 3 --no-cpu-baseline 2>/dev/null | python3 -c "
 import json,sys
 d=json.loads(sys.stdin.read().strip().splitlines()[-1])
-m=d['roofline'].get('model',{})
-print('%-10s' % '$which', round(d['value']/1e6,2), 'M/s  step', round(d['ms_per_step'],3), 'verify', round(m.get('kernel_ms',0),3), 'hash', round(m.get('hash_kernel_ms',0),3), 'double', round(d.get('double',{}).get('value',0)/1e6,2), 'vargen', round(d.get('vargen',{}).get('value',0)/1e6,2))"
+k=d['roofline']['kernels']
+ms=lambda pat: next((round(v['ms_per_launch'],3) for n,v in k.items() if pat in n), None)
+g=lambda key: round(d.get(key,{}).get('value',0)/1e6,2)
+print('%-10s' % '$which', 'single', round(d['value']/1e6,2), 'double', g('double'), 'vargen', g('vargen'), 'mixed', g('mixed'), 'ext', g('ext'), 'wire', g('wire'),
+      '| ms: verify1', ms('half<1>'), 'verify2', ms('half<2>'), 'hash1', ms('challenge<false>'), 'hash2', ms('challenge<true>'), 'var', ms('verify_var'))"
   done
 done
