@@ -303,6 +303,10 @@ int dsv_stdrng_vargen_inputs_dev(uint64_t seed, size_t first_item, size_t n, voi
  * dsv_fixed_window_bits() bits), digit magnitude d ---- */
 int dsv_debug_table_entry(int which, int window, int digit, uint8_t out96[96]);
 int dsv_fixed_window_bits(void); /* width of the (signed) fixed-base windows; digit <= 2^(bits-1) */
+/* ---- introspection: the three short scalars of the var-generator kernel (lattice3.h) for (u, c):
+ * per item 128 B = |x| || |y| || |z| (32 B LE each) || sign bytes of x, y, z || padding;
+ * x = z*u, y = z*c (mod 8r), z odd.  u is taken mod 2^252, c mod 2^250. */
+int dsv_debug_lattice3(const uint8_t *u, const uint8_t *c, size_t n, uint8_t *out128);
 /* ---- introspection: field-multiplier self test on the device: out = a*b mod q (canonical) */
 int dsv_debug_fq_mul(const uint8_t *a, const uint8_t *b, size_t n, uint8_t *out);
 

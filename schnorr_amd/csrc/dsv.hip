@@ -295,6 +295,7 @@ struct Workspace {
   uint8_t* valid;
   u32* tables;
 };
+constexpr int kTablesPerLane = 3;  // the var-generator kernel keeps three (Gen, PK, R), the others two
 size_t var_table_bytes(size_t n, int tables_per_lane) {
   return (size_t)verify_grid(n) * kVerifyBlock * kVarLaneWords * 4 * (size_t)tables_per_lane;
 }
@@ -398,7 +399,7 @@ int run_split(Context& ctx, size_t n, void* workspace, hipStream_t user, Part pa
   // wait; record + wait pairs are therefore issued under the lane lock
   std::lock_guard<std::mutex> lk(ctx.lane_mu);
   HIP_TRY(hipEventRecord(lane->fork, user));
-  const size_t tbl_words = var_table_bytes(kSplitItems, 2) / 4;  // per internal stream
+  const size_t tbl_words = var_table_bytes(kSplitItems, kTablesPerLane) / 4;  // per internal stream
   for (int k = 0; k < 2; k++) HIP_TRY(hipStreamWaitEvent(lane->stream[k], lane->fork, 0));
   size_t off = 0;
   for (size_t p = 0; off < n; p++) {
@@ -585,9 +586,9 @@ int dsv_initialized_devices(int* out, int cap) {
 size_t dsv_workspace_bytes(size_t n) {
   // window tables: one launch over n items, or (run_split) two concurrent launches over
   // kSplitItems items each — whichever is larger (they differ when -DDSV_MAX_VERIFY_GRID < 2048)
-  size_t tables = var_table_bytes(n, 2);
-  if (n >= 2 * kSplitItems && tables < 2 * var_table_bytes(kSplitItems, 2))
-    tables = 2 * var_table_bytes(kSplitItems, 2);
+  size_t tables = var_table_bytes(n, kTablesPerLane);
+  if (n >= 2 * kSplitItems && tables < 2 * var_table_bytes(kSplitItems, kTablesPerLane))
+    tables = 2 * var_table_bytes(kSplitItems, kTablesPerLane);
   return align_up(n * 32, 256) + align_up(n, 256) + tables + 256;
 }
 
@@ -1742,6 +1743,22 @@ int dsv_debug_table_entry(int which, int window, int digit, uint8_t out96[96]) {
 }
 
 int dsv_fixed_window_bits(void) { return kFixedBits; }
+
+int dsv_debug_lattice3(const uint8_t* u, const uint8_t* c, size_t n, uint8_t* out128) {
+  if (n && (!u || !c || !out128)) return fail(DSV_ERR_INVALID_ARGUMENT, "null pointer");
+  DSV_HOST_PROLOGUE(n);
+  DSV_HOST_LOCK();
+  if (int r = ensure_stage(ctx, 2 * align_up(n * 32, 256) + align_up(n * 128, 256))) return r;
+  Stager st(ctx.stage);
+  uint8_t *du = st.take(n * 32), *dc = st.take(n * 32), *dout = st.take(n * 128);
+  H2D(du, u, n * 32);
+  H2D(dc, c, n * 32);
+  launch_debug_lattice3(du, dc, n, dout, 0);
+  HIP_TRY(hipGetLastError());
+  D2H(out128, dout, n * 128);
+  HIP_TRY(hipStreamSynchronize(0));
+  return DSV_OK;
+}
 
 int dsv_debug_fq_mul(const uint8_t* a, const uint8_t* b, size_t n, uint8_t* out) {
   if (n && (!a || !b || !out)) return fail(DSV_ERR_INVALID_ARGUMENT, "null pointer");

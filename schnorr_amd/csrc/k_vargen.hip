@@ -4,70 +4,90 @@
 // (/root/reference/src/keys/secret.rs:442, src/keys/public.rs:337-344).
 #include "common.h"
 #include "decode29.h"
+#include "lattice3.h"
 
 namespace dsv {
 
-// a*P + b*Q with one shared doubling chain (Straus); a < 2^252, b < 2^252; the entries of the next
-// window are loaded one group operation ahead
-DSV_DEV Ext var_base_mul2(const u32 (&a)[8], const u32* tp, const u32 (&b)[8], const u32* tq) {
-  u32 ya[8], yb[8];
-  recode_signed4(ya, a);
-  recode_signed4(yb, b);
-  Ext acc = ext_from_niels(load_var_entry(tp, sdigit4(ya, 63)));
-  acc = ext_add_niels(acc, load_var_entry(tq, sdigit4(yb, 63)));
-  RawNiels ea = load_var_entry_raw(tp, sdigit4(ya, 62));
-  RawNiels eb = load_var_entry_raw(tq, sdigit4(yb, 62));
-#pragma unroll 1
-  for (int k = 62; k >= 0; k--) {
-    acc = ext_mul16(acc);
-    const int kn = k > 0 ? k - 1 : 0;  // last round: reloads its own entries, unused
-    acc = ext_add_niels(acc, finish_var_entry(ea));
-    ea = load_var_entry_raw(tp, sdigit4(ya, kn));
-    acc = ext_add_niels(acc, finish_var_entry(eb));
-    eb = load_var_entry_raw(tq, sdigit4(yb, kn));
-  }
-  return acc;
-}
-
+// ok = valid & [ x*Gen + y*PK - z*R == O ] with (x, y, z) the short lattice vector of lattice3.h
+// (x = z*u, y = z*c mod 8r, z odd): a three-base Straus chain of ~43 signed 4-bit windows instead of
+// the reference equation's two-base chain of 63 (r01 / r02).  Three per-lane window tables (Gen, PK,
+// R); the entry of the NEXT addition is loaded while the current one runs, so two entries are live
+// at any time, as in the two-base kernels.
 __global__ void __launch_bounds__(kVerifyBlock, kWavesVerify)
 k_verify_var(const uint8_t* __restrict__ u, const uint8_t* __restrict__ c,
              const uint8_t* __restrict__ PK_uv, const uint8_t* __restrict__ Gen_uv,
              const uint8_t* __restrict__ R_uv, const uint8_t* __restrict__ valid, size_t n,
              uint8_t* __restrict__ ok, u32* __restrict__ var_tables) {
-  u32* tp = var_tables + ((size_t)blockIdx.x * kVerifyBlock + threadIdx.x) * (2 * kVarLaneWords);
-  u32* tq = tp + kVarLaneWords;
+  u32* tg = var_tables + ((size_t)blockIdx.x * kVerifyBlock + threadIdx.x) * (3 * kVarLaneWords);
+  u32* tp = tg + kVarLaneWords;
+  u32* tr = tp + kVarLaneWords;
 #pragma unroll 1
   for (size_t base = (size_t)blockIdx.x * kVerifyBlock; base < n;
        base += (size_t)gridDim.x * kVerifyBlock) {
     const size_t i = base + threadIdx.x;
     if (i >= n) continue;
     bool good = valid[i] != 0;
+    u32 yx[8], yy[8], yz[8];
+    int sx, sy, sz, top;
+    {
+      u32 us[8], cs[8], mx[8], my[8], mz[8];
+      bool nx, ny, nz;
+      load_words8(us, u, i);
+      load_words8(cs, c, i);
+      good &= words_lt(us, kR32);
+      if (!words_lt(us, kR32)) us[7] &= 0x0fffffffu;  // keep the scalars in range; verdict is 0 anyway
+      lattice3_scalars(mx, my, mz, nx, ny, nz, us, cs);
+      recode_signed4(yx, mx);
+      recode_signed4(yy, my);
+      recode_signed4(yz, mz);
+      u32 nzd[8];
+#pragma unroll
+      for (int k = 0; k < 8; k++)
+        nzd[k] = (yx[k] ^ 0x88888888u) | (yy[k] ^ 0x88888888u) | (yz[k] ^ 0x88888888u);
+      top = top_digit4(nzd);
+      sx = nx ? -1 : 1;
+      sy = ny ? -1 : 1;
+      sz = nz ? 1 : -1;  // the chain adds (-z) * R
+    }
     {
       Fe gu, gv;
       good &= load_fq(gu, Gen_uv, 2 * i);
       good &= load_fq(gv, Gen_uv, 2 * i + 1);
-      build_var_table(tp, gu, gv);
+      build_var_table(tg, gu, gv);
     }
     {
       Fe pku, pkv;
       good &= load_fq(pku, PK_uv, 2 * i);
       good &= load_fq(pkv, PK_uv, 2 * i + 1);
-      build_var_table(tq, pku, pkv);
+      build_var_table(tp, pku, pkv);
     }
-    Ext acc;
     {
-      u32 us[8], cs[8];
-      load_words8(us, u, i);
-      load_words8(cs, c, i);
-      good &= words_lt(us, kR32);
-      if (!words_lt(us, kR32)) us[7] &= 0x0fffffffu;  // keep the recoding in range; verdict is 0 anyway
-      acc = var_base_mul2(us, tp, cs, tq);
+      Fe ru, rv;
+      good &= load_fq(ru, R_uv, 2 * i);
+      good &= load_fq(rv, R_uv, 2 * i + 1);
+      build_var_table(tr, ru, rv);
     }
-    Fe ru, rv;
-    good &= load_fq(ru, R_uv, 2 * i);
-    good &= load_fq(rv, R_uv, 2 * i + 1);
-    bool eq = ext_eq_affine(acc, ru, rv);
-    ok[i] = (good & eq) ? 1 : 0;
+    Ext acc = ext_from_niels(load_var_entry(tg, sx * sdigit4(yx, top)));
+    acc = ext_add_niels(acc, load_var_entry(tp, sy * sdigit4(yy, top)));
+    acc = ext_add_niels(acc, load_var_entry(tr, sz * sdigit4(yz, top)));
+    {
+      const int k0 = top > 0 ? top - 1 : 0;
+      RawNiels ea = load_var_entry_raw(tg, sx * sdigit4(yx, k0));
+#pragma unroll 1
+      for (int k = top - 1; k >= 0; k--) {
+        acc = ext_mul16(acc);
+        const RawNiels eb = load_var_entry_raw(tp, sy * sdigit4(yy, k));
+        acc = ext_add_niels(acc, finish_var_entry(ea));
+        const RawNiels ec = load_var_entry_raw(tr, sz * sdigit4(yz, k));
+        acc = ext_add_niels(acc, finish_var_entry(eb));
+        const int kn = k > 0 ? k - 1 : 0;  // last round: reloads its own entry, unused
+        ea = load_var_entry_raw(tg, sx * sdigit4(yx, kn));
+        acc = ext_add_niels(acc, finish_var_entry(ec));
+      }
+    }
+    // T == O  <=>  u == 0 and v == z
+    good &= (bool)((int)fe_is_zero_canon(fe_canon(acc.u)) & (int)fe_equal(acc.v, acc.z));
+    ok[i] = good ? 1 : 0;
   }
 }
 
@@ -101,6 +121,30 @@ k_var_base_points(const uint8_t* __restrict__ scalar, const uint8_t* __restrict_
       store_poison(out_uv, 2 * i + 1);
     }
   }
+}
+
+// introspection for tests: the scalars the kernel above would use for (u, c): out = |x| || |y| ||
+// |z| (3 x 32 bytes LE) || sign bytes of x, y, z || 29 zero bytes (128 B per item)
+__global__ void __launch_bounds__(64)
+k_debug_lattice3(const uint8_t* __restrict__ u, const uint8_t* __restrict__ c, size_t n,
+                 uint8_t* __restrict__ out) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  u32 us[8], cs[8], mx[8], my[8], mz[8];
+  bool nx, ny, nz;
+  load_words8(us, u, i);
+  load_words8(cs, c, i);
+  us[7] &= 0x0fffffffu;
+  cs[7] &= 0x03ffffffu;
+  lattice3_scalars(mx, my, mz, nx, ny, nz, us, cs);
+  store_words8(out, 4 * i, mx);
+  store_words8(out, 4 * i + 1, my);
+  store_words8(out, 4 * i + 2, mz);
+  const u32 sg[8] = {(nx ? 1u : 0u) | (ny ? 0x100u : 0u) | (nz ? 0x10000u : 0u), 0, 0, 0, 0, 0, 0, 0};
+  store_words8(out, 4 * i + 3, sg);
+}
+void launch_debug_lattice3(const uint8_t* u, const uint8_t* c, size_t n, uint8_t* out, hipStream_t s) {
+  hipLaunchKernelGGL(k_debug_lattice3, dim3(grid_for(n, 64)), dim3(64), 0, s, u, c, n, out);
 }
 
 void launch_verify_var(const uint8_t* u, const uint8_t* c, const uint8_t* PK_uv, const uint8_t* Gen_uv,

@@ -304,6 +304,19 @@ def fixed_window_bits():
     return int(_lib.load().dsv_fixed_window_bits())
 
 
+def debug_lattice3(u, c):
+    """(x, y, z) the var-generator kernel uses for (u, c), as Python integers per item."""
+    u, c = _arr(u, 32), _arr(c, 32)
+    n = _same_n(u, c)
+    out = np.zeros((n, 128), dtype=np.uint8)
+    _lib.check(_lib.load().dsv_debug_lattice3(_p(u), _p(c), ctypes.c_size_t(n), _p(out)))
+    res = []
+    for row in out:
+        v = [int.from_bytes(row[32 * k:32 * k + 32].tobytes(), "little") for k in range(3)]
+        res.append(tuple(-v[k] if row[96 + k] else v[k] for k in range(3)))
+    return res
+
+
 def debug_fq_mul(a, b):
     a, b = _arr(a, 32), _arr(b, 32)
     n = _same_n(a, b)

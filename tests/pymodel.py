@@ -201,3 +201,62 @@ def verify_single_half(u, R, PK, m):
     t = padd(pmul(GEN, w), pmul(PK, a))
     t = padd(t, pmul(R, b) if bn else pmul(pneg(R), b))
     return t == IDENTITY
+
+
+# ---- three short scalars for the var-generator equation (schnorr_amd/csrc/lattice3.h) --------
+def lattice3(u, c, tbound=float(1 << 31), max_batches=24, max_passes=40):
+    """(x, y, z): x = z*u, y = z*c (mod 8r), z odd — the device algorithm on Python integers and
+    floats: greedy pairwise reduction of (8r,0,0), (0,8r,0), (u,c,1), Lehmer style (passes on
+    double-precision images, the accumulated transformation applied exactly per batch)."""
+    N = 8 * R_ORDER
+    B = [[N, 0, 0], [0, N, 0], [u, c, 1]]
+    pairs = ((0, 1), (0, 2), (1, 2), (1, 0), (2, 0), (2, 1))
+    for _ in range(max_batches):
+        D = [[float(x) for x in v] for v in B]
+        T = [[1.0, 0.0, 0.0], [0.0, 1.0, 0.0], [0.0, 0.0, 1.0]]
+        any_change = stop = False
+        for _p in range(max_passes):
+            changed = False
+            for i, j in pairs:
+                njj = D[j][0] * D[j][0] + D[j][1] * D[j][1] + D[j][2] * D[j][2]
+                dij = D[i][0] * D[j][0] + D[i][1] * D[j][1] + D[i][2] * D[j][2]
+                q = float(round(dij / njj)) if njj > 0 else 0.0
+                nt = [a - q * b for a, b in zip(T[i], T[j])]
+                ok = max(abs(x) for x in nt) < tbound and not stop
+                if q != 0 and not ok:
+                    stop = True
+                if q != 0 and ok:
+                    T[i] = nt
+                    D[i] = [a - q * b for a, b in zip(D[i], D[j])]
+                    changed = True
+            any_change |= changed
+            if stop or not changed:
+                break
+        if not any_change:
+            break
+        Ti = [[int(x) for x in r] for r in T]
+        B = [[sum(Ti[i][k] * B[k][m] for k in range(3)) for m in range(3)] for i in range(3)]
+    best, blen = (u, c, 1), 252
+    for v in B:
+        ln = max(abs(x).bit_length() for x in v)
+        if v[2] & 1 and ln < blen:
+            best, blen = tuple(v), ln
+    return best
+
+
+def verify_vargen(u, R, PK, Gen, m):
+    """/root/reference/src/keys/public.rs:401-415: u*Gen + c*PK == R with c = H(R, m)"""
+    c = challenge(R, m)
+    return padd(pmul(Gen, u), pmul(PK, c)) == R
+
+
+def verify_vargen_lattice(u, R, PK, Gen, m):
+    """x*Gen + y*PK - z*R == O — must equal verify_vargen on every on-curve input."""
+    c = challenge(R, m)
+    x, y, z = lattice3(u, c)
+
+    def smul(p, k):
+        return pmul(p, k) if k >= 0 else pmul(pneg(p), -k)
+
+    t = padd(padd(smul(Gen, x), smul(PK, y)), smul(R, -z))
+    return t == IDENTITY

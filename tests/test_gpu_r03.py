@@ -278,3 +278,66 @@ def test_bench_rehearses_larger_world_sizes_on_one_gpu(world, config):
     assert line["launcher"] == "self-spawned" and line["value"] > 0
     if config == "single":
         assert line["mixed"]["n_gpus"] == world
+
+
+def test_device_lattice_scalars_satisfy_the_congruences(engine):
+    """lattice3.h on the device: x = z*u, y = z*c (mod 8r), z odd, ~170 bits; degenerate inputs fall
+    back to (u, c, 1) or still give a valid triple.  (The floating-point decisions may differ from
+    the Python model's: only the congruences, the parity and the size are properties.)"""
+    import random
+    rnd = random.Random(77)
+    N8 = 8 * M.R_ORDER
+    edge = [(0, 0), (1, 1), (0, 5), (M.R_ORDER - 1, (1 << 250) - 1), (12345, 0), (M.R_ORDER - 1, 1),
+            (1 << 200, 1 << 100), (M.R_ORDER - 1, (1 << 250) - 2), (7, (1 << 250) - 3), (1, 0), (0, 1)]
+    cases = edge + [(rnd.randrange(M.R_ORDER), rnd.getrandbits(250)) for _ in range(2000)]
+    le = lambda xs: np.frombuffer(b"".join(M.le32(x) for x in xs), np.uint8).reshape(len(xs), 32).copy()
+    got = engine.debug_lattice3(le([u for u, _ in cases]), le([c for _, c in cases]))
+    sizes = []
+    for (u, c), (x, y, z) in zip(cases, got):
+        assert (x - z * u) % N8 == 0 and (y - z * c) % N8 == 0, (u, c)
+        assert z & 1 and 0 < abs(z) < M.R_ORDER
+        assert max(abs(x), abs(y), abs(z)) < (1 << 252)
+        sizes.append(max(abs(v).bit_length() for v in (x, y, z)))
+    rand = sorted(sizes[len(edge):])
+    assert rand[len(rand) // 2] <= 171 and rand[int(0.999 * len(rand))] <= 176, (rand[len(rand) // 2], rand[-1])
+
+
+def test_vargen_order8_torsion_components_valid_and_invalid(engine):
+    """Generators, keys and nonce points carrying an order-8 component through the three-scalar
+    kernel: valid exactly when the torsion parts cancel — the reference equation's verdicts (oracle)."""
+    import test_halfgcd as TH
+    t8 = TH.order8_point()
+    rnd = TH.rnd
+    rows = {"u": [], "R": [], "PK": [], "Gen": [], "m": []}
+    want = []
+    while sum(want) < 3 or len(want) < 48:
+        sk, m, rr, g = (rnd.randrange(1, M.R_ORDER), rnd.randrange(M.Q), rnd.randrange(1, M.R_ORDER),
+                        rnd.randrange(1, M.R_ORDER))
+        k0, k1 = rnd.randrange(8), rnd.randrange(1, 8)
+        gen0 = M.pmul(M.GEN, g)
+        gen = M.padd(gen0, M.pmul(t8, k0))
+        pk = M.padd(M.pmul(gen0, sk), M.pmul(t8, k1))
+        for k2 in range(8):
+            R = M.padd(M.pmul(gen0, rr), M.pmul(t8, k2))
+            c = M.challenge(R, m)
+            u = (rr - c * sk) % M.R_ORDER
+            rows["u"].append(np.frombuffer(M.le32(u), np.uint8))
+            rows["R"].append(np.frombuffer(M.point_bytes(R), np.uint8))
+            rows["PK"].append(np.frombuffer(M.point_bytes(pk), np.uint8))
+            rows["Gen"].append(np.frombuffer(M.point_bytes(gen), np.uint8))
+            rows["m"].append(np.frombuffer(M.le32(m), np.uint8))
+            want.append(int((u * k0 + c * k1 - k2) % 8 == 0))
+    a = {k: np.stack(v) for k, v in rows.items()}
+    cpu = O.verify_vargen(a["u"], a["R"], a["PK"], a["Gen"], a["m"], nthreads=8)
+    assert list(cpu) == want
+    got = engine.verify_vargen(a["u"], a["R"], a["PK"], a["Gen"], a["m"])
+    assert list(got) == want
+    # identity / small-order generator and key, default signature: complete formulas, no special case
+    ident = np.frombuffer(M.point_bytes(M.IDENTITY), np.uint8)
+    z32 = np.zeros(32, np.uint8)
+    small = np.frombuffer(M.point_bytes(t8), np.uint8)
+    spec = {"u": np.stack([z32, z32, a["u"][0]]), "R": np.stack([ident, small, a["R"][0]]),
+            "PK": np.stack([ident, small, ident]), "Gen": np.stack([ident, ident, small]),
+            "m": np.stack([a["m"][0]] * 3)}
+    assert np.array_equal(engine.verify_vargen(*(spec[k] for k in ("u", "R", "PK", "Gen", "m"))),
+                          O.verify_vargen(*(spec[k] for k in ("u", "R", "PK", "Gen", "m"))))

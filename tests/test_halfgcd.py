@@ -73,3 +73,42 @@ def test_half_scalar_check_is_exact_with_torsion():
             valid += want
             assert not M.verify_single_half((u + 1) % M.R_ORDER, R, pk, m)
     assert valid >= 3  # each (k1, k2) pair is valid with probability 1/8
+
+
+def test_lattice3_congruences_parity_and_size():
+    """lattice3.h (var-generator kernel): x = z*u, y = z*c (mod 8r), z odd, all three ~170 bits"""
+    sizes = []
+    edge = [(0, 0), (1, 1), (0, 5), (M.R_ORDER - 1, (1 << 250) - 1), (12345, 0), (M.R_ORDER - 1, 1),
+            (1 << 200, 1 << 100), (M.R_ORDER - 1, (1 << 250) - 2), (7, (1 << 250) - 3)]
+    for u, c in edge + [(rnd.randrange(M.R_ORDER), rnd.getrandbits(250)) for _ in range(300)]:
+        x, y, z = M.lattice3(u, c)
+        assert (x - z * u) % N == 0 and (y - z * c) % N == 0
+        assert z & 1 and 0 < abs(z) < M.R_ORDER
+        assert max(abs(x), abs(y), abs(z)) < (1 << 252)
+        sizes.append(max(abs(v).bit_length() for v in (x, y, z)))
+    rand = sorted(sizes[len(edge):])
+    assert rand[len(rand) // 2] <= 171 and rand[-1] <= 176
+
+
+def test_lattice3_check_is_exact_with_torsion():
+    """The three-scalar form gives the reference's verdict for generators, keys and nonce points with a
+    small-order component: valid iff the torsion parts cancel (u*k0 + c*k1 = k2 mod 8)."""
+    t8 = order8_point()
+    valid = 0
+    for _ in range(6):
+        sk, m, rr, g = (rnd.randrange(1, M.R_ORDER), rnd.randrange(M.Q), rnd.randrange(1, M.R_ORDER),
+                        rnd.randrange(1, M.R_ORDER))
+        k0, k1 = rnd.randrange(8), rnd.randrange(8)
+        gen0 = M.pmul(M.GEN, g)
+        gen = M.padd(gen0, M.pmul(t8, k0))                   # generator with a small-order component
+        pk = M.padd(M.pmul(gen0, sk), M.pmul(t8, k1))        # so has the key
+        for k2 in range(8):
+            R = M.padd(M.pmul(gen0, rr), M.pmul(t8, k2))
+            c = M.challenge(R, m)
+            u = (rr - c * sk) % M.R_ORDER
+            want = M.verify_vargen(u, R, pk, gen, m)
+            assert M.verify_vargen_lattice(u, R, pk, gen, m) == want
+            assert want == ((u * k0 + c * k1 - k2) % 8 == 0)
+            valid += want
+            assert not M.verify_vargen_lattice((u + 1) % M.R_ORDER, R, pk, gen, m)
+    assert valid >= 2
