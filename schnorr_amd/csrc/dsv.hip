@@ -172,6 +172,7 @@ struct Context {
   bool split = true;         // DSV_SPLIT=0: one stream, whole batch per launch
   bool fuse_double = true;   // DSV_DOUBLE_FUSED=0: two single-equation launches per double batch (r01; A/B)
   bool quad = true;          // DSV_QUAD=0: batches of <= 2^14 items also take the one-lane-per-signature kernel
+  bool small_overlap = true; // DSV_SMALL_OVERLAP=0: small batches build their window tables inside the verify kernel
   u32* table[2] = {nullptr, nullptr};  // fixed-base tables for G, G'
   u32* ts_cancel = nullptr;            // square-root tables (decode29.h)
   uint8_t* ts_hash = nullptr;
@@ -321,10 +322,10 @@ struct Stager {
 // the dominant kernel: one lane per signature, or four (small batches); same verdicts
 void launch_verify_fixed(const Context& ctx, bool accumulate, const void* u, const void* c,
                          const void* PK_uv, const void* R_uv, int which, const void* valid,
-                         size_t n, void* ok, u32* tables, hipStream_t s) {
+                         size_t n, void* ok, u32* tables, hipStream_t s, bool tables_ready = false) {
   const ChainOperands op{(const uint8_t*)PK_uv, (const uint8_t*)R_uv, ctx.table[which]};
   if (ctx.quad && n <= kQuadMaxItems)
-    launch_verify_half_quad(1, accumulate, (const uint8_t*)u, (const uint8_t*)c, op, op,
+    launch_verify_half_quad(1, accumulate, tables_ready, (const uint8_t*)u, (const uint8_t*)c, op, op,
                             (const uint8_t*)valid, n, (uint8_t*)ok, tables, s);
   else
     launch_verify_half(1, accumulate, (const uint8_t*)u, (const uint8_t*)c, op, op,
@@ -334,19 +335,20 @@ void launch_verify_fixed(const Context& ctx, bool accumulate, const void* u, con
 // (DSV_DOUBLE_FUSED=0: the second pass ANDs into ok[])
 void launch_verify_fixed_double(const Context& ctx, const void* u, const void* c, const void* PK_uv,
                                 const void* R_uv, const void* PKp_uv, const void* Rp_uv,
-                                const void* valid, size_t n, void* ok, u32* tables, hipStream_t s) {
+                                const void* valid, size_t n, void* ok, u32* tables, hipStream_t s,
+                                bool tables_ready = false) {
   if (ctx.fuse_double) {
     const ChainOperands op0{(const uint8_t*)PK_uv, (const uint8_t*)R_uv, ctx.table[0]};
     const ChainOperands op1{(const uint8_t*)PKp_uv, (const uint8_t*)Rp_uv, ctx.table[1]};
     if (ctx.quad && n <= kQuadMaxItems)
-      launch_verify_half_quad(2, false, (const uint8_t*)u, (const uint8_t*)c, op0, op1,
+      launch_verify_half_quad(2, false, tables_ready, (const uint8_t*)u, (const uint8_t*)c, op0, op1,
                               (const uint8_t*)valid, n, (uint8_t*)ok, tables, s);
     else
       launch_verify_half(2, false, (const uint8_t*)u, (const uint8_t*)c, op0, op1,
                          (const uint8_t*)valid, n, (uint8_t*)ok, tables, s);
     return;
   }
-  launch_verify_fixed(ctx, false, u, c, PK_uv, R_uv, 0, valid, n, ok, tables, s);
+  launch_verify_fixed(ctx, false, u, c, PK_uv, R_uv, 0, valid, n, ok, tables, s, tables_ready);
   launch_verify_fixed(ctx, true, u, c, PKp_uv, Rp_uv, 1, valid, n, ok, tables, s);
 }
 
@@ -499,6 +501,8 @@ int dsv_init(int device) {
   ctx.split = !(split && strcmp(split, "0") == 0);
   const char* quad = getenv("DSV_QUAD");
   ctx.quad = !(quad && strcmp(quad, "0") == 0);
+  const char* sov = getenv("DSV_SMALL_OVERLAP");
+  ctx.small_overlap = !(sov && strcmp(sov, "0") == 0);
   const char* fused = getenv("DSV_DOUBLE_FUSED");
   ctx.fuse_double = !(fused && strcmp(fused, "0") == 0);
   ctx.ready.store(true, std::memory_order_release);
@@ -622,6 +626,24 @@ int dsv_challenge_double_dev(const void* R_uv, const void* Rp_uv, const void* m,
 
 namespace {
 // bodies shared by the device-pointer entry points and the host pipeline (context resolved)
+// Small batches (eight-lane kernel): the window tables of (PK, R) do not depend on the challenge, so
+// they are built on one of the lane's internal streams WHILE k_challenge runs on the caller's: fork
+// by an event here; the caller enqueues the hash, then waits for the returned join event on its own
+// stream in front of the verify kernel.  nullptr: not a small batch (or the overlap is off, or no
+// lane could be had) — the verify kernel then builds its tables itself.
+hipEvent_t prep_tables_beside_hash(Context& ctx, const void* PK_uv, const void* R_uv, size_t n,
+                                   u32* tables, hipStream_t user) {
+  if (!(ctx.quad && ctx.small_overlap && n <= kQuadMaxItems)) return nullptr;
+  SplitLane* lane = nullptr;
+  if (acquire_lane(ctx, user, lane) != DSV_OK) return nullptr;
+  std::lock_guard<std::mutex> lk(ctx.lane_mu);
+  if (hipEventRecord(lane->fork, user) != hipSuccess ||
+      hipStreamWaitEvent(lane->stream[0], lane->fork, 0) != hipSuccess)
+    return nullptr;
+  launch_prep_var_tables((const uint8_t*)PK_uv, (const uint8_t*)R_uv, n, tables, lane->stream[0]);
+  if (hipEventRecord(lane->join[0], lane->stream[0]) != hipSuccess) return nullptr;
+  return lane->join[0];
+}
 int verify_single_on(Context& ctx, const void* u, const void* R_uv, const void* PK_uv, const void* m,
                      size_t n, void* ok, void* workspace, hipStream_t stream) {
   const uint8_t *pu = (const uint8_t*)u, *pR = (const uint8_t*)R_uv, *pPK = (const uint8_t*)PK_uv,
@@ -630,9 +652,14 @@ int verify_single_on(Context& ctx, const void* u, const void* R_uv, const void* 
   Context* cp = &ctx;
   return run_split(ctx, n, workspace, stream,
                    [=](size_t off, size_t cnt, const Workspace& w, hipStream_t s) {
+    // (only for an unsplit call: inside run_split's loop the lane lock is held and cnt > 2^14 anyway,
+    //  except for a short last part, which simply builds its tables in the kernel)
+    hipEvent_t ready = cnt == n ? prep_tables_beside_hash(*cp, pPK + 64 * off, pR + 64 * off, cnt, w.tables, s)
+                                : nullptr;
     launch_challenge(false, pR + 64 * off, (const uint8_t*)nullptr, pm + 32 * off, cnt, w.c, w.valid, s);
+    if (ready && hipStreamWaitEvent(s, ready, 0) != hipSuccess) return;  // (surfaces through hipGetLastError)
     launch_verify_fixed(*cp, false, pu + 32 * off, w.c, pPK + 64 * off, pR + 64 * off, 0, w.valid,
-                        cnt, pok + off, w.tables, s);
+                        cnt, pok + off, w.tables, s, ready != nullptr);
   });
 }
 int verify_double_on(Context& ctx, const void* u, const void* R_uv, const void* Rp_uv,
@@ -644,9 +671,15 @@ int verify_double_on(Context& ctx, const void* u, const void* R_uv, const void* 
   Context* cp = &ctx;
   return run_split(ctx, n, workspace, stream,
                    [=](size_t off, size_t cnt, const Workspace& w, hipStream_t s) {
+    // (only for an unsplit call: inside run_split's loop the lane lock is held and cnt > 2^14 anyway,
+    //  except for a short last part, which simply builds its tables in the kernel)
+    hipEvent_t ready = cnt == n ? prep_tables_beside_hash(*cp, pPK + 64 * off, pR + 64 * off, cnt, w.tables, s)
+                                : nullptr;
     launch_challenge(true, pR + 64 * off, pRp + 64 * off, pm + 32 * off, cnt, w.c, w.valid, s);
+    if (ready && hipStreamWaitEvent(s, ready, 0) != hipSuccess) return;
     launch_verify_fixed_double(*cp, pu + 32 * off, w.c, pPK + 64 * off, pR + 64 * off,
-                               pPKp + 64 * off, pRp + 64 * off, w.valid, cnt, pok + off, w.tables, s);
+                               pPKp + 64 * off, pRp + 64 * off, w.valid, cnt, pok + off, w.tables, s,
+                               ready != nullptr);
   });
 }
 int verify_vargen_on(Context& ctx, const void* u, const void* R_uv, const void* PK_uv,

@@ -30,8 +30,8 @@ constexpr int kVerifyBlock = 64;        // ONE wave per workgroup: a finished wa
 constexpr unsigned kMaxVerifyGrid = 4096;                     // 16 single-wave workgroups per CU
 constexpr int kWavesVerify = 2, kWavesHash = 2;               // resident waves per SIMD (launch bounds)
 
-// ---- small batches: four lanes per signature (k_quad.hip) ----------------------------------
-constexpr int kQuadBlock = 256;              // 64 signatures per workgroup
+// ---- small batches: eight lanes per signature (k_quad.hip) ---------------------------------
+constexpr int kQuadBlock = 256;              // 32 signatures per workgroup
 constexpr size_t kQuadMaxItems = (size_t)1 << 14;
 
 // ---- mixed-batch split (k_misc.hip) ---------------------------------------------------------
@@ -64,10 +64,14 @@ void launch_challenge(bool dbl, const uint8_t* R_uv, const uint8_t* Rp_uv, const
 void launch_verify_half(int nchain, bool accumulate, const uint8_t* u, const uint8_t* c,
                         ChainOperands op0, ChainOperands op1, const uint8_t* valid, size_t n,
                         uint8_t* ok, uint32_t* var_tables, hipStream_t s);
-// ---- k_quad.hip: the same for n <= kQuadMaxItems, four lanes per signature ---------------------
-void launch_verify_half_quad(int nchain, bool accumulate, const uint8_t* u, const uint8_t* c,
-                             ChainOperands op0, ChainOperands op1, const uint8_t* valid, size_t n,
-                             uint8_t* ok, uint32_t* var_tables, hipStream_t s);
+// ---- k_quad.hip: the same for n <= kQuadMaxItems, eight lanes per signature; tables_ready: the
+// window tables of the FIRST equation's (PK, R) were built by launch_prep_var_tables already ----
+void launch_verify_half_quad(int nchain, bool accumulate, bool tables_ready, const uint8_t* u,
+                             const uint8_t* c, ChainOperands op0, ChainOperands op1,
+                             const uint8_t* valid, size_t n, uint8_t* ok, uint32_t* var_tables,
+                             hipStream_t s);
+void launch_prep_var_tables(const uint8_t* PK_uv, const uint8_t* R_uv, size_t n, uint32_t* var_tables,
+                            hipStream_t s);
 // ---- k_vargen.hip ----------------------------------------------------------------------------
 void launch_verify_var(const uint8_t* u, const uint8_t* c, const uint8_t* PK_uv, const uint8_t* Gen_uv,
                        const uint8_t* R_uv, const uint8_t* valid, size_t n, uint8_t* ok,

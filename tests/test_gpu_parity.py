@@ -753,7 +753,7 @@ def test_alternative_code_paths_in_subprocesses(engine):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     expr = ("tampering or torsion or crafted or identity_small_order or full_size_batch_properties "
             "or golden_vectors")
-    for extra in ({"DSV_SPLIT": "0"}, {"DSV_QUAD": "0", "DSV_DOUBLE_FUSED": "0"}):
+    for extra in ({"DSV_SPLIT": "0", "DSV_SMALL_OVERLAP": "0"}, {"DSV_QUAD": "0", "DSV_DOUBLE_FUSED": "0"}):
         env = dict(os.environ)
         env.update(extra)
         r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_gpu_parity.py"),

@@ -1,5 +1,5 @@
 import sys, time, torch
-sys.path.insert(0, '/root/repo')
+sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))))
 from schnorr_amd import engine as E, workload as W
 E.init(0)
 n = 1 << 18

@@ -1,5 +1,5 @@
 import time, sys
-sys.path.insert(0,'/root/repo')
+sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))))
 import torch
 from schnorr_amd import engine as E
 t0=time.perf_counter(); E.init(0); torch.cuda.synchronize(); t1=time.perf_counter()

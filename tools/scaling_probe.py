@@ -1,6 +1,6 @@
 """Kernel time vs batch size: T(n) = a + b n for the two kernels of a single verification."""
 import sys, torch
-sys.path.insert(0, '/root/repo')
+sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))))
 from schnorr_amd import engine as E, workload as W
 E.init(0)
 dev = "cuda:0"

@@ -1,5 +1,5 @@
 import sys, time
-sys.path.insert(0,'/root/repo')
+sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))))
 import torch
 from schnorr_amd import engine as E, workload as W
 E.init(0)
