@@ -598,28 +598,31 @@ def main():
             k, sample, ", ".join(checked))
         # host-buffer path of the C ABI (PCIe-inclusive), never the headline value
         hu, hR, hPK, hm = (h(batch[x], n) for x in ("u", "R", "PK", "m"))
-        E.verify_single(hu, hR, hPK, hm)  # warm: staging buffers sized for this batch
-        th0 = time.perf_counter()
-        E.verify_single(hu, hR, hPK, hm)
-        th = time.perf_counter() - th0
+        def host_best(fn, reps=3):
+            """best of `reps` whole calls after one warm call (staging buffers sized for the batch):
+            a host call's time moves by +-10 % with whatever else the box's CPU share is doing"""
+            got = fn()
+            best = 1e9
+            for _ in range(reps):
+                t0_ = time.perf_counter()
+                got = fn()
+                best = min(best, time.perf_counter() - t0_)
+            return best, got
+
+        th, _ = host_best(lambda: E.verify_single(hu, hR, hPK, hm))
         out["host_path"] = {"value": n / th, "unit": "verifies/s",
-                            "note": "dsv_verify_single on %d host-resident items incl. PCIe staging" % n}
+                            "note": "dsv_verify_single on %d host-resident items incl. PCIe staging; best "
+                                    "of 3 calls (so are host_path_ext and wire.host)" % n}
         if "ext" in out:
             # what the Rust / C++ verify_batch binds: projective points from host memory (256 B per
             # item instead of 192), normalised on the device
-            E.verify_single_ext(hu, hR_uvz, hPK_uvz, hm)
-            te0 = time.perf_counter()
-            got = E.verify_single_ext(hu, hR_uvz, hPK_uvz, hm)
-            te = time.perf_counter() - te0
+            te, got = host_best(lambda: E.verify_single_ext(hu, hR_uvz, hPK_uvz, hm))
             if (got != batch["expected"].cpu().numpy()).any():
                 raise SystemExit("host projective-input verdicts differ from the expected pattern")
             out["host_path_ext"] = {"value": n / te, "unit": "verifies/s",
                                     "note": "dsv_verify_single_ext on %d host-resident items (u, v, z "
                                             "points: 256 B per item) incl. PCIe staging" % n}
-            E.verify_single_wire(hsig, hpk, hm)
-            tw0 = time.perf_counter()
-            got = E.verify_single_wire(hsig, hpk, hm)
-            tw = time.perf_counter() - tw0
+            tw, got = host_best(lambda: E.verify_single_wire(hsig, hpk, hm))
             if (got != batch["expected"].cpu().numpy()).any():
                 raise SystemExit("host wire-format verdicts differ from the expected pattern")
             out["wire"]["host"] = {"value": n / tw, "unit": "verifies/s",

@@ -30,6 +30,7 @@
 #include <hip/hip_runtime.h>
 
 #include <atomic>
+#include <chrono>
 #include <condition_variable>
 #include <cstdarg>
 #include <cstdio>
@@ -899,7 +900,13 @@ struct HostIn {
   const uint8_t* p;
   size_t bytes;
 };
-constexpr size_t kPipeChunk = (size_t)1 << 17;  // 2048 waves: one chunk fills every SIMD twice
+// Chunk sizes double from 2^15 up to 2^18 items: the GPU starts after ~0.3 ms of staging, every
+// gather runs under the previous (half as long) chunk's kernels, and from the fourth chunk on the
+// launches are long enough to run near the device-resident rate (r03, same box, 2^20 items: chunks
+// capped at 2^17 as in r02: 68.0 M/s affine / 59.6 projective; 2^18: 72.4 / 63.6; two, three or
+// four slots: equal; profiles/r03/host_paths.txt)
+constexpr size_t kPipeChunk = (size_t)1 << 18;
+constexpr size_t kPipeFirstChunk = (size_t)1 << 15;
 
 inline int host_copy_threads() {
   static const int t = [] {
@@ -928,11 +935,10 @@ int run_pipelined(Context& ctx, const HostIn (&ins)[NIN], uint8_t* ok, size_t n,
   const size_t host_need = cap_off + align_up(chunk, 256);
   const size_t ws_bytes = align_up(dsv_workspace_bytes(chunk), 256);
   const size_t dev_need = host_need + ws_bytes + chunk * extra_item_bytes + 16 * 256;
-  // ramp: the first two chunks are short (2^15, 2^16 items) so that the GPU starts after ~0.3 ms
-  // of staging instead of a full chunk's ~1.5 ms; from the third on every chunk is kPipeChunk
   auto chunk_len = [&](size_t c, size_t left) {
-    size_t want = c == 0 ? kPipeChunk / 4 : (c == 1 ? kPipeChunk / 2 : kPipeChunk);
-    if (n <= kPipeChunk) want = n;  // one small call: no ramp
+    size_t want = c < 4 ? kPipeFirstChunk << c : kPipeChunk;
+    if (want > kPipeChunk) want = kPipeChunk;
+    if (n <= 2 * kPipeFirstChunk) want = n;  // one small call: a single chunk
     return left < want ? left : want;
   };
   size_t nchunks = 0;
@@ -948,11 +954,19 @@ int run_pipelined(Context& ctx, const HostIn (&ins)[NIN], uint8_t* ok, size_t n,
     return DSV_OK;
   };
   size_t done = 0;
+  // DSV_PIPE_TRACE=1: per call, where the host thread's time went (stderr)
+  static const bool trace = getenv("DSV_PIPE_TRACE") != nullptr;
+  double t_drain = 0, t_copy = 0, t_enq = 0;
+  auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+  const double t_begin = now();
   for (size_t c = 0; done < n; c++) {
     const int sl = (int)(c % kPipeSlots);
     hipStream_t st = ctx.pipe_stream[sl];
     const size_t cnt = chunk_len(c, n - done);
+    const double t0 = now();
     if (int r = drain(sl)) return r;  // slot free again, its verdicts delivered
+    const double t1 = now();
+    t_drain += t1 - t0;
     uint8_t* host = ctx.pipe_host[sl];
     uint8_t* dev = ctx.pipe_stage[sl];
     size_t in_off[NIN + 1];  // offsets inside the slot for THIS chunk, the same on both sides
@@ -970,6 +984,8 @@ int run_pipelined(Context& ctx, const HostIn (&ins)[NIN], uint8_t* ok, size_t n,
         memcpy(host + in_off[k] + lo, ins[k].p + done * ins[k].bytes + lo, hi - lo);
       }
     });
+    const double t2 = now();
+    t_copy += t2 - t1;
     // the input block is contiguous on both sides (pad bytes ride along)
     HIP_TRY(hipMemcpyAsync(dev, host, in_off[NIN - 1] + cnt * ins[NIN - 1].bytes,
                            hipMemcpyHostToDevice, st));
@@ -984,9 +1000,14 @@ int run_pipelined(Context& ctx, const HostIn (&ins)[NIN], uint8_t* ok, size_t n,
     slot_cnt[sl] = cnt;
     slot_ok_off[sl] = ok_off;
     done += cnt;
+    t_enq += now() - t2;
   }
+  const double t3 = now();
   for (int sl = 0; sl < nslots; sl++)
     if (int r = drain(sl)) return r;
+  if (trace)
+    fprintf(stderr, "[dsv pipe] n=%zu chunks=%zu total %.2f ms: gather %.2f, enqueue %.2f, waiting for slots %.2f, final drain %.2f\n",
+            n, nchunks, now() - t_begin, t_copy, t_enq, t_drain, now() - t3);
   return DSV_OK;
 }
 }  // namespace

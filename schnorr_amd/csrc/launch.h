@@ -86,15 +86,16 @@ void launch_fixed_base_points(const uint8_t* scalar, const uint32_t* table, size
 // to_hash_inputs on the device: `npoints` projective points per item, each (u, v, z) 96 B in its
 // own array in[k], normalised into out[k] (u/z, v/z; 64 B) with at most ONE inversion per item;
 // valid[i] = every coordinate canonical and every z != 0
-// (Montgomery's trick over the item's z's AND over the kNormalizePerLane items a lane handles once
-// the batch is large); prefix: scratch of normalize_prefix_bytes(n, npoints) device bytes
+// (Montgomery's trick over the item's z's AND over the 8 or 16 items a lane handles once the batch
+// is large); prefix: scratch of normalize_prefix_bytes(n, npoints) device bytes
 struct NormalizeArgs {
   const uint8_t* in[4];
   uint8_t* out[4];
 };
-constexpr int kNormalizePerLane = 8;
+constexpr int kNormalizePerLane = 16;  // at most (the kernel keeps one validity bit per item in a u32)
 inline size_t normalize_lanes(size_t n, int& per_lane) {
-  per_lane = n >= ((size_t)1 << 15) ? kNormalizePerLane : 1;
+  // items that share one inversion: more of them = less work, fewer lanes = longer latency
+  per_lane = n >= ((size_t)1 << 19) ? 16 : (n >= ((size_t)1 << 15) ? 8 : 1);
   return (n + per_lane - 1) / per_lane;
 }
 inline size_t normalize_prefix_bytes(size_t n, int npoints) {
