@@ -1,9 +1,10 @@
 #!/usr/bin/env python3
 """Static ISA histogram of the gfx950 kernels of libdsv.
 
-    python tools/isa_hist.py [--asm FILE] [--out profiles/rNN/isa_hist.json] [-D...]
+    python tools/isa_hist.py [--out profiles/rNN/isa_hist.json] [-D...]
 
-Compiles schnorr_amd/csrc/dsv.hip to assembly (hipcc -S --cuda-device-only; no GPU needed), then
+Compiles every kernel translation unit of schnorr_amd/csrc/ (k_*.hip) to assembly (hipcc -S
+--cuda-device-only, in parallel; no GPU needed), then
 for every kernel reports registers, spills and the static count per opcode, and for the field
 primitives (one-function probe kernels compiled from fe29.h / jubjub29.h) the split
 "v_mad_u64_u32 vs everything else" that the roofline's MAD fraction is built on.
@@ -66,11 +67,15 @@ def parse(path):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--asm", help="use an existing assembly file of dsv.hip")
     ap.add_argument("--out")
     ap.add_argument("flags", nargs="*", help="extra hipcc flags, e.g. -DDSV_FIXED_BITS=11")
     a = ap.parse_args()
-    lib = parse(a.asm or compile_asm(os.path.join(CSRC, "dsv.hip"), a.flags))
+    import concurrent.futures
+    units = sorted(f for f in os.listdir(CSRC) if f.startswith("k_") and f.endswith(".hip"))
+    lib = {}
+    with concurrent.futures.ThreadPoolExecutor(max_workers=len(units)) as ex:
+        for part in ex.map(lambda u: parse(compile_asm(os.path.join(CSRC, u), a.flags)), units):
+            lib.update(part)
     with tempfile.NamedTemporaryFile("w", suffix=".hip", delete=False) as f:
         f.write(PROBE % {"csrc": CSRC})
     probes = parse(compile_asm(f.name, a.flags))

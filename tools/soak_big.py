@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
-"""Large-batch soak of the device-pointer path: per seed a 2^20 single and a 2^19 double batch are
-generated on the GPU (StdRng stream of that seed, every 16th item corrupted), verified through
-dsv_verify_single_dev / dsv_verify_double_dev (sub-batch split, one-lane kernels), compared with the
+"""Large-batch soak of the device-pointer path: per seed a 2^20 single, a 2^19 double and a 2^18
+var-generator batch are generated on the GPU (StdRng stream of that seed, every 16th item
+corrupted), verified through dsv_verify_{single,double,vargen}_dev (sub-batch split, one-lane
+kernels, the three-scalar lattice form for the var-generator scheme), compared with the
 construction-time pattern everywhere and with the CPU oracle on a random sample.  One line per seed.
 
     python tools/soak_big.py [--seeds N] [--first-seed S] [--sample K]
@@ -52,8 +53,16 @@ def main():
         idx = torch.from_numpy(np.sort(rng.choice(nd, a.sample // 2, replace=False))).to("cuda:0")
         sub = [d[k][idx].cpu().numpy() for k in ("u", "R", "Rp", "PK", "PKp", "m")]
         assert np.array_equal(O.verify_double(*sub, nthreads=threads), ok[:nd][idx].cpu().numpy()), ("double oracle", seed)
-        total += n + nd
-        sampled += a.sample + a.sample // 2
+        nv = 1 << 18
+        v = W.gen_vargen(nv, seed=seed + 2000003)
+        E.verify_vargen_dev(v["u"], v["R"], v["PK"], v["Gen"], v["m"], ok[:nv], ws)
+        torch.cuda.synchronize()
+        assert torch.equal(ok[:nv], v["expected"]), ("vargen pattern", seed)
+        idx = torch.from_numpy(np.sort(rng.choice(nv, a.sample // 2, replace=False))).to("cuda:0")
+        sub = [v[k][idx].cpu().numpy() for k in ("u", "R", "PK", "Gen", "m")]
+        assert np.array_equal(O.verify_vargen(*sub, nthreads=threads), ok[:nv][idx].cpu().numpy()), ("vargen oracle", seed)
+        total += n + nd + nv
+        sampled += a.sample + a.sample
         print("seed %d ok  (%d verdicts pattern-checked, %d oracle-checked, %.0f s)"
               % (seed, total, sampled, time.time() - t0), flush=True)
     print("BIG SOAK OK: %d seeds, %d verdicts pattern-checked, %d oracle-checked" % (a.seeds, total, sampled))
