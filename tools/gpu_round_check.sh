@@ -1,14 +1,19 @@
 #!/bin/bash
-# r02 closing run: full GPU test suite, rocprofv3 passes of the final build, final bench line.
+# Closing run of a round on the GPU box: full GPU test suite, rocprofv3 passes of the final build
+# (kernel trace + stats, then PMC passes on their own), summaries for profiles/<round>/, final bench
+# line.  Everything lands under gpurun_out/ (progress lines on stdout as it goes).
+#   tools/gpu_round_check.sh r03
+R=${1:-r03}
 mkdir -p gpurun_out
 echo "[final] tests"
-python3 -m pytest tests -m gpu -x -q 2>&1 | tee gpurun_out/round_tests.log | tail -4
+timeout -k 10 900 python3 -m pytest tests -m gpu -x -q --timeout 300 > gpurun_out/${R}_round_tests.log 2>&1
+tail -3 gpurun_out/${R}_round_tests.log
 echo "[final] profiles"
 rm -rf gpurun_out/prof_round
 bash tools/profile_bench.sh gpurun_out/prof_round 2>&1 | grep "profile_bench"
-python3 tools/summarize_prof.py gpurun_out/prof_round gpurun_out/round > gpurun_out/round_sum.log 2>&1 || tail -5 gpurun_out/round_sum.log
-cp profiles/pmc_latest.json gpurun_out/pmc_latest_round.json
+python3 tools/summarize_prof.py gpurun_out/prof_round gpurun_out/${R}_final > gpurun_out/${R}_round_sum.log 2>&1 || tail -5 gpurun_out/${R}_round_sum.log
+cp profiles/pmc_latest.json gpurun_out/${R}_pmc_latest.json
 find gpurun_out/prof_round -name "*.db" -delete 2>/dev/null
 echo "[final] bench"
-python3 bench.py --steps 20 --warmup 3 > gpurun_out/round_bench.json 2> gpurun_out/round_bench.err
-cat gpurun_out/round_bench.json | cut -c1-600
+python3 bench.py --steps 20 --warmup 3 > gpurun_out/${R}_bench_final.json 2> gpurun_out/${R}_bench_final.err
+python3 tools/bench_summary.py gpurun_out/${R}_bench_final.json
