@@ -46,15 +46,14 @@ DSV_DEV void lat_neg(u32 (&o)[kLatWords], const u32 (&x)[kLatWords]) {
     borrow = (u32)(t >> 63);
   }
 }
-// signed 288-bit -> double (relative error < 2^-51)
+// signed 288-bit -> double (relative error < 2^-50).  Two's complement = signed top word * 2^256 +
+// the unsigned words below it: Horner from the top needs no negation, and stays exact while the
+// partial value is small (a small negative number is -1, -1 * 2^32 + 0xffffffff = -1, ...).
 DSV_DEV double lat_to_double(const u32 (&x)[kLatWords]) {
-  const bool neg = (x[kLatWords - 1] >> 31) != 0;
-  u32 n[kLatWords];
-  lat_neg(n, x);
-  double d = (double)(neg ? n[kLatWords - 1] : x[kLatWords - 1]);
+  double d = (double)(int)x[kLatWords - 1];
 #pragma unroll
-  for (int i = kLatWords - 2; i >= 0; i--) d = __builtin_fma(d, 4294967296.0, (double)(neg ? n[i] : x[i]));
-  return neg ? -d : d;
+  for (int i = kLatWords - 2; i >= 0; i--) d = __builtin_fma(d, 4294967296.0, (double)x[i]);
+  return d;
 }
 // acc += t * x (mod 2^288), t a signed 32-bit integer given as magnitude and sign; nx = -x
 DSV_DEV void lat_mul_acc(u32 (&acc)[kLatWords], u32 mag, bool neg, const u32 (&x)[kLatWords],
@@ -110,7 +109,7 @@ DSV_DEV void lattice3_scalars(u32 (&mx)[8], u32 (&my)[8], u32 (&mz)[8], bool& nx
         D[r][m] = lat_to_double(B[r][m]);
         T[r][m] = r == m ? 1.0 : 0.0;
       }
-    bool any = false, stop = false, more = true;
+    bool any = false, stop = false, more = true, converged = false;
 #pragma unroll 1
     for (int pass = 0; pass < kLatMaxPasses && more; pass++) {
       bool changed = false;
@@ -139,6 +138,7 @@ DSV_DEV void lattice3_scalars(u32 (&mx)[8], u32 (&my)[8], u32 (&mz)[8], bool& nx
       }
       any |= changed;
       more = changed & !stop;
+      converged = !changed & !stop;  // a whole pass without a step: pairwise reduced (to the images' precision)
     }
     if (!any) {
       done = true;
@@ -172,6 +172,7 @@ DSV_DEV void lattice3_scalars(u32 (&mx)[8], u32 (&my)[8], u32 (&mz)[8], bool& nx
           for (int w = 0; w < kLatWords; w++) B[r][m][w] = acc[w];
         }
       }
+      done = converged;  // (no further batch just to find that nothing changes)
     }
   }
   // the shortest row (by its longest component) with an odd z that fits the chain; else (u, c, 1)
