@@ -35,7 +35,7 @@
  * coordinates are out of contract (result unspecified, never a fault).
  *
  * Host entry points take HOST pointers (pageable is fine), stage through library-owned pinned
- * and device buffers in chunks of 2^17 items (DSV_HOST_THREADS copy threads, default 4) and block
+ * and device buffers in chunks of 2^15 .. 2^18 items (DSV_HOST_THREADS copy threads, default 4) and block
  * until the verdicts are in `ok`.  The *_dev entry points take DEVICE pointers (hipMalloc'd,
  * 16-byte aligned) plus a hipStream_t passed as void*, enqueue only, and never synchronise —
  * they are what the bench times with inputs resident in HBM.
@@ -157,8 +157,9 @@ int dsv_verify_vargen_multi(const uint8_t *u, const uint8_t *R_uv, const uint8_t
  * anything enqueued on `stream` afterwards.  Batches of >= 2^17 items are cut into 2^16-item
  * parts that run on two library-owned streams forked from / joined to `stream` by events
  * (DSV_SPLIT=0 in the environment at dsv_init keeps every launch on `stream` itself).  Batches of
- * <= 2^14 items run a four-lanes-per-signature kernel that trades throughput for latency
- * (DSV_QUAD=0 keeps them on the one-lane kernel).  Same verdicts on every path. */
+ * <= 2^14 items run an eight-lanes-per-signature kernel that trades throughput for latency, with
+ * their window tables built on a library-owned stream beside the hash (DSV_QUAD=0 keeps them on
+ * the one-lane kernel, DSV_SMALL_OVERLAP=0 builds the tables inside the verify kernel).  Same verdicts on every path. */
 size_t dsv_workspace_bytes(size_t n);
 int dsv_verify_single_dev(const void *u, const void *R_uv, const void *PK_uv, const void *m,
                           size_t n, void *ok, void *workspace, void *stream);
