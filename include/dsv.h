@@ -308,6 +308,10 @@ int dsv_fixed_window_bits(void); /* width of the (signed) fixed-base windows; di
  * per item 128 B = |x| || |y| || |z| (32 B LE each) || sign bytes of x, y, z || padding;
  * x = z*u, y = z*c (mod 8r), z odd.  u is taken mod 2^252, c mod 2^250. */
 int dsv_debug_lattice3(const uint8_t *u, const uint8_t *c, size_t n, uint8_t *out128);
+/* ---- introspection: the half-size scalars of the fixed-generator kernels (halfgcd.h) for c (taken
+ * mod 2^250): per item 96 B = |a| || |b| (32 B LE each) || sign byte of b || padding;
+ * a = b*c (mod 8r), b odd. */
+int dsv_debug_half_scalars(const uint8_t *c, size_t n, uint8_t *out96);
 /* ---- introspection: field-multiplier self test on the device: out = a*b mod q (canonical) */
 int dsv_debug_fq_mul(const uint8_t *a, const uint8_t *b, size_t n, uint8_t *out);
 

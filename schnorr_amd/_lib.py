@@ -27,7 +27,7 @@ SYMBOLS = [
     "dsv_stdrng_vargen_inputs_dev",
     # r03: projective inputs for every scheme (host / multi-device / device pointers), wire records
     # in device memory, one-call initialisation
-    "dsv_init_visible", "dsv_to_hash_inputs", "dsv_debug_lattice3",
+    "dsv_init_visible", "dsv_to_hash_inputs", "dsv_debug_lattice3", "dsv_debug_half_scalars",
     "dsv_verify_double_ext", "dsv_verify_vargen_ext",
     "dsv_verify_single_ext_multi", "dsv_verify_double_ext_multi", "dsv_verify_vargen_ext_multi",
     "dsv_ext_workspace_bytes", "dsv_verify_single_ext_dev", "dsv_verify_double_ext_dev",

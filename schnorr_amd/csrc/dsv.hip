@@ -1814,6 +1814,21 @@ int dsv_debug_lattice3(const uint8_t* u, const uint8_t* c, size_t n, uint8_t* ou
   return DSV_OK;
 }
 
+int dsv_debug_half_scalars(const uint8_t* c, size_t n, uint8_t* out96) {
+  if (n && (!c || !out96)) return fail(DSV_ERR_INVALID_ARGUMENT, "null pointer");
+  DSV_HOST_PROLOGUE(n);
+  DSV_HOST_LOCK();
+  if (int r = ensure_stage(ctx, align_up(n * 32, 256) + align_up(n * 96, 256))) return r;
+  Stager st(ctx.stage);
+  uint8_t *dc = st.take(n * 32), *dout = st.take(n * 96);
+  H2D(dc, c, n * 32);
+  launch_debug_half_scalars(dc, n, dout, 0);
+  HIP_TRY(hipGetLastError());
+  D2H(out96, dout, n * 96);
+  HIP_TRY(hipStreamSynchronize(0));
+  return DSV_OK;
+}
+
 int dsv_debug_fq_mul(const uint8_t* a, const uint8_t* b, size_t n, uint8_t* out) {
   if (n && (!a || !b || !out)) return fail(DSV_ERR_INVALID_ARGUMENT, "null pointer");
   DSV_HOST_PROLOGUE(n);

@@ -143,6 +143,24 @@ k_debug_lattice3(const uint8_t* __restrict__ u, const uint8_t* __restrict__ c, s
   const u32 sg[8] = {(nx ? 1u : 0u) | (ny ? 0x100u : 0u) | (nz ? 0x10000u : 0u), 0, 0, 0, 0, 0, 0, 0};
   store_words8(out, 4 * i + 3, sg);
 }
+// the same for halfgcd.h: out = |a| || |b| (2 x 32 bytes LE) || sign byte of b || 31 zero bytes (96 B)
+__global__ void __launch_bounds__(64)
+k_debug_half_scalars(const uint8_t* __restrict__ c, size_t n, uint8_t* __restrict__ out) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  u32 cs[8], a[8], b[8];
+  bool b_neg;
+  load_words8(cs, c, i);
+  cs[7] &= 0x03ffffffu;
+  half_scalars(a, b, b_neg, cs);
+  store_words8(out, 3 * i, a);
+  store_words8(out, 3 * i + 1, b);
+  const u32 sg[8] = {b_neg ? 1u : 0u, 0, 0, 0, 0, 0, 0, 0};
+  store_words8(out, 3 * i + 2, sg);
+}
+void launch_debug_half_scalars(const uint8_t* c, size_t n, uint8_t* out, hipStream_t s) {
+  hipLaunchKernelGGL(k_debug_half_scalars, dim3(grid_for(n, 64)), dim3(64), 0, s, c, n, out);
+}
 void launch_debug_lattice3(const uint8_t* u, const uint8_t* c, size_t n, uint8_t* out, hipStream_t s) {
   hipLaunchKernelGGL(k_debug_lattice3, dim3(grid_for(n, 64)), dim3(64), 0, s, u, c, n, out);
 }

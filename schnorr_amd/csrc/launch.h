@@ -77,6 +77,7 @@ void launch_verify_var(const uint8_t* u, const uint8_t* c, const uint8_t* PK_uv,
                        const uint8_t* R_uv, const uint8_t* valid, size_t n, uint8_t* ok,
                        uint32_t* var_tables, hipStream_t s);
 void launch_debug_lattice3(const uint8_t* u, const uint8_t* c, size_t n, uint8_t* out, hipStream_t s);
+void launch_debug_half_scalars(const uint8_t* c, size_t n, uint8_t* out, hipStream_t s);
 void launch_var_base_points(const uint8_t* scalar, const uint8_t* P_uv, size_t n, uint8_t* out_uv,
                             uint32_t* var_tables, hipStream_t s);
 // ---- k_misc.hip ------------------------------------------------------------------------------

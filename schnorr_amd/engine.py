@@ -317,6 +317,19 @@ def debug_lattice3(u, c):
     return res
 
 
+def debug_half_scalars(c):
+    """(a, b) the fixed-generator kernels use for c (a >= 0, b signed), as Python integers per item."""
+    c = _arr(c, 32)
+    n = c.shape[0]
+    out = np.zeros((n, 96), dtype=np.uint8)
+    _lib.check(_lib.load().dsv_debug_half_scalars(_p(c), ctypes.c_size_t(n), _p(out)))
+    res = []
+    for row in out:
+        a, b = (int.from_bytes(row[32 * k:32 * k + 32].tobytes(), "little") for k in range(2))
+        res.append((a, -b if row[64] else b))
+    return res
+
+
 def debug_fq_mul(a, b):
     a, b = _arr(a, 32), _arr(b, 32)
     n = _same_n(a, b)

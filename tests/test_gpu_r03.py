@@ -280,6 +280,41 @@ def test_bench_rehearses_larger_world_sizes_on_one_gpu(world, config):
         assert line["mixed"]["n_gpus"] == world
 
 
+def test_device_half_scalars_are_those_of_the_exact_euclid(engine):
+    """halfgcd.h on the device (quotient estimates from double-precision images, alternating roles)
+    against the integer model: the pair is the first Euclidean remainder below 2^128 and its
+    cofactor — EQUAL to tests/pymodel.py's half_scalars, which never touches a float — for random c,
+    for c next to the thresholds, and for c crafted so that a remainder comes within one unit of
+    its partner (the r02 spin).  Inputs that need more than the iteration cap (c = 2^128: quotient
+    2^127, taken 31 bits at a time) still give a valid, longer pair."""
+    import random
+    rnd = random.Random(4242)
+    N8 = 8 * M.R_ORDER
+    edge = [0, 1, 2, 3, (1 << 128) - 1, (1 << 250) - 1, (1 << 250) - 2, N8 >> 6, N8 >> 5, (N8 // 3) >> 4,
+            (N8 - ((N8 % 41) + 41)) // 41, (N8 - ((N8 % 1000003) + 1000003)) // 1000003,
+            (1 << 249) + 1]
+    # a first quotient far above 2^31 may hit the iteration cap: valid, but not Euclid's final pair
+    slow = [1 << 128, (1 << 128) + 1, (1 << 200) + 12345, (1 << 129) + 1, (1 << 160) - 1] + \
+        [rnd.getrandbits(rnd.randrange(129, 226)) for _ in range(500)]
+    for _ in range(64):   # c ~ N / k: the first quotient is k, the remainder small
+        k = rnd.randrange(33, 1 << rnd.randrange(6, 29))
+        edge.append(N8 // k)
+    for _ in range(64):   # two steps from the end, a remainder almost equal to its partner
+        e = rnd.randrange(1, 1 << 20)
+        edge.append(((N8 - e) // 2) & ((1 << 250) - 1))
+    cases = edge + slow + [rnd.getrandbits(250) for _ in range(20000)] + \
+        [rnd.getrandbits(rnd.randrange(226, 251)) for _ in range(2000)]
+    le = np.frombuffer(b"".join(M.le32(c) for c in cases), np.uint8).reshape(len(cases), 32).copy()
+    got = engine.debug_half_scalars(le)
+    slow_set = set(slow)
+    for c, (a, b) in zip(cases, got):
+        assert (a - b * c) % N8 == 0 and b & 1 and a >= 0, c
+        assert 0 < abs(b) < (1 << 160) and a < (1 << 251), c
+        if c not in slow_set:
+            ma, mb, mneg = M.half_scalars(c)
+            assert (a, b) == (ma, -mb if mneg else mb), c
+
+
 def test_device_lattice_scalars_satisfy_the_congruences(engine):
     """lattice3.h on the device: x = z*u, y = z*c (mod 8r), z odd, ~170 bits; degenerate inputs fall
     back to (u, c, 1) or still give a valid triple.  (The floating-point decisions may differ from
