@@ -57,6 +57,8 @@ MUL_MAD, MUL_ALL = 153, 189            # 81 + 72 MADs; + 36 digit / shift instru
 SQR_MAD, SQR_ALL = 117, 161            # 45 + 72 MADs; + 8 doublings + 36
 WINDOWS = 33.1                         # mean over waves of the longest lane's window count
 FIXED_ADDS = 16                        # signed 16-bit windows over 253 bits
+VAR_WINDOWS = 43.9                     # var-generator kernel: three ~170-bit scalars (lattice3.h)
+VAR_LATTICE = 22000                    # its lattice reduction: ~80 passes x ~170 + 7 exact updates x 1600
 
 
 def _verify_counts(chains=1):
@@ -441,11 +443,14 @@ def main():
                                      "StdRng(777): sk, g, m, nonce per item" % (nv.bit_length() - 1)}
         var_ms = event_ms(fv)
         hv_ms = event_ms(lambda: E.challenge_single_dev(bv["R"], bv["m"], c[:nv], valid[:nv]))
-        # Straus over two 252-bit scalars: 2 tables, 63 x (4 doublings + 2 additions), compare
-        vvm = 6 + 2 * (7 * 8 + 8 * 2) + 2 * 8 + 63 * (16 + 16) + 2
-        vvs = 63 * 12
+        # r03 kernel (lattice3.h): x*Gen + y*PK - z*R == O, three window tables, a three-base Straus
+        # chain of VAR_WINDOWS signed 4-bit windows (wave maximum, mean over waves), compare
+        table = 1 + 7 * 7 + 8
+        vvm = 6 + 3 * table + (2 + 2 * 8) + (VAR_WINDOWS - 1) * (4 * 3 + 3 * 8) + 2
+        vvs = (VAR_WINDOWS - 1) * 4 * 4 + 1
         kernel_block("k_verify_var (whole call minus k_challenge, 2^%d items)" % (nv.bit_length() - 1),
-                     max(var_ms - hv_ms, 1e-3), nv, vvm, vvs, other=63 * (4 * 91 + 2 * 145) + 6000,
+                     max(var_ms - hv_ms, 1e-3), nv, vvm, vvs,
+                     other=VAR_WINDOWS * (4 * 91 + 3 * 145) + VAR_LATTICE + 3 * 1500 + 4000,
                      algo_bytes=ALGO_BYTES["vargen"])
         sample_checks["vargen"] = (bv, okv.clone())
 

@@ -17,8 +17,10 @@
 //                          (b*u)*G    : 16 mixed additions from a signed 16-bit-window table of
 //                                       G (or G'), 75.5 MB, built once on the device
 //                        <2>: both equations of a double signature in one launch
-//   k_verify_fixed_half_quad  the same with four lanes per signature (batches <= 2^14)
-//   k_verify_var         both bases variable (PublicKeyVarGen)
+//   k_verify_fixed_half_oct  the same with eight lanes per signature (batches <= 2^14), its window
+//                        tables built by k_prep_var_tables on a side stream beside the hash
+//   k_verify_var         both bases variable (PublicKeyVarGen): x*Gen + y*PK - z*R == O with three
+//                        ~170-bit scalars (lattice3.h), three per-lane tables, ~44 windows
 //   k_normalize_uvz      to_hash_inputs for callers that hold projective points (*_ext entry points)
 //   k_decompress         wire-format points (JubJubAffine::from_bytes), decode29.h
 //   k_fixed_base_points / k_var_base_points / k_sign_finish : signing and key derivation
@@ -320,7 +322,7 @@ struct Stager {
   }
 };
 
-// the dominant kernel: one lane per signature, or four (small batches); same verdicts
+// the dominant kernel: one lane per signature, or eight (small batches); same verdicts
 void launch_verify_fixed(const Context& ctx, bool accumulate, const void* u, const void* c,
                          const void* PK_uv, const void* R_uv, int which, const void* valid,
                          size_t n, void* ok, u32* tables, hipStream_t s, bool tables_ready = false) {
@@ -487,17 +489,27 @@ int dsv_init(int device) {
   if (ctx.ready.load()) return DSV_OK;
   ctx.device = device;
   DSV_ON_DEVICE(ctx);
-  HIP_TRY(hash_upload_constants());  // this device's __constant__ round constants
-  HIP_TRY(hipMalloc(&ctx.ts_cancel, sizeof(DSV_TS_CANCEL_HOST)));
-  HIP_TRY(hipMemcpy(ctx.ts_cancel, DSV_TS_CANCEL_HOST, sizeof(DSV_TS_CANCEL_HOST), hipMemcpyHostToDevice));
-  HIP_TRY(hipMalloc(&ctx.ts_hash, sizeof(DSV_TS_HASH_HOST)));
-  HIP_TRY(hipMemcpy(ctx.ts_hash, DSV_TS_HASH_HOST, sizeof(DSV_TS_HASH_HOST), hipMemcpyHostToDevice));
-  for (int g = 0; g < 2; g++) {
-    HIP_TRY(hipMalloc(&ctx.table[g], kTableBytes));
-    launch_build_fixed_table(ctx.table[g], g, 0);
-    HIP_TRY(hipGetLastError());
+  // (a failure half-way releases what was allocated: a later dsv_init starts from nothing)
+  const int rc = [&]() -> int {
+    HIP_TRY(hash_upload_constants());  // this device's __constant__ round constants
+    HIP_TRY(hipMalloc(&ctx.ts_cancel, sizeof(DSV_TS_CANCEL_HOST)));
+    HIP_TRY(hipMemcpy(ctx.ts_cancel, DSV_TS_CANCEL_HOST, sizeof(DSV_TS_CANCEL_HOST), hipMemcpyHostToDevice));
+    HIP_TRY(hipMalloc(&ctx.ts_hash, sizeof(DSV_TS_HASH_HOST)));
+    HIP_TRY(hipMemcpy(ctx.ts_hash, DSV_TS_HASH_HOST, sizeof(DSV_TS_HASH_HOST), hipMemcpyHostToDevice));
+    for (int g = 0; g < 2; g++) {
+      HIP_TRY(hipMalloc(&ctx.table[g], kTableBytes));
+      launch_build_fixed_table(ctx.table[g], g, 0);
+      HIP_TRY(hipGetLastError());
+    }
+    HIP_TRY(hipDeviceSynchronize());
+    return DSV_OK;
+  }();
+  if (rc != DSV_OK) {
+    const std::string why = g_err;
+    release_context(ctx);
+    g_err = why;
+    return rc;
   }
-  HIP_TRY(hipDeviceSynchronize());
   const char* split = getenv("DSV_SPLIT");
   ctx.split = !(split && strcmp(split, "0") == 0);
   const char* quad = getenv("DSV_QUAD");
