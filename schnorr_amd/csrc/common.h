@@ -213,6 +213,91 @@ DSV_DEV int top_digit4(const u32 (&nz)[8]) {
   return len > 0 ? (len - 1) >> 2 : 0;
 }
 
+// ---- JOINT window table of two variable bases (P, R): signed 2-bit digits (da, db) in [-2, 2)^2,
+// one table entry da*P + db*R per window, ONE addition per two doublings.  Same additions per bit
+// as two 4-bit tables (one per 2 bits against two per 4), but 11 stored entries instead of 16 and a
+// table built with 67 multiplications + 12 squarings instead of 116 multiplications; the chain's
+// length follows max(bitlen a, bitlen b) in steps of 2 bits instead of 4.
+//   slot: 1 P | 2 R | 3 2P | 4 2R | 5 P+R | 6 P-R | 7 2P+R | 8 2P-R | 9 P+2R | 10 2R-P | 11 2P+2R
+// Digit pairs map to +-slot (a negative pair reads the entry with v+u / v-u swapped and 2d*t
+// negated, as in the one-base tables); (0, 0) reads the shared identity entry.
+constexpr int kJointSlots = 12;  // slot 0 is never written
+constexpr int kJointLaneWords = kJointSlots * kVarEntryWords;
+static_assert(kJointLaneWords <= 2 * kVarLaneWords, "the joint table lives in the two one-base slots");
+// signed slot of the pair (da, db) given as raw digits ra = da + 2, rb = db + 2
+DSV_DEV int joint_slot(u32 ra, u32 rb) {
+  const u32 idx = ra * 4 + rb;
+  // idx:            0   1  2  3  4  5  6  7  8  9 10 11  12 13 14 15
+  // (da, db):    -2-2 -2-1 -20 -21 -1-2 -1-1 -10 -11 0-2 0-1 00 01 1-2 1-1 10 11
+  // slot:          11   7  3  8  9  5  1  6  4  2  0  2  10  6  1  5
+  const unsigned long long slots = 0x516A20246159837BULL;
+  const int slot = (int)((slots >> (4 * idx)) & 15u);
+  const bool neg = ((0x13FFu >> idx) & 1u) != 0;
+  return neg ? -slot : slot;
+}
+// y = 0xAAAA..A + s (or - s): digit k of +-s is the 2-bit field k of y minus 2, in [-2, 1].
+// Exact for s < 2^254 (no wrap in either direction).
+DSV_DEV void recode_signed2(u32 (&y)[8], const u32 (&s)[8], bool negative) {
+  u32 carry = negative ? 1u : 0u;
+#pragma unroll
+  for (int i = 0; i < 8; i++) {
+    const u32 si = negative ? ~s[i] : s[i];  // -s = ~s + 1 (mod 2^256)
+    const u64 t = (u64)si + 0xAAAAAAAAu + carry;
+    y[i] = (u32)t;
+    carry = (u32)(t >> 32);
+  }
+}
+DSV_DEV int joint_digit(const u32 (&ya)[8], const u32 (&yb)[8], int k) {
+  const int sh = 2 * (k & 15);
+  return joint_slot((ya[k >> 4] >> sh) & 3u, (yb[k >> 4] >> sh) & 3u);
+}
+// index of the highest window with a non-zero digit in either scalar (caller: (ya | yb) ^ 0xAA..A)
+DSV_DEV int top_digit2(const u32 (&nz)[8]) {
+  int len = 0;
+#pragma unroll
+  for (int i = 0; i < 8; i++)
+    if (nz[i] != 0) len = 32 * i + (32 - __clz(nz[i]));
+  return len > 0 ? (len - 1) >> 1 : 0;
+}
+// P = (pu, pv), R = (ru, rv) affine.  Every sum is a mixed addition onto an extended point whose
+// t1*t2 is at hand (ext_add_aniels_t); the differences use the negated affine niels form.
+DSV_DEV void build_joint_table(u32* tbl, const Fe& pu, const Fe& pv, const Fe& ru, const Fe& rv) {
+  const Ext P = ext_from_affine(pu, pv), R = ext_from_affine(ru, rv);
+  const Fe ttP = fe_mul(pu, pv), ttR = fe_mul(ru, rv);
+  const Niels nP = ext_to_niels_t(P, ttP), nR = ext_to_niels_t(R, ttR);
+  store_var_entry(tbl, 1, nP);
+  store_var_entry(tbl, 2, nR);
+  const ANiels aP = {nP.vpu, nP.vmu, nP.t2d}, aR = {nR.vpu, nR.vmu, nR.t2d};
+  const ANiels aPn = {nP.vmu, nP.vpu, fe_neg2(nP.t2d)}, aRn = {nR.vmu, nR.vpu, fe_neg2(nR.t2d)};
+  auto put = [&](int slot, const Ext& x) { store_var_entry(tbl, slot, ext_to_niels(x)); };
+  {
+    const Ext S = ext_add_aniels_t(P, ttP, aR);
+    put(5, S);
+    put(11, ext_double(S));
+    put(6, ext_add_aniels_t(P, ttP, aRn));
+  }
+  {
+    const Ext P2 = ext_double(P);
+    const Fe tt = fe_mul(P2.t1, P2.t2);
+    store_var_entry(tbl, 3, ext_to_niels_t(P2, tt));
+    put(7, ext_add_aniels_t(P2, tt, aR));
+    put(8, ext_add_aniels_t(P2, tt, aRn));
+  }
+  {
+    const Ext R2 = ext_double(R);
+    const Fe tt = fe_mul(R2.t1, R2.t2);
+    store_var_entry(tbl, 4, ext_to_niels_t(R2, tt));
+    put(9, ext_add_aniels_t(R2, tt, aP));
+    put(10, ext_add_aniels_t(R2, tt, aPn));
+  }
+}
+// acc = 4 * acc
+DSV_DEV Ext ext_mul4(const Ext& p) {
+  Ext q = p;
+  ext_double_uvz(q.u, q.v, q.z);
+  return ext_double(q);
+}
+
 // acc = 16 * acc: three doublings that skip the (t1, t2) outputs nobody reads, then a full one
 DSV_DEV Ext ext_mul16(const Ext& p) {
   Fe u = p.u, v = p.v, z = p.z;

@@ -14,6 +14,10 @@
 #include "common.h"
 #include "halfgcd.h"
 
+#ifndef DSV_JOINT_WINDOWS
+#define DSV_JOINT_WINDOWS 0
+#endif
+
 namespace dsv {
 
 template <int NCHAIN>
@@ -36,6 +40,15 @@ k_verify_fixed_half(const uint8_t* __restrict__ u, const uint8_t* __restrict__ c
       u32 cs[8], a[8], b[8];
       load_words8(cs, c, i);
       half_scalars(a, b, b_neg, cs);
+#if DSV_JOINT_WINDOWS
+      // signed 2-bit digits of a and of -+|b| (the sign of the R term goes into the recoding)
+      recode_signed2(ya, a, false);
+      recode_signed2(yb, b, !b_neg);
+      u32 nz[8];
+#pragma unroll
+      for (int k = 0; k < 8; k++) nz[k] = (ya[k] ^ 0xAAAAAAAAu) | (yb[k] ^ 0xAAAAAAAAu);
+      top = top_digit2(nz);
+#else
       recode_signed4(ya, a);
       recode_signed4(yb, b);
       // index of the highest non-zero signed digit of either scalar (a zero digit is nibble 8)
@@ -43,6 +56,7 @@ k_verify_fixed_half(const uint8_t* __restrict__ u, const uint8_t* __restrict__ c
 #pragma unroll
       for (int k = 0; k < 8; k++) nz[k] = (ya[k] ^ 0x88888888u) | (yb[k] ^ 0x88888888u);
       top = top_digit4(nz);
+#endif
       u32 us[8];
       load_words8(us, u, i);
       const bool u_ok = words_lt(us, kR32);
@@ -58,9 +72,33 @@ k_verify_fixed_half(const uint8_t* __restrict__ u, const uint8_t* __restrict__ c
       }
     }
     const int rsign = b_neg ? 1 : -1;
+    (void)rsign;
+    (void)tr;
 #pragma unroll 1
     for (int h = 0; h < NCHAIN; h++) {
       const ChainOperands op = h ? op1 : op0;
+#if DSV_JOINT_WINDOWS
+      {
+        Fe pku, pkv, ru, rv;
+        good &= load_fq(pku, op.PK_uv, 2 * i);
+        good &= load_fq(pkv, op.PK_uv, 2 * i + 1);
+        good &= load_fq(ru, op.R_uv, 2 * i);
+        good &= load_fq(rv, op.R_uv, 2 * i + 1);
+        build_joint_table(tpk, pku, pkv, ru, rv);
+      }
+      // T = a*PK -+ |b|*R (+ w*G below): one joint entry per 2-bit window, loaded one window ahead
+      Ext acc = ext_from_niels(load_var_entry(tpk, joint_digit(ya, yb, top)));
+      {
+        RawNiels e = load_var_entry_raw(tpk, joint_digit(ya, yb, top > 0 ? top - 1 : 0));
+#pragma unroll 1
+        for (int k = top - 1; k >= 0; k--) {
+          acc = ext_mul4(acc);
+          const Niels cur = finish_var_entry(e);
+          e = load_var_entry_raw(tpk, joint_digit(ya, yb, k > 0 ? k - 1 : 0));  // last: unused
+          acc = ext_add_niels(acc, cur);
+        }
+      }
+#else
       {
         Fe pku, pkv;
         good &= load_fq(pku, op.PK_uv, 2 * i);
@@ -91,6 +129,7 @@ k_verify_fixed_half(const uint8_t* __restrict__ u, const uint8_t* __restrict__ c
           eb = load_var_entry_raw(tr, rsign * sdigit4(yb, kn));
         }
       }
+#endif
       acc = fixed_base_accumulate(acc, w, op.table);
       // T == O  <=>  u == 0 and v == z
       good &= (bool)((int)fe_is_zero_canon(fe_canon(acc.u)) & (int)fe_equal(acc.v, acc.z));

@@ -1,0 +1,90 @@
+"""The joint 2-bit window table of k_verify_fixed_half (schnorr_amd/csrc/common.h: joint_slot,
+recode_signed2, top_digit2): the digit-pair -> signed-slot map read from the source reproduces
+da*P + db*R for every pair, and the recoding is exact for both signs.  Integer model only (CPU)."""
+import os
+import random
+import re
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SRC = open(os.path.join(ROOT, "schnorr_amd", "csrc", "common.h")).read()
+
+# (coefficient of P, coefficient of R) held by each slot, as build_joint_table fills them
+SLOT = {1: (1, 0), 2: (0, 1), 3: (2, 0), 4: (0, 2), 5: (1, 1), 6: (1, -1), 7: (2, 1), 8: (2, -1),
+        9: (1, 2), 10: (-1, 2), 11: (2, 2)}
+A = int("AA" * 32, 16)
+
+
+def _constants():
+    slots = int(re.search(r"slots = (0x[0-9A-Fa-f]+)ULL", SRC).group(1), 16)
+    neg = int(re.search(r"\(\((0x[0-9A-Fa-f]+)u >> idx\) & 1u\)", SRC).group(1), 16)
+    return slots, neg
+
+
+def joint_slot(ra, rb):
+    slots, neg = _constants()
+    idx = ra * 4 + rb
+    s = (slots >> (4 * idx)) & 15
+    return -s if (neg >> idx) & 1 else s
+
+
+def recode_signed2(s, negative):
+    y = (A - s if negative else A + s)
+    assert 0 <= y < 1 << 256
+    return y
+
+
+def test_every_digit_pair_reads_the_right_combination():
+    for da in range(-2, 2):
+        for db in range(-2, 2):
+            s = joint_slot(da + 2, db + 2)
+            if (da, db) == (0, 0):
+                assert s == 0
+                continue
+            i, j = SLOT[abs(s)]
+            sign = -1 if s < 0 else 1
+            assert (sign * i, sign * j) == (da, db), (da, db, s)
+    assert set(abs(joint_slot(a, b)) for a in range(4) for b in range(4)) == set(range(12))
+
+
+def test_slot_layout_in_the_source_comment_matches():
+    line = re.search(r"//\s+slot: (.*)\n", SRC).group(1)
+    names = {"P": (1, 0), "R": (0, 1), "2P": (2, 0), "2R": (0, 2), "P+R": (1, 1), "P-R": (1, -1),
+             "2P+R": (2, 1), "2P-R": (2, -1), "P+2R": (1, 2), "2R-P": (-1, 2), "2P+2R": (2, 2)}
+    for part in line.split("|"):
+        k, name = part.split()
+        assert SLOT[int(k)] == names[name]
+
+
+def test_signed_2bit_recoding_is_exact_for_both_signs_and_finds_its_top_window():
+    rnd = random.Random(11)
+    cases = [0, 1, 2, 3, (1 << 128) - 1, 1 << 128, (1 << 160) - 1, (1 << 251) - 1, (1 << 254) - 1]
+    cases += [rnd.getrandbits(rnd.randrange(1, 252)) for _ in range(3000)]
+    for s in cases:
+        for negative in (False, True):
+            y = recode_signed2(s, negative)
+            digits = [((y >> (2 * k)) & 3) - 2 for k in range(128)]
+            assert sum(d << (2 * k) for k, d in enumerate(digits)) == (-s if negative else s)
+            nz = y ^ A
+            top = (nz.bit_length() - 1) >> 1 if nz else 0
+            assert all(d == 0 for d in digits[top + 1:])
+            # at most one window beyond the scalar's own length
+            assert top <= (max(s.bit_length(), 1) - 1) // 2 + 1
+
+
+def test_joint_chain_evaluates_a_p_plus_b_r():
+    """the chain of k_verify_fixed_half on integers: acc = 4*acc + (da*P + db*R) from the top window"""
+    rnd = random.Random(12)
+    for _ in range(300):
+        a, b = rnd.getrandbits(130), rnd.getrandbits(129)
+        bneg = rnd.random() < 0.5
+        ya, yb = recode_signed2(a, False), recode_signed2(b, bneg)
+        nz = (ya ^ A) | (yb ^ A)
+        top = (nz.bit_length() - 1) >> 1 if nz else 0
+        P, R = rnd.getrandbits(200), rnd.getrandbits(200)   # stand-ins for group elements (Z-module)
+        acc = 0
+        for k in range(top, -1, -1):
+            s = joint_slot((ya >> (2 * k)) & 3, (yb >> (2 * k)) & 3)
+            i, j = SLOT[abs(s)] if s else (0, 0)
+            e = i * P + j * R
+            acc = 4 * acc + (-e if s < 0 else e)
+        assert acc == a * P + (-b if bneg else b) * R
