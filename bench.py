@@ -55,21 +55,23 @@ METRIC = "Schnorr verifies/sec (single + double) at batch=2^20; 1/2/4/8 MI355X" 
 # v_mad_u64_u32 and total VALU instructions of one field operation, as hipcc emits them
 MUL_MAD, MUL_ALL = 153, 189            # 81 + 72 MADs; + 36 digit / shift instructions
 SQR_MAD, SQR_ALL = 117, 161            # 45 + 72 MADs; + 8 doublings + 36
-WINDOWS = 33.1                         # mean over waves of the longest lane's window count
+WINDOWS = 66.25                        # 2-bit joint windows: mean over waves of the longest lane's count
 FIXED_ADDS = 16                        # signed 16-bit windows over 253 bits
-VAR_WINDOWS = 43.9                     # var-generator kernel: three ~170-bit scalars (lattice3.h)
+VAR_WINDOWS = 43.9                     # var-generator kernel: three ~170-bit scalars (lattice3.h), 4-bit windows
 VAR_LATTICE = 22000                    # its lattice reduction: ~80 passes x ~170 + 7 exact updates x 1600
 
 
 def _verify_counts(chains=1):
-    """(multiplications, squarings) per verdict of k_verify_fixed_half<., chains>"""
-    table = 1 + 7 * 7 + 8                              # u*v; |d|P, d = 2..8: 7 mixed additions sharing t1*t2; 8 x (*2d)
-    dbl_m, dbl_s, add_m = 3, 4, 8                       # doubling: 2uv as (u+v)^2 - (u^2+v^2)
-    per_chain_m = (4 + 2 * table                       # PK, R to Montgomery form; two tables
-                   + 2 + add_m                         # top window: O + entry (2M + 1S), one addition
-                   + (WINDOWS - 1) * (4 * dbl_m + 2 * add_m)
-                   + FIXED_ADDS * 7)                   # += (b*u)*G, mixed additions
-    per_chain_s = (WINDOWS - 1) * 4 * dbl_s + 1
+    """(multiplications, squarings) per verdict of k_verify_fixed_half<chains>: joint table of the 11
+    combinations da*PK + db*R (common.h: build_joint_table), WINDOWS x (2 doublings + 1 addition)"""
+    table_m = 4 + 3 * 5 + 6 * 8 + 0        # P, R (u*v, *2d); 2P, 2R, 2(P+R): 3M (+4S) + 2; six sums: 6 + 2
+    table_s = 3 * 4
+    dbl_m, dbl_s, add_m = 3, 4, 8           # doubling: 2uv as (u+v)^2 - (u^2+v^2)
+    per_chain_m = (4 + table_m              # PK, R to Montgomery form; the table
+                   + 2                      # top window: O + entry (2M + 1S)
+                   + (WINDOWS - 1) * (2 * dbl_m + add_m)
+                   + FIXED_ADDS * 7)        # += (b*u)*G, mixed additions
+    per_chain_s = table_s + 1 + (WINDOWS - 1) * 2 * dbl_s
     return chains * per_chain_m, chains * per_chain_s
 
 
@@ -112,7 +114,7 @@ def _valu(m, s, dot_terms=0, dot_reds=0, other=0, mfma_rows=0):
 
 # lane-instructions outside multiplications: limb-wise add / biased subtract / carry passes of the
 # group law, half-gcd (~8 k since r02's alternating-role loop), recoding, conversions, identity test
-VERIFY_OTHER = 33.1 * (4 * 91 + 2 * 145) + 16 * 145 + 23 * 150 + 8000 + 1500 + 66 * 60
+VERIFY_OTHER = WINDOWS * (2 * 91 + 145) + 16 * 145 + 20 * 150 + 8000 + 1500 + 66 * 60
 ALGO_BYTES = {"single": 193, "double": 321, "vargen": 257}
 MAD_CYCLES = 4.12        # v_mad_u64_u32 (SGPR carry-out) per wave64, 2 waves/SIMD: profiles/r02/valu_rates.txt
 N_CU, SIMD_PER_CU, CLOCK_HZ = 256, 4, 2.4e9

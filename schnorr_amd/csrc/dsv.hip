@@ -12,8 +12,9 @@
 //   k_verify_fixed_half  ok &= [ u*G + c*PK == R ], evaluated as                      (~80 %)
 //                        (b*u mod r)*G + a*PK - b*R == O  with (a, b) ~ 128 bits, a = b*c mod 8r,
 //                        b odd (halfgcd.h: same verdict on the whole curve group):
-//                          a*PK - b*R : two per-lane signed 4-bit window tables (lane-major in a
-//                                       global workspace), one Straus chain of ~33 windows
+//                          a*PK - b*R : one per-lane table of the 11 combinations da*PK + db*R
+//                                       of signed 2-bit digits (lane-major in a global workspace),
+//                                       one Straus chain of ~66 windows (2 doublings + 1 addition)
 //                          (b*u)*G    : 16 mixed additions from a signed 16-bit-window table of
 //                                       G (or G'), 75.5 MB, built once on the device
 //                        <2>: both equations of a double signature in one launch

@@ -3,20 +3,21 @@
 // /root/reference/src/keys/public.rs:121-130, :222-244), evaluated with half-size scalars
 // (halfgcd.h): with (a, b), a = b*c (mod 8r), b odd,
 //   u*G + c*PK == R   <=>   (b*u mod r)*G + a*PK - b*R == O.
-// Two per-lane window tables (PK and R), one Straus chain of ~33 windows whose length is the
-// lane's own max(bitlen a, bitlen b) (lanes of a wave simply leave the loop at different times),
-// then 16 mixed additions from the fixed-base table; the verdict is an identity test.
+// ONE per-lane window table over both variable bases — the 11 combinations da*PK + db*R of signed
+// 2-bit digits (common.h: build_joint_table) — and one Straus chain of ~66 windows of two doublings
+// and ONE addition each, whose length is the lane's own max(bitlen a, bitlen b) (lanes of a wave
+// simply leave the loop at different times); then 16 mixed additions from the fixed-base table;
+// the verdict is an identity test.  (r01 - r03a: one 4-bit table of 8 entries per base, two
+// additions per four doublings: the same chain, but 116 multiplications of table building per
+// chain instead of 67 + 12 squarings and 16 entries written per lane instead of 11: +2.1 % single,
+// +2.5 % double, same-box A/B profiles/r03/ab_joint_windows.txt.)
 //
 // NCHAIN = 2 is PublicKeyDouble::verify in ONE launch: both equations share u and c, so (a, b), both
 // recodings and b*u mod r are computed once and the chain runs twice — (G, PK, R) then (G', PK', R')
 // — through the same code (a rolled loop over the two operand sets: the hot loop exists once in
-// the instruction cache) and the same two table slots.
+// the instruction cache) and the same table slot.
 #include "common.h"
 #include "halfgcd.h"
-
-#ifndef DSV_JOINT_WINDOWS
-#define DSV_JOINT_WINDOWS 0
-#endif
 
 namespace dsv {
 
@@ -25,8 +26,7 @@ __global__ void __launch_bounds__(kVerifyBlock, kWavesVerify)
 k_verify_fixed_half(const uint8_t* __restrict__ u, const uint8_t* __restrict__ c, ChainOperands op0,
                     ChainOperands op1, const uint8_t* __restrict__ valid, bool accumulate, size_t n,
                     uint8_t* __restrict__ ok, u32* __restrict__ var_tables) {
-  u32* tpk = var_tables + ((size_t)blockIdx.x * kVerifyBlock + threadIdx.x) * (2 * kVarLaneWords);
-  u32* tr = tpk + kVarLaneWords;
+  u32* tbl = var_tables + ((size_t)blockIdx.x * kVerifyBlock + threadIdx.x) * kJointLaneWords;
 #pragma unroll 1
   for (size_t base = (size_t)blockIdx.x * kVerifyBlock; base < n;
        base += (size_t)gridDim.x * kVerifyBlock) {
@@ -40,7 +40,6 @@ k_verify_fixed_half(const uint8_t* __restrict__ u, const uint8_t* __restrict__ c
       u32 cs[8], a[8], b[8];
       load_words8(cs, c, i);
       half_scalars(a, b, b_neg, cs);
-#if DSV_JOINT_WINDOWS
       // signed 2-bit digits of a and of -+|b| (the sign of the R term goes into the recoding)
       recode_signed2(ya, a, false);
       recode_signed2(yb, b, !b_neg);
@@ -48,15 +47,6 @@ k_verify_fixed_half(const uint8_t* __restrict__ u, const uint8_t* __restrict__ c
 #pragma unroll
       for (int k = 0; k < 8; k++) nz[k] = (ya[k] ^ 0xAAAAAAAAu) | (yb[k] ^ 0xAAAAAAAAu);
       top = top_digit2(nz);
-#else
-      recode_signed4(ya, a);
-      recode_signed4(yb, b);
-      // index of the highest non-zero signed digit of either scalar (a zero digit is nibble 8)
-      u32 nz[8];
-#pragma unroll
-      for (int k = 0; k < 8; k++) nz[k] = (ya[k] ^ 0x88888888u) | (yb[k] ^ 0x88888888u);
-      top = top_digit4(nz);
-#endif
       u32 us[8];
       load_words8(us, u, i);
       const bool u_ok = words_lt(us, kR32);
@@ -71,65 +61,29 @@ k_verify_fixed_half(const uint8_t* __restrict__ u, const uint8_t* __restrict__ c
         for (int k = 0; k < 8; k++) w[k] = t[k];
       }
     }
-    const int rsign = b_neg ? 1 : -1;
-    (void)rsign;
-    (void)tr;
 #pragma unroll 1
     for (int h = 0; h < NCHAIN; h++) {
       const ChainOperands op = h ? op1 : op0;
-#if DSV_JOINT_WINDOWS
       {
         Fe pku, pkv, ru, rv;
         good &= load_fq(pku, op.PK_uv, 2 * i);
         good &= load_fq(pkv, op.PK_uv, 2 * i + 1);
         good &= load_fq(ru, op.R_uv, 2 * i);
         good &= load_fq(rv, op.R_uv, 2 * i + 1);
-        build_joint_table(tpk, pku, pkv, ru, rv);
+        build_joint_table(tbl, pku, pkv, ru, rv);
       }
       // T = a*PK -+ |b|*R (+ w*G below): one joint entry per 2-bit window, loaded one window ahead
-      Ext acc = ext_from_niels(load_var_entry(tpk, joint_digit(ya, yb, top)));
+      Ext acc = ext_from_niels(load_var_entry(tbl, joint_digit(ya, yb, top)));
       {
-        RawNiels e = load_var_entry_raw(tpk, joint_digit(ya, yb, top > 0 ? top - 1 : 0));
+        RawNiels e = load_var_entry_raw(tbl, joint_digit(ya, yb, top > 0 ? top - 1 : 0));
 #pragma unroll 1
         for (int k = top - 1; k >= 0; k--) {
           acc = ext_mul4(acc);
           const Niels cur = finish_var_entry(e);
-          e = load_var_entry_raw(tpk, joint_digit(ya, yb, k > 0 ? k - 1 : 0));  // last: unused
+          e = load_var_entry_raw(tbl, joint_digit(ya, yb, k > 0 ? k - 1 : 0));  // last: unused
           acc = ext_add_niels(acc, cur);
         }
       }
-#else
-      {
-        Fe pku, pkv;
-        good &= load_fq(pku, op.PK_uv, 2 * i);
-        good &= load_fq(pkv, op.PK_uv, 2 * i + 1);
-        build_var_table(tpk, pku, pkv);
-      }
-      {
-        Fe ru, rv;
-        good &= load_fq(ru, op.R_uv, 2 * i);
-        good &= load_fq(rv, op.R_uv, 2 * i + 1);
-        build_var_table(tr, ru, rv);
-      }
-      // T = a*PK + (b_neg ? +|b| : -|b|) * R  (+ w*G below); entries are loaded one group
-      // operation ahead of their use
-      Ext acc = ext_from_niels(load_var_entry(tpk, sdigit4(ya, top)));
-      acc = ext_add_niels(acc, load_var_entry(tr, rsign * sdigit4(yb, top)));
-      {
-        const int k0 = top > 0 ? top - 1 : 0;
-        RawNiels ea = load_var_entry_raw(tpk, sdigit4(ya, k0));
-        RawNiels eb = load_var_entry_raw(tr, rsign * sdigit4(yb, k0));
-#pragma unroll 1
-        for (int k = top - 1; k >= 0; k--) {
-          acc = ext_mul16(acc);
-          const int kn = k > 0 ? k - 1 : 0;  // last round: reloads its own entries, unused
-          acc = ext_add_niels(acc, finish_var_entry(ea));
-          ea = load_var_entry_raw(tpk, sdigit4(ya, kn));
-          acc = ext_add_niels(acc, finish_var_entry(eb));
-          eb = load_var_entry_raw(tr, rsign * sdigit4(yb, kn));
-        }
-      }
-#endif
       acc = fixed_base_accumulate(acc, w, op.table);
       // T == O  <=>  u == 0 and v == z
       good &= (bool)((int)fe_is_zero_canon(fe_canon(acc.u)) & (int)fe_equal(acc.v, acc.z));
