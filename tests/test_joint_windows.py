@@ -5,6 +5,8 @@ import os
 import random
 import re
 
+import pymodel as M
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = open(os.path.join(ROOT, "schnorr_amd", "csrc", "common.h")).read()
 
@@ -88,3 +90,41 @@ def test_joint_chain_evaluates_a_p_plus_b_r():
             e = i * P + j * R
             acc = 4 * acc + (-e if s < 0 else e)
         assert acc == a * P + (-b if bneg else b) * R
+
+
+def test_joint_chain_on_the_curve_equals_the_reference_equation():
+    """the device chain on JubJub points (tests/pymodel.py group law): table slots = i*PK + j*R, chain
+    = 4*acc + entry from the top window, plus (b*u)*G: identity exactly when u*G + c*PK == R — incl.
+    a key with an order-8 component and tampered signatures."""
+    import test_halfgcd as TH
+    rnd = random.Random(13)
+    t8 = TH.order8_point()
+    cases = 0
+    for trial in range(12):
+        sk, m, r = rnd.randrange(1, M.R_ORDER), rnd.randrange(M.Q), rnd.randrange(1, M.R_ORDER)
+        PK = M.pmul(M.GEN, sk)
+        R = M.pmul(M.GEN, r)
+        if trial % 4 == 3:                      # torsion component in the key (cancels in no R)
+            PK = M.padd(PK, t8)
+        c = M.challenge(R, m)
+        u = (r - c * sk) % M.R_ORDER
+        if trial % 3 == 2:
+            u = (u + 1) % M.R_ORDER            # tampered
+        a, b, bneg = M.half_scalars(c)
+        table = {k: M.padd(M.pmul(PK, i) if i >= 0 else M.pneg(M.pmul(PK, -i)),
+                           M.pmul(R, j) if j >= 0 else M.pneg(M.pmul(R, -j))) for k, (i, j) in SLOT.items()}
+        ya, yb = recode_signed2(a, False), recode_signed2(b, not bneg)
+        nz = (ya ^ A) | (yb ^ A)
+        top = (nz.bit_length() - 1) >> 1 if nz else 0
+        acc = M.IDENTITY
+        for k in range(top, -1, -1):
+            acc = M.pmul(acc, 4)
+            sl = joint_slot((ya >> (2 * k)) & 3, (yb >> (2 * k)) & 3)
+            if sl:
+                acc = M.padd(acc, table[sl] if sl > 0 else M.pneg(table[-sl]))
+        w = ((-b if bneg else b) * u) % M.R_ORDER
+        acc = M.padd(acc, M.pmul(M.GEN, w))
+        want = M.padd(M.pmul(M.GEN, u), M.pmul(PK, c)) == R
+        assert (acc == M.IDENTITY) == want, trial
+        cases += want
+    assert 0 < cases < 12
