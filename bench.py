@@ -494,9 +494,10 @@ def main():
             raise SystemExit("wire-format verdicts differ from the expected pattern")
         duv = torch.empty((n, 64), dtype=torch.uint8, device=dev)
         dec_ms = event_ms(lambda: E.decompress_points_dev(dpk, duv, valid))
-        # JubJubAffine::from_bytes per point (decode29.h): z^((t-1)/2) by 3-bit windows over a 222-bit
-        # exponent, three Tonelli-Shanks window rounds, validation — squarings / multiplications
-        dec_s, dec_m = 222 + 6 + (24 + 16 + 8) + 3 + 2, 74 + 4 + 2 + 3 * 2 + 1 + 6
+        # JubJubAffine::from_bytes per point (decode29.h): z^((t-1)/2) by sliding 4-bit windows over the
+        # 222-bit constant exponent (219 + 1 squarings, 45 + 7 multiplications), three Tonelli-Shanks
+        # window rounds, validation — squarings / multiplications
+        dec_s, dec_m = 219 + 1 + (24 + 16 + 8) + 3 + 2, 45 + 7 + 4 + 2 + 3 * 2 + 1 + 6
         kernel_block("k_decompress (2^%d points)" % args.log2_batch, dec_ms, n, dec_m, dec_s, other=1500,
                      algo_bytes=32 + 65)
         out["wire"] = {"value": n * reps / tww, "unit": "verifies/s",
@@ -505,8 +506,8 @@ def main():
                                    "dsv_verify_single_wire_dev = 2 x k_decompress + the affine path"
                                    % args.log2_batch,
                        "k_decompress_ms_per_2^%d_points" % args.log2_batch: dec_ms,
-                       "note": "two square roots per signature (~94 k MADs) on top of the 274 k of the "
-                               "affine path: the wire path costs ~1.35x the affine one on the device"}
+                       "note": "two square roots per signature (~86 k MADs) on top of the 270 k of the "
+                               "affine path: the wire path costs ~1.3x the affine one on the device"}
         sample_checks["wire"] = (hsig, hpk, okw.clone())
         del wsw, duv
 

@@ -11,7 +11,7 @@
 // No inversion: u = n * (n d)^(-1/2).  q - 1 = 2^32 * t; Tonelli-Shanks is run on z = n d while
 // tracking the INVERSE square root y (invariant y^2 z = b, b = g^s in the 2^32-torsion of Fq*,
 // g = 7^t): y = z^((t-1)/2), b = z^t, then s is cancelled in four 8-bit windows (fe_inv_sqrt).
-// z^((t-1)/2) uses fixed 3-bit windows over the constant exponent (digits are wave-uniform).
+// z^((t-1)/2) uses sliding 4-bit windows over the constant exponent (its bits are wave-uniform).
 // No lane-dependent control flow at all: every lane runs the same ~350 field operations.
 #pragma once
 #include "fe29.h"
@@ -24,40 +24,61 @@ __device__ constexpr u32 kD[NL] = DSV_D;
 // a == 1 (Montgomery one) for a multiplication output (limbs < 2^29, value < 2q)
 DSV_DEV bool fe_is_one(const Fe& a) { return fe_is_zero_canon(fe_canon(fe_sub2(a, fe_one()))); }
 
-// z^e for a wave-uniform constant exponent of NBITS bits (NBITS % 3 == 0), fixed 3-bit windows:
-// NBITS squarings + at most NBITS/3 + 6 multiplications
+// z^e for a wave-uniform constant exponent of exactly NBITS bits: SLIDING windows of up to 4 bits
+// over the odd powers z, z^3, .., z^15 (1 squaring + 7 multiplications), scanned from the top —
+// every branch is on bits of the constant, i.e. scalar.  NBITS - 1 squarings (+ 1) and one
+// multiplication per window: 45 + 7 for (t-1)/2 (r02: 74 + 5 with fixed 3-bit windows), 53 + 7
+// for q - 2 (r02: 85 + 5).  One copy of the multiplication: the window's operand is selected first.
 template <int NWORDS, int NBITS>
-DSV_DEV Fe fe_pow_w3(const Fe& z, const u32 (&e)[NWORDS]) {
-  static_assert(NBITS % 3 == 0, "3-bit windows");
-  Fe t2 = fe_sqr(z), t3 = fe_mul(t2, z), t4 = fe_sqr(t2), t5 = fe_mul(t4, z), t6 = fe_sqr(t3),
-     t7 = fe_mul(t6, z);
+DSV_DEV Fe fe_pow_const(const Fe& z, const u32 (&e)[NWORDS]) {
+  const Fe z2 = fe_sqr(z);
+  const Fe t1 = z, t3 = fe_mul(t1, z2), t5 = fe_mul(t3, z2), t7 = fe_mul(t5, z2), t9 = fe_mul(t7, z2),
+           t11 = fe_mul(t9, z2), t13 = fe_mul(t11, z2), t15 = fe_mul(t13, z2);
+  auto bit = [&](int k) -> u32 { return (e[k >> 5] >> (k & 31)) & 1u; };
   Fe acc = fe_one();
+  bool first = true;
+  int i = NBITS - 1;
 #pragma unroll 1
-  for (int w = NBITS / 3 - 1; w >= 0; w--) {
-    acc = fe_sqr(fe_sqr(fe_sqr(acc)));
-    const int pos = 3 * w;
-    u32 lo = e[pos >> 5] >> (pos & 31);
-    if ((pos & 31) > 29 && (pos >> 5) + 1 < NWORDS) lo |= e[(pos >> 5) + 1] << (32 - (pos & 31));
-    switch (lo & 7u) {  // wave-uniform
-      case 1: acc = fe_mul(acc, z); break;
-      case 2: acc = fe_mul(acc, t2); break;
-      case 3: acc = fe_mul(acc, t3); break;
-      case 4: acc = fe_mul(acc, t4); break;
-      case 5: acc = fe_mul(acc, t5); break;
-      case 6: acc = fe_mul(acc, t6); break;
-      case 7: acc = fe_mul(acc, t7); break;
-      default: break;
+  while (i >= 0) {
+    if (bit(i) == 0) {  // (never before the first window: bit NBITS - 1 is set)
+      acc = fe_sqr(acc);
+      i--;
+      continue;
     }
+    int j = i >= 3 ? i - 3 : 0;  // the window is bits i .. j, j the lowest SET bit within 4 of i
+    while (bit(j) == 0) j++;
+    u32 val = 0;
+    for (int k = i; k >= j; k--) val = 2 * val + bit(k);
+    Fe m;
+    switch (val >> 1) {  // val is odd: 1, 3, .., 15
+      case 0: m = t1; break;
+      case 1: m = t3; break;
+      case 2: m = t5; break;
+      case 3: m = t7; break;
+      case 4: m = t9; break;
+      case 5: m = t11; break;
+      case 6: m = t13; break;
+      default: m = t15; break;
+    }
+    if (first) {
+      acc = m;
+      first = false;
+    } else {
+#pragma unroll 1
+      for (int k = i - j + 1; k > 0; k--) acc = fe_sqr(acc);
+      acc = fe_mul(acc, m);
+    }
+    i = j - 1;
   }
   return acc;
 }
 // z^((t-1)/2)
-DSV_DEV Fe fe_pow_sqrt_exp(const Fe& z) { return fe_pow_w3<7, DSV_SQRT_E_BITS>(z, kSqrtE); }
+DSV_DEV Fe fe_pow_sqrt_exp(const Fe& z) { return fe_pow_const<7, DSV_SQRT_E_BITS>(z, kSqrtE); }
 // z^(q-2) = 1/z  (0 for z = 0)
 DSV_DEV Fe fe_invert(const Fe& z) {
   // q - 2: the low word of q is 1, so the subtraction borrows from word 1
   const u32 e[8] = {0xffffffffu, kQ32[1] - 1, kQ32[2], kQ32[3], kQ32[4], kQ32[5], kQ32[6], kQ32[7]};
-  return fe_pow_w3<8, 255>(z, e);
+  return fe_pow_const<8, 255>(z, e);
 }
 
 // tables for the windowed discrete log (device global memory, filled at dsv_init)
