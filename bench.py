@@ -55,7 +55,7 @@ METRIC = "Schnorr verifies/sec (single + double) at batch=2^20; 1/2/4/8 MI355X" 
 # v_mad_u64_u32 and total VALU instructions of one field operation, as hipcc emits them
 MUL_MAD, MUL_ALL = 153, 189            # 81 + 72 MADs; + 36 digit / shift instructions
 SQR_MAD, SQR_ALL = 117, 161            # 45 + 72 MADs; + 8 doublings + 36
-WINDOWS = 66.25                        # 2-bit joint windows: mean over waves of the longest lane's count
+WINDOWS = 65.73                        # 2-bit joint windows: mean over waves of the longest lane's count
 FIXED_ADDS = 16                        # signed 16-bit windows over 253 bits
 VAR_WINDOWS = 43.9                     # var-generator kernel: three ~170-bit scalars (lattice3.h), 4-bit windows
 VAR_LATTICE = 22000                    # its lattice reduction: ~80 passes x ~170 + 7 exact updates x 1600

@@ -45,6 +45,22 @@ DSV_DEV bool load_fq(Fe& out, const uint8_t* base, size_t idx) {
   out = fe_to_mont(fe_from_words_plain(w));
   return ok;
 }
+// the same for -x when `negate` (the u coordinate of a point to be negated): q - x on the canonical
+// words (x = 0 gives q, which is 0 again after the conversion)
+DSV_DEV bool load_fq_signed(Fe& out, const uint8_t* base, size_t idx, bool negate) {
+  u32 w[8];
+  load_words8(w, base, idx);
+  const bool ok = words_lt(w, kQ32);
+  u32 borrow = 0;
+#pragma unroll
+  for (int i = 0; i < 8; i++) {
+    const u64 t = (u64)kQ32[i] - w[i] - borrow;
+    borrow = (u32)(t >> 63);
+    w[i] = negate ? (u32)t : w[i];
+  }
+  out = fe_to_mont(fe_from_words_plain(w));
+  return ok;
+}
 DSV_DEV void store_fq(uint8_t* base, size_t idx, const Fe& mont) {
   u32 w[8];
   fe_to_words_plain(w, fe_from_mont(mont));
@@ -213,36 +229,40 @@ DSV_DEV int top_digit4(const u32 (&nz)[8]) {
   return len > 0 ? (len - 1) >> 2 : 0;
 }
 
-// ---- JOINT window table of two variable bases (P, R): signed 2-bit digits (da, db) in [-2, 2)^2,
+// ---- JOINT window table of two variable bases (P, R): signed 2-bit digits (da, db) in [-1, 2]^2,
 // one table entry da*P + db*R per window, ONE addition per two doublings.  Same additions per bit
 // as two 4-bit tables (one per 2 bits against two per 4), but 11 stored entries instead of 16 and a
 // table built with 67 multiplications + 12 squarings instead of 116 multiplications; the chain's
 // length follows max(bitlen a, bitlen b) in steps of 2 bits instead of 4.
 //   slot: 1 P | 2 R | 3 2P | 4 2R | 5 P+R | 6 P-R | 7 2P+R | 8 2P-R | 9 P+2R | 10 2R-P | 11 2P+2R
 // Digit pairs map to +-slot (a negative pair reads the entry with v+u / v-u swapped and 2d*t
-// negated, as in the one-base tables); (0, 0) reads the shared identity entry.
+// negated, as in the one-base tables); (0, 0) reads the shared identity entry.  Both scalars are
+// non-negative: a term that enters the equation with a minus sign has its point negated instead
+// (load_fq_signed: q - u in the canonical domain, so every bound downstream is unchanged).
 constexpr int kJointSlots = 12;  // slot 0 is never written
 constexpr int kJointLaneWords = kJointSlots * kVarEntryWords;
 static_assert(kJointLaneWords <= 2 * kVarLaneWords, "the joint table lives in the two one-base slots");
-// signed slot of the pair (da, db) given as raw digits ra = da + 2, rb = db + 2
+// signed slot of the pair (da, db) given as raw digits ra = da + 1, rb = db + 1 (digits in [-1, 2]:
+// with this digit set a scalar of odd bit length never needs a window beyond its own length and
+// one of even length only when its top field is 3 or a carry arrives — 65.7 windows per wave on
+// average where the set [-2, 1] needs 66.25, tests/test_joint_windows.py)
 DSV_DEV int joint_slot(u32 ra, u32 rb) {
   const u32 idx = ra * 4 + rb;
-  // idx:            0   1  2  3  4  5  6  7  8  9 10 11  12 13 14 15
-  // (da, db):    -2-2 -2-1 -20 -21 -1-2 -1-1 -10 -11 0-2 0-1 00 01 1-2 1-1 10 11
-  // slot:          11   7  3  8  9  5  1  6  4  2  0  2  10  6  1  5
-  const unsigned long long slots = 0x516A20246159837BULL;
+  // idx:            0    1    2    3    4   5   6   7    8   9  10  11   12  13  14  15
+  // (da, db):    -1-1  -10  -11  -12  0-1  00  01  02  1-1  10  11  12  2-1  20  21  22
+  // slot:           5    1    6   10    2   0   2   4    6   1   5   9    8   3   7  11
+  const unsigned long long slots = 0xB73895164202A615ULL;
   const int slot = (int)((slots >> (4 * idx)) & 15u);
-  const bool neg = ((0x13FFu >> idx) & 1u) != 0;
+  const bool neg = ((0x17u >> idx) & 1u) != 0;
   return neg ? -slot : slot;
 }
-// y = 0xAAAA..A + s (or - s): digit k of +-s is the 2-bit field k of y minus 2, in [-2, 1].
-// Exact for s < 2^254 (no wrap in either direction).
-DSV_DEV void recode_signed2(u32 (&y)[8], const u32 (&s)[8], bool negative) {
-  u32 carry = negative ? 1u : 0u;
+// y = 0x5555..5 + s: digit k of s is the 2-bit field k of y minus 1, in [-1, 2].  Exact for
+// s < 2^255.  (A negative term is handled by negating its POINT: build_joint_table's caller.)
+DSV_DEV void recode_signed2(u32 (&y)[8], const u32 (&s)[8]) {
+  u32 carry = 0;
 #pragma unroll
   for (int i = 0; i < 8; i++) {
-    const u32 si = negative ? ~s[i] : s[i];  // -s = ~s + 1 (mod 2^256)
-    const u64 t = (u64)si + 0xAAAAAAAAu + carry;
+    const u64 t = (u64)s[i] + 0x55555555u + carry;
     y[i] = (u32)t;
     carry = (u32)(t >> 32);
   }
@@ -251,7 +271,7 @@ DSV_DEV int joint_digit(const u32 (&ya)[8], const u32 (&yb)[8], int k) {
   const int sh = 2 * (k & 15);
   return joint_slot((ya[k >> 4] >> sh) & 3u, (yb[k >> 4] >> sh) & 3u);
 }
-// index of the highest window with a non-zero digit in either scalar (caller: (ya | yb) ^ 0xAA..A)
+// index of the highest window with a non-zero digit in either scalar (caller: (ya | yb) ^ 0x55..5)
 DSV_DEV int top_digit2(const u32 (&nz)[8]) {
   int len = 0;
 #pragma unroll

@@ -4,7 +4,7 @@
 // (halfgcd.h): with (a, b), a = b*c (mod 8r), b odd,
 //   u*G + c*PK == R   <=>   (b*u mod r)*G + a*PK - b*R == O.
 // ONE per-lane window table over both variable bases — the 11 combinations da*PK + db*R of signed
-// 2-bit digits (common.h: build_joint_table) — and one Straus chain of ~66 windows of two doublings
+// 2-bit digits in [-1, 2] (common.h: build_joint_table) — and one Straus chain of ~66 windows of two doublings
 // and ONE addition each, whose length is the lane's own max(bitlen a, bitlen b) (lanes of a wave
 // simply leave the loop at different times); then 16 mixed additions from the fixed-base table;
 // the verdict is an identity test.  (r01 - r03a: one 4-bit table of 8 entries per base, two
@@ -40,12 +40,12 @@ k_verify_fixed_half(const uint8_t* __restrict__ u, const uint8_t* __restrict__ c
       u32 cs[8], a[8], b[8];
       load_words8(cs, c, i);
       half_scalars(a, b, b_neg, cs);
-      // signed 2-bit digits of a and of -+|b| (the sign of the R term goes into the recoding)
-      recode_signed2(ya, a, false);
-      recode_signed2(yb, b, !b_neg);
+      // signed 2-bit digits of a and |b| (the sign of the R term goes into the point: -R below)
+      recode_signed2(ya, a);
+      recode_signed2(yb, b);
       u32 nz[8];
 #pragma unroll
-      for (int k = 0; k < 8; k++) nz[k] = (ya[k] ^ 0xAAAAAAAAu) | (yb[k] ^ 0xAAAAAAAAu);
+      for (int k = 0; k < 8; k++) nz[k] = (ya[k] ^ 0x55555555u) | (yb[k] ^ 0x55555555u);
       top = top_digit2(nz);
       u32 us[8];
       load_words8(us, u, i);
@@ -68,11 +68,11 @@ k_verify_fixed_half(const uint8_t* __restrict__ u, const uint8_t* __restrict__ c
         Fe pku, pkv, ru, rv;
         good &= load_fq(pku, op.PK_uv, 2 * i);
         good &= load_fq(pkv, op.PK_uv, 2 * i + 1);
-        good &= load_fq(ru, op.R_uv, 2 * i);
+        good &= load_fq_signed(ru, op.R_uv, 2 * i, !b_neg);  // the chain adds -|b| * R unless b < 0
         good &= load_fq(rv, op.R_uv, 2 * i + 1);
         build_joint_table(tbl, pku, pkv, ru, rv);
       }
-      // T = a*PK -+ |b|*R (+ w*G below): one joint entry per 2-bit window, loaded one window ahead
+      // T = a*PK + |b|*(-+R) (+ w*G below): one joint entry per 2-bit window, loaded one window ahead
       Ext acc = ext_from_niels(load_var_entry(tbl, joint_digit(ya, yb, top)));
       {
         RawNiels e = load_var_entry_raw(tbl, joint_digit(ya, yb, top > 0 ? top - 1 : 0));
