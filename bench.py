@@ -64,13 +64,13 @@ VAR_LATTICE = 22000                    # its lattice reduction: ~80 passes x ~17
 def _verify_counts(chains=1):
     """(multiplications, squarings) per verdict of k_verify_fixed_half<chains>: joint table of the 11
     combinations da*PK + db*R (common.h: build_joint_table), WINDOWS x (2 doublings + 1 addition)"""
-    table_m = 4 + 3 * 5 + 6 * 8 + 0        # P, R (u*v, *2d); 2P, 2R, 2(P+R): 3M (+4S) + 2; six sums: 6 + 2
+    table_m = 4 + 3 * 5 + 3 * (10 + 4)     # P, R (u*v, *2d); 2P, 2R, 2(P+R): 3M (+4S) + 2; three sum / difference pairs: 10 + 2 x 2
     table_s = 3 * 4
     dbl_m, dbl_s, add_m = 3, 4, 8           # doubling: 2uv as (u+v)^2 - (u^2+v^2)
     per_chain_m = (4 + table_m              # PK, R to Montgomery form; the table
                    + 2                      # top window: O + entry (2M + 1S)
                    + (WINDOWS - 1) * (2 * dbl_m + add_m)
-                   + FIXED_ADDS * 7)        # += (b*u)*G, mixed additions
+                   + (FIXED_ADDS - 1) * 7 + 4)   # += (b*u)*G, mixed additions; the last only as far as the identity test needs it
     per_chain_s = table_s + 1 + (WINDOWS - 1) * 2 * dbl_s
     return chains * per_chain_m, chains * per_chain_s
 

@@ -124,6 +124,20 @@ DSV_DEV Ext fixed_base_accumulate(Ext acc, const u32 (&s)[8], const u32* __restr
   return acc;
 }
 
+// [ acc + s * Gen == O ]: the same, the last of the kFixedWindows additions only as far as the
+// identity test needs it (ext_add_aniels_is_identity)
+DSV_DEV bool fixed_base_accumulate_is_identity(Ext acc, const u32 (&s)[8], const u32* __restrict__ table) {
+  u32 y[9];
+  recode_fixed(y, s);
+#pragma unroll 1
+  for (int w = 0; w < kFixedWindows - 1; w++) {
+    const int d = next_fixed_digit(y);
+    ANiels e = load_aniels(table, w, d);
+    acc = ext_add_aniels(acc, e);
+  }
+  return ext_add_aniels_is_identity(acc, load_aniels(table, kFixedWindows - 1, next_fixed_digit(y)));
+}
+
 // ---- per-lane window table of a variable base, in global memory, LANE-MAJOR ---------------
 // Signed 4-bit digits d in [-8, 8): entries |d| * P for |d| = 1..8, each stored as extended niels
 // (v+u, v-u, z, 2d*t), 4 x 9 words = 144 B; 1296 B per lane, contiguous (slot 0 is never written:
@@ -232,7 +246,7 @@ DSV_DEV int top_digit4(const u32 (&nz)[8]) {
 // ---- JOINT window table of two variable bases (P, R): signed 2-bit digits (da, db) in [-1, 2]^2,
 // one table entry da*P + db*R per window, ONE addition per two doublings.  Same additions per bit
 // as two 4-bit tables (one per 2 bits against two per 4), but 11 stored entries instead of 16 and a
-// table built with 67 multiplications + 12 squarings instead of 116 multiplications; the chain's
+// table built with 61 multiplications + 12 squarings instead of 116 multiplications; the chain's
 // length follows max(bitlen a, bitlen b) in steps of 2 bits instead of 4.
 //   slot: 1 P | 2 R | 3 2P | 4 2R | 5 P+R | 6 P-R | 7 2P+R | 8 2P-R | 9 P+2R | 10 2R-P | 11 2P+2R
 // Digit pairs map to +-slot (a negative pair reads the entry with v+u / v-u swapped and 2d*t
@@ -279,8 +293,8 @@ DSV_DEV int top_digit2(const u32 (&nz)[8]) {
     if (nz[i] != 0) len = 32 * i + (32 - __clz(nz[i]));
   return len > 0 ? (len - 1) >> 1 : 0;
 }
-// P = (pu, pv), R = (ru, rv) affine.  Every sum is a mixed addition onto an extended point whose
-// t1*t2 is at hand (ext_add_aniels_t); the differences use the negated affine niels form.
+// P = (pu, pv), R = (ru, rv) affine.  Every sum / difference pair is one shared mixed addition onto
+// an extended point whose t1*t2 is at hand (ext_add_sub_aniels_t: 10 M per pair).
 DSV_DEV void build_joint_table(u32* tbl, const Fe& pu, const Fe& pv, const Fe& ru, const Fe& rv) {
   const Ext P = ext_from_affine(pu, pv), R = ext_from_affine(ru, rv);
   const Fe ttP = fe_mul(pu, pv), ttR = fe_mul(ru, rv);
@@ -288,27 +302,29 @@ DSV_DEV void build_joint_table(u32* tbl, const Fe& pu, const Fe& pv, const Fe& r
   store_var_entry(tbl, 1, nP);
   store_var_entry(tbl, 2, nR);
   const ANiels aP = {nP.vpu, nP.vmu, nP.t2d}, aR = {nR.vpu, nR.vmu, nR.t2d};
-  const ANiels aPn = {nP.vmu, nP.vpu, fe_neg2(nP.t2d)}, aRn = {nR.vmu, nR.vpu, fe_neg2(nR.t2d)};
   auto put = [&](int slot, const Ext& x) { store_var_entry(tbl, slot, ext_to_niels(x)); };
+  Ext sum, diff;
   {
-    const Ext S = ext_add_aniels_t(P, ttP, aR);
-    put(5, S);
-    put(11, ext_double(S));
-    put(6, ext_add_aniels_t(P, ttP, aRn));
+    ext_add_sub_aniels_t(sum, diff, P, ttP, aR);  // P + R, P - R
+    put(5, sum);
+    put(6, diff);
+    put(11, ext_double(sum));
   }
   {
     const Ext P2 = ext_double(P);
     const Fe tt = fe_mul(P2.t1, P2.t2);
     store_var_entry(tbl, 3, ext_to_niels_t(P2, tt));
-    put(7, ext_add_aniels_t(P2, tt, aR));
-    put(8, ext_add_aniels_t(P2, tt, aRn));
+    ext_add_sub_aniels_t(sum, diff, P2, tt, aR);  // 2P + R, 2P - R
+    put(7, sum);
+    put(8, diff);
   }
   {
     const Ext R2 = ext_double(R);
     const Fe tt = fe_mul(R2.t1, R2.t2);
     store_var_entry(tbl, 4, ext_to_niels_t(R2, tt));
-    put(9, ext_add_aniels_t(R2, tt, aP));
-    put(10, ext_add_aniels_t(R2, tt, aPn));
+    ext_add_sub_aniels_t(sum, diff, R2, tt, aP);  // 2R + P, 2R - P
+    put(9, sum);
+    put(10, diff);
   }
 }
 // acc = 4 * acc

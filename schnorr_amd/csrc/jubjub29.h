@@ -126,6 +126,17 @@ DSV_DEV Ext ext_add_aniels(const Ext& p, const ANiels& n) {
   Fe d = fe_dbl(p.z);                       // < 3.0, limbs < 2^30
   return ext_add_tail(a, b, c, d);
 }
+// [ p + n == O ] without finishing the addition: the sum is ((b-a)(d-c), (b+a)(d+c), (d+c)(d-c))
+// and z3 != 0 for points of the curve (the formulas are complete), so
+//   u3 == 0 and v3 == z3   <=>   b == a  and  b + a == d - c
+// — the last addition of a verification costs 4 multiplications instead of 7.
+DSV_DEV bool ext_add_aniels_is_identity(const Ext& p, const ANiels& n) {
+  const Fe a = fe_mul(fe_sub2_raw(p.v, p.u), n.vmu);
+  const Fe b = fe_mul(fe_add(p.v, p.u), n.vpu);
+  const Fe c = fe_mul(fe_mul(p.t1, p.t2), n.t2d);
+  const Fe d = fe_dbl(p.z);
+  return (bool)((int)fe_equal(b, a) & (int)fe_equal(fe_add(b, a), fe_sub2(d, c)));
+}
 // O + n as an extended point: the addition formulas with p = (0, 1, 1, 0, 0) — a = n.vmu,
 // b = n.vpu, c = 0, d = 2 n.z — i.e. three multiplications instead of eight
 DSV_DEV Ext ext_from_niels(const Niels& n) {
@@ -148,6 +159,30 @@ DSV_DEV Ext ext_add_aniels_t(const Ext& p, const Fe& tt, const ANiels& n) {
   Fe c = fe_mul(tt, n.t2d);
   Fe d = fe_dbl(p.z);
   return ext_add_tail(a, b, c, d);
+}
+// sum = p + n AND diff = p - n for an affine niels n, tt = p.t1 * p.t2 handed in: -n swaps n.vpu /
+// n.vmu and negates c, which only swaps the roles of cz = d + c and ct = d - c in the tail — the two
+// results share c, d and z = cz * ct: 10 multiplications instead of 12 (the joint table build has
+// three such pairs).  Bounds as ext_add_tail; the carried copy of cz takes ct's place next to a raw
+// cu (tests/fe29_bounds.py: ext_add_sub_aniels).
+DSV_DEV void ext_add_sub_aniels_t(Ext& sum, Ext& diff, const Ext& p, const Fe& tt, const ANiels& n) {
+  const Fe pm = fe_sub2_raw(p.v, p.u), pp = fe_add(p.v, p.u);
+  const Fe a = fe_mul(pm, n.vmu), b = fe_mul(pp, n.vpu);
+  const Fe a2 = fe_mul(pm, n.vpu), b2 = fe_mul(pp, n.vmu);
+  const Fe c = fe_mul(tt, n.t2d);
+  const Fe d = fe_dbl(p.z);
+  const Fe cu = fe_sub2_raw(b, a), cv = fe_add(b, a), cz = fe_add(d, c), ct = fe_sub2(d, c);
+  sum.u = fe_mul(cu, ct);
+  sum.v = fe_mul(cv, cz);
+  sum.z = fe_mul(cz, ct);
+  sum.t1 = cu;
+  sum.t2 = cv;
+  const Fe cu2 = fe_sub2_raw(b2, a2), cv2 = fe_add(b2, a2);
+  diff.u = fe_mul(cu2, fe_carry(cz));
+  diff.v = fe_mul(cv2, ct);
+  diff.z = sum.z;
+  diff.t1 = cu2;
+  diff.t2 = cv2;
 }
 DSV_DEV Niels ext_to_niels_t(const Ext& p, const Fe& tt) {
   Niels n;

@@ -84,9 +84,8 @@ k_verify_fixed_half(const uint8_t* __restrict__ u, const uint8_t* __restrict__ c
           acc = ext_add_niels(acc, cur);
         }
       }
-      acc = fixed_base_accumulate(acc, w, op.table);
-      // T == O  <=>  u == 0 and v == z
-      good &= (bool)((int)fe_is_zero_canon(fe_canon(acc.u)) & (int)fe_equal(acc.v, acc.z));
+      // T + w*G == O  (T == O  <=>  u == 0 and v == z, decided inside the last addition)
+      good &= fixed_base_accumulate_is_identity(acc, w, op.table);
     }
     ok[i] = good ? 1 : 0;
   }

@@ -211,6 +211,21 @@ def ext_add_aniels(p, n):
     return _add_tail(a, b, c, d)
 
 
+def ext_add_sub_aniels(p, n):
+    """jubjub29.h: ext_add_sub_aniels_t — (p + n, p - n) sharing c, d and z (joint table build)"""
+    pm, pp = sub_raw(p["v"], p["u"], 2), add(p["v"], p["u"])
+    a, b = mul(pm, n["vmu"]), mul(pp, n["vpu"])
+    a2, b2 = mul(pm, n["vpu"]), mul(pp, n["vmu"])
+    c = mul(mul(p["t1"], p["t2"]), n["t2d"])
+    d = dbl(p["z"])
+    cu, cv, cz, ct = sub_raw(b, a, 2), add(b, a), add(d, c), sub(d, c, 2)
+    z = mul(cz, ct)
+    s_ = {"u": mul(cu, ct), "v": mul(cv, cz), "z": z, "t1": cu, "t2": cv}
+    cu2, cv2 = sub_raw(b2, a2, 2), add(b2, a2)
+    d_ = {"u": mul(cu2, carry(cz)), "v": mul(cv2, ct), "z": z, "t1": cu2, "t2": cv2}
+    return s_, d_
+
+
 def ext_from_niels(n):
     cu = sub(n["vpu"], n["vmu"], 4)
     cv = add(n["vpu"], n["vmu"])
@@ -265,6 +280,9 @@ def prove_group_law(max_rounds=40):
         nxt = join_pt(nxt, ext_add_aniels(acc, fixed))
         # table build: i*P + P with P's own (affine, z = 1) niels form; chain start: O + entry
         nxt = join_pt(nxt, ext_add_aniels(acc, {k: niels[k] for k in ("vpu", "vmu", "t2d")}))
+        # joint table build: the sum / difference pair of one shared mixed addition
+        for pt in ext_add_sub_aniels(acc, {k: niels[k] for k in ("vpu", "vmu", "t2d")}):
+            nxt = join_pt(nxt, pt)
         nxt = join_pt(nxt, ext_from_niels(niels))
         nn = join_pt(niels, table_entry(nxt, d2))
         if rnd >= 2:
@@ -276,6 +294,13 @@ def prove_group_law(max_rounds=40):
             equal_ok(acc["v"], mul(mont_in, acc["z"]))
             equal_ok(acc["u"], B([0] * NL))
             equal_ok(acc["v"], acc["z"])
+            # ext_add_aniels_is_identity: b == a and b + a == d - c inside the last mixed addition
+            a_ = mul(sub_raw(acc["v"], acc["u"], 2), fixed["vmu"])
+            b_ = mul(add(acc["v"], acc["u"]), fixed["vpu"])
+            c_ = mul(mul(acc["t1"], acc["t2"]), fixed["t2d"])
+            d_ = dbl(acc["z"])
+            equal_ok(b_, a_)
+            equal_ok(add(b_, a_), sub(d_, c_, 2))
             return {"acc": acc, "niels": niels, "rounds": rnd}
         acc, niels = nxt, nn
     raise OverflowError_("bounds keep growing: no fixpoint after %d rounds" % max_rounds)

@@ -234,6 +234,30 @@ def ext_add_aniels(p, n):
     return _add_tail(a, b, c, d)
 
 
+def ext_add_sub_aniels(p, n):
+    """jubjub29.h: ext_add_sub_aniels_t — (p + n, p - n) sharing c, d and z"""
+    pm, pp = sub_raw(p["v"], p["u"], 2), add(p["v"], p["u"])
+    a, b = mul(pm, n["vmu"]), mul(pp, n["vpu"])
+    a2, b2 = mul(pm, n["vpu"]), mul(pp, n["vmu"])
+    c = mul(mul(p["t1"], p["t2"]), n["t2d"])
+    d = dbl(p["z"])
+    cu, cv, cz, ct = sub_raw(b, a, 2), add(b, a), add(d, c), sub(d, c, 2)
+    z = mul(cz, ct)
+    s_ = {"u": mul(cu, ct), "v": mul(cv, cz), "z": z, "t1": cu, "t2": cv}
+    cu2, cv2 = sub_raw(b2, a2, 2), add(b2, a2)
+    d_ = {"u": mul(cu2, carry(cz)), "v": mul(cv2, ct), "z": z, "t1": cu2, "t2": cv2}
+    return s_, d_
+
+
+def ext_add_aniels_is_identity(p, n):
+    """jubjub29.h: [p + n == O] from the addition's a, b, c, d alone"""
+    a = mul(sub_raw(p["v"], p["u"], 2), n["vmu"])
+    b = mul(add(p["v"], p["u"]), n["vpu"])
+    c = mul(mul(p["t1"], p["t2"]), n["t2d"])
+    d = dbl(p["z"])
+    return equal(b, a) and equal(add(b, a), sub(d, c, 2))
+
+
 def ext_from_niels(n):
     cu = sub(n["vpu"], n["vmu"], 4)
     cv = add(n["vpu"], n["vmu"])

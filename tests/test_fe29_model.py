@@ -88,6 +88,47 @@ def test_chain_start_and_mixed_table_build_match_the_affine_model():
     assert F.affine_of(F.ext_from_niels(ident)) == (0, 1)
 
 
+def test_shared_sum_and_difference_of_the_joint_table_build():
+    """ext_add_sub_aniels_t: (p + n, p - n) from one shared addition, for affine and projective p"""
+    for _ in range(4):
+        P = M.pmul(M.GEN, rnd.randrange(1, M.R_ORDER))
+        R = M.pmul(M.GEN, rnd.randrange(1, M.R_ORDER))
+        p = F.ext_from_affine(F.to_mont_int(P[0]), F.to_mont_int(P[1]))
+        r = F.ext_from_affine(F.to_mont_int(R[0]), F.to_mont_int(R[1]))
+        nr = F.ext_to_niels(r)
+        ar = {k: nr[k] for k in ("vpu", "vmu", "t2d")}
+        for base, want in ((p, P), (F.ext_double(p), M.pmul(P, 2)),
+                           (F.ext_add_niels(F.ext_double(F.ext_double(p)), nr), M.padd(M.pmul(P, 4), R))):
+            s_, d_ = F.ext_add_sub_aniels(base, ar)
+            assert F.affine_of(s_) == M.padd(want, R)
+            assert F.affine_of(d_) == M.padd(want, M.pneg(R))
+            # both feed the next operations like any other accumulator
+            assert F.affine_of(F.ext_double(d_)) == M.pmul(M.padd(want, M.pneg(R)), 2)
+            assert F.affine_of(F.ext_from_niels(F.ext_to_niels(d_))) == M.padd(want, M.pneg(R))
+
+
+def test_identity_decided_inside_the_last_addition():
+    """ext_add_aniels_is_identity(p, n) == [p + n == O], for p = -n (true), p = -n + torsion and
+    random p (false), affine and projective p"""
+    import test_halfgcd as TH
+    t8 = TH.order8_point()
+    for trial in range(6):
+        N = M.pmul(M.GEN, rnd.randrange(1, M.R_ORDER))
+        n_ext = F.ext_from_affine(F.to_mont_int(N[0]), F.to_mont_int(N[1]))
+        nn = F.ext_to_niels(n_ext)
+        an = {k: nn[k] for k in ("vpu", "vmu", "t2d")}
+        for P in (M.pneg(N), M.padd(M.pneg(N), M.pmul(t8, 1 + trial)), M.pmul(M.GEN, rnd.randrange(1, M.R_ORDER)),
+                  M.IDENTITY, N):
+            p = F.ext_from_affine(F.to_mont_int(P[0]), F.to_mont_int(P[1]))
+            # a projective representative: p = (2P - P) through the formulas
+            p2 = F.ext_add_niels(F.ext_double(p), F.ext_to_niels(F.ext_from_affine(
+                F.to_mont_int(M.pneg(P)[0]), F.to_mont_int(M.pneg(P)[1]))))
+            want = M.padd(P, N) == M.IDENTITY
+            assert F.ext_add_aniels_is_identity(p, an) == want
+            assert F.ext_add_aniels_is_identity(p2, an) == want
+            assert (F.affine_of(F.ext_add_aniels(p2, an)) == (0, 1)) == want
+
+
 def test_identity_and_torsion_through_the_formulas():
     ident = F.ext_identity()
     d = F.ext_double(ident)
