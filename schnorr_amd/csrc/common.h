@@ -311,7 +311,7 @@ DSV_DEV void build_joint_table(u32* tbl, const Fe& pu, const Fe& pv, const Fe& r
     put(11, ext_double(sum));
   }
   {
-    const Ext P2 = ext_double(P);
+    const Ext P2 = ext_double_affine(pu, pv);
     const Fe tt = fe_mul(P2.t1, P2.t2);
     store_var_entry(tbl, 3, ext_to_niels_t(P2, tt));
     ext_add_sub_aniels_t(sum, diff, P2, tt, aR);  // 2P + R, 2P - R
@@ -319,7 +319,7 @@ DSV_DEV void build_joint_table(u32* tbl, const Fe& pu, const Fe& pv, const Fe& r
     put(8, diff);
   }
   {
-    const Ext R2 = ext_double(R);
+    const Ext R2 = ext_double_affine(ru, rv);
     const Fe tt = fe_mul(R2.t1, R2.t2);
     store_var_entry(tbl, 4, ext_to_niels_t(R2, tt));
     ext_add_sub_aniels_t(sum, diff, R2, tt, aP);  // 2R + P, 2R - P

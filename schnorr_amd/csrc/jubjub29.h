@@ -82,6 +82,23 @@ DSV_DEV Ext ext_double(const Ext& p) {
   return r;
 }
 
+// 2 * (u, v) for an affine point (z = 1): 2 z^2 is the constant 2
+DSV_DEV Ext ext_double_affine(const Fe& u, const Fe& v) {
+  Fe uu = fe_sqr(u);
+  Fe vv = fe_sqr(v);
+  Fe zz2 = fe_dbl(fe_one());
+  Fe vpu = fe_add(vv, uu);
+  Fe cu = ext_two_uv(u, v, vpu);
+  Fe vmu = fe_sub2_raw(vv, uu);
+  Fe ct = fe_sub4w(zz2, vmu);
+  Ext r;
+  r.u = fe_mul(cu, ct);
+  r.v = fe_mul(vpu, vmu);
+  r.z = fe_mul(vmu, ct);
+  r.t1 = cu;
+  r.t2 = vpu;
+  return r;
+}
 // doubling that keeps only (u, v, z): inside a run of doublings nobody reads t1/t2
 DSV_DEV void ext_double_uvz(Fe& u, Fe& v, Fe& z) {
   Fe uu = fe_sqr(u);

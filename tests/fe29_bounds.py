@@ -276,6 +276,8 @@ def prove_group_law(max_rounds=40):
     niels = table_entry(acc, d2)
     for rnd in range(max_rounds):
         nxt = join_pt(acc, ext_double(acc))
+        # ext_double_affine (table build): z = 1, 2 z^2 = the constant 2
+        nxt = join_pt(nxt, ext_double(dict(acc, z=canonical())))   # (ONE is a canonical residue)
         nxt = join_pt(nxt, ext_add_niels(acc, niels))
         nxt = join_pt(nxt, ext_add_aniels(acc, fixed))
         # table build: i*P + P with P's own (affine, z = 1) niels form; chain start: O + entry

@@ -210,6 +210,17 @@ def ext_double(p):
     return {"u": mul(cu, ct), "v": mul(vpu, vmu), "z": mul(vmu, ct), "t1": cu, "t2": vpu}
 
 
+def ext_double_affine(u, v):
+    """jubjub29.h: doubling of an affine point: 2 z^2 is the constant 2"""
+    uu, vv = sqr(u), sqr(v)
+    zz2 = dbl(list(ONE))
+    vpu = add(vv, uu)
+    cu = sub(sqr(add(u, v)), vpu, "4w")
+    vmu = sub_raw(vv, uu, 2)
+    ct = sub(zz2, vmu, "4w")
+    return {"u": mul(cu, ct), "v": mul(vpu, vmu), "z": mul(vmu, ct), "t1": cu, "t2": vpu}
+
+
 def _add_tail(a, b, c, d):
     cu = sub_raw(b, a, 2)
     cv = add(b, a)

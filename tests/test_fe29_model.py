@@ -97,7 +97,8 @@ def test_shared_sum_and_difference_of_the_joint_table_build():
         r = F.ext_from_affine(F.to_mont_int(R[0]), F.to_mont_int(R[1]))
         nr = F.ext_to_niels(r)
         ar = {k: nr[k] for k in ("vpu", "vmu", "t2d")}
-        for base, want in ((p, P), (F.ext_double(p), M.pmul(P, 2)),
+        assert F.affine_of(F.ext_double_affine(p["u"], p["v"])) == M.pmul(P, 2)
+        for base, want in ((p, P), (F.ext_double_affine(p["u"], p["v"]), M.pmul(P, 2)),
                            (F.ext_add_niels(F.ext_double(F.ext_double(p)), nr), M.padd(M.pmul(P, 4), R))):
             s_, d_ = F.ext_add_sub_aniels(base, ar)
             assert F.affine_of(s_) == M.padd(want, R)
