@@ -301,7 +301,7 @@ DSV_DEV void build_joint_table(u32* tbl, const Fe& pu, const Fe& pv, const Fe& r
   const Niels nP = ext_to_niels_t(P, ttP), nR = ext_to_niels_t(R, ttR);
   store_var_entry(tbl, 1, nP);
   store_var_entry(tbl, 2, nR);
-  const ANiels aP = {nP.vpu, nP.vmu, nP.t2d}, aR = {nR.vpu, nR.vmu, nR.t2d};
+  const ANiels aR = {nR.vpu, nR.vmu, nR.t2d};
   auto put = [&](int slot, const Ext& x) { store_var_entry(tbl, slot, ext_to_niels(x)); };
   Ext sum, diff;
   {
@@ -322,6 +322,12 @@ DSV_DEV void build_joint_table(u32* tbl, const Fe& pu, const Fe& pv, const Fe& r
     const Ext R2 = ext_double_affine(ru, rv);
     const Fe tt = fe_mul(R2.t1, R2.t2);
     store_var_entry(tbl, 4, ext_to_niels_t(R2, tt));
+    // P's niels form comes back from its table slot: three fields fewer to keep live — or to spill —
+    // across the two blocks above (57 instead of 78 spilled VGPRs in the single-equation kernel:
+    // +0.9 %; reloading R's form for the second block as well and reordering the blocks leaves 25
+    // but waits on the stores in flight: slower — profiles/r03/ab_joint_windows.txt)
+    const u32* e1 = tbl + 1 * kVarEntryWords;
+    const ANiels aP = {load_fe_words(e1), load_fe_words(e1 + NL), load_fe_words(e1 + 3 * NL)};
     ext_add_sub_aniels_t(sum, diff, R2, tt, aP);  // 2R + P, 2R - P
     put(9, sum);
     put(10, diff);
