@@ -163,8 +163,8 @@ def _spawn_ranks(n):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--log2-batch", type=int, default=20)
     ap.add_argument("--config", choices=("single", "mixed"), default="single")
     ap.add_argument("--no-cpu-baseline", action="store_true")
