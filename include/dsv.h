@@ -141,6 +141,63 @@ int dsv_verify_vargen_ext_dev(const void *u, const void *R_uvz, const void *PK_u
                               const void *Gen_uvz, const void *m, size_t n, void *ok, void *workspace,
                               void *stream);
 
+/* ---- verify, the reference's IN-MEMORY representation (Montgomery limbs) -----------------------
+ * The Rust types hold every field element as `[u64; 4]` little-endian limbs in Montgomery form,
+ * R = 2^256: `BlsScalar(pub [u64; 4])` (dusk-bls12_381 0.13), `JubJubScalar` and the coordinates
+ * of `JubJubExtended` (dusk-jubjub 0.14) — /root/reference/Cargo.toml:25-26; the fields that verify
+ * reads: /root/reference/src/signatures.rs:58-61, 180-184, 337-340 (u, R, R'),
+ * src/keys/public.rs:59, 189, 331-334 (pk, pk', generator), the `BlsScalar` message of
+ * src/keys/public.rs:121, 222-226, 401-405.  Every `to_bytes()` is a Montgomery reduction on the
+ * host (8 per single signature, 14 per double one).  These entry points take the limbs as they
+ * lie in memory, so a binding copies bytes and does no arithmetic at all:
+ *   scalar (u, m)              : 32 B = the four u64 limbs of x * 2^256 mod (r | q)
+ *   point  (R, R', PK, PK', Gen): 96 B = limbs of u || v || z of the JubJubExtended (t1, t2 are not
+ *                                read; a common factor of the three coordinates does not change
+ *                                the point, so the device normalises them exactly like *_ext input)
+ * Limbs that are not below their modulus (the Rust types cannot hold them) or z = 0: ok[i] = 0.
+ * Same verdicts as dsv_verify_*_ext on the `to_bytes()` of the same values.
+ *
+ * The *_mont_cols forms read the typed objects WHERE THEY LIE: one dsv_column per field, item i at
+ * base + i * stride (stride = sizeof of the struct the field lives in).  The pipeline's copy threads
+ * gather the fields straight into pinned staging while the GPU works on the previous chunk — no
+ * intermediate structure of arrays, no second pass over host memory.  Column order:
+ *   single: u, R, PK, m            double: u, R, R', PK, PK', m            vargen: u, R, PK, Gen, m
+ * They shard over every initialised device like the *_multi forms (what verify_batch* bind). */
+typedef struct dsv_column {
+  const void *base;   /* field of item 0 */
+  size_t stride;      /* bytes from one item's field to the next (>= the field's width) */
+} dsv_column;
+int dsv_verify_single_mont_cols(const dsv_column *cols /*[4]*/, size_t n, uint8_t *ok);
+int dsv_verify_double_mont_cols(const dsv_column *cols /*[6]*/, size_t n, uint8_t *ok);
+int dsv_verify_vargen_mont_cols(const dsv_column *cols /*[5]*/, size_t n, uint8_t *ok);
+/* ... dense arrays (structure of arrays), this thread's device */
+int dsv_verify_single_mont(const uint8_t *u, const uint8_t *R_uvz, const uint8_t *PK_uvz,
+                           const uint8_t *m, size_t n, uint8_t *ok);
+int dsv_verify_double_mont(const uint8_t *u, const uint8_t *R_uvz, const uint8_t *Rp_uvz,
+                           const uint8_t *PK_uvz, const uint8_t *PKp_uvz, const uint8_t *m, size_t n,
+                           uint8_t *ok);
+int dsv_verify_vargen_mont(const uint8_t *u, const uint8_t *R_uvz, const uint8_t *PK_uvz,
+                           const uint8_t *Gen_uvz, const uint8_t *m, size_t n, uint8_t *ok);
+/* ... dense arrays, sharded over every initialised device */
+int dsv_verify_single_mont_multi(const uint8_t *u, const uint8_t *R_uvz, const uint8_t *PK_uvz,
+                                 const uint8_t *m, size_t n, uint8_t *ok);
+int dsv_verify_double_mont_multi(const uint8_t *u, const uint8_t *R_uvz, const uint8_t *Rp_uvz,
+                                 const uint8_t *PK_uvz, const uint8_t *PKp_uvz, const uint8_t *m,
+                                 size_t n, uint8_t *ok);
+int dsv_verify_vargen_mont_multi(const uint8_t *u, const uint8_t *R_uvz, const uint8_t *PK_uvz,
+                                 const uint8_t *Gen_uvz, const uint8_t *m, size_t n, uint8_t *ok);
+/* ... device buffers (enqueue only); workspace: dsv_mont_workspace_bytes(n) device bytes, 256-byte
+ * aligned */
+size_t dsv_mont_workspace_bytes(size_t n);
+int dsv_verify_single_mont_dev(const void *u, const void *R_uvz, const void *PK_uvz, const void *m,
+                               size_t n, void *ok, void *workspace, void *stream);
+int dsv_verify_double_mont_dev(const void *u, const void *R_uvz, const void *Rp_uvz,
+                               const void *PK_uvz, const void *PKp_uvz, const void *m, size_t n,
+                               void *ok, void *workspace, void *stream);
+int dsv_verify_vargen_mont_dev(const void *u, const void *R_uvz, const void *PK_uvz,
+                               const void *Gen_uvz, const void *m, size_t n, void *ok, void *workspace,
+                               void *stream);
+
 /* ---- verify, host buffers, sharded over every initialised device (see "Devices and threads") ---- */
 int dsv_verify_single_multi(const uint8_t *u, const uint8_t *R_uv, const uint8_t *PK_uv,
                             const uint8_t *m, size_t n, uint8_t *ok);

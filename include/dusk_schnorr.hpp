@@ -2,8 +2,15 @@
 // signature surface for the native verification path, on top of the C ABI in dsv.h.
 //
 // The reference is a Rust crate; this image has no Rust toolchain, so the compiled-language host
-// layer is C++ with the reference's names, argument meaning and error behaviour:
+// layer is C++ with the reference's names, argument meaning, error behaviour AND in-memory
+// representation:
 //
+//   BlsScalar, JubJubScalar                         four u64 limbs in Montgomery form, R = 2^256, as
+//                                                   dusk-bls12_381 0.13 / dusk-jubjub 0.14 hold them
+//                                                   (/root/reference/Cargo.toml:25-26); `to_bytes()`
+//                                                   is a Montgomery reduction, `from_bytes()` a
+//                                                   multiplication by R^2 — what they cost upstream
+//   JubJubExtended{u, v, z, t1, t2}                 160 B, five BlsScalar
 //   SecretKey::random / sign / sign_double          /root/reference/src/keys/secret.rs:79-86, 150-168, 217-240
 //   SecretKeyVarGen::{new, random, sign}            /root/reference/src/keys/secret.rs:352-376, 433-451
 //   PublicKey::from(&sk) / verify                   /root/reference/src/keys/public.rs:61-67, 121-130
@@ -20,14 +27,18 @@
 //
 // `verify` is infallible and returns bool exactly like the reference; a failure of the engine
 // itself (no GPU, HIP error) is not a verdict and is thrown as std::runtime_error.
-// All arithmetic happens on the GPU (libdsv.so); the only host arithmetic here is the 512-bit
-// reduction of `random()` (ff::Field::random = from_bytes_wide of 64 random bytes).
-// Keys and signatures hold JubJubExtended points (u, v, z) like the reference's types do; the
-// normalisation `to_hash_inputs` that the reference's verify starts with
-// (/root/reference/src/signatures.rs:131, :280-281) runs on the device inside the dsv_verify_*_ext
-// entry points — verify() and verify_batch*() do no field arithmetic on the host.
+//
+// verify() and verify_batch*() do NO field arithmetic on the host: they hand the engine the limbs
+// where they lie (dsv_verify_*_mont_cols: one strided column per field of the typed objects; the
+// engine's copy threads gather them into pinned staging while the GPU works on the previous
+// chunk) — no `to_bytes()`, i.e. none of the 8 (single) / 14 (double) / 11 (var-generator)
+// Montgomery reductions per signature a byte-oriented binding would run on one host thread, and
+// no `to_hash_inputs` inversion.  The host arithmetic below (Montgomery multiplication, inversion,
+// projective equality) serves the parts of the surface that are host work in the reference too:
+// (de)serialisation, `random`, `PartialEq`.
 #pragma once
 #include <array>
+#include <cstddef>
 #include <cstdint>
 #include <cstring>
 #include <optional>
@@ -47,7 +58,7 @@ inline void check(int rc, const char* what) {
 }
 inline void ensure_init() {
   // the GPUs named in $DSV_DEVICES, else every GPU of the node: verify_batch* shard over all of
-  // them (dsv_verify_*_ext_multi).  First call: two 75.5 MB window tables per device, ~50 ms each.
+  // them.  First call: two 75.5 MB window tables per device, ~50 ms each.
   static const bool once = [] {
     const int rc = dsv_init_visible();
     if (rc < 0) check(rc, "dsv_init_visible");  // e.g. DSV_ERR_NO_DEVICE
@@ -55,114 +66,233 @@ inline void ensure_init() {
   }();
   (void)once;
 }
-// x mod m for a 512-bit little-endian x and a 256-bit little-endian modulus (shift-subtract)
-inline std::array<uint8_t, 32> mod_wide(const uint8_t x[64], const uint8_t m[32]) {
-  uint64_t r[5] = {0, 0, 0, 0, 0}, mod[4];
-  std::memcpy(mod, m, 32);
-  for (int bit = 511; bit >= 0; bit--) {
-    for (int i = 4; i > 0; i--) r[i] = (r[i] << 1) | (r[i - 1] >> 63);
-    r[0] = (r[0] << 1) | ((x[bit >> 3] >> (bit & 7)) & 1);
-    // if r >= mod: r -= mod
-    uint64_t d[5];
-    unsigned __int128 borrow = 0;
-    for (int i = 0; i < 5; i++) {
-      unsigned __int128 t = (unsigned __int128)r[i] - (i < 4 ? mod[i] : 0) - (uint64_t)borrow;
-      d[i] = (uint64_t)t;
-      borrow = (t >> 64) & 1;
-    }
-    if (!borrow) std::memcpy(r, d, sizeof d);
-  }
-  std::array<uint8_t, 32> out;
-  std::memcpy(out.data(), r, 32);
-  return out;
+
+// One prime field in Montgomery form, R = 2^256 (every constant is
+// re-derived from the modulus by tests/test_cpp_mirror.py)
+struct FieldParams {
+  uint64_t p[4];   // modulus
+  uint64_t inv;    // -p^-1 mod 2^64
+  uint64_t r[4];   // R mod p   (= one)
+  uint64_t r2[4];  // R^2 mod p
+  uint64_t r3[4];  // R^3 mod p
+};
+inline constexpr FieldParams kFq = {
+    {0xffffffff00000001ULL, 0x53bda402fffe5bfeULL, 0x3339d80809a1d805ULL, 0x73eda753299d7d48ULL},
+    0xfffffffeffffffffULL,
+    {0x00000001fffffffeULL, 0x5884b7fa00034802ULL, 0x998c4fefecbc4ff5ULL, 0x1824b159acc5056fULL},
+    {0xc999e990f3f29c6dULL, 0x2b6cedcb87925c23ULL, 0x05d314967254398fULL, 0x0748d9d99f59ff11ULL},
+    {0xc62c1807439b73afULL, 0x1b3e0d188cf06990ULL, 0x73d13c71c7b5f418ULL, 0x6e2a5bb9c8db33e9ULL}};
+inline constexpr FieldParams kFr = {
+    {0xd0970e5ed6f72cb7ULL, 0xa6682093ccc81082ULL, 0x06673b0101343b00ULL, 0x0e7db4ea6533afa9ULL},
+    0x1ba3a358ef788ef9ULL,
+    {0x25f80bb3b99607d9ULL, 0xf315d62f66b6e750ULL, 0x932514eeeb8814f4ULL, 0x09a6fc6f479155c6ULL},
+    {0x67719aa495e57731ULL, 0x51b0cef09ce3fc26ULL, 0x69dab7fac026e9a5ULL, 0x04f6547b8d127688ULL},
+    {0xe0d6c6563d830544ULL, 0x323e3883598d0f85ULL, 0xf0fea3004c2e2ba8ULL, 0x05874f84946737ecULL}};
+
+using u128 = unsigned __int128;
+inline bool geq(const uint64_t a[4], const uint64_t b[4]) {
+  for (int i = 3; i >= 0; i--)
+    if (a[i] != b[i]) return a[i] > b[i];
+  return true;
 }
-inline constexpr uint8_t kFrModulus[32] = {
-    0xb7, 0x2c, 0xf7, 0xd6, 0x5e, 0x0e, 0x97, 0xd0, 0x82, 0x10, 0xc8, 0xcc, 0x93, 0x20, 0x68, 0xa6,
-    0x00, 0x3b, 0x34, 0x01, 0x01, 0x3b, 0x67, 0x06, 0xa9, 0xaf, 0x33, 0x65, 0xea, 0xb4, 0x7d, 0x0e};
-inline constexpr uint8_t kFqModulus[32] = {
-    0x01, 0x00, 0x00, 0x00, 0xff, 0xff, 0xff, 0xff, 0xfe, 0x5b, 0xfe, 0xff, 0x02, 0xa4, 0xbd, 0x53,
-    0x05, 0xd8, 0xa1, 0x09, 0x08, 0xd8, 0x39, 0x33, 0x48, 0x7d, 0x9d, 0x29, 0x53, 0xa7, 0xed, 0x73};
+inline void sub_in_place(uint64_t a[4], const uint64_t b[4]) {
+  u128 borrow = 0;
+  for (int i = 0; i < 4; i++) {
+    const u128 t = (u128)a[i] - b[i] - (uint64_t)borrow;
+    a[i] = (uint64_t)t;
+    borrow = (t >> 64) & 1;
+  }
+}
+// out = a * b * 2^-256 mod p   (operand scanning; a, b < p)
+inline void mont_mul(const FieldParams& f, uint64_t out[4], const uint64_t a[4], const uint64_t b[4]) {
+  uint64_t t[6] = {0, 0, 0, 0, 0, 0};
+  for (int i = 0; i < 4; i++) {
+    u128 c = 0;
+    for (int j = 0; j < 4; j++) {
+      c += (u128)a[j] * b[i] + t[j];
+      t[j] = (uint64_t)c;
+      c >>= 64;
+    }
+    c += t[4];
+    t[4] = (uint64_t)c;
+    t[5] = (uint64_t)(c >> 64);
+    const uint64_t m = t[0] * f.inv;
+    c = ((u128)m * f.p[0] + t[0]) >> 64;
+    for (int j = 1; j < 4; j++) {
+      c += (u128)m * f.p[j] + t[j];
+      t[j - 1] = (uint64_t)c;
+      c >>= 64;
+    }
+    c += t[4];
+    t[3] = (uint64_t)c;
+    t[4] = t[5] + (uint64_t)(c >> 64);
+  }
+  if (t[4] || geq(t, f.p)) sub_in_place(t, f.p);
+  std::memcpy(out, t, 32);
+}
 }  // namespace detail
 
-template <const uint8_t* MOD>
-struct Scalar32 {
-  std::array<uint8_t, 32> bytes{};  // canonical little-endian, as `to_bytes()`
-  static Scalar32 from_u64(uint64_t x) {
-    Scalar32 s;
-    std::memcpy(s.bytes.data(), &x, 8);
+// A field element as the reference holds it: `.0` = four u64 Montgomery limbs.
+template <const detail::FieldParams& F>
+struct MontScalar {
+  uint64_t l[4] = {0, 0, 0, 0};  // x * 2^256 mod p, little-endian limbs
+
+  static MontScalar zero() { return MontScalar{}; }
+  static MontScalar one() { return from_limbs(F.r); }
+  static MontScalar from_limbs(const uint64_t limbs[4]) {  // the reference's tuple field, as is
+    MontScalar s;
+    std::memcpy(s.l, limbs, 32);
     return s;
   }
-  static Scalar32 from_bytes_wide(const uint8_t wide[64]) {
-    Scalar32 s;
-    s.bytes = detail::mod_wide(wide, MOD);
+  // `from_raw([u64; 4])`: canonical integer limbs -> Montgomery form
+  static MontScalar from_raw(const uint64_t raw[4]) {
+    MontScalar s;
+    detail::mont_mul(F, s.l, raw, F.r2);
     return s;
+  }
+  static MontScalar from(uint64_t x) {
+    const uint64_t raw[4] = {x, 0, 0, 0};
+    return from_raw(raw);
+  }
+  // `from_bytes_wide`: 512-bit little-endian integer mod p = lo * R^2 + hi * R^3 (Montgomery products)
+  static MontScalar from_bytes_wide(const uint8_t wide[64]) {
+    uint64_t lo[4], hi[4];
+    std::memcpy(lo, wide, 32);
+    std::memcpy(hi, wide + 32, 32);
+    // the halves may exceed p; mont_mul only needs a * b < p * 2^256, true for any 256-bit a and b < p
+    MontScalar a, b;
+    detail::mont_mul(F, a.l, lo, F.r2);
+    detail::mont_mul(F, b.l, hi, F.r3);
+    return a + b;
   }
   // `Field::random`: 64 bytes from the rng, reduced.  Rng: void operator()(uint8_t*, size_t)
   template <class Rng>
-  static Scalar32 random(Rng& rng) {
+  static MontScalar random(Rng& rng) {
     uint8_t wide[64];
     rng(wide, 64);
     return from_bytes_wide(wide);
   }
-  const std::array<uint8_t, 32>& to_bytes() const { return bytes; }
-  // Serializable::from_bytes: rejects encodings >= the modulus
-  static std::optional<Scalar32> from_bytes(const uint8_t b[32]) {
-    for (int i = 31; i >= 0; i--) {
-      if (b[i] < MOD[i]) {
-        Scalar32 s;
-        std::memcpy(s.bytes.data(), b, 32);
-        return s;
-      }
-      if (b[i] > MOD[i]) return std::nullopt;
-    }
-    return std::nullopt;  // equal to the modulus
-  }
-  bool operator==(const Scalar32& o) const { return bytes == o.bytes; }
-};
-using BlsScalar = Scalar32<detail::kFqModulus>;
-using JubJubScalar = Scalar32<detail::kFrModulus>;
-
-struct JubJubAffine {  // (u, v), canonical LE — the pair to_hash_inputs() returns
-  std::array<uint8_t, 64> uv{};
-  bool operator==(const JubJubAffine& o) const { return uv == o.uv; }
-  // compressed form: canonical v, bit 255 = lowest bit of u
+  // `to_bytes()`: one Montgomery reduction, canonical little-endian
   std::array<uint8_t, 32> to_bytes() const {
-    std::array<uint8_t, 32> out;
-    detail::check(dsv_compress_points(uv.data(), 1, out.data()), "dsv_compress_points");
+    const uint64_t one_raw[4] = {1, 0, 0, 0};
+    uint64_t c[4];
+    detail::mont_mul(F, c, l, one_raw);
+    std::array<uint8_t, 32> b;
+    std::memcpy(b.data(), c, 32);
+    return b;
+  }
+  // `Serializable::from_bytes`: rejects encodings >= the modulus
+  static std::optional<MontScalar> from_bytes(const uint8_t b[32]) {
+    uint64_t raw[4];
+    std::memcpy(raw, b, 32);
+    if (detail::geq(raw, F.p)) return std::nullopt;
+    return from_raw(raw);
+  }
+  static std::array<uint8_t, 32> modulus_bytes() {
+    std::array<uint8_t, 32> b;
+    std::memcpy(b.data(), F.p, 32);
+    return b;
+  }
+  bool is_zero() const { return (l[0] | l[1] | l[2] | l[3]) == 0; }
+  bool operator==(const MontScalar& o) const { return std::memcmp(l, o.l, 32) == 0; }
+  bool operator!=(const MontScalar& o) const { return !(*this == o); }
+  MontScalar operator+(const MontScalar& o) const {
+    MontScalar s;
+    detail::u128 c = 0;
+    for (int i = 0; i < 4; i++) {
+      c += (detail::u128)l[i] + o.l[i];
+      s.l[i] = (uint64_t)c;
+      c >>= 64;
+    }
+    if (detail::geq(s.l, F.p)) detail::sub_in_place(s.l, F.p);  // both moduli < 2^255: no carry out
+    return s;
+  }
+  MontScalar operator-() const {
+    if (is_zero()) return *this;
+    MontScalar s = from_limbs(F.p);
+    detail::sub_in_place(s.l, l);
+    return s;
+  }
+  MontScalar operator-(const MontScalar& o) const { return *this + (-o); }
+  MontScalar operator*(const MontScalar& o) const {
+    MontScalar s;
+    detail::mont_mul(F, s.l, l, o.l);
+    return s;
+  }
+  // x^(p-2): `invert()`; empty for zero
+  std::optional<MontScalar> invert() const {
+    if (is_zero()) return std::nullopt;
+    uint64_t e[4];
+    std::memcpy(e, F.p, 32);
+    e[0] -= 2;  // neither modulus ends in 0 or 1
+    MontScalar acc = one();
+    for (int bit = 255; bit >= 0; bit--) {
+      acc = acc * acc;
+      if ((e[bit >> 6] >> (bit & 63)) & 1) acc = acc * *this;
+    }
+    return acc;
+  }
+};
+using BlsScalar = MontScalar<detail::kFq>;
+using JubJubScalar = MontScalar<detail::kFr>;
+static_assert(sizeof(BlsScalar) == 32 && sizeof(JubJubScalar) == 32, "four u64 limbs");
+
+struct JubJubAffine {  // (u, v) — the pair to_hash_inputs() returns
+  BlsScalar u, v = BlsScalar::one();
+  const BlsScalar& get_u() const { return u; }
+  const BlsScalar& get_v() const { return v; }
+  bool operator==(const JubJubAffine& o) const { return u == o.u && v == o.v; }
+  // compressed form: canonical v, bit 255 = lowest bit of canonical u
+  std::array<uint8_t, 32> to_bytes() const {
+    std::array<uint8_t, 32> out = v.to_bytes();
+    out[31] |= (uint8_t)((u.to_bytes()[0] & 1) << 7);
     return out;
   }
+  // JubJubAffine::from_bytes: the square root runs on the device (k_decompress)
   static std::optional<JubJubAffine> from_bytes(const uint8_t b[32]) {
     detail::ensure_init();
-    JubJubAffine p;
-    uint8_t ok = 0;
-    detail::check(dsv_decompress_points(b, 1, p.uv.data(), &ok), "dsv_decompress_points");
+    uint8_t uv[64], ok = 0;
+    detail::check(dsv_decompress_points(b, 1, uv, &ok), "dsv_decompress_points");
     if (!ok) return std::nullopt;
-    return p;
+    return JubJubAffine{*BlsScalar::from_bytes(uv), *BlsScalar::from_bytes(uv + 32)};
+  }
+  static JubJubAffine from_canonical(const uint8_t uv[64]) {  // what the engine's kernels emit
+    auto u = BlsScalar::from_bytes(uv), v = BlsScalar::from_bytes(uv + 32);
+    if (!u || !v) throw std::runtime_error("engine returned a non-canonical coordinate");
+    return JubJubAffine{*u, *v};
+  }
+  std::array<uint8_t, 64> to_canonical() const {
+    std::array<uint8_t, 64> out;
+    std::memcpy(out.data(), u.to_bytes().data(), 32);
+    std::memcpy(out.data() + 32, v.to_bytes().data(), 32);
+    return out;
   }
 };
 
-// (u, v, z) with z != 0, canonical LE each: the coordinates a JubJubExtended holds.  Points that
-// come out of this library's own kernels (sign, key derivation, from_bytes) have z = 1; a caller
-// may hand in any projective representation (from_raw_unchecked): verify() treats equal points
-// alike whatever their z (/root/reference/tests/keys.rs:33-59).
+// (u, v, z, t1, t2) with u/z, v/z the affine coordinates and t1 * t2 = u v / z: the reference's
+// JubJubExtended, 160 B.  Points that come out of this library's kernels (sign, key derivation,
+// from_bytes) have z = 1; a caller may hand in any projective representation
+// (from_raw_unchecked): verify() treats equal points alike whatever their z
+// (/root/reference/tests/keys.rs:33-59).
 struct JubJubExtended {
-  std::array<uint8_t, 96> uvz{};
-  JubJubExtended() { uvz[32] = 1; uvz[64] = 1; }  // identity (0, 1, 1), like Default in the reference
-  static JubJubExtended from(const JubJubAffine& a) {
-    JubJubExtended p;
-    std::memcpy(p.uvz.data(), a.uv.data(), 64);
-    std::memset(p.uvz.data() + 64, 0, 32);
-    p.uvz[64] = 1;
-    return p;
+  BlsScalar u, v = BlsScalar::one(), z = BlsScalar::one(), t1, t2;  // identity, like Default upstream
+  static JubJubExtended from(const JubJubAffine& a) { return JubJubExtended{a.u, a.v, BlsScalar::one(), a.u, a.v}; }
+  static JubJubExtended from_raw_unchecked(const BlsScalar& u, const BlsScalar& v, const BlsScalar& z,
+                                           const BlsScalar& t1, const BlsScalar& t2) {
+    return JubJubExtended{u, v, z, t1, t2};
   }
-  // JubJubExtended::to_hash_inputs / JubJubAffine::from(ext): (u/z, v/z), computed on the GPU
+  const BlsScalar& get_u() const { return u; }
+  const BlsScalar& get_v() const { return v; }
+  const BlsScalar& get_z() const { return z; }
+  // JubJubExtended::to_hash_inputs / JubJubAffine::from(ext): (u/z, v/z); z = 0 panics upstream
   JubJubAffine to_affine() const {
-    ensure_init_();
-    JubJubAffine a;
-    uint8_t ok = 0;
-    detail::check(dsv_to_hash_inputs(uvz.data(), 1, a.uv.data(), &ok), "dsv_to_hash_inputs");
-    if (!ok) throw std::domain_error("JubJubExtended with z = 0 (the reference panics here)");
-    return a;
+    const auto zi = z.invert();
+    if (!zi) throw std::domain_error("JubJubExtended with z = 0 (the reference panics here)");
+    return JubJubAffine{u * *zi, v * *zi};
+  }
+  std::array<BlsScalar, 2> to_hash_inputs() const {
+    const JubJubAffine a = to_affine();
+    return {a.u, a.v};
   }
   std::array<uint8_t, 32> to_bytes() const { return to_affine().to_bytes(); }
   static std::optional<JubJubExtended> from_bytes(const uint8_t b[32]) {
@@ -170,12 +300,14 @@ struct JubJubExtended {
     if (!a) return std::nullopt;
     return from(*a);
   }
-  // PartialEq of the reference: projective equality (u1 z2 == u2 z1 and v1 z2 == v2 z1)
-  bool operator==(const JubJubExtended& o) const { return uvz == o.uvz || to_affine() == o.to_affine(); }
-
- private:
-  static void ensure_init_() { detail::ensure_init(); }
+  // PartialEq of the reference: u1 z2 == u2 z1 and v1 z2 == v2 z1 — four host multiplications, never
+  // a panic (z = 0 simply compares by the products)
+  bool operator==(const JubJubExtended& o) const { return u * o.z == o.u * z && v * o.z == o.v * z; }
+  bool operator!=(const JubJubExtended& o) const { return !(*this == o); }
 };
+static_assert(sizeof(JubJubExtended) == 160 && offsetof(JubJubExtended, u) == 0 &&
+                  offsetof(JubJubExtended, v) == 32 && offsetof(JubJubExtended, z) == 64,
+              "u || v || z are the first 96 bytes: what dsv_verify_*_mont reads");
 
 struct Signature {
   static constexpr size_t SIZE = 64;  // u || compressed R
@@ -186,7 +318,7 @@ struct Signature {
   bool operator==(const Signature& o) const { return u_ == o.u_ && R_ == o.R_; }
   std::array<uint8_t, SIZE> to_bytes() const {
     std::array<uint8_t, SIZE> b;
-    std::memcpy(b.data(), u_.bytes.data(), 32);
+    std::memcpy(b.data(), u_.to_bytes().data(), 32);
     std::memcpy(b.data() + 32, R_.to_bytes().data(), 32);
     return b;
   }
@@ -209,7 +341,7 @@ struct SignatureDouble {
   }
   std::array<uint8_t, SIZE> to_bytes() const {
     std::array<uint8_t, SIZE> b;
-    std::memcpy(b.data(), u_.bytes.data(), 32);
+    std::memcpy(b.data(), u_.to_bytes().data(), 32);
     std::memcpy(b.data() + 32, R_.to_bytes().data(), 32);
     std::memcpy(b.data() + 64, R_prime_.to_bytes().data(), 32);
     return b;
@@ -231,7 +363,7 @@ struct SignatureVarGen {
   bool operator==(const SignatureVarGen& o) const { return u_ == o.u_ && R_ == o.R_; }
   std::array<uint8_t, SIZE> to_bytes() const {
     std::array<uint8_t, SIZE> b;
-    std::memcpy(b.data(), u_.bytes.data(), 32);
+    std::memcpy(b.data(), u_.to_bytes().data(), 32);
     std::memcpy(b.data() + 32, R_.to_bytes().data(), 32);
     return b;
   }
@@ -242,13 +374,35 @@ struct SignatureVarGen {
     return SignatureVarGen{*u, *R};
   }
 };
+static_assert(sizeof(Signature) == 192 && sizeof(SignatureDouble) == 352 && sizeof(SignatureVarGen) == 192,
+              "the Rust structs' sizes");
+
+namespace detail {
+inline JubJubScalar scalar_from_engine(const uint8_t b[32]) {
+  auto s = JubJubScalar::from_bytes(b);
+  if (!s) throw std::runtime_error("engine returned a non-canonical scalar");
+  return *s;
+}
+// sk * G (which = 0), sk * G' (1), or sk * gen: the engine's key-derivation kernels take canonical bytes
+inline JubJubExtended derive(const JubJubScalar& sk, int which, const JubJubExtended* gen, const char* what) {
+  ensure_init();
+  uint8_t out[64];
+  if (gen) {
+    const auto g = gen->to_affine().to_canonical();
+    check(dsv_public_keys(sk.to_bytes().data(), which, g.data(), 1, out), what);
+  } else {
+    check(dsv_public_keys(sk.to_bytes().data(), which, nullptr, 1, out), what);
+  }
+  return JubJubExtended::from(JubJubAffine::from_canonical(out));
+}
+}  // namespace detail
 
 struct SecretKey {
   JubJubScalar sk;
   template <class Rng>
   static SecretKey random(Rng& rng) { return SecretKey{JubJubScalar::random(rng)}; }
   bool operator==(const SecretKey& o) const { return sk == o.sk; }
-  std::array<uint8_t, 32> to_bytes() const { return sk.bytes; }
+  std::array<uint8_t, 32> to_bytes() const { return sk.to_bytes(); }
   static std::optional<SecretKey> from_bytes(const std::array<uint8_t, 32>& b) {
     auto s = JubJubScalar::from_bytes(b.data());
     if (!s) return std::nullopt;
@@ -259,36 +413,22 @@ struct SecretKey {
   Signature sign(Rng& rng, const BlsScalar& message) const {
     detail::ensure_init();
     const JubJubScalar r = JubJubScalar::random(rng);
-    Signature s;
-    JubJubAffine R;
-    detail::check(dsv_sign_single(sk.bytes.data(), message.bytes.data(), r.bytes.data(), 1,
-                                  s.u_.bytes.data(), R.uv.data()), "dsv_sign_single");
-    s.R_ = JubJubExtended::from(R);
-    return s;
+    uint8_t u[32], R[64];
+    detail::check(dsv_sign_single(sk.to_bytes().data(), message.to_bytes().data(), r.to_bytes().data(), 1,
+                                  u, R), "dsv_sign_single");
+    return Signature{detail::scalar_from_engine(u), JubJubExtended::from(JubJubAffine::from_canonical(R))};
   }
   template <class Rng>
   SignatureDouble sign_double(Rng& rng, const BlsScalar& message) const {
     detail::ensure_init();
     const JubJubScalar r = JubJubScalar::random(rng);
-    SignatureDouble s;
-    JubJubAffine R, Rp;
-    detail::check(dsv_sign_double(sk.bytes.data(), message.bytes.data(), r.bytes.data(), 1,
-                                  s.u_.bytes.data(), R.uv.data(), Rp.uv.data()),
-                  "dsv_sign_double");
-    s.R_ = JubJubExtended::from(R);
-    s.R_prime_ = JubJubExtended::from(Rp);
-    return s;
+    uint8_t u[32], R[64], Rp[64];
+    detail::check(dsv_sign_double(sk.to_bytes().data(), message.to_bytes().data(), r.to_bytes().data(), 1,
+                                  u, R, Rp), "dsv_sign_double");
+    return SignatureDouble{detail::scalar_from_engine(u), JubJubExtended::from(JubJubAffine::from_canonical(R)),
+                           JubJubExtended::from(JubJubAffine::from_canonical(Rp))};
   }
 };
-
-namespace detail {
-inline JubJubExtended derive(const JubJubScalar& sk, int which, const uint8_t* gen_uv, const char* what) {
-  ensure_init();
-  JubJubAffine a;
-  check(dsv_public_keys(sk.bytes.data(), which, gen_uv, 1, a.uv.data()), what);
-  return JubJubExtended::from(a);
-}
-}  // namespace detail
 
 struct PublicKey {
   JubJubExtended pk;
@@ -302,12 +442,12 @@ struct PublicKey {
     if (!p) return std::nullopt;
     return PublicKey{*p};
   }
-  // u*G + c*PK == R  with c = H(R || m)
+  // u*G + c*PK == R  with c = H(R || m): the limbs of (u, R, pk, m) go to the engine as they are
   bool verify(const Signature& sig, const BlsScalar& message) const {
     detail::ensure_init();
     uint8_t ok = 0;
-    detail::check(dsv_verify_single_ext(sig.u_.bytes.data(), sig.R_.uvz.data(), pk.uvz.data(),
-                                        message.bytes.data(), 1, &ok), "dsv_verify_single_ext");
+    const dsv_column cols[4] = {{&sig.u_, sizeof sig}, {&sig.R_, sizeof sig}, {&pk, sizeof *this}, {&message, 32}};
+    detail::check(dsv_verify_single_mont_cols(cols, 1, &ok), "dsv_verify_single_mont_cols");
     return ok == 1;
   }
   bool operator==(const PublicKey& o) const { return pk == o.pk; }
@@ -339,9 +479,9 @@ struct PublicKeyDouble {
   bool verify(const SignatureDouble& sig, const BlsScalar& message) const {
     detail::ensure_init();
     uint8_t ok = 0;
-    detail::check(dsv_verify_double_ext(sig.u_.bytes.data(), sig.R_.uvz.data(), sig.R_prime_.uvz.data(),
-                                        pk_.uvz.data(), pk_prime_.uvz.data(), message.bytes.data(), 1,
-                                        &ok), "dsv_verify_double_ext");
+    const dsv_column cols[6] = {{&sig.u_, sizeof sig},        {&sig.R_, sizeof sig}, {&sig.R_prime_, sizeof sig},
+                                {&pk_, sizeof *this},         {&pk_prime_, sizeof *this}, {&message, 32}};
+    detail::check(dsv_verify_double_mont_cols(cols, 1, &ok), "dsv_verify_double_mont_cols");
     return ok == 1;
   }
 };
@@ -355,7 +495,6 @@ struct SecretKeyVarGen {
   // random: sk, then a generator scalar g; generator = g * G   (secret.rs:367-376)
   template <class Rng>
   static SecretKeyVarGen random(Rng& rng) {
-    detail::ensure_init();
     SecretKeyVarGen k;
     k.sk = JubJubScalar::random(rng);
     const JubJubScalar g = JubJubScalar::random(rng);
@@ -366,7 +505,7 @@ struct SecretKeyVarGen {
   bool operator==(const SecretKeyVarGen& o) const { return sk == o.sk && generator_ == o.generator_; }
   std::array<uint8_t, 64> to_bytes() const {  // sk || compressed generator
     std::array<uint8_t, 64> b;
-    std::memcpy(b.data(), sk.bytes.data(), 32);
+    std::memcpy(b.data(), sk.to_bytes().data(), 32);
     std::memcpy(b.data() + 32, generator_.to_bytes().data(), 32);
     return b;
   }
@@ -380,22 +519,18 @@ struct SecretKeyVarGen {
   SignatureVarGen sign(Rng& rng, const BlsScalar& message) const {
     detail::ensure_init();
     const JubJubScalar r = JubJubScalar::random(rng);
-    SignatureVarGen s;
-    const JubJubAffine gen = generator_.to_affine();  // the signing kernels take affine bases
-    JubJubAffine R;
-    detail::check(dsv_sign_vargen(sk.bytes.data(), gen.uv.data(), message.bytes.data(),
-                                  r.bytes.data(), 1, s.u_.bytes.data(), R.uv.data()),
-                  "dsv_sign_vargen");
-    s.R_ = JubJubExtended::from(R);
-    return s;
+    const auto gen = generator_.to_affine().to_canonical();  // the signing kernels take affine bases
+    uint8_t u[32], R[64];
+    detail::check(dsv_sign_vargen(sk.to_bytes().data(), gen.data(), message.to_bytes().data(),
+                                  r.to_bytes().data(), 1, u, R), "dsv_sign_vargen");
+    return SignatureVarGen{detail::scalar_from_engine(u), JubJubExtended::from(JubJubAffine::from_canonical(R))};
   }
 };
 
 struct PublicKeyVarGen {
   JubJubExtended pk_, generator_;
   static PublicKeyVarGen from(const SecretKeyVarGen& sk) {
-    const JubJubAffine gen = sk.generator_.to_affine();
-    return PublicKeyVarGen{detail::derive(sk.sk, 0, gen.uv.data(), "dsv_public_keys(gen)"), sk.generator_};
+    return PublicKeyVarGen{detail::derive(sk.sk, 0, &sk.generator_, "dsv_public_keys(gen)"), sk.generator_};
   }
   static PublicKeyVarGen from_raw_unchecked(const JubJubExtended& pk, const JubJubExtended& gen) {
     return PublicKeyVarGen{pk, gen};
@@ -418,76 +553,75 @@ struct PublicKeyVarGen {
   bool verify(const SignatureVarGen& sig, const BlsScalar& message) const {
     detail::ensure_init();
     uint8_t ok = 0;
-    detail::check(dsv_verify_vargen_ext(sig.u_.bytes.data(), sig.R_.uvz.data(), pk_.uvz.data(),
-                                        generator_.uvz.data(), message.bytes.data(), 1, &ok),
-                  "dsv_verify_vargen_ext");
+    const dsv_column cols[5] = {{&sig.u_, sizeof sig}, {&sig.R_, sizeof sig}, {&pk_, sizeof *this},
+                                {&generator_, sizeof *this}, {&message, 32}};
+    detail::check(dsv_verify_vargen_mont_cols(cols, 1, &ok), "dsv_verify_vargen_mont_cols");
     return ok == 1;
   }
 };
+static_assert(sizeof(PublicKey) == 160 && sizeof(PublicKeyDouble) == 320 && sizeof(PublicKeyVarGen) == 320,
+              "the Rust structs' sizes");
 
 // ---- the new batch entry points (north_star): out[i] == pks[i].verify(sigs[i], msgs[i]) --------
-inline std::vector<bool> verify_batch(const std::vector<Signature>& sigs,
-                                      const std::vector<PublicKey>& pks,
-                                      const std::vector<BlsScalar>& msgs) {
-  if (sigs.size() != pks.size() || sigs.size() != msgs.size())
-    throw std::invalid_argument("verify_batch: slice lengths differ");
+// No copy and no arithmetic here: the engine reads u / R / pk / m out of the typed objects through
+// one strided column per field (dsv_verify_*_mont_cols) and shards over every initialised GPU.
+// `verify_batch_bytes*` return the engine's verdict bytes (1 = true) for callers that do not want
+// the std::vector<bool> packing pass.
+inline std::vector<uint8_t> verify_batch_bytes(const Signature* sigs, const PublicKey* pks,
+                                               const BlsScalar* msgs, size_t n) {
   detail::ensure_init();
-  const size_t n = sigs.size();
-  std::vector<uint8_t> u(32 * n), r(96 * n), pk(96 * n), m(32 * n), ok(n);
-  for (size_t i = 0; i < n; i++) {  // byte copies only: no to_hash_inputs on the host
-    std::memcpy(&u[32 * i], sigs[i].u_.bytes.data(), 32);
-    std::memcpy(&r[96 * i], sigs[i].R_.uvz.data(), 96);
-    std::memcpy(&pk[96 * i], pks[i].pk.uvz.data(), 96);
-    std::memcpy(&m[32 * i], msgs[i].bytes.data(), 32);
-  }
-  detail::check(dsv_verify_single_ext_multi(u.data(), r.data(), pk.data(), m.data(), n, ok.data()),
-                "dsv_verify_single_ext_multi");
-  std::vector<bool> out(n);
-  for (size_t i = 0; i < n; i++) out[i] = ok[i] == 1;
+  std::vector<uint8_t> ok(n);
+  if (!n) return ok;
+  const dsv_column cols[4] = {{&sigs->u_, sizeof *sigs}, {&sigs->R_, sizeof *sigs}, {&pks->pk, sizeof *pks}, {msgs, 32}};
+  detail::check(dsv_verify_single_mont_cols(cols, n, ok.data()), "dsv_verify_single_mont_cols");
+  return ok;
+}
+inline std::vector<uint8_t> verify_batch_double_bytes(const SignatureDouble* sigs, const PublicKeyDouble* pks,
+                                                      const BlsScalar* msgs, size_t n) {
+  detail::ensure_init();
+  std::vector<uint8_t> ok(n);
+  if (!n) return ok;
+  const dsv_column cols[6] = {{&sigs->u_, sizeof *sigs},  {&sigs->R_, sizeof *sigs},       {&sigs->R_prime_, sizeof *sigs},
+                              {&pks->pk_, sizeof *pks},   {&pks->pk_prime_, sizeof *pks},  {msgs, 32}};
+  detail::check(dsv_verify_double_mont_cols(cols, n, ok.data()), "dsv_verify_double_mont_cols");
+  return ok;
+}
+inline std::vector<uint8_t> verify_batch_var_gen_bytes(const SignatureVarGen* sigs, const PublicKeyVarGen* pks,
+                                                       const BlsScalar* msgs, size_t n) {
+  detail::ensure_init();
+  std::vector<uint8_t> ok(n);
+  if (!n) return ok;
+  const dsv_column cols[5] = {{&sigs->u_, sizeof *sigs}, {&sigs->R_, sizeof *sigs}, {&pks->pk_, sizeof *pks},
+                              {&pks->generator_, sizeof *pks}, {msgs, 32}};
+  detail::check(dsv_verify_vargen_mont_cols(cols, n, ok.data()), "dsv_verify_vargen_mont_cols");
+  return ok;
+}
+namespace detail {
+inline std::vector<bool> to_bools(const std::vector<uint8_t>& ok) {
+  std::vector<bool> out(ok.size());
+  for (size_t i = 0; i < ok.size(); i++) out[i] = ok[i] == 1;
   return out;
+}
+inline void same_len(size_t a, size_t b, size_t c, const char* what) {
+  if (a != b || a != c) throw std::invalid_argument(std::string(what) + ": slice lengths differ");
+}
+}  // namespace detail
+inline std::vector<bool> verify_batch(const std::vector<Signature>& sigs, const std::vector<PublicKey>& pks,
+                                      const std::vector<BlsScalar>& msgs) {
+  detail::same_len(sigs.size(), pks.size(), msgs.size(), "verify_batch");
+  return detail::to_bools(verify_batch_bytes(sigs.data(), pks.data(), msgs.data(), sigs.size()));
 }
 inline std::vector<bool> verify_batch_double(const std::vector<SignatureDouble>& sigs,
                                              const std::vector<PublicKeyDouble>& pks,
                                              const std::vector<BlsScalar>& msgs) {
-  if (sigs.size() != pks.size() || sigs.size() != msgs.size())
-    throw std::invalid_argument("verify_batch_double: slice lengths differ");
-  detail::ensure_init();
-  const size_t n = sigs.size();
-  std::vector<uint8_t> u(32 * n), r(96 * n), rp(96 * n), pk(96 * n), pkp(96 * n), m(32 * n), ok(n);
-  for (size_t i = 0; i < n; i++) {
-    std::memcpy(&u[32 * i], sigs[i].u_.bytes.data(), 32);
-    std::memcpy(&r[96 * i], sigs[i].R_.uvz.data(), 96);
-    std::memcpy(&rp[96 * i], sigs[i].R_prime_.uvz.data(), 96);
-    std::memcpy(&pk[96 * i], pks[i].pk_.uvz.data(), 96);
-    std::memcpy(&pkp[96 * i], pks[i].pk_prime_.uvz.data(), 96);
-    std::memcpy(&m[32 * i], msgs[i].bytes.data(), 32);
-  }
-  detail::check(dsv_verify_double_ext_multi(u.data(), r.data(), rp.data(), pk.data(), pkp.data(),
-                                            m.data(), n, ok.data()), "dsv_verify_double_ext_multi");
-  std::vector<bool> out(n);
-  for (size_t i = 0; i < n; i++) out[i] = ok[i] == 1;
-  return out;
+  detail::same_len(sigs.size(), pks.size(), msgs.size(), "verify_batch_double");
+  return detail::to_bools(verify_batch_double_bytes(sigs.data(), pks.data(), msgs.data(), sigs.size()));
 }
 inline std::vector<bool> verify_batch_var_gen(const std::vector<SignatureVarGen>& sigs,
                                               const std::vector<PublicKeyVarGen>& pks,
                                               const std::vector<BlsScalar>& msgs) {
-  if (sigs.size() != pks.size() || sigs.size() != msgs.size())
-    throw std::invalid_argument("verify_batch_var_gen: slice lengths differ");
-  detail::ensure_init();
-  const size_t n = sigs.size();
-  std::vector<uint8_t> u(32 * n), r(96 * n), pk(96 * n), g(96 * n), m(32 * n), ok(n);
-  for (size_t i = 0; i < n; i++) {
-    std::memcpy(&u[32 * i], sigs[i].u_.bytes.data(), 32);
-    std::memcpy(&r[96 * i], sigs[i].R_.uvz.data(), 96);
-    std::memcpy(&pk[96 * i], pks[i].pk_.uvz.data(), 96);
-    std::memcpy(&g[96 * i], pks[i].generator_.uvz.data(), 96);
-    std::memcpy(&m[32 * i], msgs[i].bytes.data(), 32);
-  }
-  detail::check(dsv_verify_vargen_ext_multi(u.data(), r.data(), pk.data(), g.data(), m.data(), n,
-                                            ok.data()), "dsv_verify_vargen_ext_multi");
-  std::vector<bool> out(n);
-  for (size_t i = 0; i < n; i++) out[i] = ok[i] == 1;
-  return out;
+  detail::same_len(sigs.size(), pks.size(), msgs.size(), "verify_batch_var_gen");
+  return detail::to_bools(verify_batch_var_gen_bytes(sigs.data(), pks.data(), msgs.data(), sigs.size()));
 }
 
 }  // namespace dusk_schnorr

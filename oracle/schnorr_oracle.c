@@ -679,6 +679,114 @@ int oracle_verify_vargen_ext(const uint8_t *u, const uint8_t *R_ext, const uint8
   }
   return 0;
 }
+/* ---- the reference's in-memory representation -------------------------------------------------
+ * BlsScalar / JubJubScalar / the coordinates of JubJubExtended hold [u64; 4] Montgomery limbs,
+ * R = 2^256 (dusk-bls12_381 0.13, dusk-jubjub 0.14: /root/reference/Cargo.toml:25-26) — exactly
+ * this file's ofq_t / ofr_t.  The *_mont functions take those limbs (32 B little-endian per
+ * element) as the fields of Signature / PublicKey hold them (/root/reference/src/signatures.rs:
+ * 58-61, src/keys/public.rs:59) and run the reference's verify on them with no conversion at all;
+ * a point comes as the limbs of u || v || z (96 B) and is completed to a JubJubExtended of the
+ * same projective class, (u z, v z, z^2, t1 = u, t2 = v): every step of verify (to_hash_inputs,
+ * Mul, Add, PartialEq) depends on the class only.  Limbs >= the modulus (the Rust types cannot
+ * hold them) or z = 0 (to_hash_inputs would panic): ok = 0. */
+static int load_mont_fq(ofq_t *r, const uint8_t b[32]) {
+  load_le(r->l, b);
+  return f_is_canonical(&FQ, r->l);
+}
+static int load_mont_point(oext_t *p, const uint8_t b[96]) {
+  ofq_t u, v, z;
+  int ok = load_mont_fq(&u, b) & load_mont_fq(&v, b + 32) & load_mont_fq(&z, b + 64);
+  static const ofq_t zero = {{0, 0, 0, 0}};
+  ok &= !ofq_eq(&z, &zero);
+  ofq_mul(&p->u, &u, &z);
+  ofq_mul(&p->v, &v, &z);
+  ofq_square(&p->z, &z);
+  p->t1 = u;
+  p->t2 = v;
+  return ok;
+}
+static int load_mont_u(uint8_t u_le[32], const uint8_t b[32]) {
+  ofr_t us;
+  load_le(us.l, b);
+  const int ok = f_is_canonical(&FR, us.l);
+  ofr_to_bytes(u_le, &us); /* what Mul<&JubJubScalar> starts with: scalar.to_bytes() */
+  return ok;
+}
+int oracle_verify_single_mont(const uint8_t *u, const uint8_t *R_uvz, const uint8_t *PK_uvz,
+                              const uint8_t *m, size_t n, uint8_t *ok) {
+  ensure_init();
+  for (size_t i = 0; i < n; i++) {
+    oext_t R, pk;
+    ofq_t mm;
+    uint8_t ub[32];
+    int good = load_mont_u(ub, u + 32 * i);
+    good &= load_mont_point(&R, R_uvz + 96 * i);
+    good &= load_mont_point(&pk, PK_uvz + 96 * i);
+    good &= load_mont_fq(&mm, m + 32 * i);
+    ok[i] = (uint8_t)(good ? verify_one(&pk, ub, &R, &mm) : 0);
+  }
+  return 0;
+}
+int oracle_verify_double_mont(const uint8_t *u, const uint8_t *R_uvz, const uint8_t *Rp_uvz,
+                              const uint8_t *PK_uvz, const uint8_t *PKp_uvz, const uint8_t *m,
+                              size_t n, uint8_t *ok) {
+  ensure_init();
+  for (size_t i = 0; i < n; i++) {
+    oext_t R, Rp, pk, pkp;
+    ofq_t mm;
+    uint8_t ub[32];
+    int good = load_mont_u(ub, u + 32 * i);
+    good &= load_mont_point(&R, R_uvz + 96 * i);
+    good &= load_mont_point(&Rp, Rp_uvz + 96 * i);
+    good &= load_mont_point(&pk, PK_uvz + 96 * i);
+    good &= load_mont_point(&pkp, PKp_uvz + 96 * i);
+    good &= load_mont_fq(&mm, m + 32 * i);
+    ok[i] = (uint8_t)(good ? verify_one_double(&pk, &pkp, ub, &R, &Rp, &mm) : 0);
+  }
+  return 0;
+}
+int oracle_verify_vargen_mont(const uint8_t *u, const uint8_t *R_uvz, const uint8_t *PK_uvz,
+                              const uint8_t *Gen_uvz, const uint8_t *m, size_t n, uint8_t *ok) {
+  ensure_init();
+  for (size_t i = 0; i < n; i++) {
+    oext_t R, pk, gen;
+    ofq_t mm;
+    uint8_t ub[32];
+    int good = load_mont_u(ub, u + 32 * i);
+    good &= load_mont_point(&R, R_uvz + 96 * i);
+    good &= load_mont_point(&pk, PK_uvz + 96 * i);
+    good &= load_mont_point(&gen, Gen_uvz + 96 * i);
+    good &= load_mont_fq(&mm, m + 32 * i);
+    ok[i] = (uint8_t)(good ? verify_one_vargen(&pk, &gen, ub, &R, &mm) : 0);
+  }
+  return 0;
+}
+/* canonical bytes <-> the in-memory limbs (`from_bytes` / `to_bytes` of the two scalar types);
+ * which = 0: BlsScalar (mod q), 1: JubJubScalar (mod r).  Returns 0 if an input is not below the
+ * modulus (its output is then unspecified). */
+int oracle_to_mont(int which, const uint8_t *canonical, size_t n, uint8_t *limbs) {
+  const field_t *f = which ? &FR : &FQ;
+  int all = 1;
+  for (size_t i = 0; i < n; i++) {
+    uint64_t t[4];
+    all &= f_from_bytes(f, t, canonical + 32 * i);
+    store_le(limbs + 32 * i, t);
+  }
+  return all;
+}
+int oracle_from_mont(int which, const uint8_t *limbs, size_t n, uint8_t *canonical) {
+  const field_t *f = which ? &FR : &FQ;
+  int all = 1;
+  for (size_t i = 0; i < n; i++) {
+    uint64_t t[4], c[4];
+    load_le(t, limbs + 32 * i);
+    all &= f_is_canonical(f, t);
+    f_to_canonical(f, c, t);
+    store_le(canonical + 32 * i, c);
+  }
+  return all;
+}
+
 int oracle_challenge_single(const uint8_t *R_uv, const uint8_t *m, size_t n, uint8_t *c) {
   ensure_init();
   for (size_t i = 0; i < n; i++) {

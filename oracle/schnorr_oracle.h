@@ -113,6 +113,21 @@ int oracle_verify_double_ext(const uint8_t *u, const uint8_t *R_ext, const uint8
 int oracle_verify_vargen_ext(const uint8_t *u, const uint8_t *R_ext, const uint8_t *PK_ext,
                              const uint8_t *Gen_ext, const uint8_t *m, size_t n, uint8_t *ok);
 
+/* the same on the reference's IN-MEMORY representation: every 32-byte element is the four u64
+ * Montgomery limbs (R = 2^256) of a BlsScalar / JubJubScalar as the Rust types hold them
+ * (/root/reference/src/signatures.rs:58-61, src/keys/public.rs:59, Cargo.toml:25-26); points as
+ * the limbs of u || v || z (96 B).  Limbs >= the modulus or z = 0: ok[i] = 0. */
+int oracle_verify_single_mont(const uint8_t *u, const uint8_t *R_uvz, const uint8_t *PK_uvz,
+                              const uint8_t *m, size_t n, uint8_t *ok);
+int oracle_verify_double_mont(const uint8_t *u, const uint8_t *R_uvz, const uint8_t *Rp_uvz,
+                              const uint8_t *PK_uvz, const uint8_t *PKp_uvz, const uint8_t *m,
+                              size_t n, uint8_t *ok);
+int oracle_verify_vargen_mont(const uint8_t *u, const uint8_t *R_uvz, const uint8_t *PK_uvz,
+                              const uint8_t *Gen_uvz, const uint8_t *m, size_t n, uint8_t *ok);
+/* canonical bytes <-> in-memory limbs; which = 0: BlsScalar, 1: JubJubScalar; 0 if an input >= modulus */
+int oracle_to_mont(int which, const uint8_t *canonical, size_t n, uint8_t *limbs);
+int oracle_from_mont(int which, const uint8_t *limbs, size_t n, uint8_t *canonical);
+
 /* challenge scalar only (for kernel-level parity of the hash stage) */
 int oracle_challenge_single(const uint8_t *R_uv, const uint8_t *m, size_t n, uint8_t *c);
 int oracle_challenge_double(const uint8_t *R_uv, const uint8_t *Rp_uv, const uint8_t *m,

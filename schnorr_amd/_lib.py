@@ -34,9 +34,21 @@ SYMBOLS = [
     "dsv_verify_vargen_ext_dev",
     "dsv_wire_workspace_bytes", "dsv_verify_single_wire_dev", "dsv_verify_double_wire_dev",
     "dsv_verify_vargen_wire_dev",
+    # r04: the reference's in-memory representation (Montgomery limbs), dense arrays / strided
+    # columns of typed objects / device pointers
+    "dsv_verify_single_mont", "dsv_verify_double_mont", "dsv_verify_vargen_mont",
+    "dsv_verify_single_mont_multi", "dsv_verify_double_mont_multi", "dsv_verify_vargen_mont_multi",
+    "dsv_verify_single_mont_cols", "dsv_verify_double_mont_cols", "dsv_verify_vargen_mont_cols",
+    "dsv_mont_workspace_bytes", "dsv_verify_single_mont_dev", "dsv_verify_double_mont_dev",
+    "dsv_verify_vargen_mont_dev",
 ]
 _SIZE_T_FUNCS = ("dsv_workspace_bytes", "dsv_mixed_workspace_bytes", "dsv_split_scratch_bytes",
-                 "dsv_ext_workspace_bytes", "dsv_wire_workspace_bytes")
+                 "dsv_ext_workspace_bytes", "dsv_wire_workspace_bytes", "dsv_mont_workspace_bytes")
+
+
+class Column(ctypes.Structure):
+    """dsv_column: one field of n typed objects, item i at base + i * stride"""
+    _fields_ = [("base", ctypes.c_void_p), ("stride", ctypes.c_size_t)]
 
 
 class DsvError(RuntimeError):

@@ -911,8 +911,23 @@ namespace {
 //   the rate; a pageable hipMemcpyAsync would serialise staging and DMA on one runtime thread.
 struct HostIn {
   const uint8_t* p;
-  size_t bytes;
+  size_t bytes;       // per item
+  size_t stride = 0;  // distance between items in the caller's memory; 0 = `bytes` (a dense array)
 };
+// `count` items of `bytes` bytes, `stride` apart, packed densely into dst (the typed objects of a
+// language binding: one field out of every struct)
+inline void copy_strided(uint8_t* dst, const uint8_t* src, size_t stride, size_t bytes, size_t count) {
+  switch (bytes) {  // constant sizes: the copies are inlined vector moves
+    case 32:
+      for (size_t i = 0; i < count; i++) memcpy(dst + 32 * i, src + stride * i, 32);
+      break;
+    case 96:
+      for (size_t i = 0; i < count; i++) memcpy(dst + 96 * i, src + stride * i, 96);
+      break;
+    default:
+      for (size_t i = 0; i < count; i++) memcpy(dst + bytes * i, src + stride * i, bytes);
+  }
+}
 // Chunk sizes double from 2^15 up to 2^18 items: the GPU starts after ~0.3 ms of staging, every
 // gather runs under the previous (half as long) chunk's kernels, and from the fourth chunk on the
 // launches are long enough to run near the device-resident rate (r03, same box, 2^20 items: chunks
@@ -991,6 +1006,12 @@ int run_pipelined(Context& ctx, const HostIn (&ins)[NIN], uint8_t* ok, size_t n,
     const int T = bytes >= ((size_t)1 << 20) ? host_copy_threads() : 1;
     ctx.copiers.run(T, [&](int t, int nt) {
       for (size_t k = 0; k < NIN; k++) {
+        if (ins[k].stride && ins[k].stride != ins[k].bytes) {  // one field out of every object
+          const size_t lo = cnt * (size_t)t / (size_t)nt, hi = cnt * (size_t)(t + 1) / (size_t)nt;
+          copy_strided(host + in_off[k] + lo * ins[k].bytes, ins[k].p + (done + lo) * ins[k].stride,
+                       ins[k].stride, ins[k].bytes, hi - lo);
+          continue;
+        }
         const size_t len = cnt * ins[k].bytes;
         const size_t lo = len * (size_t)t / (size_t)nt / 64 * 64;
         const size_t hi = t + 1 == nt ? len : len * (size_t)(t + 1) / (size_t)nt / 64 * 64;
@@ -1367,6 +1388,169 @@ int dsv_verify_vargen_ext_dev(const void* u, const void* R_uvz, const void* PK_u
   DSV_DEV_PROLOGUE(n, ok);
   const void* pts[3] = {R_uvz, PK_uvz, Gen_uvz};
   return verify_ext_on(ctx, 2, u, pts, m, n, ok, workspace, (hipStream_t)stream);
+}
+
+// ---- the reference's in-memory representation: Montgomery limbs --------------------------------
+// The Rust types hold every field element as `[u64; 4]` Montgomery limbs with R = 2^256
+// (`BlsScalar(pub [u64; 4])`, dusk-bls12_381 0.13; `JubJubScalar`, the coordinates of
+// `JubJubExtended`, dusk-jubjub 0.14 — /root/reference/Cargo.toml:25-26; the fields:
+// src/signatures.rs:58-61, src/keys/public.rs:59).  `to_bytes()` is one Montgomery reduction per
+// element — eight per single signature, fourteen per double one — on ONE host thread: ~30x below the
+// engine.  The *_mont entry points take the limbs as they lie in memory:
+//   points  (u R, v R, z R) : straight into k_normalize_uvz — a quotient does not see the common factor
+//   u, m                    : k_scalars_from_mont (two reductions per signature, on the device)
+// so a binding copies bytes and nothing else; the *_mont_cols forms even take the typed objects
+// where they lie (one strided column per field) and gather them into the pinned staging with the
+// pipeline's copy threads — no intermediate structure of arrays on the host.
+extern "C++" {
+namespace {
+size_t mont_workspace_bytes(size_t n) { return 2 * align_up(n * 32, 256) + ext_workspace_bytes(n); }
+int verify_mont_on(Context& ctx, int kind, const void* u, const void* const* pts_uvz, const void* m,
+                   size_t n, void* ok, void* workspace, hipStream_t s) {
+  Stager st(static_cast<uint8_t*>(workspace));
+  uint8_t *cu = st.take(n * 32), *cm = st.take(n * 32);
+  launch_scalars_from_mont((const uint8_t*)u, (const uint8_t*)m, n, cu, cm, s);
+  return verify_ext_on(ctx, kind, cu, pts_uvz, cm, n, ok, st.take(0), s);
+}
+constexpr size_t kMontItemBytes = kExtItemBytes + 64;
+// ins: u, points..., m — dense arrays or strided columns of typed objects
+template <size_t NIN>
+int verify_mont_host(Context& ctx, int kind, const HostIn (&ins)[NIN], size_t n, uint8_t* ok) {
+  Context* cp = &ctx;
+  return run_pipelined(ctx, ins, ok, n, kMontItemBytes,
+                       [cp, kind](const void* const* d, size_t cnt, void* dok, void* ws, Stager& x, hipStream_t st) {
+    const int np = kind == 0 ? 2 : (kind == 1 ? 4 : 3);
+    uint8_t *cu = x.take(cnt * 32), *cm = x.take(cnt * 32);
+    launch_scalars_from_mont((const uint8_t*)d[0], (const uint8_t*)d[1 + np], cnt, cu, cm, st);
+    ExtWs w;
+    for (int k = 0; k < 4; k++) w.pts[k] = x.take(cnt * 64);
+    w.valid = x.take(cnt);
+    w.prefix = reinterpret_cast<u32*>(x.take(normalize_prefix_bytes(cnt, np)));
+    NormalizeArgs a = {};
+    for (int k = 0; k < np; k++) {
+      a.in[k] = (const uint8_t*)d[1 + k];
+      a.out[k] = w.pts[k];
+    }
+    launch_normalize_uvz(a, np, cnt, w.valid, w.prefix, st);
+    int rc;
+    if (kind == 0) rc = verify_single_on(*cp, cu, w.pts[0], w.pts[1], cm, cnt, dok, ws, st);
+    else if (kind == 1) rc = verify_double_on(*cp, cu, w.pts[0], w.pts[1], w.pts[2], w.pts[3], cm, cnt, dok, ws, st);
+    else rc = verify_vargen_on(*cp, cu, w.pts[0], w.pts[1], w.pts[2], cm, cnt, dok, ws, st);
+    if (rc) return rc;
+    launch_and_bytes((uint8_t*)dok, w.valid, cnt, st);
+    HIP_TRY(hipGetLastError());
+    return (int)DSV_OK;
+  });
+}
+// columns of one scheme: u (32 B), its points (96 B each), m (32 B)
+constexpr int kMontCols[3] = {4, 6, 5};
+int check_cols(int kind, const dsv_column* cols, size_t n, const uint8_t* ok) {
+  if (int r = check_n(n)) return r;
+  if (n == 0) return DSV_OK;
+  if (!cols || !ok) return fail(DSV_ERR_INVALID_ARGUMENT, "null pointer");
+  const int nc = kMontCols[kind];
+  for (int k = 0; k < nc; k++) {
+    const size_t width = (k == 0 || k == nc - 1) ? 32 : 96;
+    if (!cols[k].base) return fail(DSV_ERR_INVALID_ARGUMENT, "column %d: null pointer", k);
+    if (cols[k].stride < width) return fail(DSV_ERR_INVALID_ARGUMENT, "column %d: stride %zu < %zu", k, cols[k].stride, width);
+  }
+  return DSV_OK;
+}
+// one shard [off, off + cnt) of a column batch on one device
+int verify_mont_cols_shard(Context& ctx, int kind, const dsv_column* cols, size_t off, size_t cnt, uint8_t* ok) {
+  auto in = [&](int k, size_t width) {
+    return HostIn{static_cast<const uint8_t*>(cols[k].base) + off * cols[k].stride, width, cols[k].stride};
+  };
+  if (kind == 0) {
+    const HostIn ins[4] = {in(0, 32), in(1, 96), in(2, 96), in(3, 32)};
+    return verify_mont_host(ctx, 0, ins, cnt, ok + off);
+  }
+  if (kind == 1) {
+    const HostIn ins[6] = {in(0, 32), in(1, 96), in(2, 96), in(3, 96), in(4, 96), in(5, 32)};
+    return verify_mont_host(ctx, 1, ins, cnt, ok + off);
+  }
+  const HostIn ins[5] = {in(0, 32), in(1, 96), in(2, 96), in(3, 96), in(4, 32)};
+  return verify_mont_host(ctx, 2, ins, cnt, ok + off);
+}
+int verify_mont_cols(int kind, const dsv_column* cols, size_t n, uint8_t* ok, bool multi) {
+  if (int r = check_cols(kind, cols, n, ok)) return r;
+  if (n == 0) return DSV_OK;
+  if (multi)
+    return run_multi(n, [=](Context& ctx, size_t off, size_t cnt) {
+      return verify_mont_cols_shard(ctx, kind, cols, off, cnt, ok);
+    });
+  Context* ctxp = nullptr;
+  if (int r = host_context(ctxp)) return r;
+  return verify_mont_cols_shard(*ctxp, kind, cols, 0, n, ok);
+}
+}  // namespace
+}  // extern "C++"
+
+size_t dsv_mont_workspace_bytes(size_t n) { return mont_workspace_bytes(n); }
+
+int dsv_verify_single_mont_cols(const dsv_column* cols, size_t n, uint8_t* ok) { return verify_mont_cols(0, cols, n, ok, true); }
+int dsv_verify_double_mont_cols(const dsv_column* cols, size_t n, uint8_t* ok) { return verify_mont_cols(1, cols, n, ok, true); }
+int dsv_verify_vargen_mont_cols(const dsv_column* cols, size_t n, uint8_t* ok) { return verify_mont_cols(2, cols, n, ok, true); }
+
+#define DSV_DENSE_COLS_SINGLE {{u, 32}, {R_uvz, 96}, {PK_uvz, 96}, {m, 32}}
+#define DSV_DENSE_COLS_DOUBLE {{u, 32}, {R_uvz, 96}, {Rp_uvz, 96}, {PK_uvz, 96}, {PKp_uvz, 96}, {m, 32}}
+#define DSV_DENSE_COLS_VARGEN {{u, 32}, {R_uvz, 96}, {PK_uvz, 96}, {Gen_uvz, 96}, {m, 32}}
+int dsv_verify_single_mont(const uint8_t* u, const uint8_t* R_uvz, const uint8_t* PK_uvz, const uint8_t* m,
+                           size_t n, uint8_t* ok) {
+  const dsv_column cols[4] = DSV_DENSE_COLS_SINGLE;
+  return verify_mont_cols(0, cols, n, ok, false);
+}
+int dsv_verify_double_mont(const uint8_t* u, const uint8_t* R_uvz, const uint8_t* Rp_uvz,
+                           const uint8_t* PK_uvz, const uint8_t* PKp_uvz, const uint8_t* m, size_t n,
+                           uint8_t* ok) {
+  const dsv_column cols[6] = DSV_DENSE_COLS_DOUBLE;
+  return verify_mont_cols(1, cols, n, ok, false);
+}
+int dsv_verify_vargen_mont(const uint8_t* u, const uint8_t* R_uvz, const uint8_t* PK_uvz,
+                           const uint8_t* Gen_uvz, const uint8_t* m, size_t n, uint8_t* ok) {
+  const dsv_column cols[5] = DSV_DENSE_COLS_VARGEN;
+  return verify_mont_cols(2, cols, n, ok, false);
+}
+int dsv_verify_single_mont_multi(const uint8_t* u, const uint8_t* R_uvz, const uint8_t* PK_uvz,
+                                 const uint8_t* m, size_t n, uint8_t* ok) {
+  const dsv_column cols[4] = DSV_DENSE_COLS_SINGLE;
+  return verify_mont_cols(0, cols, n, ok, true);
+}
+int dsv_verify_double_mont_multi(const uint8_t* u, const uint8_t* R_uvz, const uint8_t* Rp_uvz,
+                                 const uint8_t* PK_uvz, const uint8_t* PKp_uvz, const uint8_t* m, size_t n,
+                                 uint8_t* ok) {
+  const dsv_column cols[6] = DSV_DENSE_COLS_DOUBLE;
+  return verify_mont_cols(1, cols, n, ok, true);
+}
+int dsv_verify_vargen_mont_multi(const uint8_t* u, const uint8_t* R_uvz, const uint8_t* PK_uvz,
+                                 const uint8_t* Gen_uvz, const uint8_t* m, size_t n, uint8_t* ok) {
+  const dsv_column cols[5] = DSV_DENSE_COLS_VARGEN;
+  return verify_mont_cols(2, cols, n, ok, true);
+}
+int dsv_verify_single_mont_dev(const void* u, const void* R_uvz, const void* PK_uvz, const void* m,
+                               size_t n, void* ok, void* workspace, void* stream) {
+  if (n && (!u || !R_uvz || !PK_uvz || !m || !ok || !workspace))
+    return fail(DSV_ERR_INVALID_ARGUMENT, "null pointer");
+  DSV_DEV_PROLOGUE(n, ok);
+  const void* pts[2] = {R_uvz, PK_uvz};
+  return verify_mont_on(ctx, 0, u, pts, m, n, ok, workspace, (hipStream_t)stream);
+}
+int dsv_verify_double_mont_dev(const void* u, const void* R_uvz, const void* Rp_uvz, const void* PK_uvz,
+                               const void* PKp_uvz, const void* m, size_t n, void* ok, void* workspace,
+                               void* stream) {
+  if (n && (!u || !R_uvz || !Rp_uvz || !PK_uvz || !PKp_uvz || !m || !ok || !workspace))
+    return fail(DSV_ERR_INVALID_ARGUMENT, "null pointer");
+  DSV_DEV_PROLOGUE(n, ok);
+  const void* pts[4] = {R_uvz, Rp_uvz, PK_uvz, PKp_uvz};
+  return verify_mont_on(ctx, 1, u, pts, m, n, ok, workspace, (hipStream_t)stream);
+}
+int dsv_verify_vargen_mont_dev(const void* u, const void* R_uvz, const void* PK_uvz, const void* Gen_uvz,
+                               const void* m, size_t n, void* ok, void* workspace, void* stream) {
+  if (n && (!u || !R_uvz || !PK_uvz || !Gen_uvz || !m || !ok || !workspace))
+    return fail(DSV_ERR_INVALID_ARGUMENT, "null pointer");
+  DSV_DEV_PROLOGUE(n, ok);
+  const void* pts[3] = {R_uvz, PK_uvz, Gen_uvz};
+  return verify_mont_on(ctx, 2, u, pts, m, n, ok, workspace, (hipStream_t)stream);
 }
 
 int dsv_challenge_single(const uint8_t* R_uv, const uint8_t* m, size_t n, uint8_t* c) {

@@ -106,6 +106,10 @@ inline size_t normalize_prefix_bytes(size_t n, int npoints) {
 }
 void launch_normalize_uvz(const NormalizeArgs& a, int npoints, size_t n, uint8_t* valid,
                           uint32_t* prefix, hipStream_t s);
+// JubJubScalar u and BlsScalar m from the reference's in-memory Montgomery limbs (R = 2^256) to the
+// canonical bytes every other kernel reads; limbs >= the modulus are poisoned (verdict 0)
+void launch_scalars_from_mont(const uint8_t* u_mont, const uint8_t* m_mont, size_t n, uint8_t* u_out,
+                              uint8_t* m_out, hipStream_t s);
 void launch_and_bytes(uint8_t* ok, const uint8_t* valid, size_t n, hipStream_t s);
 void launch_sign_finish(const uint8_t* r, const uint8_t* c, const uint8_t* sk, size_t n, uint8_t* u_out,
                         hipStream_t s);

@@ -174,6 +174,49 @@ def verify_vargen_ext(u, R_uvz, PK_uvz, Gen_uvz, m, multi=False):
                      (u, R_uvz, PK_uvz, Gen_uvz, m))
 
 
+# ---- the reference's in-memory representation: every element = four u64 Montgomery limbs (R = 2^256)
+def verify_single_mont(u, R_uvz, PK_uvz, m, multi=False):
+    return _ext_call("dsv_verify_single_mont" + ("_multi" if multi else ""), (32, 96, 96, 32),
+                     (u, R_uvz, PK_uvz, m))
+
+
+def verify_double_mont(u, R_uvz, Rp_uvz, PK_uvz, PKp_uvz, m, multi=False):
+    return _ext_call("dsv_verify_double_mont" + ("_multi" if multi else ""), (32, 96, 96, 96, 96, 32),
+                     (u, R_uvz, Rp_uvz, PK_uvz, PKp_uvz, m))
+
+
+def verify_vargen_mont(u, R_uvz, PK_uvz, Gen_uvz, m, multi=False):
+    return _ext_call("dsv_verify_vargen_mont" + ("_multi" if multi else ""), (32, 96, 96, 96, 32),
+                     (u, R_uvz, PK_uvz, Gen_uvz, m))
+
+
+_MONT_COLS = {"single": ("dsv_verify_single_mont_cols", (32, 96, 96, 32)),
+              "double": ("dsv_verify_double_mont_cols", (32, 96, 96, 96, 96, 32)),
+              "vargen": ("dsv_verify_vargen_mont_cols", (32, 96, 96, 96, 32))}
+
+
+def verify_mont_cols(scheme, cols):
+    """dsv_verify_*_mont_cols: the fields of typed objects where they lie.  cols: one uint8 array
+    [n, width] per field in the scheme's column order (single: u, R, PK, m; double: u, R, R', PK, PK',
+    m; vargen: u, R, PK, Gen, m) — typically VIEWS into arrays of records (numpy structured arrays,
+    `records["R"][:, :96]`): only the last axis has to be contiguous, the row stride is passed on."""
+    name, widths = _MONT_COLS[scheme]
+    if len(cols) != len(widths):
+        raise ValueError("%s takes %d columns" % (name, len(widths)))
+    n = cols[0].shape[0]
+    arr = (_lib.Column * len(cols))()
+    for k, (c, w) in enumerate(zip(cols, widths)):
+        if c.dtype != np.uint8 or c.ndim != 2 or c.shape != (n, w) or (w > 1 and c.strides[1] != 1) \
+                or c.strides[0] < w:
+            raise ValueError("column %d: expected uint8 [n, %d] rows with contiguous bytes, got %r / strides %r"
+                             % (k, w, c.shape, c.strides))
+        arr[k].base = c.ctypes.data
+        arr[k].stride = c.strides[0]
+    ok = np.zeros(n, dtype=np.uint8)
+    _lib.check(getattr(_lib.load(), name)(arr, ctypes.c_size_t(n), _p(ok)))
+    return ok
+
+
 def challenge_single(R, m):
     R, m = _arr(R, 64), _arr(m, 32)
     n = _same_n(R, m)
@@ -460,6 +503,34 @@ def verify_vargen_ext_dev(u, R_uvz, PK_uvz, Gen_uvz, m, ok, workspace, stream=No
         _tp(u, 32), _tp(R_uvz, 96), _tp(PK_uvz, 96), _tp(Gen_uvz, 96), _tp(m, 32), ctypes.c_size_t(n),
         _bytes_out(ok, n, dev, "ok"), _bytes_out(workspace, ext_workspace_bytes(n), dev, "workspace"),
         _stream_ptr(stream, dev)))
+
+
+def mont_workspace_bytes(n):
+    return int(_lib.load().dsv_mont_workspace_bytes(ctypes.c_size_t(n)))
+
+
+def _mont_dev(name, widths, arrays, ok, workspace, stream):
+    names = ["col%d" % k for k in range(len(arrays))]
+    n, dev = _rows(*[(a, w, nm) for a, w, nm in zip(arrays, widths, names)])
+    _lib.check(getattr(_lib.load(), name)(
+        *([_tp(a, w) for a, w in zip(arrays, widths)] +
+          [ctypes.c_size_t(n), _bytes_out(ok, n, dev, "ok"),
+           _bytes_out(workspace, mont_workspace_bytes(n), dev, "workspace"), _stream_ptr(stream, dev)])))
+
+
+def verify_single_mont_dev(u, R_uvz, PK_uvz, m, ok, workspace, stream=None):
+    """Montgomery limbs (the Rust types' in-memory form) resident in HBM."""
+    _mont_dev("dsv_verify_single_mont_dev", (32, 96, 96, 32), (u, R_uvz, PK_uvz, m), ok, workspace, stream)
+
+
+def verify_double_mont_dev(u, R_uvz, Rp_uvz, PK_uvz, PKp_uvz, m, ok, workspace, stream=None):
+    _mont_dev("dsv_verify_double_mont_dev", (32, 96, 96, 96, 96, 32),
+              (u, R_uvz, Rp_uvz, PK_uvz, PKp_uvz, m), ok, workspace, stream)
+
+
+def verify_vargen_mont_dev(u, R_uvz, PK_uvz, Gen_uvz, m, ok, workspace, stream=None):
+    _mont_dev("dsv_verify_vargen_mont_dev", (32, 96, 96, 96, 32), (u, R_uvz, PK_uvz, Gen_uvz, m), ok,
+              workspace, stream)
 
 
 def _wire_dev(name, sig, sig_w, pk, pk_w, m, ok, workspace, stream):

@@ -40,6 +40,8 @@ def lib():
             "oracle_keygen_sign_vargen", "oracle_scalar_mul", "oracle_fixed_base_entry",
             "oracle_decompress", "oracle_verify_single_wire", "oracle_verify_double_wire",
             "oracle_verify_vargen_wire",
+            "oracle_verify_single_mont", "oracle_verify_double_mont", "oracle_verify_vargen_mont",
+            "oracle_to_mont", "oracle_from_mont",
         ):
             getattr(L, name).restype = ctypes.c_int
         _lib = L
@@ -107,6 +109,45 @@ def verify_vargen_ext(u, R_ext, PK_ext, Gen_ext, m):
     lib().oracle_verify_vargen_ext(_p(u), _p(R_ext), _p(PK_ext), _p(Gen_ext), _p(m),
                                    ctypes.c_size_t(n), _p(ok))
     return ok
+
+
+def _mont(fn, *arrs):
+    arrs = [_u8(a) for a in arrs]
+    n = arrs[0].shape[0]
+    ok = np.zeros(n, dtype=np.uint8)
+    getattr(lib(), fn)(*([_p(a) for a in arrs] + [ctypes.c_size_t(n), _p(ok)]))
+    return ok
+
+
+def verify_single_mont(u, R_uvz, PK_uvz, m):
+    """every element = the four u64 Montgomery limbs (R = 2^256) the Rust types hold"""
+    return _mont("oracle_verify_single_mont", u, R_uvz, PK_uvz, m)
+
+
+def verify_double_mont(u, R_uvz, Rp_uvz, PK_uvz, PKp_uvz, m):
+    return _mont("oracle_verify_double_mont", u, R_uvz, Rp_uvz, PK_uvz, PKp_uvz, m)
+
+
+def verify_vargen_mont(u, R_uvz, PK_uvz, Gen_uvz, m):
+    return _mont("oracle_verify_vargen_mont", u, R_uvz, PK_uvz, Gen_uvz, m)
+
+
+def to_mont(x, fr=False):
+    """canonical 32-byte elements [..., 32 k] -> in-memory limbs of the same shape
+    (BlsScalar::from_bytes / JubJubScalar::from_bytes); every element must be below the modulus"""
+    x = _u8(x)
+    out = np.zeros_like(x)
+    good = lib().oracle_to_mont(ctypes.c_int(1 if fr else 0), _p(x), ctypes.c_size_t(x.size // 32), _p(out))
+    assert good, "to_mont: an element is not below the modulus"
+    return out
+
+
+def from_mont(x, fr=False):
+    """in-memory limbs -> canonical bytes (`to_bytes()`); returns (bytes, all_below_modulus)"""
+    x = _u8(x)
+    out = np.zeros_like(x)
+    good = lib().oracle_from_mont(ctypes.c_int(1 if fr else 0), _p(x), ctypes.c_size_t(x.size // 32), _p(out))
+    return out, bool(good)
 
 
 def challenge_single(R, m):

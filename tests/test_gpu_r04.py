@@ -1,0 +1,94 @@
+"""GPU tests of what round 4 added.  Parity is always against the CPU oracle (oracle/).
+
+* dsv_verify_{single,double,vargen}_mont[_multi|_dev|_cols]: the reference's IN-MEMORY representation
+  (four u64 Montgomery limbs per element, R = 2^256: /root/reference/Cargo.toml:25-26,
+  src/signatures.rs:58-61, src/keys/public.rs:59) — dense arrays, device pointers, and the typed
+  objects read in place as strided columns.
+"""
+import os
+
+import numpy as np
+import pytest
+
+import mont_cases as C
+import oracle_lib as O
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SEEDS = {"single": 31, "double": 32, "vargen": 33}
+
+
+def _dev(a):
+    import torch
+    return torch.from_numpy(np.ascontiguousarray(a)).to("cuda:0")
+
+
+@pytest.mark.parametrize("scheme", ["single", "double", "vargen"])
+def test_montgomery_limb_entry_points_match_the_oracle(engine, scheme):
+    """Tampered items, random z per point, z = 0, coordinate / message limbs >= q, u limbs >= r —
+    through the host entry point, the sharded one, the device-pointer one and the strided columns of
+    record arrays laid out like the Rust structs."""
+    import torch
+    n = 300 + 13
+    cols, want = C.mont_case(scheme, n, SEEDS[scheme])
+    assert 0 < want.sum() < n
+    host = getattr(engine, "verify_%s_mont" % scheme)
+    assert np.array_equal(host(*cols), want)
+    # the typed objects where they lie: Signature { u, R: JubJubExtended(160 B) }, PublicKey(160 B) ...
+    sigs, pks, msgs, views = C.as_records(scheme, cols)
+    assert np.array_equal(engine.verify_mont_cols(scheme, views), want)
+    os.environ["DSV_MULTI_SHARDS"] = "3"          # the sharding arithmetic (offset * stride) on one GPU
+    try:
+        reps = 12                                  # below nd * 1024 items the multi form takes one device
+        tile = lambda a: np.tile(a, (reps, 1))
+        assert np.array_equal(host(*[tile(c) for c in cols], multi=True), np.tile(want, reps))
+        big = C.as_records(scheme, [tile(c) for c in cols])[3]
+        assert np.array_equal(engine.verify_mont_cols(scheme, big), np.tile(want, reps))
+    finally:
+        del os.environ["DSV_MULTI_SHARDS"]
+    ok = torch.full((n,), 9, dtype=torch.uint8, device="cuda:0")
+    ws = torch.full((engine.mont_workspace_bytes(n),), 0xFF, dtype=torch.uint8, device="cuda:0")
+    getattr(engine, "verify_%s_mont_dev" % scheme)(*[_dev(c) for c in cols], ok, ws)
+    torch.cuda.synchronize()
+    assert np.array_equal(ok.cpu().numpy(), want)
+
+
+def test_montgomery_limbs_equal_the_projective_entry_point_on_to_bytes(engine):
+    """`_mont` on the limbs == `_ext` on the to_bytes() of the same values (the oracle does the
+    conversion), on a batch large enough for the chunked pipeline, the multi-threaded strided gather
+    and the one-inversion-per-16-items normalisation."""
+    scheme, base = "single", 509
+    cols, want = C.mont_case(scheme, base, 77, period=5)
+    n = (1 << 16) + 4099
+    reps = -(-n // base)
+    tile = lambda a: np.ascontiguousarray(np.tile(a, (reps, 1))[:n])
+    tcols = [tile(c) for c in cols]
+    twant = np.tile(want, reps)[:n]
+    views = C.as_records(scheme, tcols)[3]
+    got = engine.verify_mont_cols(scheme, views)
+    assert np.array_equal(got, twant)
+    assert np.array_equal(engine.verify_single_mont(*tcols), twant)
+    # canonical bytes of the same values through the r03 projective path
+    canon = [O.from_mont(tcols[0], fr=True)[0]] + [O.from_mont(c)[0] for c in tcols[1:]]
+    bad = (got != engine.verify_single_ext(*canon))
+    # the two paths may only differ where limbs were not below the modulus (no canonical form)
+    planted = np.flatnonzero(bad) % base
+    assert len(set(planted.tolist())) <= 4 and not twant[bad].any()
+
+
+def test_montgomery_column_arguments_are_validated(engine):
+    cols, _ = C.mont_case("single", 8, 5, plant=False)
+    with pytest.raises(ValueError):
+        engine.verify_mont_cols("single", cols[:3])
+    with pytest.raises(ValueError):
+        engine.verify_mont_cols("single", [cols[0], cols[1][:, :64], cols[2], cols[3]])
+    from schnorr_amd import _lib
+    import ctypes
+    arr = (_lib.Column * 4)()
+    for k, c in enumerate(cols):
+        arr[k].base, arr[k].stride = c.ctypes.data, c.strides[0]
+    arr[1].stride = 64                            # a 96-byte field cannot repeat every 64 bytes
+    ok = np.zeros(8, np.uint8)
+    rc = _lib.load().dsv_verify_single_mont_cols(arr, ctypes.c_size_t(8), ctypes.c_void_p(ok.ctypes.data))
+    assert rc == -2 and b"stride" in _lib.load().dsv_last_error()
+    assert _lib.load().dsv_verify_single_mont_cols(arr, ctypes.c_size_t(0), None) == 0   # empty batch
