@@ -134,6 +134,59 @@ def _pmc():
         return None
 
 
+def _verify_batch_e2e(E, hu, hR, hPK, hm, expected, cores):
+    """Time `verify_batch(&[Signature], &[PublicKey], &[BlsScalar]) -> Vec<bool>` of the C++ mirror
+    (include/dusk_schnorr.hpp) over the whole batch as typed objects: 1 copy thread and the default
+    number, best and median of 5 calls each; beside it the byte-oriented way of the r03 shim (8
+    to_bytes() per signature in a serial loop) on a 2^17 subset."""
+    import ctypes
+
+    lib_path = os.path.join(ROOT, "tools", "libvb_e2e.so")
+    if not os.path.exists(lib_path):
+        return None
+    L = ctypes.CDLL(lib_path)
+    n = hu.shape[0]
+    p = lambda a: ctypes.c_void_p(a.ctypes.data)
+    bad = L.vb_e2e_prepare(p(hu), p(hR), p(hPK), p(hm), ctypes.c_size_t(n), ctypes.c_int(max(1, min(cores, 16))))
+    ok = np.zeros(n, dtype=np.uint8)
+    ms = ctypes.c_double(0)
+    res = {"unit": "verifies/s", "items": n, "objects_not_representable": int(bad),
+           "workload": "verify_batch over %d typed objects (Signature 192 B, PublicKey 160 B, BlsScalar "
+                       "32 B; Montgomery limbs, random z per point) -> vector<bool>: field gather by the "
+                       "engine's copy threads (dsv_verify_single_mont_cols), PCIe, k_scalars_from_mont + "
+                       "k_normalize_uvz + the affine path, verdict packing; no host field arithmetic" % n}
+    try:
+        for label, threads in (("threads_1", 1), ("threads_default", 0)):
+            in_force = E.set_host_threads(threads)
+            times = []
+            for rep in range(6):
+                if L.vb_e2e_run(p(ok), ctypes.byref(ms)) != 0:
+                    raise SystemExit("verify_batch_e2e: engine error")
+                if rep:
+                    times.append(ms.value)
+            if (ok != expected).any():
+                raise SystemExit("verify_batch_e2e: verdicts differ from the expected pattern")
+            times.sort()
+            res[label] = {"copy_threads": in_force, "best_ms": times[0], "median_ms": times[len(times) // 2],
+                          "value": n / (times[0] * 1e-3)}
+        res["value"] = res["threads_default"]["value"]
+        sub = min(n, 1 << 17)
+        conv, tot = ctypes.c_double(0), ctypes.c_double(0)
+        if L.vb_e2e_to_bytes_path(ctypes.c_size_t(sub), p(ok), ctypes.byref(conv), ctypes.byref(tot)) != 0:
+            raise SystemExit("verify_batch_e2e: to_bytes path failed")
+        if (ok[:sub] != expected[:sub]).any():
+            raise SystemExit("verify_batch_e2e: to_bytes path verdicts differ")
+        res["to_bytes_path"] = {"items": sub, "convert_ms": conv.value, "total_ms": tot.value,
+                                "value": sub / (tot.value * 1e-3),
+                                "convert_only_value": sub / (conv.value * 1e-3),
+                                "note": "the r03 binding: 8 to_bytes() (a Montgomery reduction each) per "
+                                        "signature in one serial host loop, then dsv_verify_single_ext_multi"}
+    finally:
+        E.set_host_threads(0)
+        L.vb_e2e_release()
+    return res
+
+
 def _free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -190,6 +243,7 @@ def main():
     torch.cuda.set_device(dev_index)
     dev = "cuda:%d" % dev_index
 
+    t_init0 = time.perf_counter()
     dist = None
     # DSV_BENCH_FORCE_DIST=1: create the process group even for one rank, so that a one-GPU box
     # exercises the real RCCL collectives (all_gather / all_reduce / barrier over one rank)
@@ -212,9 +266,23 @@ def main():
     from schnorr_amd.distributed import MixedShardedVerifier
 
     E.init(dev_index)
+    torch.cuda.synchronize()
+    init_s = time.perf_counter() - t_init0     # process group + engine context (two 75.5 MB tables)
     n = 1 << args.log2_batch
 
     multi = dist is not None
+
+    def per_rank(x):
+        """one float per rank -> {"min", "max", "argmax", "all"} (N > 1: the line must say WHICH rank lags)"""
+        t = torch.tensor([x], dtype=torch.float64, device=dev)
+        if multi:
+            g = torch.empty(world, dtype=torch.float64, device=dev)
+            dist.all_gather_into_tensor(g, t)
+            t = g
+        v = [float(y) for y in t.cpu()]
+        return {"min": min(v), "max": max(v), "argmax": v.index(max(v)), "all": [round(y, 4) for y in v]}
+
+    last_ranks = {}
 
     def sync_all():
         if multi:
@@ -232,10 +300,15 @@ def main():
             step()
         sync_all()
         dt = time.perf_counter() - t0
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        if multi:
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        return float(t.item())
+        pr = per_rank(dt / steps * 1e3)          # every rank's own clock around the same K steps
+        last_ranks["ms_per_step"] = pr
+        return pr["max"] * steps / 1e3           # max over ranks
+
+    def event_pairs(k):
+        return [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(k)]
+
+    def mean_ms(pairs):
+        return sum(a.elapsed_time(b) for a, b in pairs) / max(1, len(pairs))
 
     # ------------------------------------------------------------------ configs[4]: mixed batch
     def run_mixed(steps, warmup):
@@ -256,11 +329,22 @@ def main():
         if bad or ver.local_counts() != (n - mb["n_double"], mb["n_double"]):
             raise SystemExit("rank %d: mixed batch: %d verdicts differ / counts %r"
                              % (rank, bad, ver.local_counts()))
+        ranks = None
+        if multi:
+            ranks = {"ms_per_step": last_ranks["ms_per_step"]}
+            prof = ver.profile(mb, gk, reps=3)   # HIP events around each stage, outside the timed region
+            for k_, v_ in prof.items():
+                ranks[k_] = per_rank(v_)
+            # the slowest rank's stage times, side by side
+            slow = ranks["ms_per_step"]["argmax"]
+            ranks["slowest_rank"] = {"rank": slow, **{k_: ranks[k_]["all"][slow] for k_ in prof}}
         res = {"value": world * n * steps / dtm, "unit": "verifies/s", "ms_per_step": dtm / steps * 1e3,
                "workload": "2^%d mixed items per GPU (single on even, double on odd positions; "
                            "BASELINE configs[4] = 2^23 over 8 GPUs), device-side kind split, "
                            "two all_gathers, scatter back" % args.log2_batch,
                "n_gpus": world}
+        if ranks:
+            res["ranks"] = ranks
         return res, mb
 
     base = {
@@ -275,6 +359,8 @@ def main():
 
     if args.config == "mixed":
         res, _ = run_mixed(args.steps, args.warmup)
+        if multi:
+            base["ranks"] = dict(res.pop("ranks"), init_s=per_rank(init_s))
         out = dict(base, value=res["value"], ms_per_step=res["ms_per_step"],
                    data="synthetic: reference harness inputs (StdRng 2321 / 2322), GPU-signed, every "
                         "16th item of each kind corrupted",
@@ -295,6 +381,27 @@ def main():
     valid = torch.empty(n, dtype=torch.uint8, device=dev)
     gathered = torch.empty(world * n, dtype=torch.uint8, device=dev) if multi else None
 
+    # ---- BASELINE configs[0] size through the host entry point: latency of a 1024-item call,
+    # measured FIRST (a fresh process, nothing else in flight): 200 calls after 10 warm ones
+    small_batch = None
+    if rank == 0 and world == 1 and not args.no_double:
+        sb = [batch[k][:1024].cpu().numpy() for k in ("u", "R", "PK", "m")]
+        for _ in range(10):
+            E.verify_single(*sb)
+        lat = []
+        for _ in range(200):
+            t0_ = time.perf_counter()
+            got_ = E.verify_single(*sb)
+            lat.append((time.perf_counter() - t0_) * 1e3)
+        if (got_ != batch["expected"][:1024].cpu().numpy()).any():
+            raise SystemExit("small batch: verdicts differ from the expected pattern")
+        lat.sort()
+        med = lat[len(lat) // 2]
+        small_batch = {"ms_per_call": med, "min_ms": lat[0], "median_ms": med, "p95_ms": lat[int(len(lat) * 0.95)],
+                       "calls": len(lat), "value": 1024 / (med * 1e-3), "unit": "verifies/s",
+                       "workload": "1024 single signatures per call, host buffers (BASELINE configs[0] "
+                                   "size), eight-lanes-per-signature kernel; measured before the long legs"}
+
     def step():
         E.verify_single_dev(batch["u"], batch["R"], batch["PK"], batch["m"], ok, ws)
         if multi:
@@ -304,6 +411,23 @@ def main():
         dist.all_gather_into_tensor(gathered, ok)  # RCCL connects lazily: not a step
     dt = timed(step, args.steps, args.warmup)
     ok_api = ok.clone()
+    ranks = None
+    if multi:
+        # where each rank's step goes (outside the timed region: HIP events on the current stream around
+        # the verify call and around the all_gather, which includes the wait for the slowest rank)
+        ranks = {"ms_per_step": last_ranks["ms_per_step"], "init_s": per_rank(init_s)}
+        ev_v, ev_g = event_pairs(5), event_pairs(5)
+        sync_all()
+        for (a, b), (c_, d_) in zip(ev_v, ev_g):
+            a.record()
+            E.verify_single_dev(batch["u"], batch["R"], batch["PK"], batch["m"], ok, ws)
+            b.record()
+            c_.record()
+            dist.all_gather_into_tensor(gathered, ok)
+            d_.record()
+        torch.cuda.synchronize()
+        ranks["verify_ms"] = per_rank(mean_ms(ev_v))
+        ranks["all_gather_ms"] = per_rank(mean_ms(ev_g))
 
     # ---- per-kernel launch durations: one whole-batch launch each on the current stream,
     # bracketed by HIP events (outside the timed region: inside it the sub-batches of the two
@@ -339,6 +463,8 @@ def main():
                                    % args.log2_batch,
                        "batch_per_gpu": n, "parallelism": "dp%d" % world,
                        "collective": "all_gather of verdict bytes" if multi else "none"})
+    if ranks:
+        out["ranks"] = ranks
 
     kernels = {}
 
@@ -366,7 +492,14 @@ def main():
         kernel_block("k_challenge<false>", hash_ms, n, hm, hs, other=600, mfma_rows=hrows, mfma_instr=hmi)
         pmc = _pmc()
         traffic = clock = valu_busy = None
+        pmc_source = None
         if pmc:
+            pmc_source = {"file": "profiles/pmc_latest.json", "live": False,
+                          "captured": pmc.get("captured"), "commit": pmc.get("commit"),
+                          "command": pmc.get("command"), "box_clock_held_ghz": pmc.get("clock_held_ghz"),
+                          "note": "rocprofv3 --pmc passes cannot run inside the timed process: traffic and "
+                                  "everything under `recorded` are REPLAYED from that file (another box of the "
+                                  "same pool); frac / achieved / kernel_ms are live"}
             traffic = (pmc["FETCH_SIZE_KB"] + pmc["WRITE_SIZE_KB"]) * 1024.0 * n / pmc["batch"]
             if "SQ_INSTS_VALU" in pmc and "GRBM_GUI_ACTIVE" in pmc:
                 # north_star's "VALU-busy": issue slots taken by VALU instructions in the PMC pass
@@ -385,18 +518,19 @@ def main():
             "frac": dom["mad_frac"],
             "mad_frac": dom["mad_frac"],
             "valu_issue_frac": dom["valu_issue_frac"],
-            "clock_held_ghz": clock,
-            # what limits the kernel, in one place: the SIMDs are full
-            # (valu_busy_from_pmc), 31 % of what they issue is not a MAD (non_mad_share: digit / shift
-            # of every column, limb-wise add / sub / carry, half-gcd, recoding), and the chip holds
-            # clock_held_ghz of its 2.4 GHz at the power limit: frac_at_held_clock is the MAD
-            # fraction against the peak at the clock the kernel actually gets
-            "frac_at_held_clock": dom["mad_frac"] * (CLOCK_HZ / 1e9) / clock if clock else None,
+            # what limits the kernel, in one place: the SIMDs are full (recorded.valu_busy), 31 % of what
+            # they issue is not a MAD (non_mad_share: digit / shift of every column, limb-wise add / sub /
+            # carry, half-gcd, recoding), and the chip holds recorded.clock_held_ghz of its 2.4 GHz at the
+            # power limit: recorded.frac_at_held_clock is the live MAD fraction against the peak at the
+            # clock the PMC pass saw
             "non_mad_share": 1.0 - dom["mad_lane_ops_per_item"] / float(dom["valu_lane_instr_per_item"]),
             "limit": "power (held clock) x issue slots spent on non-MAD instructions; neither HBM nor MFMA",
-            "valu_busy_from_pmc": valu_busy,
-            "traffic": traffic,
-            "traffic_ratio": traffic / algo if traffic else None,
+            "traffic": traffic,          # HBM / fabric bytes per launch, REPLAYED (pmc_source)
+            "pmc_source": pmc_source,
+            "recorded": {"traffic_ratio": traffic / algo if traffic else None,
+                         "clock_held_ghz": clock,
+                         "frac_at_held_clock": dom["mad_frac"] * (CLOCK_HZ / 1e9) / clock if clock else None,
+                         "valu_busy": valu_busy},
             "step_mad_frac": (_mads(vm, vs) + _mads(hm, hs, mfma_rows=hrows)) * n / (dt / args.steps) / MAD_PEAK,
             "model": {"mad_cycles_per_wave_instr": MAD_CYCLES, "windows": WINDOWS,
                       "mul_sqr_per_verdict": [round(vm), round(vs)], "kernel_ms": core_ms,
@@ -415,10 +549,11 @@ def main():
         bd = W.gen_double(n, seed=4242, device=dev)
         okd = torch.zeros(n, dtype=torch.uint8, device=dev)
         fd = lambda: E.verify_double_dev(bd["u"], bd["R"], bd["Rp"], bd["PK"], bd["PKp"], bd["m"], okd, ws)
-        tdd = timed(fd, reps, 1)
+        tdd = timed(fd, args.steps, args.warmup)      # the other half of the metric: the headline's protocol
         if int((okd != bd["expected"]).sum().item()):
             raise SystemExit("double-signature verdicts differ from the expected pattern")
-        out["double"] = {"value": n * reps / tdd, "unit": "verifies/s",
+        out["double"] = {"value": n * args.steps / tdd, "unit": "verifies/s", "steps": args.steps,
+                         "warmup": args.warmup, "ms_per_step": tdd / args.steps * 1e3,
                          "workload": "2^%d double-signature batch (BASELINE configs[2]), fused "
                                      "two-equation kernel" % args.log2_batch}
         hd_ms = event_ms(lambda: E.challenge_double_dev(bd["R"], bd["Rp"], bd["m"], c, valid))
@@ -431,6 +566,16 @@ def main():
                      algo_bytes=ALGO_BYTES["double"])
         hm2, hs2, hrows2, hmi2 = _hash_counts(True)
         kernel_block("k_challenge<true>", hd_ms, n, hm2, hs2, other=900, mfma_rows=hrows2, mfma_instr=hmi2)
+        dom2 = kernels["k_verify_fixed_half<2>"]
+        out["roofline_double"] = {
+            "kernel": "k_verify_fixed_half<2> (dominant: %.0f %% of a double step)" % (100 * cd_ms / (cd_ms + hd_ms)),
+            "bound": "valu", "achieved": dom2["mad_lane_ops_per_item"] * n / (cd_ms * 1e-3) / 1e12,
+            "peak": MAD_PEAK / 1e12, "unit": "T lane-MAD/s", "frac": dom2["mad_frac"],
+            "traffic": None,        # no PMC pass of the double kernel is committed
+            "kernel_ms": cd_ms, "hash_kernel_ms": hd_ms,
+            "step_mad_frac": (_mads(vm2, vs2) + _mads(hm2, hs2, mfma_rows=hrows2)) * n / (tdd / args.steps) / MAD_PEAK,
+            "hbm": {"achieved": ALGO_BYTES["double"] * n / (tdd / args.steps) / 1e9, "peak": HBM_PEAK_GBS,
+                    "unit": "GB/s", "algorithmic_bytes_per_verdict": ALGO_BYTES["double"]}}
         sample_checks["double"] = (bd, okd.clone())
 
         nv = min(n, 1 << 18)
@@ -636,15 +781,16 @@ def main():
             out["wire"]["host"] = {"value": n / tw, "unit": "verifies/s",
                                    "note": "dsv_verify_single_wire on %d host-resident records (128 B "
                                            "per item) incl. PCIe staging" % n}
-        # BASELINE configs[0] size through the same host entry point: latency of a 1024-item call
-        E.verify_single(hu[:1024], hR[:1024], hPK[:1024], hm[:1024])
-        tl0 = time.perf_counter()
-        for _ in range(20):
-            E.verify_single(hu[:1024], hR[:1024], hPK[:1024], hm[:1024])
-        tl = (time.perf_counter() - tl0) / 20
-        out["small_batch"] = {"ms_per_call": tl * 1e3, "value": 1024 / tl, "unit": "verifies/s",
-                              "workload": "1024 single signatures per call, host buffers "
-                                          "(BASELINE configs[0] size)"}
+        # ---- verify_batch END TO END from typed objects (what north_star names): the C++ mirror of the
+        # reference's types holds Montgomery limbs and 160-byte projective points; conversion, PCIe,
+        # engine and Vec<bool> packing are all inside the timed call (tools/verify_batch_e2e.cpp)
+        e2e = _verify_batch_e2e(E, hu, hR, hPK, hm, batch["expected"].cpu().numpy(), cores)
+        if e2e:
+            out["verify_batch_e2e"] = e2e
+            if "host_path_ext" in out:
+                e2e["vs_host_path_ext"] = e2e["value"] / out["host_path_ext"]["value"]
+    if small_batch:
+        out["small_batch"] = small_batch
 
     if rank == 0:
         print(json.dumps(out))

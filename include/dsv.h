@@ -95,6 +95,10 @@ int dsv_initialized_devices(int *out, int cap); /* returns how many; fills out[0
 const char *dsv_version(void);
 const char *dsv_last_error(void);
 int dsv_device_count(void);
+int dsv_set_host_threads(int n);      /* copy threads the host entry points gather the caller's arrays with
+                                         (per process, 1..16): n >= 1 sets, 0 restores the default (the
+                                         environment variable DSV_HOST_THREADS, else 4); returns the value
+                                         in force */
 
 /* ---- verify, host buffers ---- */
 int dsv_verify_single(const uint8_t *u, const uint8_t *R_uv, const uint8_t *PK_uv,

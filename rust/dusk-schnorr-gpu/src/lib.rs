@@ -6,31 +6,56 @@
 //!
 //! Replaces, batch-wise: `PublicKey::verify` (dusk-schnorr src/keys/public.rs:121-130),
 //! `PublicKeyDouble::verify` (:222-244), `PublicKeyVarGen::verify` (:401-415).
-use core::ffi::{c_char, c_int, CStr};
+//!
+//! **No field arithmetic on the host.**  The reference's types hold every field element as
+//! `[u64; 4]` Montgomery limbs (R = 2^256): `BlsScalar(pub [u64; 4])`, `JubJubScalar`, the five
+//! coordinates of `JubJubExtended`.  A `to_bytes()` is a Montgomery reduction (8 per single
+//! signature, 14 per double one — ~0.4 us per signature on one thread, ~30x below the engine), so
+//! this crate never calls it: `dsv_verify_*_mont_cols` take the limbs where they lie, one strided
+//! column per field — base = the address the accessor of item 0 returns, stride =
+//! `size_of::<Signature>()` etc. — and the engine's copy threads gather them into pinned staging
+//! while the GPU works on the previous chunk.  The device performs the two scalar reductions and
+//! `to_hash_inputs`.  Measured on the C++ mirror of these types (include/dusk_schnorr.hpp,
+//! bench.py `verify_batch_e2e`): the typed-object call runs at the rate of the byte-array host
+//! path.
+//!
+//! The only thing this relies on beyond the public API is the in-memory layout of two upstream
+//! types, checked once at start-up by `layout_ok()` against values computed through the public API:
+//!   * `JubJubScalar` is its four limbs (a one-field tuple struct),
+//!   * `JubJubExtended` starts with the limbs of u, v, z in this order (`{u, v, z, t1, t2}`).
+//! If the probe fails (a future dusk-jubjub reorders fields) the crate falls back to copying the
+//! limbs through the accessors (`get_u().0` ...: field reads, no arithmetic) into dense arrays on
+//! several threads and passes those as columns; the limbs of `u`, which has no public limb
+//! accessor, are then obtained as `(u * R).to_bytes()` — two host multiplications per signature,
+//! against the 8-14 reductions a byte-oriented binding pays.
+use core::ffi::{c_char, c_int, c_void, CStr};
+use std::sync::OnceLock;
 
 use dusk_bls12_381::BlsScalar;
-use dusk_bytes::Serializable;
-use dusk_jubjub::JubJubExtended;
+use dusk_jubjub::{JubJubExtended, JubJubScalar, GENERATOR_EXTENDED};
 use dusk_schnorr::{
     PublicKey, PublicKeyDouble, PublicKeyVarGen, Signature, SignatureDouble, SignatureVarGen,
 };
+
+/// `dsv_column` of include/dsv.h: one field of n typed objects, item i at `base + i * stride`.
+#[repr(C)]
+#[derive(Clone, Copy)]
+struct Column {
+    base: *const c_void,
+    stride: usize,
+}
 
 #[allow(non_snake_case)]
 extern "C" {
     fn dsv_init(device: c_int) -> c_int;
     fn dsv_init_visible() -> c_int;
     fn dsv_last_error() -> *const c_char;
-    // Points go over as (u, v, z), 96 bytes: the coordinates the JubJubExtended values hold, with
-    // NO normalisation on the host — the device performs `to_hash_inputs` (one field inversion per
-    // signature at most).  The *_multi entry points shard one host batch over EVERY initialised
+    // columns: single u, R, PK, m | double u, R, R', PK, PK', m | vargen u, R, PK, Gen, m
+    // (u, m: 32 B of limbs; points: 96 B = limbs of u || v || z).  Sharded over every initialised
     // device (contiguous shards, one host thread per device, no collective).
-    fn dsv_verify_single_ext_multi(u: *const u8, R_uvz: *const u8, PK_uvz: *const u8, m: *const u8,
-                                   n: usize, ok: *mut u8) -> c_int;
-    fn dsv_verify_double_ext_multi(u: *const u8, R_uvz: *const u8, Rp_uvz: *const u8,
-                                   PK_uvz: *const u8, PKp_uvz: *const u8, m: *const u8, n: usize,
-                                   ok: *mut u8) -> c_int;
-    fn dsv_verify_vargen_ext_multi(u: *const u8, R_uvz: *const u8, PK_uvz: *const u8,
-                                   Gen_uvz: *const u8, m: *const u8, n: usize, ok: *mut u8) -> c_int;
+    fn dsv_verify_single_mont_cols(cols: *const Column, n: usize, ok: *mut u8) -> c_int;
+    fn dsv_verify_double_mont_cols(cols: *const Column, n: usize, ok: *mut u8) -> c_int;
+    fn dsv_verify_vargen_mont_cols(cols: *const Column, n: usize, ok: *mut u8) -> c_int;
 }
 
 /// Engine failure (no GPU, HIP error).  Never a verdict.
@@ -62,13 +87,30 @@ pub fn init_all() -> Result<usize, EngineError> {
     Ok(n as usize)
 }
 
-fn push_point(dst: &mut Vec<u8>, p: &JubJubExtended) {
-    // three `to_bytes()` (a Montgomery reduction each, ~50 ns): no inversion, no multiplication.
-    // The reference's verify would start with `p.to_hash_inputs()` here (src/signatures.rs:131,
-    // :280-281) — that step now runs on the device.
-    dst.extend_from_slice(&p.get_u().to_bytes());
-    dst.extend_from_slice(&p.get_v().to_bytes());
-    dst.extend_from_slice(&p.get_z().to_bytes());
+const _: () = assert!(core::mem::size_of::<JubJubScalar>() == 32);
+const _: () = assert!(core::mem::size_of::<BlsScalar>() == 32);
+const _: () = assert!(core::mem::size_of::<JubJubExtended>() == 160);
+
+/// The two layout facts the zero-copy path rests on, checked against the public API.
+fn layout_ok() -> bool {
+    static OK: OnceLock<bool> = OnceLock::new();
+    *OK.get_or_init(|| {
+        // JubJubScalar::one() must read as R mod r
+        let one: [u64; 4] = unsafe { core::mem::transmute(JubJubScalar::one()) };
+        let r_mod_r = [0x25f8_0bb3_b996_07d9u64, 0xf315_d62f_66b6_e750, 0x9325_14ee_eb88_14f4,
+                       0x09a6_fc6f_4791_55c6];
+        // a point with three distinct, non-trivial coordinates
+        let p = GENERATOR_EXTENDED * JubJubScalar::from(7u64);
+        let raw: [u64; 20] = unsafe { core::mem::transmute(p) };
+        one == r_mod_r
+            && raw[0..4] == p.get_u().0
+            && raw[4..8] == p.get_v().0
+            && raw[8..12] == p.get_z().0
+    })
+}
+
+fn col<T, F>(first: &F, _outer: &[T]) -> Column {
+    Column { base: first as *const F as *const c_void, stride: core::mem::size_of::<T>() }
 }
 
 fn verdicts(ok: Vec<u8>) -> Vec<bool> {
@@ -79,20 +121,20 @@ pub fn verify_batch(sigs: &[Signature], pks: &[PublicKey], msgs: &[BlsScalar])
     -> Result<Vec<bool>, EngineError> {
     assert!(sigs.len() == pks.len() && sigs.len() == msgs.len());
     let n = sigs.len();
-    let (mut u, mut r, mut pk, mut m) =
-        (Vec::with_capacity(32 * n), Vec::with_capacity(96 * n), Vec::with_capacity(96 * n),
-         Vec::with_capacity(32 * n));
-    for i in 0..n {
-        u.extend_from_slice(&sigs[i].u().to_bytes());
-        push_point(&mut r, sigs[i].R());
-        push_point(&mut pk, pks[i].as_ref());
-        m.extend_from_slice(&msgs[i].to_bytes());
+    if n == 0 {
+        return Ok(Vec::new());
     }
-    let mut ok = vec![0u8; n];
     init_all()?;
-    check(unsafe {
-        dsv_verify_single_ext_multi(u.as_ptr(), r.as_ptr(), pk.as_ptr(), m.as_ptr(), n, ok.as_mut_ptr())
-    })?;
+    let mut ok = vec![0u8; n];
+    if layout_ok() {
+        // the objects are read in place: no copy, no arithmetic, nothing allocated but `ok`
+        let cols = [col(sigs[0].u(), sigs), col(sigs[0].R(), sigs), col(pks[0].as_ref(), pks),
+                    col(&msgs[0], msgs)];
+        check(unsafe { dsv_verify_single_mont_cols(cols.as_ptr(), n, ok.as_mut_ptr()) })?;
+    } else {
+        let soa = fallback::Soa::gather(n, |i| sigs[i].u(), |i| [sigs[i].R(), pks[i].as_ref()], |i| &msgs[i]);
+        check(unsafe { dsv_verify_single_mont_cols(soa.cols().as_ptr(), n, ok.as_mut_ptr()) })?;
+    }
     Ok(verdicts(ok))
 }
 
@@ -100,22 +142,20 @@ pub fn verify_batch_double(sigs: &[SignatureDouble], pks: &[PublicKeyDouble], ms
     -> Result<Vec<bool>, EngineError> {
     assert!(sigs.len() == pks.len() && sigs.len() == msgs.len());
     let n = sigs.len();
-    let (mut u, mut r, mut rp, mut pk, mut pkp, mut m) =
-        (Vec::new(), Vec::new(), Vec::new(), Vec::new(), Vec::new(), Vec::new());
-    for i in 0..n {
-        u.extend_from_slice(&sigs[i].u().to_bytes());
-        push_point(&mut r, sigs[i].R());
-        push_point(&mut rp, sigs[i].R_prime());
-        push_point(&mut pk, pks[i].pk());
-        push_point(&mut pkp, pks[i].pk_prime());
-        m.extend_from_slice(&msgs[i].to_bytes());
+    if n == 0 {
+        return Ok(Vec::new());
     }
-    let mut ok = vec![0u8; n];
     init_all()?;
-    check(unsafe {
-        dsv_verify_double_ext_multi(u.as_ptr(), r.as_ptr(), rp.as_ptr(), pk.as_ptr(), pkp.as_ptr(),
-                                m.as_ptr(), n, ok.as_mut_ptr())
-    })?;
+    let mut ok = vec![0u8; n];
+    if layout_ok() {
+        let cols = [col(sigs[0].u(), sigs), col(sigs[0].R(), sigs), col(sigs[0].R_prime(), sigs),
+                    col(pks[0].pk(), pks), col(pks[0].pk_prime(), pks), col(&msgs[0], msgs)];
+        check(unsafe { dsv_verify_double_mont_cols(cols.as_ptr(), n, ok.as_mut_ptr()) })?;
+    } else {
+        let soa = fallback::Soa::gather(n, |i| sigs[i].u(),
+            |i| [sigs[i].R(), sigs[i].R_prime(), pks[i].pk(), pks[i].pk_prime()], |i| &msgs[i]);
+        check(unsafe { dsv_verify_double_mont_cols(soa.cols().as_ptr(), n, ok.as_mut_ptr()) })?;
+    }
     Ok(verdicts(ok))
 }
 
@@ -123,22 +163,88 @@ pub fn verify_batch_var_gen(sigs: &[SignatureVarGen], pks: &[PublicKeyVarGen], m
     -> Result<Vec<bool>, EngineError> {
     assert!(sigs.len() == pks.len() && sigs.len() == msgs.len());
     let n = sigs.len();
-    let (mut u, mut r, mut pk, mut g, mut m) =
-        (Vec::new(), Vec::new(), Vec::new(), Vec::new(), Vec::new());
-    for i in 0..n {
-        u.extend_from_slice(&sigs[i].u().to_bytes());
-        push_point(&mut r, sigs[i].R());
-        push_point(&mut pk, pks[i].public_key());
-        push_point(&mut g, pks[i].generator());
-        m.extend_from_slice(&msgs[i].to_bytes());
+    if n == 0 {
+        return Ok(Vec::new());
     }
-    let mut ok = vec![0u8; n];
     init_all()?;
-    check(unsafe {
-        dsv_verify_vargen_ext_multi(u.as_ptr(), r.as_ptr(), pk.as_ptr(), g.as_ptr(), m.as_ptr(), n,
-                                ok.as_mut_ptr())
-    })?;
+    let mut ok = vec![0u8; n];
+    if layout_ok() {
+        let cols = [col(sigs[0].u(), sigs), col(sigs[0].R(), sigs), col(pks[0].public_key(), pks),
+                    col(pks[0].generator(), pks), col(&msgs[0], msgs)];
+        check(unsafe { dsv_verify_vargen_mont_cols(cols.as_ptr(), n, ok.as_mut_ptr()) })?;
+    } else {
+        let soa = fallback::Soa::gather(n, |i| sigs[i].u(),
+            |i| [sigs[i].R(), pks[i].public_key(), pks[i].generator()], |i| &msgs[i]);
+        check(unsafe { dsv_verify_vargen_mont_cols(soa.cols().as_ptr(), n, ok.as_mut_ptr()) })?;
+    }
     Ok(verdicts(ok))
+}
+
+/// Layout-agnostic path: limb COPIES through the public accessors (`get_u().0`: a field read, no
+/// arithmetic) into dense arrays, in parallel chunks, then the same entry points with dense columns.
+mod fallback {
+    use super::*;
+
+    pub struct Soa<const NP: usize> {
+        u: Vec<[u64; 4]>,
+        pts: [Vec<[u64; 12]>; NP],
+        m: Vec<[u64; 4]>,
+    }
+
+    /// Montgomery limbs of `u` through the public API only: the canonical bytes of `u * R` (R = 2^256
+    /// mod r as a scalar) ARE the limbs of `u`.  One multiplication + one reduction on the host.
+    fn scalar_limbs(u: &JubJubScalar) -> [u64; 4] {
+        let r_mod_r = JubJubScalar::from_raw([0x25f8_0bb3_b996_07d9, 0xf315_d62f_66b6_e750,
+                                              0x9325_14ee_eb88_14f4, 0x09a6_fc6f_4791_55c6]);
+        let b = (u * r_mod_r).to_bytes();
+        let mut l = [0u64; 4];
+        for k in 0..4 {
+            l[k] = u64::from_le_bytes(b[8 * k..8 * k + 8].try_into().unwrap());
+        }
+        l
+    }
+
+    impl<const NP: usize> Soa<NP> {
+        pub fn gather<'a>(n: usize, u: impl Fn(usize) -> &'a JubJubScalar + Sync,
+                          pts: impl Fn(usize) -> [&'a JubJubExtended; NP] + Sync,
+                          m: impl Fn(usize) -> &'a BlsScalar + Sync) -> Self {
+            let mut s = Soa { u: vec![[0; 4]; n], pts: core::array::from_fn(|_| vec![[0; 12]; n]),
+                              m: vec![[0; 4]; n] };
+            let threads = std::thread::available_parallelism().map(|x| x.get()).unwrap_or(4).min(16);
+            let chunk = (n + threads - 1) / threads;
+            std::thread::scope(|sc| {
+                let mut us = s.u.chunks_mut(chunk);
+                let mut ms = s.m.chunks_mut(chunk);
+                let mut ps: Vec<_> = s.pts.iter_mut().map(|v| v.chunks_mut(chunk)).collect();
+                for t in 0..threads {
+                    let (Some(uc), Some(mc)) = (us.next(), ms.next()) else { break };
+                    let mut pc: Vec<_> = ps.iter_mut().map(|it| it.next().unwrap()).collect();
+                    let (u, pts, m) = (&u, &pts, &m);
+                    sc.spawn(move || {
+                        for (j, i) in (t * chunk..(t * chunk + uc.len())).enumerate() {
+                            uc[j] = scalar_limbs(u(i));
+                            mc[j] = m(i).0;
+                            for (k, p) in pts(i).iter().enumerate() {
+                                pc[k][j][0..4].copy_from_slice(&p.get_u().0);
+                                pc[k][j][4..8].copy_from_slice(&p.get_v().0);
+                                pc[k][j][8..12].copy_from_slice(&p.get_z().0);
+                            }
+                        }
+                    });
+                }
+            });
+            s
+        }
+
+        pub fn cols(&self) -> Vec<Column> {
+            let mut c = vec![Column { base: self.u.as_ptr() as *const c_void, stride: 32 }];
+            for p in &self.pts {
+                c.push(Column { base: p.as_ptr() as *const c_void, stride: 96 });
+            }
+            c.push(Column { base: self.m.as_ptr() as *const c_void, stride: 32 });
+            c
+        }
+    }
 }
 
 #[cfg(test)]
@@ -147,6 +253,11 @@ mod tests {
     use dusk_schnorr::SecretKey;
     use ff::Field;
     use rand::{rngs::StdRng, SeedableRng};
+
+    #[test]
+    fn upstream_layout_is_what_the_zero_copy_path_assumes() {
+        assert!(layout_ok());
+    }
 
     /// tests/schnorr.rs:14-40 of the reference, batch-wise, CPU and GPU side by side
     #[test]
@@ -166,5 +277,12 @@ mod tests {
             assert_eq!(gpu[i], pks[i].verify(&sigs[i], msgs[i]), "item {i}");
         }
         assert!(!gpu[3] && !gpu[4] && gpu[5]);
+        // the layout-agnostic path gives the same verdicts
+        let soa = fallback::Soa::gather(sigs.len(), |i| sigs[i].u(),
+                                        |i| [sigs[i].R(), pks[i].as_ref()], |i| &msgs[i]);
+        let mut ok = vec![0u8; sigs.len()];
+        check(unsafe { dsv_verify_single_mont_cols(soa.cols().as_ptr(), sigs.len(), ok.as_mut_ptr()) })
+            .expect("engine");
+        assert_eq!(verdicts(ok), gpu);
     }
 }

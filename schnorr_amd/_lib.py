@@ -40,7 +40,7 @@ SYMBOLS = [
     "dsv_verify_single_mont_multi", "dsv_verify_double_mont_multi", "dsv_verify_vargen_mont_multi",
     "dsv_verify_single_mont_cols", "dsv_verify_double_mont_cols", "dsv_verify_vargen_mont_cols",
     "dsv_mont_workspace_bytes", "dsv_verify_single_mont_dev", "dsv_verify_double_mont_dev",
-    "dsv_verify_vargen_mont_dev",
+    "dsv_verify_vargen_mont_dev", "dsv_set_host_threads",
 ]
 _SIZE_T_FUNCS = ("dsv_workspace_bytes", "dsv_mixed_workspace_bytes", "dsv_split_scratch_bytes",
                  "dsv_ext_workspace_bytes", "dsv_wire_workspace_bytes", "dsv_mont_workspace_bytes")

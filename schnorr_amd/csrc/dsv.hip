@@ -936,15 +936,19 @@ inline void copy_strided(uint8_t* dst, const uint8_t* src, size_t stride, size_t
 constexpr size_t kPipeChunk = (size_t)1 << 18;
 constexpr size_t kPipeFirstChunk = (size_t)1 << 15;
 
+std::atomic<int> g_host_threads{0};  // dsv_set_host_threads; 0 = $DSV_HOST_THREADS, else 4
+inline int clamp_host_threads(int v) {
+  const int hw = (int)std::thread::hardware_concurrency();
+  if (hw > 0 && v > hw) v = hw;
+  return v < 1 ? 1 : (v > 16 ? 16 : v);
+}
 inline int host_copy_threads() {
-  static const int t = [] {
+  static const int from_env = [] {
     const char* e = getenv("DSV_HOST_THREADS");
-    int v = e ? atoi(e) : 4;
-    const int hw = (int)std::thread::hardware_concurrency();
-    if (hw > 0 && v > hw) v = hw;
-    return v < 1 ? 1 : (v > 16 ? 16 : v);
+    return clamp_host_threads(e ? atoi(e) : 4);
   }();
-  return t;
+  const int set = g_host_threads.load(std::memory_order_relaxed);
+  return set > 0 ? set : from_env;
 }
 
 //   extra_item_bytes: further device scratch per item that `launch` needs (decoded points of the
@@ -1487,6 +1491,13 @@ int verify_mont_cols(int kind, const dsv_column* cols, size_t n, uint8_t* ok, bo
 }  // extern "C++"
 
 size_t dsv_mont_workspace_bytes(size_t n) { return mont_workspace_bytes(n); }
+
+// copy threads of the host entry points (per process): n >= 1 sets, 0 restores the default
+// ($DSV_HOST_THREADS, else 4); returns the value now in force
+int dsv_set_host_threads(int n) {
+  g_host_threads.store(n > 0 ? clamp_host_threads(n) : 0, std::memory_order_relaxed);
+  return host_copy_threads();
+}
 
 int dsv_verify_single_mont_cols(const dsv_column* cols, size_t n, uint8_t* ok) { return verify_mont_cols(0, cols, n, ok, true); }
 int dsv_verify_double_mont_cols(const dsv_column* cols, size_t n, uint8_t* ok) { return verify_mont_cols(1, cols, n, ok, true); }

@@ -135,12 +135,44 @@ class MixedShardedVerifier:
         self.gscratch = u8(E.split_scratch_bytes(N))
         self.out = u8(N)
 
+    def profile(self, batch, global_kinds, reps=3):
+        """Where a step's time goes on THIS rank: mean ms of `reps` calls per stage, from HIP events on
+        the current stream around each stage (split + row gathers, the single kind's kernels, the
+        double kind's kernels, the two all_gathers incl. the wait for the slowest rank, the scatter
+        back).  Synchronises; not for use inside a timed region."""
+        torch = self.torch
+        marks = []
+        self._mark = lambda: marks.append(self._record())
+        try:
+            for _ in range(reps):
+                self(batch, global_kinds)
+        finally:
+            self._mark = None
+        torch.cuda.synchronize(self.dev)
+        names = ("split_gather_ms", "single_kernels_ms", "double_kernels_ms", "all_gather_ms", "scatter_ms")
+        per = len(names) + 1
+        out = dict.fromkeys(names, 0.0)
+        for r in range(reps):
+            ev = marks[r * per:(r + 1) * per]
+            for k, name in enumerate(names):
+                out[name] += ev[k].elapsed_time(ev[k + 1]) / reps
+        return out
+
+    _mark = None
+
+    def _record(self):
+        e = self.torch.cuda.Event(enable_timing=True)
+        e.record()
+        return e
+
     def __call__(self, batch, global_kinds):
         """batch: dict kinds,u,R,Rp,PK,PKp,m (local slice); global_kinds: uint8 [world*n_local].
         Returns the global verdict vector (uint8 [world*n_local], owned by this object)."""
         import torch.distributed as dist
 
         E, ns, nd = self.E, self.ns, self.nd
+        mark = self._mark or (lambda: None)
+        mark()
         E.split_kinds_dev(batch["kinds"], self.idx_s, self.idx_d, self.scratch)
         # every gather / scatter below is bounded ON THE DEVICE by the split's own counts: whatever
         # (ns, nd) the caller declared, an index entry the split did not write is never read
@@ -149,13 +181,16 @@ class MixedShardedVerifier:
             E.gather_rows_dev(batch[k], self.idx_s, ns, dst, limit=cnt[0:1])
         for k, dst in self.cd.items():
             E.gather_rows_dev(batch[k], self.idx_d, nd, dst, limit=cnt[1:2])
+        mark()
         if ns:
             E.verify_single_dev(self.cs["u"][:ns], self.cs["R"][:ns], self.cs["PK"][:ns],
                                 self.cs["m"][:ns], self.ok_s, self.ws)
+        mark()
         if nd:
             E.verify_double_dev(self.cd["u"][:nd], self.cd["R"][:nd], self.cd["Rp"][:nd],
                                 self.cd["PK"][:nd], self.cd["PKp"][:nd], self.cd["m"][:nd],
                                 self.ok_d, self.ws)
+        mark()
         if self.collective:
             if ns:
                 dist.all_gather_into_tensor(self.all_s[:self.world * ns], self.ok_s[:ns], group=self.group)
@@ -164,6 +199,7 @@ class MixedShardedVerifier:
             all_s, all_d = self.all_s, self.all_d
         else:
             all_s, all_d = self.ok_s, self.ok_d
+        mark()
         # kind-k item number j of the global batch: rank-major, i.e. j-th in global order
         E.split_kinds_dev(global_kinds, self.gidx_s, self.gidx_d, self.gscratch)
         gcnt = E.split_counts(self.gscratch)
@@ -177,6 +213,7 @@ class MixedShardedVerifier:
         good = ((cnt[0] == ns) & (cnt[1] == nd) & (gcnt[0] == self.world * ns)
                 & (gcnt[1] == self.world * nd))
         self.out.mul_(good.to(self.out.dtype))
+        mark()
         return self.out
 
     def local_counts(self):

@@ -58,6 +58,11 @@ def shutdown(device=None):
         _initialised.discard(device)
 
 
+def set_host_threads(n):
+    """Copy threads of the host entry points (0 = default); returns the value in force."""
+    return int(_lib.load().dsv_set_host_threads(ctypes.c_int(n)))
+
+
 def version():
     return _lib.load().dsv_version().decode()
 

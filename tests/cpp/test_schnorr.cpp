@@ -85,9 +85,9 @@ static void batch() {
     pks.push_back(PublicKey::from(sk));
     msgs.push_back(m);
   }
-  pks[3] = pks[4];                     // wrong key
-  msgs[10].bytes[0] ^= 1;              // wrong message
-  sigs[20].u_.bytes[5] ^= 0x40;        // corrupted u
+  pks[3] = pks[4];                                   // wrong key
+  msgs[10] = msgs[10] + BlsScalar::one();            // wrong message
+  sigs[20].u_ = sigs[20].u_ + JubJubScalar::from(64);  // corrupted u
   std::vector<bool> ok = verify_batch(sigs, pks, msgs);
   CHECK(ok.size() == n);
   for (size_t i = 0; i < n; i++) {
@@ -142,34 +142,17 @@ static void to_from_bytes() {
     rejected += !PublicKey::from_bytes(b);
   }
   CHECK(rejected > 5 && rejected < 33);
-  std::array<uint8_t, 32> r_bytes;
-  std::memcpy(r_bytes.data(), detail::kFrModulus, 32);
+  std::array<uint8_t, 32> r_bytes = JubJubScalar::modulus_bytes();
   CHECK(!SecretKey::from_bytes(r_bytes));  // exactly r
   r_bytes[0] -= 1;
   CHECK(SecretKey::from_bytes(r_bytes).has_value());  // r - 1
 }
-// (2x mod q) for a canonical little-endian x: enough host arithmetic to re-represent a point
-static std::array<uint8_t, 32> dbl_mod_q(const uint8_t x[32]) {
-  uint8_t wide[64] = {};
-  unsigned carry = 0;
-  for (int i = 0; i < 32; i++) {
-    const unsigned t = 2u * x[i] + carry;
-    wide[i] = (uint8_t)t;
-    carry = t >> 8;
-  }
-  wide[32] = (uint8_t)carry;
-  return BlsScalar::from_bytes_wide(wide).bytes;
-}
 // /root/reference/tests/keys.rs:17-60, :62-75, :77-127: the same point in another projective
 // representation (all coordinates different) is the same key, verifies the same signatures, and
-// serialises to the same bytes — here (2u, 2v, 2) against (u, v, 1)
-static JubJubExtended rescaled(const JubJubExtended& p) {
-  JubJubExtended q;
-  for (int k = 0; k < 3; k++) {
-    const auto d = dbl_mod_q(p.uvz.data() + 32 * k);
-    std::memcpy(q.uvz.data() + 32 * k, d.data(), 32);
-  }
-  return q;
+// serialises to the same bytes — here (k u, k v, k z, t1, k t2) against (u, v, z, t1, t2)
+static JubJubExtended rescaled(const JubJubExtended& p, uint64_t k = 2) {
+  const BlsScalar f = BlsScalar::from(k);
+  return JubJubExtended::from_raw_unchecked(p.u * f, p.v * f, p.z * f, p.t1, p.t2 * f);
 }
 static void partial_eq_and_projective_inputs() {
   Rng rng(77);
@@ -177,7 +160,7 @@ static void partial_eq_and_projective_inputs() {
   BlsScalar message = BlsScalar::random(rng);
   PublicKey pk = PublicKey::from(sk);
   PublicKey pk2 = PublicKey::from_raw_unchecked(rescaled(rescaled(pk.as_ref())));
-  CHECK(pk.as_ref().uvz != pk2.as_ref().uvz);
+  CHECK(pk.as_ref().u != pk2.as_ref().u && pk.as_ref().v != pk2.as_ref().v && pk.as_ref().z != pk2.as_ref().z);
   CHECK(pk == pk2);
   CHECK(pk.to_bytes() == pk2.to_bytes());
   PublicKey other = PublicKey::from(SecretKey::random(rng));
@@ -215,10 +198,56 @@ static void random_is_reduced() {
   static const uint8_t want[32] = {0x30, 0x77, 0xe5, 0x95, 0xa4, 0x9a, 0x71, 0x67, 0x26, 0xfc, 0xe3,
                                    0x9c, 0xf0, 0xce, 0xb0, 0x51, 0xa5, 0xe9, 0x26, 0xc0, 0xfa, 0xb7,
                                    0xda, 0x69, 0x88, 0x76, 0x12, 0x8d, 0x7b, 0x54, 0xf6, 0x04};
-  CHECK(std::memcmp(s.bytes.data(), want, 32) == 0);
+  CHECK(std::memcmp(s.to_bytes().data(), want, 32) == 0);
+}
+// The types hold what the reference's hold: Montgomery limbs, R = 2^256 (SURVEY.md Appendix A.1 /
+// A.2), and the host arithmetic around them is a field.
+static void in_memory_representation() {
+  // BlsScalar::one().0 == R mod q; JubJubScalar::one().0 == R mod r
+  const uint64_t rq[4] = {0x00000001fffffffeULL, 0x5884b7fa00034802ULL, 0x998c4fefecbc4ff5ULL, 0x1824b159acc5056fULL};
+  const uint64_t rr[4] = {0x25f80bb3b99607d9ULL, 0xf315d62f66b6e750ULL, 0x932514eeeb8814f4ULL, 0x09a6fc6f479155c6ULL};
+  CHECK(std::memcmp(BlsScalar::one().l, rq, 32) == 0 && std::memcmp(JubJubScalar::one().l, rr, 32) == 0);
+  CHECK(std::memcmp(BlsScalar::from(1).l, rq, 32) == 0);
+  std::array<uint8_t, 32> one_bytes{};
+  one_bytes[0] = 1;
+  CHECK(BlsScalar::one().to_bytes() == one_bytes && *JubJubScalar::from_bytes(one_bytes.data()) == JubJubScalar::one());
+  Rng rng(5);
+  for (int k = 0; k < 50; k++) {
+    const BlsScalar a = BlsScalar::random(rng), b = BlsScalar::random(rng), c = BlsScalar::random(rng);
+    CHECK((a + b) * c == a * c + b * c);
+    CHECK(a - a == BlsScalar::zero() && a + (-a) == BlsScalar::zero());
+    CHECK(*BlsScalar::from_bytes(a.to_bytes().data()) == a);
+    if (!a.is_zero()) CHECK(a * *a.invert() == BlsScalar::one());
+    const JubJubScalar x = JubJubScalar::random(rng), y = JubJubScalar::random(rng);
+    CHECK(x * y == y * x && *JubJubScalar::from_bytes(x.to_bytes().data()) == x);
+    CHECK(x * *x.invert() == JubJubScalar::one());
+  }
+  CHECK(!BlsScalar::zero().invert());
+  // -1 is the largest canonical value: to_bytes() = q - 1
+  auto m1 = (-BlsScalar::one()).to_bytes(), q = BlsScalar::modulus_bytes();
+  q[0] -= 1;
+  CHECK(m1 == q);
+  // PartialEq never panics: a z = 0 "point" compares by cross products (the reference's derive)
+  JubJubExtended z0 = JubJubExtended::from_raw_unchecked(BlsScalar::one(), BlsScalar::one(), BlsScalar::zero(),
+                                                         BlsScalar::one(), BlsScalar::one());
+  CHECK(!(z0 == JubJubExtended{}));
+  bool threw = false;
+  try {
+    z0.to_affine();
+  } catch (const std::domain_error&) {
+    threw = true;
+  }
+  CHECK(threw);
+  // such a key never verifies anything (the device rejects z = 0), and verify does not throw
+  SecretKey sk = SecretKey::random(rng);
+  BlsScalar m = BlsScalar::random(rng);
+  Signature sig = sk.sign(rng, m);
+  CHECK(!PublicKey::from_raw_unchecked(z0).verify(sig, m));
+  CHECK(PublicKey::from(sk).verify(sig, m));
 }
 
 int main() {
+  in_memory_representation();
   to_from_bytes();
   random_is_reduced();
   partial_eq_and_projective_inputs();
