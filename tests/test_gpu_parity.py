@@ -490,14 +490,30 @@ def test_predicted_reference_vectors_on_gpu(engine):
 
 def test_reference_fixtures_on_gpu(engine):
     """PARITY HAND-OFF, GPU side: the same dropped-in fixtures of the real crate
-    (tests/reference_fixtures.py) through the HIP engine.  Skipped while there is none."""
+    (tests/reference_fixtures.py) through the HIP engine — every record kind: the three schemes'
+    verdicts from affine arrays and from wire records, challenge bytes of the single and the double
+    hash, decompression, and the GPU's own StdRng generator against the raw keystream.  Skipped while
+    there is none."""
     import reference_fixtures as RF
-    from test_oracle import _check_reference_records
+    from test_oracle import Backend, _check_reference_records
     recs = RF.load()
     if not recs:
         pytest.skip("no tests/golden/reference_* fixture present: parity unpinned (DESIGN.md §2)")
-    _check_reference_records(recs, engine.verify_single_wire, engine.verify_single,
-                             engine.decompress_points)
+    _check_reference_records(recs, Backend(engine, engine.decompress_points,
+                                           stdrng=lambda seed, n: engine.stdrng_sign_inputs(seed, n)))
+
+
+def test_predicted_records_of_every_kind_on_gpu(engine):
+    """What the fixture test will run the day a real file is dropped in, on the PREDICTED records
+    (tests/golden/predicted_reference.json: "records"): the engine agrees with the predictions of
+    all three schemes (verdicts, wire verdicts, challenge bytes incl. the 5-input double hash),
+    decompression edge cases and the StdRng stream."""
+    import json, os
+    from test_oracle import Backend, _check_reference_records
+    P = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "predicted_reference.json")))
+    seen = _check_reference_records(P["records"], Backend(engine, engine.decompress_points,
+                                                          stdrng=lambda seed, n: engine.stdrng_sign_inputs(seed, n)))
+    assert seen["sigd"] == 8 and seen["sigv"] == 8 and seen["sig"] == 8 and seen["stdrng"] == 1
 
 
 def test_stdrng_input_generator_matches_restatement(engine):

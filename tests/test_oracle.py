@@ -1,6 +1,7 @@
 """CPU tests of the oracle (oracle/schnorr_oracle.c): constants re-derived with Python integers,
 agreement with the independent big-int model, the reference's own relational tests
 (tests/schnorr.rs, schnorr_double.rs, schnorr_var_generator.rs, keys.rs), golden fixtures."""
+import ctypes
 import json
 import os
 
@@ -209,68 +210,153 @@ def test_stdrng_restatement_and_predicted_reference_vectors():
         assert int(O.verify_single_wire(sig, pk, unhex(rec["m"]).reshape(1, 32))[0]) == 1
 
 
-def _check_reference_records(recs, verify_wire, verify_plain, decompress):
-    """shared by the CPU (oracle) and GPU (engine) forms of the hand-off test"""
-    n_sig = 0
+class Backend:
+    """the functions a fixture check drives: the oracle's (CPU) or the HIP engine's (GPU)"""
+    def __init__(self, mod, decompress, stdrng=None):
+        for k in ("verify_single", "verify_double", "verify_vargen", "verify_single_wire", "verify_double_wire",
+                  "verify_vargen_wire", "challenge_single", "challenge_double"):
+            setattr(self, k, getattr(mod, k))
+        self.decompress = decompress
+        self.stdrng = stdrng          # engine only: (seed, n) -> (sk, m, nonce) of the GPU's own ChaCha12
+
+
+ORACLE_BACKEND = Backend(O, O.decompress)
+
+
+def _check_reference_records(recs, be=ORACLE_BACKEND):
+    """shared by the CPU (oracle) and GPU (engine) forms of the hand-off test; returns the number
+    of records checked per kind"""
+    import refrng
+    from collections import Counter
+    seen = Counter()
+    row = lambda h, w: unhex(h).reshape(1, w)
     for r in recs:
-        if r["kind"] == "sponge_hash_1_2_3_le":
-            assert M.le32(M.sponge_hash([1, 2, 3])).hex() == r["hex"], "Poseidon sponge differs from the crate"
-        elif r["kind"] == "truncated_hash_1_2_3_le":
-            assert M.le32(M.truncated_hash([1, 2, 3])).hex() == r["hex"], "250-bit truncation differs"
-        elif r["kind"] == "sig":
-            n_sig += 1
-            u, m = unhex(r["u"]).reshape(1, 32), unhex(r["m"]).reshape(1, 32)
-            R, PK = unhex(r["R"]).reshape(1, 64), unhex(r["PK"]).reshape(1, 64)
-            assert int(verify_plain(u, R, PK, m)[0]) == int(r["verdict"]), ("verdict", r["i"])
-            sig, pk = unhex(r["sig_bytes"]).reshape(1, 64), unhex(r["pk_bytes"]).reshape(1, 32)
-            assert int(verify_wire(sig, pk, m)[0]) == int(r["verdict"]), ("wire verdict", r["i"])
+        k = r["kind"]
+        seen[k] += 1
+        if k == "sponge_hash":
+            assert M.le32(M.sponge_hash(list(range(1, r["n"] + 1)))).hex() == r["hex"], \
+                "Poseidon sponge of %d inputs differs from the crate" % r["n"]
+        elif k == "truncated_hash":
+            assert M.le32(M.truncated_hash(list(range(1, r["n"] + 1)))).hex() == r["hex"], \
+                "250-bit truncated hash of %d inputs differs" % r["n"]
+        elif k == "sig":
+            u, m = row(r["u"], 32), row(r["m"], 32)
+            R, PK = row(r["R"], 64), row(r["PK"], 64)
+            assert int(be.verify_single(u, R, PK, m)[0]) == int(r["verdict"]), ("verdict", r["i"])
+            sig, pk = row(r["sig_bytes"], 64), row(r["pk_bytes"], 32)
+            assert int(be.verify_single_wire(sig, pk, m)[0]) == int(r["verdict"]), ("wire verdict", r["i"])
+            if "c" in r:
+                assert bytes(be.challenge_single(R, m)[0]).hex() == r["c"], ("challenge", r["i"])
             # the crate's own PK = sk * G and serialisation
             sk = M.from_le(unhex(r["sk"]))
             assert M.point_bytes(M.pmul(M.GEN, sk)).hex() == r["PK"], ("PK = sk*G", r["i"])
             assert M.compress(H.to_int_point(PK[0])).hex() == r["pk_bytes"]
             assert r["sig_bytes"] == r["u"] + M.compress(H.to_int_point(R[0])).hex()
-        elif r["kind"] == "from_bytes":
-            out, ok = decompress(unhex(r["enc"]).reshape(1, 32))
+        elif k == "sigd":
+            u, m = row(r["u"], 32), row(r["m"], 32)
+            R, Rp, PK, PKp = (row(r[x], 64) for x in ("R", "Rp", "PK", "PKp"))
+            assert int(be.verify_double(u, R, Rp, PK, PKp, m)[0]) == int(r["verdict"]), ("verdict", r["i"])
+            assert int(be.verify_double_wire(row(r["sig_bytes"], 96), row(r["pk_bytes"], 64), m)[0]) == \
+                int(r["verdict"]), ("wire verdict", r["i"])
+            assert bytes(be.challenge_double(R, Rp, m)[0]).hex() == r["c"], ("double challenge", r["i"])
+            sk = M.from_le(unhex(r["sk"]))
+            assert M.point_bytes(M.pmul(M.GEN, sk)).hex() == r["PK"], ("PK = sk*G", r["i"])
+            assert M.point_bytes(M.pmul(M.GEN_NUMS, sk)).hex() == r["PKp"], ("PK' = sk*G'", r["i"])
+            comp = lambda x: M.compress(H.to_int_point(x[0])).hex()
+            assert r["pk_bytes"] == comp(PK) + comp(PKp) and r["sig_bytes"] == r["u"] + comp(R) + comp(Rp)
+        elif k == "sigv":
+            u, m = row(r["u"], 32), row(r["m"], 32)
+            R, PK, Gen = (row(r[x], 64) for x in ("R", "PK", "Gen"))
+            assert int(be.verify_vargen(u, R, PK, Gen, m)[0]) == int(r["verdict"]), ("verdict", r["i"])
+            assert int(be.verify_vargen_wire(row(r["sig_bytes"], 64), row(r["pk_bytes"], 64), m)[0]) == \
+                int(r["verdict"]), ("wire verdict", r["i"])
+            assert bytes(be.challenge_single(R, m)[0]).hex() == r["c"], ("challenge", r["i"])
+            comp = lambda x: M.compress(H.to_int_point(x[0])).hex()
+            # SecretKeyVarGen::to_bytes = sk || compressed generator; PublicKeyVarGen = pk || generator
+            sk = M.from_le(unhex(r["sk_bytes"][:64]))
+            assert r["sk_bytes"][64:] == comp(Gen) and r["pk_bytes"] == comp(PK) + comp(Gen)
+            assert M.point_bytes(M.pmul(H.to_int_point(Gen[0]), sk)).hex() == r["PK"], ("PK = sk*Gen", r["i"])
+            assert r["sig_bytes"] == r["u"] + comp(R)
+        elif k == "stdrng":
+            assert refrng.StdRng(r["seed"]).fill_bytes(r["n"]).hex() == r["hex"], "StdRng keystream differs"
+            if be.stdrng and r["n"] >= 192:
+                sk, m, nonce = be.stdrng(r["seed"], r["n"] // 192)
+                raw = bytes.fromhex(r["hex"])
+                for i in range(r["n"] // 192):
+                    w = [int.from_bytes(raw[192 * i + 64 * j:192 * i + 64 * j + 64], "little") for j in range(3)]
+                    assert (M.from_le(sk[i]), M.from_le(m[i]), M.from_le(nonce[i])) == \
+                        (w[0] % M.R_ORDER, w[1] % M.Q, w[2] % M.R_ORDER)
+        elif k == "wide":
+            v = int.from_bytes(bytes.fromhex(r["wide"]), "little")
+            mod = M.R_ORDER if r["field"] == "fr" else M.Q
+            assert M.le32(v % mod).hex() == r["hex"], "from_bytes_wide / Field::random differs"
+            # the oracle's own wide reduction (lo * R^2 + hi * R^3), through its keygen entry point
+            if r["field"] == "fr":
+                w = unhex(r["wide"]).reshape(1, 64)
+                d = {x: np.zeros((1, s), np.uint8) for x, s in (("sk", 32), ("m", 32), ("u", 32), ("R", 64), ("PK", 64))}
+                O.lib().oracle_keygen_sign_single(O._p(w), O._p(w), O._p(w), ctypes.c_size_t(1), O._p(d["sk"]),
+                                                  O._p(d["m"]), O._p(d["u"]), O._p(d["R"]), O._p(d["PK"]), ctypes.c_int(1))
+                assert bytes(d["sk"][0]).hex() == r["hex"]
+        elif k == "from_bytes":
+            out, ok = be.decompress(unhex(r["enc"]).reshape(1, 32))
             assert bool(ok[0]) == r["ok"], ("from_bytes accept/reject", r["i"])
             if r["ok"]:
                 assert bytes(out[0]).hex() == r["u"] + r["v"], ("from_bytes value", r["i"])
-    return n_sig
+        else:
+            raise AssertionError("unknown record kind %r" % k)
+    return seen
 
 
 def test_reference_fixtures_pin_the_oracle():
     """PARITY HAND-OFF: fixtures dumped from the real dusk-schnorr (tests/reference_fixtures.py,
     rust/dusk-schnorr-gpu/src/bin/golden_gen.rs), when someone has dropped them into
-    tests/golden/, must agree with the oracle: raw sponge, truncation, sign / key bytes, verdicts,
-    decompression edge cases.  Skipped (parity stays "unpinned") while there is none."""
+    tests/golden/, must agree with the oracle: raw sponge of 3 / 4 / 5 / 8 inputs, truncation, the
+    three schemes' challenges, signatures, key bytes and verdicts, the raw StdRng stream, the wide
+    reductions, decompression edge cases.  Skipped (parity stays "unpinned") while there is none."""
     import reference_fixtures as RF
     recs = RF.load()
     if not recs:
         pytest.skip("no tests/golden/reference_* fixture present: parity unpinned (DESIGN.md §2)")
-    n = _check_reference_records(recs, O.verify_single_wire, O.verify_single, O.decompress)
-    assert n >= 1
+    seen = _check_reference_records(recs)
+    assert seen["sig"] >= 1
 
 
 def test_reference_fixture_parser_on_a_synthetic_file(tmp_path, monkeypatch):
-    """the hand-off path itself is exercised: a file in golden_gen.rs's format built from the
-    PREDICTED vectors parses and passes; one corrupted challenge-dependent byte fails."""
+    """the hand-off path itself is exercised for EVERY record kind: a file in golden_gen.rs's format
+    built from the PREDICTED records (tests/golden/predicted_reference.json: "records") parses back
+    to the same records and passes; the r03 line names still parse; one corrupted byte in a record
+    of each challenge-dependent kind fails."""
     import reference_fixtures as RF
     P = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "predicted_reference.json")))
-    lines = ["sponge_hash_1_2_3_le " + M.le32(M.sponge_hash([1, 2, 3])).hex(),
-             "truncated_hash_1_2_3_le " + M.le32(M.truncated_hash([1, 2, 3])).hex()]
-    for rec in P["seed_2321"][:3]:
-        lines.append("sig %d sk %s m %s u %s R %s PK %s sig_bytes %s pk_bytes %s verdict true"
-                     % (rec["i"], rec["sk"], rec["m"], rec["u"], rec["R"], rec["PK"], rec["sig_bytes"],
-                        rec["pk_bytes"]))
-    one = M.le32(1).hex()
-    lines.append("from_bytes 0 %s ok u %s v %s" % (one, M.le32(0).hex(), one))
+    pred = P["records"]
+    assert {r["kind"] for r in pred} == set(RF.KINDS)
+    lines = [RF.format_record(r) for r in pred]
+    lines += ["sponge_hash_1_2_3_le " + M.le32(M.sponge_hash([1, 2, 3])).hex(),
+              "truncated_hash_1_2_3_le " + M.le32(M.truncated_hash([1, 2, 3])).hex(), ""]
     (tmp_path / "reference_synthetic.txt").write_text("\n".join(lines) + "\n")
     monkeypatch.setattr(RF, "GOLDEN_DIR", str(tmp_path))
     recs = RF.load()
-    assert len(recs) == 6
-    assert _check_reference_records(recs, O.verify_single_wire, O.verify_single, O.decompress) == 3
-    bad = [dict(r) for r in recs]
-    u = bytearray(unhex(bad[2]["u"]).tobytes())
-    u[0] ^= 1
-    bad[2]["u"] = bytes(u).hex()
-    with pytest.raises(AssertionError):
-        _check_reference_records(bad, O.verify_single_wire, O.verify_single, O.decompress)
+    assert recs[:len(pred)] == pred and len(recs) == len(pred) + 2
+    seen = _check_reference_records(recs)
+    assert seen == {"sponge_hash": 5, "truncated_hash": 3, "sig": 8, "sigd": 8, "sigv": 8, "stdrng": 1,
+                    "wide": 6, "from_bytes": 6}
+    # the predictions are regenerable
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("make_predicted", os.path.join(os.path.dirname(__file__), "golden", "make_predicted.py"))
+    mp = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mp)
+    assert mp.predict_records() == pred
+    # a wrong byte is noticed in every kind that depends on the hash / the schemes / the RNG
+    def flip(h, pos=0):
+        b = bytearray(bytes.fromhex(h))
+        b[pos] ^= 1
+        return bytes(b).hex()
+    for kind, field in (("sig", "u"), ("sigd", "c"), ("sigd", "Rp"), ("sigv", "u"), ("sigv", "pk_bytes"),
+                        ("sponge_hash", "hex"), ("truncated_hash", "hex"), ("stdrng", "hex"), ("wide", "hex")):
+        bad = [dict(r) for r in recs]
+        victim = next(r for r in bad if r["kind"] == kind)
+        victim[field] = flip(victim[field])
+        with pytest.raises(AssertionError):
+            _check_reference_records(bad)
+    with pytest.raises(ValueError):
+        RF._parse_line("sigx 0 u 00")
