@@ -47,10 +47,31 @@ def _stale():
     return any(os.path.exists(d) and os.path.getmtime(d) > t for d in _deps())
 
 
-def build(force=False, extra_flags=(), verbose=False, out=None, jobs=None):
-    """Returns the path of the library.  extra_flags / out: A/B builds (another -D set, another file)."""
+# Test builds of single units (the other units' objects are shared with the default build):
+#   lat0: the var-generator kernel without its lattice reduction — every item takes the fallback row
+#         (u, c, 1), the branch no hash output can steer a challenge to (lattice3.h)
+VARIANTS = {"lat0": {"k_vargen.hip": ["-DDSV_LAT_MAX_BATCHES=0"]}}
+
+
+def variant_path(name):
+    return os.path.join(HERE, "libdsv_%s.so" % name)
+
+
+def _toolchain_stamp(hipcc):
+    """what an object depends on besides its sources: compiler, target, flags (a changed
+    FLAGS / ARCH / ROCm version must not link stale objects)"""
+    try:
+        ver = subprocess.run([hipcc, "--version"], capture_output=True, text=True).stdout
+    except OSError:
+        ver = "?"
+    return hashlib.sha256((ver + ARCH + " ".join(FLAGS)).encode()).hexdigest()[:12]
+
+
+def build(force=False, extra_flags=(), verbose=False, out=None, jobs=None, unit_flags=None):
+    """Returns the path of the library.  extra_flags / out: A/B builds (another -D set, another file);
+    unit_flags = {unit: [flags]}: a variant in which only those units are compiled differently."""
     out = out or LIB
-    if not force and not extra_flags and out == LIB and not _stale():
+    if not force and not extra_flags and not unit_flags and out == LIB and not _stale():
         return LIB
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     if not os.path.exists(hipcc):
@@ -59,12 +80,14 @@ def build(force=False, extra_flags=(), verbose=False, out=None, jobs=None):
     gen = os.path.join(CSRC, "gen_constants.py")
     if not os.path.exists(const_h) or os.path.getmtime(gen) > os.path.getmtime(const_h):
         subprocess.check_call([sys.executable, gen])
-    tag = hashlib.sha256(" ".join(extra_flags).encode()).hexdigest()[:8] if extra_flags else "default"
-    objdir = os.path.join(ROOT, "build", "obj", tag)
-    os.makedirs(objdir, exist_ok=True)
-    stamp = _headers_stamp()
+    unit_flags = unit_flags or {}
+    stamp = _headers_stamp() + _toolchain_stamp(hipcc)
 
     def compile_unit(unit):
+        flags = list(extra_flags) + list(unit_flags.get(unit, ()))
+        tag = hashlib.sha256(" ".join(flags).encode()).hexdigest()[:8] if flags else "default"
+        objdir = os.path.join(ROOT, "build", "obj", tag)
+        os.makedirs(objdir, exist_ok=True)
         src = os.path.join(CSRC, unit)
         obj = os.path.join(objdir, unit.replace(".hip", ".o"))
         key = obj + ".key"
@@ -72,7 +95,7 @@ def build(force=False, extra_flags=(), verbose=False, out=None, jobs=None):
             want = stamp + hashlib.sha256(f.read()).hexdigest()[:16]
         if not force and os.path.exists(obj) and os.path.exists(key) and open(key).read() == want:
             return obj
-        cmd = [hipcc] + FLAGS + list(extra_flags) + ["-c", src, "-o", obj]
+        cmd = [hipcc] + FLAGS + flags + ["-c", src, "-o", obj]
         if verbose:
             print(" ".join(cmd), file=sys.stderr)
         subprocess.check_call(cmd)
@@ -89,6 +112,20 @@ def build(force=False, extra_flags=(), verbose=False, out=None, jobs=None):
     return out
 
 
+def build_variant(name, force=False, verbose=False):
+    """schnorr_amd/libdsv_<name>.so (git-ignored, travels to the GPU box like libdsv.so)"""
+    out = variant_path(name)
+    deps = _deps()
+    if not force and os.path.exists(out) and all(os.path.getmtime(d) <= os.path.getmtime(out) for d in deps if os.path.exists(d)):
+        return out
+    return build(force=force, verbose=verbose, out=out, unit_flags=VARIANTS[name])
+
+
 if __name__ == "__main__":
     flags = [a for a in sys.argv[1:] if a.startswith("-D")]
-    print(build(force="--force" in sys.argv, extra_flags=flags, verbose=True))
+    names = [a.split("=", 1)[1] for a in sys.argv[1:] if a.startswith("--variant=")]
+    if names:
+        for nm in names:
+            print(build_variant(nm, force="--force" in sys.argv, verbose=True))
+    else:
+        print(build(force="--force" in sys.argv, extra_flags=flags, verbose=True))

@@ -187,13 +187,19 @@ struct Context {
   // sub-batch lanes of the device-pointer entry points (run_split)
   std::mutex lane_mu;
   SplitLane lanes[kSplitLanes];
-  // pipeline of the host verify entry points (run_pipelined): kPipeSlots chunks in flight, each
-  // with its own stream, device staging and pinned host staging
-  hipStream_t pipe_stream[kPipeSlots] = {};
-  uint8_t* pipe_stage[kPipeSlots] = {};   // device side of a slot
+  // pipeline of the host verify entry points (run_pipelined): kPipeSlots chunks in flight, each with
+  // its own device and pinned host staging; FOUR streams in all — one for the transfers in, two
+  // compute lanes that every chunk's sub-batches alternate between, one for the verdicts out
+  hipStream_t pipe_in = nullptr, pipe_out = nullptr, pipe_lane[2] = {nullptr, nullptr};
+  hipStream_t pipe_small = nullptr;       // a call of one small chunk runs on this stream alone
+  hipEvent_t pipe_ev_in[kPipeSlots] = {}, pipe_ev_lane[kPipeSlots][2] = {}, pipe_ev_done[kPipeSlots] = {};
+  uint8_t* pipe_stage[kPipeSlots] = {};   // device side of a slot: the input block, then the verdicts
   size_t pipe_bytes[kPipeSlots] = {};
   uint8_t* pipe_host[kPipeSlots] = {};    // pinned host side of a slot (inputs, then verdicts)
   size_t pipe_host_bytes[kPipeSlots] = {};
+  uint8_t* pipe_work[2] = {};             // per compute lane: verify workspace + scratch of one sub-batch
+  size_t pipe_work_bytes[2] = {};
+  uint64_t pipe_parts = 0;                // sub-batches enqueued so far: part p runs on lane p & 1
   CopyPool copiers;
 };
 Context g_ctx[kMaxDevices];
@@ -238,9 +244,42 @@ int ensure_stage(Context& ctx, size_t bytes) {
   return DSV_OK;
 }
 
+int ensure_pipe_streams(Context& ctx) {
+  if (ctx.pipe_ev_done[kPipeSlots - 1]) return DSV_OK;  // (the last thing created below)
+  if (ctx.pipe_lane[0]) return fail(DSV_ERR_HIP, "the host pipeline's streams could not be created earlier");
+  // The two compute lanes MUST sit on different hardware queues: ROCm multiplexes streams onto
+  // GPU_MAX_HW_QUEUES (default 4) hardware queues per priority level, and two streams that land on one
+  // queue run strictly one after the other — measured: both lanes on queue 4, no overlap at all, every
+  // host path 10 - 20 % slower (profiles/r04/host_pipeline_streams.txt).  Which queue a stream gets
+  // depends on every stream the process created before; the priority level does not: streams of
+  // different priorities never share a queue.  So lane 0 is created at the highest priority, lane 1
+  // at the middle one, the two transfer streams (no kernels but a 2 us verdict copy) at the lowest.
+  // The lanes carry alternating sub-batches of equal work, so the priority only decides whose waves
+  // are dispatched first.
+  int least = 0, greatest = 0;
+  HIP_TRY(hipDeviceGetStreamPriorityRange(&least, &greatest));
+  HIP_TRY(hipStreamCreateWithPriority(&ctx.pipe_lane[0], hipStreamNonBlocking, greatest));
+  HIP_TRY(hipStreamCreateWithPriority(&ctx.pipe_lane[1], hipStreamNonBlocking, (least + greatest) / 2));
+  HIP_TRY(hipStreamCreateWithPriority(&ctx.pipe_in, hipStreamNonBlocking, least));
+  HIP_TRY(hipStreamCreateWithPriority(&ctx.pipe_out, hipStreamNonBlocking, least));
+  HIP_TRY(hipStreamCreateWithFlags(&ctx.pipe_small, hipStreamNonBlocking));
+  for (int sl = 0; sl < kPipeSlots; sl++) {
+    HIP_TRY(hipEventCreateWithFlags(&ctx.pipe_ev_in[sl], hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&ctx.pipe_ev_done[sl], hipEventDisableTiming));
+    for (int k = 0; k < 2; k++) HIP_TRY(hipEventCreateWithFlags(&ctx.pipe_ev_lane[sl][k], hipEventDisableTiming));
+  }
+  return DSV_OK;
+}
+int ensure_pipe_work(Context& ctx, int lane, size_t bytes) {
+  if (ctx.pipe_work_bytes[lane] >= bytes) return DSV_OK;
+  if (ctx.pipe_work[lane]) HIP_TRY(hipFree(ctx.pipe_work[lane]));
+  ctx.pipe_work[lane] = nullptr;
+  ctx.pipe_work_bytes[lane] = 0;
+  HIP_TRY(hipMalloc(&ctx.pipe_work[lane], bytes));
+  ctx.pipe_work_bytes[lane] = bytes;
+  return DSV_OK;
+}
 int ensure_pipe_slot(Context& ctx, int slot, size_t dev_bytes, size_t host_bytes) {
-  if (!ctx.pipe_stream[slot])
-    HIP_TRY(hipStreamCreateWithFlags(&ctx.pipe_stream[slot], hipStreamNonBlocking));
   if (ctx.pipe_bytes[slot] < dev_bytes) {
     if (ctx.pipe_stage[slot]) HIP_TRY(hipFree(ctx.pipe_stage[slot]));
     ctx.pipe_stage[slot] = nullptr;
@@ -456,13 +495,29 @@ void release_context(Context& ctx) {
   for (int k = 0; k < kPipeSlots; k++) {
     if (ctx.pipe_stage[k]) (void)hipFree(ctx.pipe_stage[k]);
     if (ctx.pipe_host[k]) (void)hipHostFree(ctx.pipe_host[k]);
-    if (ctx.pipe_stream[k]) (void)hipStreamDestroy(ctx.pipe_stream[k]);
     ctx.pipe_stage[k] = nullptr;
     ctx.pipe_host[k] = nullptr;
-    ctx.pipe_stream[k] = nullptr;
     ctx.pipe_bytes[k] = 0;
     ctx.pipe_host_bytes[k] = 0;
+    if (ctx.pipe_ev_in[k]) (void)hipEventDestroy(ctx.pipe_ev_in[k]);
+    if (ctx.pipe_ev_done[k]) (void)hipEventDestroy(ctx.pipe_ev_done[k]);
+    ctx.pipe_ev_in[k] = ctx.pipe_ev_done[k] = nullptr;
+    for (int j = 0; j < 2; j++) {
+      if (ctx.pipe_ev_lane[k][j]) (void)hipEventDestroy(ctx.pipe_ev_lane[k][j]);
+      ctx.pipe_ev_lane[k][j] = nullptr;
+    }
   }
+  for (int k = 0; k < 2; k++) {
+    if (ctx.pipe_work[k]) (void)hipFree(ctx.pipe_work[k]);
+    ctx.pipe_work[k] = nullptr;
+    ctx.pipe_work_bytes[k] = 0;
+    if (ctx.pipe_lane[k]) (void)hipStreamDestroy(ctx.pipe_lane[k]);
+    ctx.pipe_lane[k] = nullptr;
+  }
+  if (ctx.pipe_in) (void)hipStreamDestroy(ctx.pipe_in);
+  if (ctx.pipe_out) (void)hipStreamDestroy(ctx.pipe_out);
+  if (ctx.pipe_small) (void)hipStreamDestroy(ctx.pipe_small);
+  ctx.pipe_in = ctx.pipe_out = ctx.pipe_small = nullptr;
   ctx.copiers.stop();
 }
 
@@ -470,7 +525,7 @@ void release_context(Context& ctx) {
 
 extern "C" {
 
-const char* dsv_version(void) { return "dsv 0.3.0 (gfx950, fe29)"; }
+const char* dsv_version(void) { return "dsv 0.4.0 (gfx950, fe29)"; }
 const char* dsv_last_error(void) { return g_err.c_str(); }
 
 int dsv_device_count(void) {
@@ -645,9 +700,10 @@ namespace {
 // by an event here; the caller enqueues the hash, then waits for the returned join event on its own
 // stream in front of the verify kernel.  nullptr: not a small batch (or the overlap is off, or no
 // lane could be had) — the verify kernel then builds its tables itself.
+thread_local bool t_pipeline_part = false;  // run_pipelined, several chunks: its four streams are all there is
 hipEvent_t prep_tables_beside_hash(Context& ctx, const void* PK_uv, const void* R_uv, size_t n,
                                    u32* tables, hipStream_t user) {
-  if (!(ctx.quad && ctx.small_overlap && n <= kQuadMaxItems)) return nullptr;
+  if (!(ctx.quad && ctx.small_overlap && n <= kQuadMaxItems) || t_pipeline_part) return nullptr;
   SplitLane* lane = nullptr;
   if (acquire_lane(ctx, user, lane) != DSV_OK) return nullptr;
   std::lock_guard<std::mutex> lk(ctx.lane_mu);
@@ -655,7 +711,12 @@ hipEvent_t prep_tables_beside_hash(Context& ctx, const void* PK_uv, const void* 
       hipStreamWaitEvent(lane->stream[0], lane->fork, 0) != hipSuccess)
     return nullptr;
   launch_prep_var_tables((const uint8_t*)PK_uv, (const uint8_t*)R_uv, n, tables, lane->stream[0]);
-  if (hipEventRecord(lane->join[0], lane->stream[0]) != hipSuccess) return nullptr;
+  if (hipEventRecord(lane->join[0], lane->stream[0]) != hipSuccess) {
+    // the prep kernel is already writing this call's table slots: it must have finished before the
+    // verify kernel, told to build its tables itself, writes the same slots from the caller's stream
+    (void)hipStreamSynchronize(lane->stream[0]);
+    return nullptr;
+  }
   return lane->join[0];
 }
 int verify_single_on(Context& ctx, const void* u, const void* R_uv, const void* PK_uv, const void* m,
@@ -901,14 +962,29 @@ int dsv_verify_mixed_dev(const void* kinds, const void* u, const void* R_uv, con
 
 extern "C++" {
 namespace {
-// Chunked host path shared by the three verify entry points.
-//   ins[k] = {host array, bytes per item}; launch(dev_ptrs, count, dok, ws, extra, stream) enqueues
-//   the kernels for one chunk.  Chunk c uses slot c % kPipeSlots.  Per chunk: the copy threads gather
-//   the caller's arrays (pageable in general) into the slot's pinned staging, ONE asynchronous
-//   DMA moves the block to the device, the kernels run, the verdict bytes come back into the
-//   pinned block; they are handed to the caller when the slot is recycled.  While the GPU works on
-//   chunk c the host is already gathering chunk c + 1, so the slower of (host memcpy, GPU) sets
-//   the rate; a pageable hipMemcpyAsync would serialise staging and DMA on one runtime thread.
+// Chunked host path shared by the verify entry points.
+//   ins[k] = {host array, bytes per item[, stride]}; launch(dev_ptrs, count, dok, ws, extra, stream)
+//   enqueues the kernels for `count` items on `stream` (it is handed sub-batches, not chunks).
+// Per chunk c (slot c % kPipeSlots): the copy threads gather the caller's arrays (pageable in general,
+// or one field out of every typed object) into the slot's pinned staging, ONE asynchronous DMA moves
+// the block to the device, the chunk's sub-batches of 2^16 items run, the verdict bytes come back into
+// the pinned block; they are handed to the caller when the slot is recycled.  While the GPU works
+// on chunk c the host is already gathering chunk c + 1.
+//
+// Streams (r04): FOUR per device for the whole pipeline —
+//   pipe_in      every chunk's transfer to the device
+//   pipe_lane[2] the two compute lanes: sub-batch p of the CALL (not of the chunk) runs on lane p & 1
+//                with everything it needs — normalisation / decompression / limb conversion of ITS
+//                items, hash, verify, validity AND — as one in-order chain, so a lane never waits for
+//                another chunk's preprocessing and two sub-batches are co-resident at any time, as in
+//                the device-resident entry points
+//   pipe_out     every chunk's verdicts back to the host
+// chained by events (transfer done -> lanes; lanes done -> verdicts out -> slot free).  r01 - r03 gave
+// every slot its own stream plus a pair of sub-batch streams: nine streams on the four hardware
+// queues ROCm multiplexes streams onto by default, i.e. kernels of one chunk queued behind another
+// chunk's on the same hardware queue although nothing ordered them — the wire path, with the most
+// kernels per chunk, lost 22 % against the device-resident rate and gained 12 - 15 % from
+// GPU_MAX_HW_QUEUES=8 alone (profiles/r04/host_pipeline_streams.txt).
 struct HostIn {
   const uint8_t* p;
   size_t bytes;       // per item
@@ -930,9 +1006,10 @@ inline void copy_strided(uint8_t* dst, const uint8_t* src, size_t stride, size_t
 }
 // Chunk sizes double from 2^15 up to 2^18 items: the GPU starts after ~0.3 ms of staging, every
 // gather runs under the previous (half as long) chunk's kernels, and from the fourth chunk on the
-// launches are long enough to run near the device-resident rate (r03, same box, 2^20 items: chunks
+// transfers are long enough to run near the link rate (r03, same box, 2^20 items: chunks
 // capped at 2^17 as in r02: 68.0 M/s affine / 59.6 projective; 2^18: 72.4 / 63.6; two, three or
-// four slots: equal; profiles/r03/host_paths.txt)
+// four slots: equal; profiles/r03/host_paths.txt; r04: first chunk 2^16 / 2^17, a merged last chunk:
+// equal, profiles/r04/ab_host_chunk_policy.txt)
 constexpr size_t kPipeChunk = (size_t)1 << 18;
 constexpr size_t kPipeFirstChunk = (size_t)1 << 15;
 
@@ -951,8 +1028,8 @@ inline int host_copy_threads() {
   return set > 0 ? set : from_env;
 }
 
-//   extra_item_bytes: further device scratch per item that `launch` needs (decoded points of the
-//   wire-format entry points); handed to it as a Stager positioned behind the workspace.
+//   extra_item_bytes: further device scratch per item that `launch` needs (normalised / decoded
+//   points, converted scalars); handed to it as a Stager positioned behind the lane's verify workspace.
 template <size_t NIN, class Launch>
 int run_pipelined(Context& ctx, const HostIn (&ins)[NIN], uint8_t* ok, size_t n,
                   size_t extra_item_bytes, Launch launch) {
@@ -960,13 +1037,12 @@ int run_pipelined(Context& ctx, const HostIn (&ins)[NIN], uint8_t* ok, size_t n,
   if (!ctx.ready.load(std::memory_order_acquire))
     return fail(DSV_ERR_NOT_INITIALIZED, "device %d was shut down", ctx.device);
   DSV_ON_DEVICE(ctx);
+  if (int r = ensure_pipe_streams(ctx)) return r;
   const size_t chunk = n < kPipeChunk ? n : kPipeChunk;
   // slot capacity: offsets of a FULL chunk (a shorter chunk packs its arrays tighter, see below)
   size_t cap_off = 0;
   for (size_t k = 0; k < NIN; k++) cap_off += align_up(chunk * ins[k].bytes, 256);
   const size_t host_need = cap_off + align_up(chunk, 256);
-  const size_t ws_bytes = align_up(dsv_workspace_bytes(chunk), 256);
-  const size_t dev_need = host_need + ws_bytes + chunk * extra_item_bytes + 16 * 256;
   auto chunk_len = [&](size_t c, size_t left) {
     size_t want = c < 4 ? kPipeFirstChunk << c : kPipeChunk;
     if (want > kPipeChunk) want = kPipeChunk;
@@ -977,14 +1053,39 @@ int run_pipelined(Context& ctx, const HostIn (&ins)[NIN], uint8_t* ok, size_t n,
   for (size_t left = n; left; nchunks++) left -= chunk_len(nchunks, left);
   const int nslots = nchunks < (size_t)kPipeSlots ? (int)nchunks : kPipeSlots;
   for (int sl = 0; sl < nslots; sl++)
-    if (int r = ensure_pipe_slot(ctx, sl, dev_need, host_need)) return r;
+    if (int r = ensure_pipe_slot(ctx, sl, host_need, host_need)) return r;
+  // a sub-batch: kSplitItems items (run_split's unit), or the whole chunk when the split is off or the
+  // call is one small chunk; each compute lane owns the workspace + scratch of one sub-batch
+  const bool one_part = !ctx.split || nchunks == 1;
+  const size_t part_max = one_part ? chunk : (chunk < kSplitItems ? chunk : kSplitItems);
+  const size_t ws_bytes = align_up(dsv_workspace_bytes(part_max), 256);
+  const size_t work_need = ws_bytes + part_max * extra_item_bytes + 16 * 256;
+  const int nlanes = one_part && nchunks == 1 ? 1 : 2;
+  for (int k = 0; k < nlanes; k++)
+    if (int r = ensure_pipe_work(ctx, k, work_need)) return r;
   size_t slot_first[kPipeSlots] = {}, slot_cnt[kPipeSlots] = {}, slot_ok_off[kPipeSlots] = {};
   auto drain = [&](int sl) -> int {
-    HIP_TRY(hipStreamSynchronize(ctx.pipe_stream[sl]));
-    if (slot_cnt[sl]) memcpy(ok + slot_first[sl], ctx.pipe_host[sl] + slot_ok_off[sl], slot_cnt[sl]);
+    if (!slot_cnt[sl]) return DSV_OK;
+    if (nchunks == 1) HIP_TRY(hipStreamSynchronize(ctx.pipe_small));  // (the one-stream path of a small call)
+    else HIP_TRY(hipEventSynchronize(ctx.pipe_ev_done[sl]));
+    memcpy(ok + slot_first[sl], ctx.pipe_host[sl] + slot_ok_off[sl], slot_cnt[sl]);
     slot_cnt[sl] = 0;
     return DSV_OK;
   };
+  // an error half-way: nothing of this call may still be in flight when the caller's buffers go away
+  auto bail = [&](int rc) {
+    const std::string why = g_err;
+    (void)hipStreamSynchronize(ctx.pipe_in);
+    (void)hipStreamSynchronize(ctx.pipe_small);
+    for (int k = 0; k < 2; k++) (void)hipStreamSynchronize(ctx.pipe_lane[k]);
+    (void)hipStreamSynchronize(ctx.pipe_out);
+    g_err = why;
+    return rc;
+  };
+  struct PartScope {  // a short last sub-batch of a long call builds its window tables in its own kernel
+    explicit PartScope(bool on) { t_pipeline_part = on; }
+    ~PartScope() { t_pipeline_part = false; }
+  } part_scope(nchunks > 1);
   size_t done = 0;
   // DSV_PIPE_TRACE=1: per call, where the host thread's time went (stderr)
   static const bool trace = getenv("DSV_PIPE_TRACE") != nullptr;
@@ -993,10 +1094,9 @@ int run_pipelined(Context& ctx, const HostIn (&ins)[NIN], uint8_t* ok, size_t n,
   const double t_begin = now();
   for (size_t c = 0; done < n; c++) {
     const int sl = (int)(c % kPipeSlots);
-    hipStream_t st = ctx.pipe_stream[sl];
     const size_t cnt = chunk_len(c, n - done);
     const double t0 = now();
-    if (int r = drain(sl)) return r;  // slot free again, its verdicts delivered
+    if (int r = drain(sl)) return bail(r);  // slot free again, its verdicts delivered
     const double t1 = now();
     t_drain += t1 - t0;
     uint8_t* host = ctx.pipe_host[sl];
@@ -1024,16 +1124,43 @@ int run_pipelined(Context& ctx, const HostIn (&ins)[NIN], uint8_t* ok, size_t n,
     });
     const double t2 = now();
     t_copy += t2 - t1;
-    // the input block is contiguous on both sides (pad bytes ride along)
-    HIP_TRY(hipMemcpyAsync(dev, host, in_off[NIN - 1] + cnt * ins[NIN - 1].bytes,
-                           hipMemcpyHostToDevice, st));
-    const void* dptr[NIN];
-    for (size_t k = 0; k < NIN; k++) dptr[k] = dev + in_off[k];
     uint8_t* dok = dev + ok_off;
-    uint8_t* ws = dev + host_need;
-    Stager extra(ws + ws_bytes);
-    if (int r = launch(dptr, cnt, dok, ws, extra, st)) return r;
-    HIP_TRY(hipMemcpyAsync(host + ok_off, dok, cnt, hipMemcpyDeviceToHost, st));
+    // a single small chunk: transfer, kernels and verdicts on ONE stream (no event hop on the
+    // latency path of a 1024-signature call); else the four-stream pipeline
+    hipStream_t s_in = nchunks == 1 ? ctx.pipe_small : ctx.pipe_in;
+    hipStream_t s_out = nchunks == 1 ? ctx.pipe_small : ctx.pipe_out;
+    // the input block is contiguous on both sides (pad bytes ride along)
+    if (hipMemcpyAsync(dev, host, in_off[NIN - 1] + cnt * ins[NIN - 1].bytes, hipMemcpyHostToDevice, s_in) != hipSuccess ||
+        (nchunks > 1 && hipEventRecord(ctx.pipe_ev_in[sl], s_in) != hipSuccess))
+      return bail(fail(DSV_ERR_HIP, "transfer to the device failed: %s", hipGetErrorString(hipGetLastError())));
+    bool used[2] = {false, false};
+    for (size_t off = 0; off < cnt;) {
+      const size_t pc = one_part ? cnt : (cnt - off < kSplitItems ? cnt - off : kSplitItems);
+      const int k = nchunks == 1 ? 0 : (int)(ctx.pipe_parts++ & 1);
+      hipStream_t st = nchunks == 1 ? ctx.pipe_small : ctx.pipe_lane[k];
+      if (nchunks > 1 && !used[k]) {
+        if (hipStreamWaitEvent(st, ctx.pipe_ev_in[sl], 0) != hipSuccess)
+          return bail(fail(DSV_ERR_HIP, "hipStreamWaitEvent failed"));
+        used[k] = true;
+      }
+      const void* dptr[NIN];
+      for (size_t j = 0; j < NIN; j++) dptr[j] = dev + in_off[j] + off * ins[j].bytes;
+      uint8_t* ws = ctx.pipe_work[k];
+      Stager extra(ws + ws_bytes);
+      if (int r = launch(dptr, pc, dok + off, ws, extra, st)) return bail(r);
+      off += pc;
+    }
+    if (nchunks > 1) {
+      for (int k = 0; k < 2; k++)
+        if (used[k]) {
+          if (hipEventRecord(ctx.pipe_ev_lane[sl][k], ctx.pipe_lane[k]) != hipSuccess ||
+              hipStreamWaitEvent(s_out, ctx.pipe_ev_lane[sl][k], 0) != hipSuccess)
+            return bail(fail(DSV_ERR_HIP, "event record / wait failed"));
+        }
+    }
+    if (hipMemcpyAsync(host + ok_off, dok, cnt, hipMemcpyDeviceToHost, s_out) != hipSuccess ||
+        (nchunks > 1 && hipEventRecord(ctx.pipe_ev_done[sl], s_out) != hipSuccess))
+      return bail(fail(DSV_ERR_HIP, "verdict copy failed: %s", hipGetErrorString(hipGetLastError())));
     slot_first[sl] = done;
     slot_cnt[sl] = cnt;
     slot_ok_off[sl] = ok_off;
@@ -1042,7 +1169,7 @@ int run_pipelined(Context& ctx, const HostIn (&ins)[NIN], uint8_t* ok, size_t n,
   }
   const double t3 = now();
   for (int sl = 0; sl < nslots; sl++)
-    if (int r = drain(sl)) return r;
+    if (int r = drain(sl)) return bail(r);
   if (trace)
     fprintf(stderr, "[dsv pipe] n=%zu chunks=%zu total %.2f ms: gather %.2f, enqueue %.2f, waiting for slots %.2f, final drain %.2f\n",
             n, nchunks, now() - t_begin, t_copy, t_enq, t_drain, now() - t3);

@@ -33,7 +33,14 @@
 namespace dsv {
 
 constexpr int kLatWords = 9;          // 288-bit two's complement
-constexpr int kLatMaxBatches = 24;
+// -DDSV_LAT_MAX_BATCHES=0 builds the kernel WITHOUT any reduction: every item then takes the fallback
+// row (u, c, 1), i.e. the reference equation as a 63-window chain — the test build
+// schnorr_amd/libdsv_lat0.so (build.py: VARIANTS), which is how that branch gets exercised at all:
+// no hash output steers a challenge there
+#ifndef DSV_LAT_MAX_BATCHES
+#define DSV_LAT_MAX_BATCHES 24
+#endif
+constexpr int kLatMaxBatches = DSV_LAT_MAX_BATCHES;
 constexpr int kLatMaxPasses = 40;     // per batch
 
 // -x
@@ -78,7 +85,9 @@ DSV_DEV int lat_bitlen_mag(u32 (&mag)[8], bool& neg, const u32 (&x)[kLatWords], 
   return bitlen8(mag);
 }
 
-// out: magnitudes (8 words each, < 2^251) and signs of (x, y, z); z odd, z != 0.
+// out: magnitudes (8 words each) and signs of (x, y, z); z odd, z != 0.  A reduced row is only taken
+// when all three components are below 2^251; the fallback row (u, c, 1) has x = u < 2^252 — the bound
+// the chain's recoding (recode_signed4: exact below 2^252) and its 63-window top digit are built for.
 // u < 2^252 (callers mask a non-canonical u), c < 2^250.
 DSV_DEV void lattice3_scalars(u32 (&mx)[8], u32 (&my)[8], u32 (&mz)[8], bool& nx, bool& ny, bool& nz,
                               const u32 (&u)[8], const u32 (&c)[8]) {

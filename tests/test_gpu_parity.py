@@ -768,7 +768,7 @@ def test_alternative_code_paths_in_subprocesses(engine):
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     expr = ("tampering or torsion or crafted or identity_small_order or full_size_batch_properties "
-            "or golden_vectors")
+            "or golden_vectors or structured_relations")
     for extra in ({"DSV_SPLIT": "0", "DSV_SMALL_OVERLAP": "0"}, {"DSV_QUAD": "0", "DSV_DOUBLE_FUSED": "0"}):
         env = dict(os.environ)
         env.update(extra)
@@ -848,6 +848,17 @@ def test_structured_relations_grid(engine):
     Gen = np.roll(a["PK"], 3, axis=0)
     assert np.array_equal(engine.verify_vargen(a["u"], a["R"], a["PK"], Gen, a["m"]),
                           O.verify_vargen(a["u"], a["R"], a["PK"], Gen, a["m"], nthreads=8))
+    # the grid has ~1.4 k items, i.e. the eight-lane small-batch kernel; tiled beyond 2^14 items it
+    # runs through the one-lane kernel, whose JOINT window table holds P - R, 2P - R, 2R - P and
+    # 2(P + R): with PK = +-R, 2P or O those entries hit the identity or coincide
+    reps = -(-((1 << 14) + 1) // len(want))
+    tile = lambda x: np.tile(x, (reps, 1))
+    assert len(want) * reps > (1 << 14)
+    assert np.array_equal(engine.verify_single(tile(a["u"]), tile(a["R"]), tile(a["PK"]), tile(a["m"])),
+                          np.tile(want, reps))
+    want_d = O.verify_double(a["u"], a["R"], Rp, a["PK"], PKp, a["m"], nthreads=8)
+    assert np.array_equal(engine.verify_double(tile(a["u"]), tile(a["R"]), tile(Rp), tile(a["PK"]), tile(PKp),
+                                               tile(a["m"])), np.tile(want_d, reps))
 
 
 def test_shutdown_and_reinitialise(engine):

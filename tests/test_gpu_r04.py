@@ -92,3 +92,32 @@ def test_montgomery_column_arguments_are_validated(engine):
     rc = _lib.load().dsv_verify_single_mont_cols(arr, ctypes.c_size_t(8), ctypes.c_void_p(ok.ctypes.data))
     assert rc == -2 and b"stride" in _lib.load().dsv_last_error()
     assert _lib.load().dsv_verify_single_mont_cols(arr, ctypes.c_size_t(0), None) == 0   # empty batch
+
+
+def test_vargen_kernel_on_its_fallback_row_in_a_test_build(engine):
+    """lattice3.h falls back to the row (u, c, 1) — the reference equation as a 63-window chain with a
+    252-bit x = u — when no reduced row has an odd z below 2^251; no hash output steers a challenge
+    there, so the branch is exercised in a TEST BUILD whose reduction does no batch at all
+    (schnorr_amd/libdsv_lat0.so: -DDSV_LAT_MAX_BATCHES=0 on k_vargen.hip only): every item
+    takes the fallback, and the var-generator tampering / torsion / projective / wire tests must still
+    equal the oracle."""
+    import subprocess
+    import sys
+    from schnorr_amd import build as B
+    lib = B.variant_path("lat0")
+    assert os.path.exists(lib), "run __graft_entry__.build() first: it makes the lat0 test build"
+    # the fallback really is what this build computes: (x, y, z) = (u, c, 1) for arbitrary inputs
+    probe = ("import numpy as np; from schnorr_amd import engine as E; E.init(0); "
+             "u = np.arange(64, dtype=np.uint8).reshape(2, 32); u[:, 31] &= 7; c = u[::-1].copy(); c[:, 31] &= 3; "
+             "le = lambda r: int.from_bytes(bytes(r), 'little'); "
+             "assert E.debug_lattice3(u, c) == [(le(u[i]), le(c[i]), 1) for i in range(2)]; print('fallback ok')")
+    env = dict(os.environ, DSV_LIB_PATH=lib)
+    r = subprocess.run([sys.executable, "-c", probe], cwd=ROOT, env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "fallback ok" in r.stdout, (r.stdout[-1000:], r.stderr[-2000:])
+    expr = "vargen and not lattice and not config_size and not input_stream and not fallback_row"
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_gpu_parity.py"),
+                        os.path.join(ROOT, "tests", "test_gpu_r03.py"), os.path.join(ROOT, "tests", "test_gpu_r04.py"),
+                        "-m", "gpu", "-q", "-x", "-p", "no:cacheprovider", "-k", expr],
+                       cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-2000:])
+    assert " passed" in r.stdout and "failed" not in r.stdout, r.stdout[-500:]

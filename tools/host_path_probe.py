@@ -41,9 +41,35 @@ def best_of(fn, reps=5):
     return best
 
 
+def dev_rate(fn, reps=10):
+    import torch
+    fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / reps
+
+
+if os.environ.get("WITH_DEVICE", "1") == "1":
+    import torch
+    dv = lambda a: torch.from_numpy(a).to("cuda:0")
+    okd = torch.zeros(n, dtype=torch.uint8, device="cuda:0")
+    ws = torch.empty(max(E.ext_workspace_bytes(n), E.wire_workspace_bytes(n)), dtype=torch.uint8, device="cuda:0")
+    dR3, dPK3, dsig, dpk = dv(R3), dv(PK3), dv(sig), dv(pk)
+    dres = {"affine": dev_rate(lambda: E.verify_single_dev(b["u"], b["R"], b["PK"], b["m"], okd, ws)),
+            "ext": dev_rate(lambda: E.verify_single_ext_dev(b["u"], dR3, dPK3, b["m"], okd, ws)),
+            "wire": dev_rate(lambda: E.verify_single_wire_dev(dsig, dpk, b["m"], okd, ws))}
+    assert (okd.cpu().numpy() == want).all()
+    print("device-resident, same box: " + "  ".join("%s %.2f ms = %.2f M/s" % (k, v * 1e3, n / v / 1e6) for k, v in dres.items()))
+    del dR3, dPK3, dsig, dpk, ws
+
 res = {"affine": best_of(lambda: E.verify_single(h["u"], h["R"], h["PK"], h["m"])),
        "ext": best_of(lambda: E.verify_single_ext(h["u"], R3, PK3, h["m"])),
        "wire": best_of(lambda: E.verify_single_wire(sig, pk, h["m"]))}
 print("DSV_HOST_THREADS=%s DSV_PIPE_CHUNK_LOG2=%s n=2^%d: " % (
     os.environ.get("DSV_HOST_THREADS", "default"), os.environ.get("DSV_PIPE_CHUNK_LOG2", "default"),
     n.bit_length() - 1) + "  ".join("%s %.2f ms = %.2f M/s" % (k, v * 1e3, n / v / 1e6) for k, v in res.items()))
+if os.environ.get("WITH_DEVICE", "1") == "1":
+    print("host / device-resident: " + "  ".join("%s %.3f" % (k, dres[k] / res[k]) for k in res))
