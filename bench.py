@@ -571,7 +571,9 @@ def main():
             "kernel": "k_verify_fixed_half<2> (dominant: %.0f %% of a double step)" % (100 * cd_ms / (cd_ms + hd_ms)),
             "bound": "valu", "achieved": dom2["mad_lane_ops_per_item"] * n / (cd_ms * 1e-3) / 1e12,
             "peak": MAD_PEAK / 1e12, "unit": "T lane-MAD/s", "frac": dom2["mad_frac"],
-            "traffic": None,        # no PMC pass of the double kernel is committed
+            # HBM / fabric bytes per launch of the fused kernel, REPLAYED like roofline.traffic (pmc_source)
+            "traffic": ((_pmc() or {}).get("double") or {}).get("FETCH_SIZE_KB") and
+                       ((_pmc()["double"]["FETCH_SIZE_KB"] + _pmc()["double"]["WRITE_SIZE_KB"]) * 1024.0 * n / _pmc()["batch"]),
             "kernel_ms": cd_ms, "hash_kernel_ms": hd_ms,
             "step_mad_frac": (_mads(vm2, vs2) + _mads(hm2, hs2, mfma_rows=hrows2)) * n / (tdd / args.steps) / MAD_PEAK,
             "hbm": {"achieved": ALGO_BYTES["double"] * n / (tdd / args.steps) / 1e9, "peak": HBM_PEAK_GBS,

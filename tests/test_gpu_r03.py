@@ -278,6 +278,29 @@ def test_bench_rehearses_larger_world_sizes_on_one_gpu(world, config):
     assert line["launcher"] == "self-spawned" and line["value"] > 0
     if config == "single":
         assert line["mixed"]["n_gpus"] == world
+    # r04: with N > 1 the line says which rank lags and where its time goes
+    def per_rank(d, unit_positive=True):
+        assert set(d) >= {"min", "max", "argmax", "all"} and len(d["all"]) == world
+        assert 0 <= d["argmax"] < world and d["min"] <= d["max"]
+        assert abs(d["all"][d["argmax"]] - d["max"]) < 1e-3
+        if unit_positive:
+            assert d["min"] > 0
+    ranks = line["ranks"]
+    per_rank(ranks["ms_per_step"])
+    per_rank(ranks["init_s"])
+    assert abs(ranks["ms_per_step"]["max"] - line["ms_per_step"]) < 1e-6 * max(1.0, line["ms_per_step"])
+    if config == "single":
+        per_rank(ranks["verify_ms"])
+        per_rank(ranks["all_gather_ms"], unit_positive=False)
+        mixed = line["mixed"]["ranks"]
+    else:
+        mixed = ranks
+    stages = ("split_gather_ms", "single_kernels_ms", "double_kernels_ms", "all_gather_ms", "scatter_ms")
+    for k in stages:
+        per_rank(mixed[k], unit_positive=False)
+    slow = mixed["slowest_rank"]
+    assert slow["rank"] == mixed["ms_per_step"]["argmax"] and all(k in slow for k in stages)
+    assert slow["single_kernels_ms"] > 0 and slow["double_kernels_ms"] > 0
 
 
 def test_device_half_scalars_are_those_of_the_exact_euclid(engine):

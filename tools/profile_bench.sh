@@ -25,4 +25,10 @@ step "rocprofv3 --pmc FETCH_SIZE"
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -- python3 $ARGS > $OUT/pmc_fetch.log 2>&1
 step "rocprofv3 --pmc WRITE_SIZE"
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -- python3 $ARGS > $OUT/pmc_write.log 2>&1
+# the fused double kernel (roofline_double.traffic): the same two counters over a run that includes the double leg
+ARGS2="bench.py --steps 2 --warmup 1 --no-cpu-baseline"
+step "rocprofv3 --pmc FETCH_SIZE (double leg)"
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch2 -- python3 $ARGS2 > $OUT/pmc_fetch2.log 2>&1
+step "rocprofv3 --pmc WRITE_SIZE GRBM_GUI_ACTIVE (double leg)"
+rocprofv3 --pmc WRITE_SIZE GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT/pmc_write2 -- python3 $ARGS2 > $OUT/pmc_write2.log 2>&1
 find $OUT -name "*.csv" | head -50

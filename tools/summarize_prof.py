@@ -43,6 +43,15 @@ def main():
                 k = short(row["Kernel_Name"])
                 if not k.startswith("dsv::"):
                     continue
+                # the passes over the double leg also run the mixed leg (2^19-item launches of both
+                # verify kernels) and further single-signature legs: keep only the fused double kernel's
+                # whole-batch launches from them (the half-size ones take half as long)
+                if "pmc_fetch2" in path or "pmc_write2" in path:
+                    if "k_verify_fixed_half<2>" not in k:
+                        continue
+                    d_ns = float(row["End_Timestamp"]) - float(row["Start_Timestamp"])
+                    if d_ns < 15e6:
+                        continue
                 acc[k][row["Counter_Name"]].append(float(row["Counter_Value"]))
                 if row["Counter_Name"] == "GRBM_GUI_ACTIVE":
                     d_ns = float(row["End_Timestamp"]) - float(row["Start_Timestamp"])
@@ -61,22 +70,36 @@ def main():
             out[k]["clock_held_ghz"] = sum(clk[k]) / len(clk[k])
     with open(prefix + "_pmc_summary.json", "w") as f:
         json.dump(out, f, indent=1)
-    dom = [k for k in out if k.startswith("dsv::k_verify_fixed_half")]
+    dom = [k for k in out if k.startswith("dsv::k_verify_fixed_half<")]
     if dom:
-        d = out[dom[0]]
         stats = {}
         nos = prefix + "_kernel_stats_nosplit.csv"
         if os.path.exists(nos):
             with open(nos) as f:
                 for row in csv.DictReader(f):
-                    if "k_verify_fixed_half" in row["Name"]:
+                    if "k_verify_fixed_half<1>" in row["Name"]:
                         stats = row
+        import datetime
+        single = [k for k in dom if "<1>" in k] or dom
+        d = out[single[0]]
         latest = {
             "source": "tools/profile_bench.sh + tools/summarize_prof.py -> %s_*; DSV_SPLIT=0 passes, "
                       "per launch over 2^20 signatures" % os.path.relpath(prefix, ROOT),
-            "kernel": dom[0],
+            # provenance (bench.py: roofline.pmc_source): when, which build, which command
+            "captured": datetime.datetime.utcnow().strftime("%Y-%m-%dT%H:%M:%SZ"),
+            "commit": os.environ.get("DSV_COMMIT"),
+            "command": "DSV_SPLIT=0 rocprofv3 --pmc <one group per pass> --kernel-trace -- python3 bench.py "
+                       "--steps 3 --warmup 1 --no-cpu-baseline --no-double (tools/profile_bench.sh)",
+            "kernel": single[0],
             "batch": 1 << 20,
         }
+        dbl = [k for k in dom if "<2>" in k]
+        if dbl and "FETCH_SIZE" in out[dbl[0]] and "WRITE_SIZE" in out[dbl[0]]:
+            dd = out[dbl[0]]
+            latest["double"] = {"kernel": dbl[0], "FETCH_SIZE_KB": dd["FETCH_SIZE"]["avg_per_launch"],
+                                "WRITE_SIZE_KB": dd["WRITE_SIZE"]["avg_per_launch"],
+                                "avg_duration_ns_under_pmc": dd["avg_duration_ns_under_pmc"],
+                                "clock_held_ghz": dd.get("clock_held_ghz")}
         for c in ("FETCH_SIZE", "WRITE_SIZE"):
             if c in d:
                 latest[c + "_KB"] = d[c]["avg_per_launch"]
