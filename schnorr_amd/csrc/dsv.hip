@@ -177,7 +177,6 @@ struct Context {
   bool fuse_double = true;   // DSV_DOUBLE_FUSED=0: two single-equation launches per double batch (r01; A/B)
   bool quad = true;          // DSV_QUAD=0: batches of <= 2^14 items also take the one-lane-per-signature kernel
   bool small_overlap = true; // DSV_SMALL_OVERLAP=0: small batches build their window tables inside the verify kernel
-  bool sort = true;          // DSV_SORT=0: the lanes of the verify kernel take the items in batch order
   u32* table[2] = {nullptr, nullptr};  // fixed-base tables for G, G'
   u32* ts_cancel = nullptr;            // square-root tables (decode29.h)
   uint8_t* ts_hash = nullptr;
@@ -339,21 +338,16 @@ struct Workspace {
   uint8_t* c;
   uint8_t* valid;
   u32* tables;
-  uint8_t* sort;  // scalar preparation records + permutation (sort_ws_bytes) of the chain-length sort
 };
-// launches of at least this many items walk their items sorted by chain length (launch.h: SortWs)
-constexpr size_t kSortMinItems = (size_t)1 << 15;
 constexpr int kTablesPerLane = 3;  // the var-generator kernel keeps three (Gen, PK, R), the others two
 size_t var_table_bytes(size_t n, int tables_per_lane) {
   return (size_t)verify_grid(n) * kVerifyBlock * kVarLaneWords * 4 * (size_t)tables_per_lane;
 }
-size_t workspace_tables_bytes(size_t n);
 Workspace carve(void* ws, size_t n) {
   Workspace w;
   w.c = static_cast<uint8_t*>(ws);
   w.valid = w.c + align_up(n * 32, 256);
   w.tables = reinterpret_cast<u32*>(w.valid + align_up(n, 256));
-  w.sort = reinterpret_cast<uint8_t*>(w.tables) + workspace_tables_bytes(n);
   return w;
 }
 
@@ -371,43 +365,34 @@ struct Stager {
 // the dominant kernel: one lane per signature, or eight (small batches); same verdicts
 void launch_verify_fixed(const Context& ctx, bool accumulate, const void* u, const void* c,
                          const void* PK_uv, const void* R_uv, int which, const void* valid,
-                         size_t n, void* ok, u32* tables, hipStream_t s, bool tables_ready = false,
-                         uint8_t* sort_ws = nullptr) {
+                         size_t n, void* ok, u32* tables, hipStream_t s, bool tables_ready = false) {
   const ChainOperands op{(const uint8_t*)PK_uv, (const uint8_t*)R_uv, ctx.table[which]};
-  if (ctx.quad && n <= kQuadMaxItems) {
+  if (ctx.quad && n <= kQuadMaxItems)
     launch_verify_half_quad(1, accumulate, tables_ready, (const uint8_t*)u, (const uint8_t*)c, op, op,
                             (const uint8_t*)valid, n, (uint8_t*)ok, tables, s);
-    return;
-  }
-  SortWs sw;
-  const bool sorted = ctx.sort && sort_ws && n >= kSortMinItems;
-  if (sorted) sw = carve_sort(sort_ws, n);
-  launch_verify_half(1, accumulate, (const uint8_t*)u, (const uint8_t*)c, op, op, (const uint8_t*)valid, n,
-                     (uint8_t*)ok, tables, s, sorted ? &sw : nullptr);
+  else
+    launch_verify_half(1, accumulate, (const uint8_t*)u, (const uint8_t*)c, op, op,
+                       (const uint8_t*)valid, n, (uint8_t*)ok, tables, s);
 }
 // both equations of a double signature: one fused launch, or two single-equation ones
 // (DSV_DOUBLE_FUSED=0: the second pass ANDs into ok[])
 void launch_verify_fixed_double(const Context& ctx, const void* u, const void* c, const void* PK_uv,
                                 const void* R_uv, const void* PKp_uv, const void* Rp_uv,
                                 const void* valid, size_t n, void* ok, u32* tables, hipStream_t s,
-                                bool tables_ready = false, uint8_t* sort_ws = nullptr) {
+                                bool tables_ready = false) {
   if (ctx.fuse_double) {
     const ChainOperands op0{(const uint8_t*)PK_uv, (const uint8_t*)R_uv, ctx.table[0]};
     const ChainOperands op1{(const uint8_t*)PKp_uv, (const uint8_t*)Rp_uv, ctx.table[1]};
-    if (ctx.quad && n <= kQuadMaxItems) {
+    if (ctx.quad && n <= kQuadMaxItems)
       launch_verify_half_quad(2, false, tables_ready, (const uint8_t*)u, (const uint8_t*)c, op0, op1,
                               (const uint8_t*)valid, n, (uint8_t*)ok, tables, s);
-      return;
-    }
-    SortWs sw;
-    const bool sorted = ctx.sort && sort_ws && n >= kSortMinItems;
-    if (sorted) sw = carve_sort(sort_ws, n);
-    launch_verify_half(2, false, (const uint8_t*)u, (const uint8_t*)c, op0, op1, (const uint8_t*)valid, n,
-                       (uint8_t*)ok, tables, s, sorted ? &sw : nullptr);
+    else
+      launch_verify_half(2, false, (const uint8_t*)u, (const uint8_t*)c, op0, op1,
+                         (const uint8_t*)valid, n, (uint8_t*)ok, tables, s);
     return;
   }
-  launch_verify_fixed(ctx, false, u, c, PK_uv, R_uv, 0, valid, n, ok, tables, s, tables_ready, sort_ws);
-  launch_verify_fixed(ctx, true, u, c, PKp_uv, Rp_uv, 1, valid, n, ok, tables, s, false, sort_ws);
+  launch_verify_fixed(ctx, false, u, c, PK_uv, R_uv, 0, valid, n, ok, tables, s, tables_ready);
+  launch_verify_fixed(ctx, true, u, c, PKp_uv, Rp_uv, 1, valid, n, ok, tables, s);
 }
 
 // Sub-batch scheduling of the device-pointer verify entry points.
@@ -469,7 +454,6 @@ int run_split(Context& ctx, size_t n, void* workspace, hipStream_t user, Part pa
     wp.c = w.c + off * 32;
     wp.valid = w.valid + off;
     wp.tables = w.tables + (size_t)k * tbl_words;
-    wp.sort = w.sort + (size_t)k * sort_ws_bytes(kSplitItems);
     part(off, cnt, wp, lane->stream[k]);
     off += cnt;
   }
@@ -588,8 +572,6 @@ int dsv_init(int device) {
   ctx.quad = !(quad && strcmp(quad, "0") == 0);
   const char* sov = getenv("DSV_SMALL_OVERLAP");
   ctx.small_overlap = !(sov && strcmp(sov, "0") == 0);
-  const char* srt = getenv("DSV_SORT");
-  ctx.sort = !(srt && strcmp(srt, "0") == 0);
   const char* fused = getenv("DSV_DOUBLE_FUSED");
   ctx.fuse_double = !(fused && strcmp(fused, "0") == 0);
   ctx.ready.store(true, std::memory_order_release);
@@ -674,25 +656,13 @@ int dsv_initialized_devices(int* out, int cap) {
   return n;
 }
 
-}  // extern "C"
-namespace {
-// window tables: one launch over n items, or (run_split) two concurrent launches over
-// kSplitItems items each — whichever is larger (they differ when -DDSV_MAX_VERIFY_GRID < 2048)
-size_t workspace_tables_bytes(size_t n) {
+size_t dsv_workspace_bytes(size_t n) {
+  // window tables: one launch over n items, or (run_split) two concurrent launches over
+  // kSplitItems items each — whichever is larger (they differ when -DDSV_MAX_VERIFY_GRID < 2048)
   size_t tables = var_table_bytes(n, kTablesPerLane);
   if (n >= 2 * kSplitItems && tables < 2 * var_table_bytes(kSplitItems, kTablesPerLane))
     tables = 2 * var_table_bytes(kSplitItems, kTablesPerLane);
-  return align_up(tables, 256);
-}
-}  // namespace
-extern "C" {
-size_t dsv_workspace_bytes(size_t n) {
-  // c | valid | window tables | scratch of the chain-length sort: one launch over n items, or two
-  // concurrent sub-batches (with DSV_SPLIT=0 a launch covers the whole batch: n items' worth)
-  const size_t sort = n >= 2 * kSplitItems ? 2 * sort_ws_bytes(kSplitItems) : sort_ws_bytes(n);
-  const size_t sort_whole = sort_ws_bytes(n);
-  return align_up(n * 32, 256) + align_up(n, 256) + workspace_tables_bytes(n) +
-         align_up(sort > sort_whole ? sort : sort_whole, 256) + 256;
+  return align_up(n * 32, 256) + align_up(n, 256) + tables + 256;
 }
 
 // ---- device-pointer entry points --------------------------------------------------------
@@ -764,7 +734,7 @@ int verify_single_on(Context& ctx, const void* u, const void* R_uv, const void* 
     launch_challenge(false, pR + 64 * off, (const uint8_t*)nullptr, pm + 32 * off, cnt, w.c, w.valid, s);
     if (ready && hipStreamWaitEvent(s, ready, 0) != hipSuccess) return;  // (surfaces through hipGetLastError)
     launch_verify_fixed(*cp, false, pu + 32 * off, w.c, pPK + 64 * off, pR + 64 * off, 0, w.valid,
-                        cnt, pok + off, w.tables, s, ready != nullptr, w.sort);
+                        cnt, pok + off, w.tables, s, ready != nullptr);
   });
 }
 int verify_double_on(Context& ctx, const void* u, const void* R_uv, const void* Rp_uv,
@@ -784,7 +754,7 @@ int verify_double_on(Context& ctx, const void* u, const void* R_uv, const void* 
     if (ready && hipStreamWaitEvent(s, ready, 0) != hipSuccess) return;
     launch_verify_fixed_double(*cp, pu + 32 * off, w.c, pPK + 64 * off, pR + 64 * off,
                                pPKp + 64 * off, pRp + 64 * off, w.valid, cnt, pok + off, w.tables, s,
-                               ready != nullptr, w.sort);
+                               ready != nullptr);
   });
 }
 int verify_vargen_on(Context& ctx, const void* u, const void* R_uv, const void* PK_uv,
@@ -827,7 +797,7 @@ int dsv_verify_core_dev(const void* u, const void* c, const void* valid, const v
   DSV_DEV_PROLOGUE(n, ok);
   Workspace w = carve(workspace, n);
   launch_verify_fixed(ctx, accumulate != 0, u, c, PK_uv, R_uv, which, valid, n, ok, w.tables,
-                      (hipStream_t)stream, false, w.sort);
+                      (hipStream_t)stream);
   HIP_TRY(hipGetLastError());
   return DSV_OK;
 }
@@ -840,7 +810,7 @@ int dsv_verify_core_double_dev(const void* u, const void* c, const void* valid, 
   DSV_DEV_PROLOGUE(n, ok);
   Workspace w = carve(workspace, n);
   launch_verify_fixed_double(ctx, u, c, PK_uv, R_uv, PKp_uv, Rp_uv, valid, n, ok, w.tables,
-                             (hipStream_t)stream, false, w.sort);
+                             (hipStream_t)stream);
   HIP_TRY(hipGetLastError());
   return DSV_OK;
 }

@@ -61,24 +61,9 @@ hipError_t hash_upload_constants();  // the selected device's __constant__ round
 void launch_challenge(bool dbl, const uint8_t* R_uv, const uint8_t* Rp_uv, const uint8_t* m, size_t n,
                       uint8_t* c, uint8_t* valid, hipStream_t s);
 // ---- k_verify.hip: ok[i] = (accumulate ? ok[i] : valid[i]) & [every chain's equation holds] ----
-// sw != null: the lanes walk the items sorted by chain length (k_half_prep + k_bucket_scatter in
-// front of the verify kernel); scratch of sort_ws_bytes(n) bytes carved by carve_sort
-struct SortWs {
-  uint32_t* rec;   // n x 24 words: the scalar preparation of every item
-  uint32_t* perm;  // n: items, longest chains first
-  uint32_t* hist;  // 256 words: counts and cursors of the 128 chain lengths
-};
-inline size_t sort_ws_bytes(size_t n) { return n * 96 + (n * 4 + 255) / 256 * 256 + 1024; }
-inline SortWs carve_sort(void* p, size_t n) {
-  SortWs w;
-  w.rec = static_cast<uint32_t*>(p);
-  w.perm = w.rec + n * 24;
-  w.hist = w.perm + (n * 4 + 255) / 256 * 64;
-  return w;
-}
 void launch_verify_half(int nchain, bool accumulate, const uint8_t* u, const uint8_t* c,
                         ChainOperands op0, ChainOperands op1, const uint8_t* valid, size_t n,
-                        uint8_t* ok, uint32_t* var_tables, hipStream_t s, const SortWs* sw = nullptr);
+                        uint8_t* ok, uint32_t* var_tables, hipStream_t s);
 // ---- k_quad.hip: the same for n <= kQuadMaxItems, eight lanes per signature; tables_ready: the
 // window tables of the FIRST equation's (PK, R) were built by launch_prep_var_tables already ----
 void launch_verify_half_quad(int nchain, bool accumulate, bool tables_ready, const uint8_t* u,
