@@ -34,7 +34,10 @@ against the measured MAD issue peak.  DESIGN.md §4 has the instruction model.
 Riding along at N = 1: `double` (configs[2]), `vargen` (configs[3]), `mixed` (configs[4] shape),
 `sign`, `ext` (projective inputs, to_hash_inputs on the device), `wire` (serialized records,
 decompression on the device), `host_path` / `host_path_ext` / `wire.host` (PCIe-inclusive, never the
-headline value), `small_batch`.
+headline value), `verify_batch_e2e` (the named entry point over 2^20 typed objects holding the
+reference's in-memory representation, conversion included; tools/verify_batch_e2e.cpp),
+`small_batch` (measured first).  What is live and what is replayed from a committed PMC pass:
+`roofline.pmc_source`.  With N > 1: `ranks` (per-rank step / init / gather / stage times).
 """
 import argparse
 import json
