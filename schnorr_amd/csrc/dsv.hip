@@ -42,6 +42,7 @@
 #include <mutex>
 #include <string>
 #include <thread>
+#include <type_traits>
 #include <vector>
 
 #include "../../include/dsv.h"
@@ -192,6 +193,9 @@ struct Context {
   // compute lanes that every chunk's sub-batches alternate between, one for the verdicts out
   hipStream_t pipe_in = nullptr, pipe_out = nullptr, pipe_lane[2] = {nullptr, nullptr};
   hipStream_t pipe_small = nullptr;       // a call of one small chunk runs on this stream alone
+  hipEvent_t pipe_ev_pre[kPipeSlots] = {};  // a chunk's whole-chunk preprocessing (on one of the lanes) is done
+  uint8_t* pipe_prep[kPipeSlots] = {};      // per slot: what that preprocessing produced
+  size_t pipe_prep_bytes[kPipeSlots] = {};
   hipEvent_t pipe_ev_in[kPipeSlots] = {}, pipe_ev_lane[kPipeSlots][2] = {}, pipe_ev_done[kPipeSlots] = {};
   uint8_t* pipe_stage[kPipeSlots] = {};   // device side of a slot: the input block, then the verdicts
   size_t pipe_bytes[kPipeSlots] = {};
@@ -265,6 +269,7 @@ int ensure_pipe_streams(Context& ctx) {
   HIP_TRY(hipStreamCreateWithFlags(&ctx.pipe_small, hipStreamNonBlocking));
   for (int sl = 0; sl < kPipeSlots; sl++) {
     HIP_TRY(hipEventCreateWithFlags(&ctx.pipe_ev_in[sl], hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&ctx.pipe_ev_pre[sl], hipEventDisableTiming));
     HIP_TRY(hipEventCreateWithFlags(&ctx.pipe_ev_done[sl], hipEventDisableTiming));
     for (int k = 0; k < 2; k++) HIP_TRY(hipEventCreateWithFlags(&ctx.pipe_ev_lane[sl][k], hipEventDisableTiming));
   }
@@ -279,7 +284,14 @@ int ensure_pipe_work(Context& ctx, int lane, size_t bytes) {
   ctx.pipe_work_bytes[lane] = bytes;
   return DSV_OK;
 }
-int ensure_pipe_slot(Context& ctx, int slot, size_t dev_bytes, size_t host_bytes) {
+int ensure_pipe_slot(Context& ctx, int slot, size_t dev_bytes, size_t host_bytes, size_t prep_bytes) {
+  if (ctx.pipe_prep_bytes[slot] < prep_bytes) {
+    if (ctx.pipe_prep[slot]) HIP_TRY(hipFree(ctx.pipe_prep[slot]));
+    ctx.pipe_prep[slot] = nullptr;
+    ctx.pipe_prep_bytes[slot] = 0;
+    HIP_TRY(hipMalloc(&ctx.pipe_prep[slot], prep_bytes));
+    ctx.pipe_prep_bytes[slot] = prep_bytes;
+  }
   if (ctx.pipe_bytes[slot] < dev_bytes) {
     if (ctx.pipe_stage[slot]) HIP_TRY(hipFree(ctx.pipe_stage[slot]));
     ctx.pipe_stage[slot] = nullptr;
@@ -500,8 +512,12 @@ void release_context(Context& ctx) {
     ctx.pipe_bytes[k] = 0;
     ctx.pipe_host_bytes[k] = 0;
     if (ctx.pipe_ev_in[k]) (void)hipEventDestroy(ctx.pipe_ev_in[k]);
+    if (ctx.pipe_ev_pre[k]) (void)hipEventDestroy(ctx.pipe_ev_pre[k]);
     if (ctx.pipe_ev_done[k]) (void)hipEventDestroy(ctx.pipe_ev_done[k]);
-    ctx.pipe_ev_in[k] = ctx.pipe_ev_done[k] = nullptr;
+    ctx.pipe_ev_in[k] = ctx.pipe_ev_pre[k] = ctx.pipe_ev_done[k] = nullptr;
+    if (ctx.pipe_prep[k]) (void)hipFree(ctx.pipe_prep[k]);
+    ctx.pipe_prep[k] = nullptr;
+    ctx.pipe_prep_bytes[k] = 0;
     for (int j = 0; j < 2; j++) {
       if (ctx.pipe_ev_lane[k][j]) (void)hipEventDestroy(ctx.pipe_ev_lane[k][j]);
       ctx.pipe_ev_lane[k][j] = nullptr;
@@ -1028,11 +1044,28 @@ inline int host_copy_threads() {
   return set > 0 ? set : from_env;
 }
 
-//   extra_item_bytes: further device scratch per item that `launch` needs (normalised / decoded
-//   points, converted scalars); handed to it as a Stager positioned behind the lane's verify workspace.
-template <size_t NIN, class Launch>
-int run_pipelined(Context& ctx, const HostIn (&ins)[NIN], uint8_t* ok, size_t n,
-                  size_t extra_item_bytes, Launch launch) {
+// What a chunk looks like to its sub-batches: arrays in the argument order of the entry point that
+// handles a sub-batch, element k of item i at p[k] + i * bytes[k]; `valid` (may be null): per-item
+// bytes that a chunk-level preprocessing wants AND-ed into the verdicts.
+struct Staged {
+  const uint8_t* p[8] = {};
+  size_t bytes[8] = {};
+  const uint8_t* valid = nullptr;
+};
+struct NoPrep {};
+//   prep(dev_ptrs, count, scratch, stream, staged)  [or NoPrep{}: the chunk is used as transferred]:
+//     preprocessing of the WHOLE chunk — projective -> affine, limb conversion: kernels with one
+//     inversion chain per 8 - 16 items, i.e. few waves — enqueued once per chunk on the lane of the
+//     chunk's first sub-batch (the other lane waits for its event), results in the slot's own
+//     scratch (prep_item_bytes per item).  Per SUB-BATCH these kernels would be 128 waves each in
+//     front of every hash: 16 low-occupancy phases per 2^20 items instead of 4.
+//   part(staged, offset, count, dok, ws, extra, stream): one sub-batch; `extra`: scratch of
+//     extra_item_bytes per item behind the lane's verify workspace (the wire path decompresses per
+//     sub-batch: full-occupancy kernels, no reason to serialise a chunk's worth on one lane).
+template <size_t NIN, class Prep, class Part>
+int run_pipelined(Context& ctx, const HostIn (&ins)[NIN], uint8_t* ok, size_t n, size_t prep_item_bytes,
+                  size_t extra_item_bytes, Prep prep, Part part) {
+  constexpr bool has_prep = !std::is_same<Prep, NoPrep>::value;
   std::lock_guard<std::mutex> lk(ctx.mu);
   if (!ctx.ready.load(std::memory_order_acquire))
     return fail(DSV_ERR_NOT_INITIALIZED, "device %d was shut down", ctx.device);
@@ -1052,8 +1085,9 @@ int run_pipelined(Context& ctx, const HostIn (&ins)[NIN], uint8_t* ok, size_t n,
   size_t nchunks = 0;
   for (size_t left = n; left; nchunks++) left -= chunk_len(nchunks, left);
   const int nslots = nchunks < (size_t)kPipeSlots ? (int)nchunks : kPipeSlots;
+  const size_t prep_need = has_prep ? chunk * prep_item_bytes + 16 * 256 : 0;
   for (int sl = 0; sl < nslots; sl++)
-    if (int r = ensure_pipe_slot(ctx, sl, host_need, host_need)) return r;
+    if (int r = ensure_pipe_slot(ctx, sl, host_need, host_need, prep_need)) return r;
   // a sub-batch: kSplitItems items (run_split's unit), or the whole chunk when the split is off or the
   // call is one small chunk; each compute lane owns the workspace + scratch of one sub-batch
   const bool one_part = !ctx.split || nchunks == 1;
@@ -1134,20 +1168,48 @@ int run_pipelined(Context& ctx, const HostIn (&ins)[NIN], uint8_t* ok, size_t n,
         (nchunks > 1 && hipEventRecord(ctx.pipe_ev_in[sl], s_in) != hipSuccess))
       return bail(fail(DSV_ERR_HIP, "transfer to the device failed: %s", hipGetErrorString(hipGetLastError())));
     bool used[2] = {false, false};
+    auto lane_for = [&](int k) -> int {  // first use of a lane by this chunk: its inputs must have arrived
+      if (nchunks > 1 && !used[k]) {
+        if (hipStreamWaitEvent(ctx.pipe_lane[k], ctx.pipe_ev_in[sl], 0) != hipSuccess)
+          return fail(DSV_ERR_HIP, "hipStreamWaitEvent failed");
+        used[k] = true;
+      }
+      return DSV_OK;
+    };
+    Staged sg;
+    int prep_lane = -1;
+    if constexpr (has_prep) {
+      // on the lane that takes this chunk's first sub-batch (the counter is not advanced here)
+      prep_lane = nchunks == 1 ? 0 : (int)(ctx.pipe_parts & 1);
+      if (int r = lane_for(prep_lane)) return bail(r);
+      hipStream_t sp = nchunks == 1 ? ctx.pipe_small : ctx.pipe_lane[prep_lane];
+      const void* dptr[NIN];
+      for (size_t j = 0; j < NIN; j++) dptr[j] = dev + in_off[j];
+      Stager scratch(ctx.pipe_prep[sl]);
+      if (int r = prep(dptr, cnt, scratch, sp, sg)) return bail(r);
+      if (nchunks > 1 && hipEventRecord(ctx.pipe_ev_pre[sl], sp) != hipSuccess)
+        return bail(fail(DSV_ERR_HIP, "hipEventRecord failed"));
+    } else {
+      (void)prep;
+      for (size_t j = 0; j < NIN; j++) {
+        sg.p[j] = dev + in_off[j];
+        sg.bytes[j] = ins[j].bytes;
+      }
+    }
+    bool waited_pre[2] = {false, false};
     for (size_t off = 0; off < cnt;) {
       const size_t pc = one_part ? cnt : (cnt - off < kSplitItems ? cnt - off : kSplitItems);
       const int k = nchunks == 1 ? 0 : (int)(ctx.pipe_parts++ & 1);
       hipStream_t st = nchunks == 1 ? ctx.pipe_small : ctx.pipe_lane[k];
-      if (nchunks > 1 && !used[k]) {
-        if (hipStreamWaitEvent(st, ctx.pipe_ev_in[sl], 0) != hipSuccess)
+      if (int r = lane_for(k)) return bail(r);
+      if (has_prep && nchunks > 1 && k != prep_lane && !waited_pre[k]) {
+        if (hipStreamWaitEvent(st, ctx.pipe_ev_pre[sl], 0) != hipSuccess)
           return bail(fail(DSV_ERR_HIP, "hipStreamWaitEvent failed"));
-        used[k] = true;
+        waited_pre[k] = true;
       }
-      const void* dptr[NIN];
-      for (size_t j = 0; j < NIN; j++) dptr[j] = dev + in_off[j] + off * ins[j].bytes;
       uint8_t* ws = ctx.pipe_work[k];
       Stager extra(ws + ws_bytes);
-      if (int r = launch(dptr, pc, dok + off, ws, extra, st)) return bail(r);
+      if (int r = part(sg, off, pc, dok + off, ws, extra, st)) return bail(r);
       off += pc;
     }
     if (nchunks > 1) {
@@ -1194,30 +1256,41 @@ int run_pipelined(Context& ctx, const HostIn (&ins)[NIN], uint8_t* ok, size_t n,
 
 extern "C++" {
 namespace {
+// one sub-batch of a staged chunk through the affine path of its scheme (0 single, 1 double, 2 vargen)
+int part_verify(Context& ctx, int kind, const Staged& g, size_t off, size_t cnt, void* dok, void* ws,
+                hipStream_t st) {
+  auto at = [&](int k) { return g.p[k] + off * g.bytes[k]; };
+  int rc;
+  if (kind == 0) rc = verify_single_on(ctx, at(0), at(1), at(2), at(3), cnt, dok, ws, st);
+  else if (kind == 1) rc = verify_double_on(ctx, at(0), at(1), at(2), at(3), at(4), at(5), cnt, dok, ws, st);
+  else rc = verify_vargen_on(ctx, at(0), at(1), at(2), at(3), at(4), cnt, dok, ws, st);
+  if (rc) return rc;
+  if (g.valid) launch_and_bytes((uint8_t*)dok, g.valid + off, cnt, st);
+  HIP_TRY(hipGetLastError());
+  return DSV_OK;
+}
+#define DSV_PART(kind_)                                                                                     \
+  [=](const Staged& g, size_t off, size_t cnt, void* dok, void* ws, Stager&, hipStream_t st) {              \
+    return part_verify(*cp, kind_, g, off, cnt, dok, ws, st);                                               \
+  }
 int verify_single_host(Context& ctx, const uint8_t* u, const uint8_t* R_uv, const uint8_t* PK_uv,
                        const uint8_t* m, size_t n, uint8_t* ok) {
   const HostIn ins[4] = {{u, 32}, {R_uv, 64}, {PK_uv, 64}, {m, 32}};
   Context* cp = &ctx;
-  return run_pipelined(ctx, ins, ok, n, 0, [cp](const void* const* d, size_t cnt, void* dok, void* ws, Stager&, hipStream_t st) {
-    return verify_single_on(*cp, d[0], d[1], d[2], d[3], cnt, dok, ws, st);
-  });
+  return run_pipelined(ctx, ins, ok, n, 0, 0, NoPrep{}, DSV_PART(0));
 }
 int verify_double_host(Context& ctx, const uint8_t* u, const uint8_t* R_uv, const uint8_t* Rp_uv,
                        const uint8_t* PK_uv, const uint8_t* PKp_uv, const uint8_t* m, size_t n,
                        uint8_t* ok) {
   const HostIn ins[6] = {{u, 32}, {R_uv, 64}, {Rp_uv, 64}, {PK_uv, 64}, {PKp_uv, 64}, {m, 32}};
   Context* cp = &ctx;
-  return run_pipelined(ctx, ins, ok, n, 0, [cp](const void* const* d, size_t cnt, void* dok, void* ws, Stager&, hipStream_t st) {
-    return verify_double_on(*cp, d[0], d[1], d[2], d[3], d[4], d[5], cnt, dok, ws, st);
-  });
+  return run_pipelined(ctx, ins, ok, n, 0, 0, NoPrep{}, DSV_PART(1));
 }
 int verify_vargen_host(Context& ctx, const uint8_t* u, const uint8_t* R_uv, const uint8_t* PK_uv,
                        const uint8_t* Gen_uv, const uint8_t* m, size_t n, uint8_t* ok) {
   const HostIn ins[5] = {{u, 32}, {R_uv, 64}, {PK_uv, 64}, {Gen_uv, 64}, {m, 32}};
   Context* cp = &ctx;
-  return run_pipelined(ctx, ins, ok, n, 0, [cp](const void* const* d, size_t cnt, void* dok, void* ws, Stager&, hipStream_t st) {
-    return verify_vargen_on(*cp, d[0], d[1], d[2], d[3], d[4], cnt, dok, ws, st);
-  });
+  return run_pipelined(ctx, ins, ok, n, 0, 0, NoPrep{}, DSV_PART(2));
 }
 
 // One host batch over every initialised device: contiguous shards, one host thread per device
@@ -1368,33 +1441,36 @@ int verify_ext_on(Context& ctx, int kind, const void* u, const void* const* pts_
 // host buffers: the same through the chunked pipeline; the ext workspace of a chunk sits in the
 // slot's `extra` area and the pipeline's own verify workspace is not used
 constexpr size_t kExtItemBytes = 4 * 64 + 1 + 4 * kLimbs * 4 + 1;
+// whole-chunk `to_hash_inputs` of the scheme's points (d: u, points..., m; [u_alt, m_alt]: converted
+// scalars to use instead of d's); fills the staged view of the affine path
+int prep_normalize(int kind, const void* const* d, size_t cnt, Stager& x, hipStream_t st, Staged& g,
+                   const uint8_t* u_alt = nullptr, const uint8_t* m_alt = nullptr) {
+  const int np = kind == 0 ? 2 : (kind == 1 ? 4 : 3);
+  NormalizeArgs a = {};
+  for (int k = 0; k < np; k++) {
+    a.in[k] = (const uint8_t*)d[1 + k];
+    a.out[k] = x.take(cnt * 64);
+    g.p[1 + k] = a.out[k];
+    g.bytes[1 + k] = 64;
+  }
+  uint8_t* valid = x.take(cnt);
+  u32* prefix = reinterpret_cast<u32*>(x.take(normalize_prefix_bytes(cnt, np)));
+  launch_normalize_uvz(a, np, cnt, valid, prefix, st);
+  HIP_TRY(hipGetLastError());
+  g.p[0] = u_alt ? u_alt : (const uint8_t*)d[0];
+  g.p[1 + np] = m_alt ? m_alt : (const uint8_t*)d[1 + np];
+  g.bytes[0] = g.bytes[1 + np] = 32;
+  g.valid = valid;
+  return DSV_OK;
+}
 template <size_t NIN>
 int verify_ext_host(Context& ctx, int kind, const HostIn (&ins)[NIN], size_t n, uint8_t* ok) {
   Context* cp = &ctx;
-  return run_pipelined(ctx, ins, ok, n, kExtItemBytes,
-                       [cp, kind](const void* const* d, size_t cnt, void* dok, void* ws, Stager& x, hipStream_t st) {
-    // layout of d: u, points..., m
-    const int np = kind == 0 ? 2 : (kind == 1 ? 4 : 3);
-    ExtWs w;
-    for (int k = 0; k < 4; k++) w.pts[k] = x.take(cnt * 64);
-    w.valid = x.take(cnt);
-    w.prefix = reinterpret_cast<u32*>(x.take(normalize_prefix_bytes(cnt, np)));
-    NormalizeArgs a = {};
-    for (int k = 0; k < np; k++) {
-      a.in[k] = (const uint8_t*)d[1 + k];
-      a.out[k] = w.pts[k];
-    }
-    launch_normalize_uvz(a, np, cnt, w.valid, w.prefix, st);
-    const void* m = d[1 + np];
-    int rc;
-    if (kind == 0) rc = verify_single_on(*cp, d[0], w.pts[0], w.pts[1], m, cnt, dok, ws, st);
-    else if (kind == 1) rc = verify_double_on(*cp, d[0], w.pts[0], w.pts[1], w.pts[2], w.pts[3], m, cnt, dok, ws, st);
-    else rc = verify_vargen_on(*cp, d[0], w.pts[0], w.pts[1], w.pts[2], m, cnt, dok, ws, st);
-    if (rc) return rc;
-    launch_and_bytes((uint8_t*)dok, w.valid, cnt, st);
-    HIP_TRY(hipGetLastError());
-    return (int)DSV_OK;
-  });
+  return run_pipelined(ctx, ins, ok, n, kExtItemBytes, 0,
+                       [kind](const void* const* d, size_t cnt, Stager& x, hipStream_t st, Staged& g) {
+                         return prep_normalize(kind, d, cnt, x, st, g);
+                       },
+                       DSV_PART(kind));
 }
 int verify_single_ext_host(Context& ctx, const uint8_t* u, const uint8_t* R, const uint8_t* PK,
                            const uint8_t* m, size_t n, uint8_t* ok) {
@@ -1548,30 +1624,14 @@ constexpr size_t kMontItemBytes = kExtItemBytes + 64;
 template <size_t NIN>
 int verify_mont_host(Context& ctx, int kind, const HostIn (&ins)[NIN], size_t n, uint8_t* ok) {
   Context* cp = &ctx;
-  return run_pipelined(ctx, ins, ok, n, kMontItemBytes,
-                       [cp, kind](const void* const* d, size_t cnt, void* dok, void* ws, Stager& x, hipStream_t st) {
-    const int np = kind == 0 ? 2 : (kind == 1 ? 4 : 3);
-    uint8_t *cu = x.take(cnt * 32), *cm = x.take(cnt * 32);
-    launch_scalars_from_mont((const uint8_t*)d[0], (const uint8_t*)d[1 + np], cnt, cu, cm, st);
-    ExtWs w;
-    for (int k = 0; k < 4; k++) w.pts[k] = x.take(cnt * 64);
-    w.valid = x.take(cnt);
-    w.prefix = reinterpret_cast<u32*>(x.take(normalize_prefix_bytes(cnt, np)));
-    NormalizeArgs a = {};
-    for (int k = 0; k < np; k++) {
-      a.in[k] = (const uint8_t*)d[1 + k];
-      a.out[k] = w.pts[k];
-    }
-    launch_normalize_uvz(a, np, cnt, w.valid, w.prefix, st);
-    int rc;
-    if (kind == 0) rc = verify_single_on(*cp, cu, w.pts[0], w.pts[1], cm, cnt, dok, ws, st);
-    else if (kind == 1) rc = verify_double_on(*cp, cu, w.pts[0], w.pts[1], w.pts[2], w.pts[3], cm, cnt, dok, ws, st);
-    else rc = verify_vargen_on(*cp, cu, w.pts[0], w.pts[1], w.pts[2], cm, cnt, dok, ws, st);
-    if (rc) return rc;
-    launch_and_bytes((uint8_t*)dok, w.valid, cnt, st);
-    HIP_TRY(hipGetLastError());
-    return (int)DSV_OK;
-  });
+  return run_pipelined(ctx, ins, ok, n, kMontItemBytes, 0,
+                       [kind](const void* const* d, size_t cnt, Stager& x, hipStream_t st, Staged& g) {
+                         const int np = kind == 0 ? 2 : (kind == 1 ? 4 : 3);
+                         uint8_t *cu = x.take(cnt * 32), *cm = x.take(cnt * 32);
+                         launch_scalars_from_mont((const uint8_t*)d[0], (const uint8_t*)d[1 + np], cnt, cu, cm, st);
+                         return prep_normalize(kind, d, cnt, x, st, g, cu, cm);
+                       },
+                       DSV_PART(kind));
 }
 // columns of one scheme: u (32 B), its points (96 B each), m (32 B)
 constexpr int kMontCols[3] = {4, 6, 5};
@@ -1979,7 +2039,8 @@ int verify_wire(Context& ctx, int kind, const uint8_t* sig, const uint8_t* pk, c
   const size_t sig_bytes = kind == 1 ? 96 : 64, pk_bytes = kind == 0 ? 32 : 64;
   const HostIn ins[3] = {{sig, sig_bytes}, {pk, pk_bytes}, {m, 32}};
   Context* cp = &ctx;
-  return run_pipelined(ctx, ins, ok, n, kWireItemBytes, [=](const void* const* d, size_t cnt, void* dok, void* ws, Stager& x, hipStream_t st) {
+  return run_pipelined(ctx, ins, ok, n, 0, kWireItemBytes, NoPrep{},
+                       [=](const Staged& g, size_t off, size_t cnt, void* dok, void* ws, Stager& x, hipStream_t st) {
     WireWs w;
     w.u = x.take(cnt * 32);
     w.R = x.take(cnt * 64);
@@ -1987,7 +2048,8 @@ int verify_wire(Context& ctx, int kind, const uint8_t* sig, const uint8_t* pk, c
     w.P0 = x.take(cnt * 64);
     w.P1 = x.take(cnt * 64);
     w.valid = x.take(cnt);
-    return verify_wire_on(*cp, kind, (const uint8_t*)d[0], (const uint8_t*)d[1], d[2], cnt, dok, w, ws, st);
+    return verify_wire_on(*cp, kind, g.p[0] + off * g.bytes[0], g.p[1] + off * g.bytes[1],
+                          g.p[2] + off * g.bytes[2], cnt, dok, w, ws, st);
   });
 }
 // device-pointer form: serialized records already resident in HBM
