@@ -137,6 +137,42 @@ def _pmc():
         return None
 
 
+def _verify_batch_e2e_double(E, bd, cores):
+    """`verify_batch_double` of the C++ mirror over the double batch as typed objects (SignatureDouble
+    352 B, PublicKeyDouble 320 B): six strided columns, 448 B gathered per item."""
+    import ctypes
+
+    lib_path = os.path.join(ROOT, "tools", "libvb_e2e.so")
+    if not os.path.exists(lib_path):
+        return None
+    L = ctypes.CDLL(lib_path)
+    h = {k: bd[k].cpu().numpy() for k in ("u", "R", "Rp", "PK", "PKp", "m")}
+    expected = bd["expected"].cpu().numpy()
+    n = h["u"].shape[0]
+    p = lambda a: ctypes.c_void_p(a.ctypes.data)
+    bad = L.vb_e2e_prepare_double(p(h["u"]), p(h["R"]), p(h["Rp"]), p(h["PK"]), p(h["PKp"]), p(h["m"]),
+                                  ctypes.c_size_t(n), ctypes.c_int(max(1, min(cores, 16))))
+    ok = np.zeros(n, dtype=np.uint8)
+    ms = ctypes.c_double(0)
+    try:
+        times = []
+        for rep in range(6):
+            if L.vb_e2e_run_double(p(ok), ctypes.byref(ms)) != 0:
+                raise SystemExit("verify_batch_e2e (double): engine error")
+            if rep:
+                times.append(ms.value)
+        if (ok != expected).any():
+            raise SystemExit("verify_batch_e2e (double): verdicts differ from the expected pattern")
+    finally:
+        L.vb_e2e_release()
+    times.sort()
+    return {"value": n / (times[0] * 1e-3), "unit": "verifies/s", "items": n, "best_ms": times[0],
+            "median_ms": times[len(times) // 2], "objects_not_representable": int(bad),
+            "copy_threads": E.set_host_threads(0),
+            "workload": "verify_batch_double over %d typed objects (SignatureDouble 352 B, PublicKeyDouble "
+                        "320 B, BlsScalar 32 B) -> vector<bool>; dsv_verify_double_mont_cols" % n}
+
+
 def _verify_batch_e2e(E, hu, hR, hPK, hm, expected, cores):
     """Time `verify_batch(&[Signature], &[PublicKey], &[BlsScalar]) -> Vec<bool>` of the C++ mirror
     (include/dusk_schnorr.hpp) over the whole batch as typed objects: 1 copy thread and the default
@@ -794,6 +830,11 @@ def main():
             out["verify_batch_e2e"] = e2e
             if "host_path_ext" in out:
                 e2e["vs_host_path_ext"] = e2e["value"] / out["host_path_ext"]["value"]
+            if "double" in sample_checks:
+                e2d = _verify_batch_e2e_double(E, sample_checks["double"][0], cores)
+                if e2d:
+                    e2d["vs_device_resident_double"] = e2d["value"] / out["double"]["value"]
+                    e2e["double"] = e2d
     if small_batch:
         out["small_batch"] = small_batch
 

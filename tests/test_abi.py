@@ -50,6 +50,17 @@ def test_version_and_uninitialised_calls_fail_loudly():
     assert L.dsv_workspace_bytes(ctypes.c_size_t(1 << 20)) >= (1 << 20) * 33
 
 
+def test_host_thread_setting_needs_no_device():
+    """dsv_set_host_threads: 1..16 sets the copy pool of the host entry points, 0 restores the default
+    ($DSV_HOST_THREADS, else 4, at most the machine's hardware threads); the value in force is returned."""
+    L = _lib.load()
+    default = L.dsv_set_host_threads(0)
+    assert 1 <= default <= 16
+    assert L.dsv_set_host_threads(1) == 1
+    assert L.dsv_set_host_threads(1000) <= 16
+    assert L.dsv_set_host_threads(-3) == default and L.dsv_set_host_threads(0) == default
+
+
 @pytest.mark.skipif(not NO_GPU, reason="only meaningful on a box without a GPU")
 def test_no_gpu_means_error_not_fallback():
     L = _lib.load()

@@ -76,6 +76,27 @@ def test_montgomery_limbs_equal_the_projective_entry_point_on_to_bytes(engine):
     assert len(set(planted.tolist())) <= 4 and not twant[bad].any()
 
 
+@pytest.mark.parametrize("scheme", ["double", "vargen"])
+def test_montgomery_record_columns_across_several_chunks(engine, scheme):
+    """The strided gather out of record arrays for the six- and five-column schemes on a batch that
+    takes several pipeline chunks and sub-batches (2^16 + 2^15 + a ragged tail), with one and with four
+    copy threads: every chunk's whole-chunk normalisation, both compute lanes, per-slot scratch."""
+    base = 211
+    cols, want = C.mont_case(scheme, base, SEEDS[scheme] + 100, period=4)
+    n = (1 << 16) + (1 << 15) + 77
+    reps = -(-n // base)
+    tcols = [np.ascontiguousarray(np.tile(c, (reps, 1))[:n]) for c in cols]
+    twant = np.tile(want, reps)[:n]
+    views = C.as_records(scheme, tcols)[3]
+    try:
+        for threads in (1, 4):
+            assert engine.set_host_threads(threads) == threads
+            assert np.array_equal(engine.verify_mont_cols(scheme, views), twant), threads
+    finally:
+        engine.set_host_threads(0)
+    assert 0 < twant.sum() < n
+
+
 def test_montgomery_column_arguments_are_validated(engine):
     cols, _ = C.mont_case("single", 8, 5, plant=False)
     with pytest.raises(ValueError):
