@@ -161,11 +161,19 @@ constexpr int kSplitLanes = 8;
 // batch of every caller queued on them).  With more than kSplitLanes distinct caller streams in
 // flight lanes are shared by hashing — still correct (work is ordered by the events), only
 // serialised.
+// The two sub-batch streams sit on DIFFERENT PRIORITY LEVELS (highest / lowest): ROCm multiplexes
+// streams onto four hardware queues per priority level, two streams that land on one queue run
+// strictly one after the other, and which queue a plain stream gets depends on every stream the
+// process — torch, RCCL, the caller — created before; streams of different levels never share a
+// queue (profiles/r04/host_pipeline_streams.txt: the 2^20 headline is the same with plain streams
+// when they happen not to collide, 6 - 10 % lower when they do).  The side stream of the small-batch
+// table preparation stays a plain one: on a priority stream a 1024-signature call takes 25 % longer.
 struct SplitLane {
   hipStream_t owner = nullptr;
   bool made = false;
   hipStream_t stream[2] = {nullptr, nullptr};
-  hipEvent_t fork = nullptr, join[2] = {nullptr, nullptr};
+  hipStream_t side = nullptr;
+  hipEvent_t fork = nullptr, join[2] = {nullptr, nullptr}, side_join = nullptr;
 };
 
 // Everything the library owns on one GPU.  One Context per device ordinal; several devices can be
@@ -430,10 +438,17 @@ int acquire_lane(Context& ctx, hipStream_t user, SplitLane*& out) {
       }
   if (!pick) pick = &ctx.lanes[((uintptr_t)user >> 6) % kSplitLanes];  // all taken: share one
   if (!pick->made) {
+    int least = 0, greatest = 0;
+    HIP_TRY(hipDeviceGetStreamPriorityRange(&least, &greatest));
+    // (the side stream FIRST: created behind the two priority streams it came to share a hardware
+    //  queue with the caller's stream in the probe process and the small-batch overlap was gone —
+    //  0.437 -> 0.539 ms per 1024-signature device call, profiles/r04/host_pipeline_streams.txt 10.)
+    HIP_TRY(hipStreamCreateWithFlags(&pick->side, hipStreamNonBlocking));
     for (int k = 0; k < 2; k++) {
-      HIP_TRY(hipStreamCreateWithFlags(&pick->stream[k], hipStreamNonBlocking));
+      HIP_TRY(hipStreamCreateWithPriority(&pick->stream[k], hipStreamNonBlocking, k == 0 ? greatest : least));
       HIP_TRY(hipEventCreateWithFlags(&pick->join[k], hipEventDisableTiming));
     }
+    HIP_TRY(hipEventCreateWithFlags(&pick->side_join, hipEventDisableTiming));
     HIP_TRY(hipEventCreateWithFlags(&pick->fork, hipEventDisableTiming));
     pick->owner = user;
     pick->made = true;
@@ -501,6 +516,8 @@ void release_context(Context& ctx) {
       (void)hipStreamDestroy(l.stream[k]);
       (void)hipEventDestroy(l.join[k]);
     }
+    if (l.side) (void)hipStreamDestroy(l.side);
+    if (l.side_join) (void)hipEventDestroy(l.side_join);
     (void)hipEventDestroy(l.fork);
     l = SplitLane();
   }
@@ -724,16 +741,16 @@ hipEvent_t prep_tables_beside_hash(Context& ctx, const void* PK_uv, const void* 
   if (acquire_lane(ctx, user, lane) != DSV_OK) return nullptr;
   std::lock_guard<std::mutex> lk(ctx.lane_mu);
   if (hipEventRecord(lane->fork, user) != hipSuccess ||
-      hipStreamWaitEvent(lane->stream[0], lane->fork, 0) != hipSuccess)
+      hipStreamWaitEvent(lane->side, lane->fork, 0) != hipSuccess)
     return nullptr;
-  launch_prep_var_tables((const uint8_t*)PK_uv, (const uint8_t*)R_uv, n, tables, lane->stream[0]);
-  if (hipEventRecord(lane->join[0], lane->stream[0]) != hipSuccess) {
+  launch_prep_var_tables((const uint8_t*)PK_uv, (const uint8_t*)R_uv, n, tables, lane->side);
+  if (hipEventRecord(lane->side_join, lane->side) != hipSuccess) {
     // the prep kernel is already writing this call's table slots: it must have finished before the
     // verify kernel, told to build its tables itself, writes the same slots from the caller's stream
-    (void)hipStreamSynchronize(lane->stream[0]);
+    (void)hipStreamSynchronize(lane->side);
     return nullptr;
   }
-  return lane->join[0];
+  return lane->side_join;
 }
 int verify_single_on(Context& ctx, const void* u, const void* R_uv, const void* PK_uv, const void* m,
                      size_t n, void* ok, void* workspace, hipStream_t stream) {
