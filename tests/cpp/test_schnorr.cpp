@@ -105,6 +105,54 @@ static void batch() {
   CHECK(threw);
   CHECK(verify_batch({}, {}, {}).empty());
 }
+// verify_batch_double / verify_batch_var_gen over typed objects (six and five strided columns), and a
+// batch long enough for several pipeline chunks (the objects of a small signed set repeated)
+static void batch_double_vargen_and_chunks() {
+  Rng rng(99);
+  const size_t n = 60;
+  std::vector<SignatureDouble> dsigs;
+  std::vector<PublicKeyDouble> dpks;
+  std::vector<SignatureVarGen> vsigs;
+  std::vector<PublicKeyVarGen> vpks;
+  std::vector<Signature> sigs;
+  std::vector<PublicKey> pks;
+  std::vector<BlsScalar> msgs;
+  for (size_t i = 0; i < n; i++) {
+    SecretKey sk = SecretKey::random(rng);
+    BlsScalar m = BlsScalar::random(rng);
+    msgs.push_back(m);
+    dsigs.push_back(sk.sign_double(rng, m));
+    dpks.push_back(PublicKeyDouble::from(sk));
+    sigs.push_back(sk.sign(rng, m));
+    pks.push_back(PublicKey::from(sk));
+    SecretKeyVarGen skv = SecretKeyVarGen::random(rng);
+    vsigs.push_back(skv.sign(rng, m));
+    vpks.push_back(PublicKeyVarGen::from(skv));
+  }
+  std::swap(dsigs[5].R_, dsigs[5].R_prime_);            // R and R' exchanged
+  dpks[11] = dpks[12];                                   // wrong key pair
+  vpks[7] = PublicKeyVarGen::from_raw_unchecked(vpks[7].public_key(), vpks[8].generator());  // wrong generator
+  vsigs[20].u_ = vsigs[20].u_ + JubJubScalar::one();
+  const std::vector<bool> okd = verify_batch_double(dsigs, dpks, msgs), okv = verify_batch_var_gen(vsigs, vpks, msgs);
+  for (size_t i = 0; i < n; i++) {
+    CHECK(okd[i] == !(i == 5 || i == 11) && okd[i] == dpks[i].verify(dsigs[i], msgs[i]));
+    CHECK(okv[i] == !(i == 7 || i == 20) && okv[i] == vpks[i].verify(vsigs[i], msgs[i]));
+  }
+  // 70 020 single signatures: two chunks and a ragged sub-batch through the strided gather
+  sigs[3].R_ = sigs[4].R_;
+  const size_t reps = 1167;
+  std::vector<Signature> big_s;
+  std::vector<PublicKey> big_p;
+  std::vector<BlsScalar> big_m;
+  for (size_t r = 0; r < reps; r++) {
+    big_s.insert(big_s.end(), sigs.begin(), sigs.end());
+    big_p.insert(big_p.end(), pks.begin(), pks.end());
+    big_m.insert(big_m.end(), msgs.begin(), msgs.end());
+  }
+  const std::vector<uint8_t> okb = verify_batch_bytes(big_s.data(), big_p.data(), big_m.data(), big_s.size());
+  CHECK(okb.size() == n * reps);
+  for (size_t i = 0; i < okb.size(); i++) CHECK(okb[i] == (i % n == 3 ? 0 : 1));
+}
 static void to_from_bytes() {
   Rng rng(2321);
   SecretKey sk = SecretKey::random(rng);
@@ -256,6 +304,7 @@ int main() {
   sign_verify_double();
   sign_verify_var_gen();
   batch();
+  batch_double_vargen_and_chunks();
   std::printf("ok: %s\n", dsv_version());
   return 0;
 }
