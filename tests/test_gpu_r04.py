@@ -142,3 +142,34 @@ def test_vargen_kernel_on_its_fallback_row_in_a_test_build(engine):
                        cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-2000:])
     assert " passed" in r.stdout and "failed" not in r.stdout, r.stdout[-500:]
+
+
+def test_bench_under_the_drivers_launcher(engine):
+    """The driver starts N > 1 as `python -m torch.distributed.run --nnodes=1 --nproc-per-node N
+    --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...`: rehearsed with two ranks on this
+    one GPU over gloo (DSV_BENCH_DEVICE / DSV_BENCH_BACKEND); the line must come from rank 0 alone, be
+    the last line of stdout, name the launcher and carry the per-rank fields."""
+    import json
+    import socket
+    import subprocess
+    import sys
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    drop = ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")
+    env = {k: v for k, v in os.environ.items() if k not in drop}
+    env.update({"DSV_BENCH_DEVICE": "0", "DSV_BENCH_BACKEND": "gloo"})
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"),
+           "--gpus", "2", "--steps", "2", "--warmup", "1", "--log2-batch", "14", "--no-cpu-baseline"]
+    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [l for l in p.stdout.strip().splitlines() if l.strip()]
+    json_lines = [l for l in lines if l.startswith("{")]
+    assert len(json_lines) == 1 and lines[-1] == json_lines[0], lines[-3:]
+    line = json.loads(json_lines[0])
+    assert line["launcher"] == "torch.distributed.run" and line["n_gpus"] == 2 and line["backend"] == "gloo"
+    assert line["steps"] == 2 and line["warmup"] == 1 and line["value"] > 0
+    assert len(line["ranks"]["ms_per_step"]["all"]) == 2 and line["mixed"]["n_gpus"] == 2
+    assert abs(line["value"] - 2 * (1 << 14) * 2 / (line["ms_per_step"] * 2 / 1e3)) < 1e-6 * line["value"]
