@@ -35,8 +35,10 @@
  * coordinates are out of contract (result unspecified, never a fault).
  *
  * Host entry points take HOST pointers (pageable is fine), stage through library-owned pinned
- * and device buffers in chunks of 2^15 .. 2^18 items (DSV_HOST_THREADS copy threads, default 4) and block
- * until the verdicts are in `ok`.  The *_dev entry points take DEVICE pointers (hipMalloc'd,
+ * and device buffers in chunks of 2^15 .. 2^18 items (DSV_HOST_THREADS / dsv_set_host_threads copy
+ * threads, default 4; four library-owned streams per device, the two that carry the kernels on
+ * different priority levels so that they never share a hardware queue) and block until the verdicts
+ * are in `ok`.  The *_dev entry points take DEVICE pointers (hipMalloc'd,
  * 16-byte aligned) plus a hipStream_t passed as void*, enqueue only, and never synchronise —
  * they are what the bench times with inputs resident in HBM.
  *
