@@ -11,6 +11,7 @@ import numpy as np
 import pytest
 
 import mont_cases as C
+import pymodel as M
 import oracle_lib as O
 
 pytestmark = pytest.mark.gpu
@@ -173,3 +174,42 @@ def test_bench_under_the_drivers_launcher(engine):
     assert line["steps"] == 2 and line["warmup"] == 1 and line["value"] > 0
     assert len(line["ranks"]["ms_per_step"]["all"]) == 2 and line["mixed"]["n_gpus"] == 2
     assert abs(line["value"] - 2 * (1 << 14) * 2 / (line["ms_per_step"] * 2 / 1e3)) < 1e-6 * line["value"]
+
+
+def test_inversion_edge_values_through_to_hash_inputs(engine):
+    """k_normalize_uvz inverts by the extended Euclidean algorithm with float-guided quotients
+    (inv29.h) and falls back to Fermat for z = 0, for quotients beyond 31 bits (z = 1, 2, small z) and at
+    the iteration cap: `dsv_to_hash_inputs` against Python integers on z values at both ends of the
+    range, powers of two and their neighbours, values whose Euclidean quotients are huge or all 1
+    (Fibonacci-like), and random ones — alone (one inversion per point) and in a batch large enough
+    for sixteen points to share one inversion (the product of their z's is what gets inverted)."""
+    import random
+    rnd = random.Random(2718)
+    q = M.Q
+    fib = [1, 2]
+    while fib[-1] < q:
+        fib.append(fib[-1] + fib[-2])
+    zs = [1, 2, 3, 5, 255, 256, (1 << 31) - 1, 1 << 31, (1 << 32) + 1, q - 1, q - 2, (q - 1) // 2, (q + 1) // 2,
+          q // 3, q // 3 + 1, (1 << 128) - 1, 1 << 128, (1 << 254) + 12345, fib[-2], fib[-3], q - fib[-4],
+          pow(2, -1, q), pow(3, -1, q), pow(7, 200, q)]
+    zs += [1 << k for k in range(1, 255, 17)] + [(1 << k) - 1 for k in range(2, 255, 19)]
+    zs += [q // d for d in (5, 17, 257, 65537, (1 << 31) - 1, (1 << 40) + 3)]
+    zs += [rnd.randrange(1, q) for _ in range(400)] + [rnd.randrange(1, 1 << rnd.randrange(1, 255)) for _ in range(200)]
+    u0, v0 = M.GEN
+    def rows(zlist):
+        a = np.zeros((len(zlist), 96), np.uint8)
+        for i, z in enumerate(zlist):
+            uu, vv = (u0 + i) % q, (v0 * (i + 1)) % q           # any field elements will do here
+            a[i] = np.frombuffer(M.le32(uu * z % q) + M.le32(vv * z % q) + M.le32(z), np.uint8)
+        return a
+    def check(zlist):
+        out, ok = engine.to_hash_inputs(rows(zlist))
+        assert ok.all()
+        for i in range(len(zlist)):
+            assert M.from_le(out[i, :32]) == (u0 + i) % q and M.from_le(out[i, 32:]) == (v0 * (i + 1)) % q, (i, zlist[i])
+    check(zs)                                    # n < 2^15: one inversion per point
+    big = (zs * (-(-((1 << 15) + 100) // len(zs))))[:(1 << 15) + 100]
+    check(big)                                   # eight points per inversion
+    zero = rows([0, 5, 0, 7])
+    out, ok = engine.to_hash_inputs(zero)
+    assert ok.tolist() == [0, 1, 0, 1]
