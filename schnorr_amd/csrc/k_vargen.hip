@@ -4,6 +4,7 @@
 // (/root/reference/src/keys/secret.rs:442, src/keys/public.rs:337-344).
 #include "common.h"
 #include "decode29.h"
+#include "inv29.h"
 #include "lattice3.h"
 
 namespace dsv {
@@ -113,7 +114,7 @@ k_var_base_points(const uint8_t* __restrict__ scalar, const uint8_t* __restrict_
     s[7] &= 0x0fffffffu;  // keeps the signed recoding in range for a non-canonical scalar
     Ext acc = var_base_mul<63>(s, lane_tbl);
     if (canonical) {
-      Fe zi = fe_invert(acc.z);
+      Fe zi = fe_invert_euclid(acc.z);
       store_fq(out_uv, 2 * i, fe_mul(acc.u, zi));
       store_fq(out_uv, 2 * i + 1, fe_mul(acc.v, zi));
     } else {
