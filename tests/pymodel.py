@@ -203,6 +203,64 @@ def verify_single_half(u, R, PK, m):
     return t == IDENTITY
 
 
+# ---- inversion by extended Euclid (schnorr_amd/csrc/inv29.h), the device's step rules -------------
+def _image(x):
+    """double-precision image of a non-negative integer as to_double8 builds it (Horner over 32-bit
+    words, one rounding per step); only its relative accuracy (< 2^-50) matters to the algorithm"""
+    d = 0.0
+    for i in range(7, -1, -1):
+        d = d * 4294967296.0 + float((x >> (32 * i)) & 0xFFFFFFFF)
+    return d
+
+
+def inv_euclid(x, mod=Q, max_iter=1024):
+    """(inverse or None, half_steps, fell_back): the algorithm of inv29.h on Python integers and floats —
+    quotient estimates floor(dX / dY * (1 - 2^-30)) from the images, alternating roles, exact compare
+    when the images are within 2^-28, stop when one side is 0; anything irregular (x = 0, a quotient
+    that does not fit 31 bits, the cap) reports a fall-back (the device then runs Fermat).  Raises if an
+    estimate ever exceeds the true quotient (the subtraction would borrow) or a cofactor passes 2^256."""
+    A, B, tA, tB = mod, x, 0, 1
+    steps = 0
+
+    def step(X, tX, Y, tY):
+        qd = _image(X) / _image(Y) * (1.0 - 2.0 ** -30)
+        if not qd < 2147483647.0:
+            return None
+        qe = int(qd)
+        if qe == 0 and _image(X) >= _image(Y) * (1.0 - 2.0 ** -28) and X >= Y:
+            qe = 1
+        assert qe * Y <= X, "estimate above the true quotient"
+        tX += qe * tY
+        assert tX < (1 << 256)
+        return X - qe * Y, tX
+
+    it = 0
+    ok = True
+    while it < max_iter and ok and B != 0:
+        r = step(A, tA, B, tB)
+        steps += 1
+        if r is None:
+            ok = False
+            break
+        A, tA = r
+        if A == 0:
+            break
+        r = step(B, tB, A, tA)
+        steps += 1
+        if r is None:
+            ok = False
+            break
+        B, tB = r
+        it += 1
+    on_b = A == 0
+    good = ok and it < max_iter and ((on_b and B == 1) or (not on_b and B == 0 and A == 1))
+    if not good:
+        return (pow(x, -1, mod) if x % mod else 0), steps, True
+    t = tB if on_b else tA
+    assert t < mod
+    return (t if on_b else (mod - t) % mod), steps, False
+
+
 # ---- three short scalars for the var-generator equation (schnorr_amd/csrc/lattice3.h) --------
 def lattice3(u, c, tbound=float(1 << 31), max_batches=24, max_passes=40):
     """(x, y, z): x = z*u, y = z*c (mod 8r), z odd — the device algorithm on Python integers and

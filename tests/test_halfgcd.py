@@ -112,3 +112,40 @@ def test_lattice3_check_is_exact_with_torsion():
             valid += want
             assert not M.verify_vargen_lattice((u + 1) % M.R_ORDER, R, pk, gen, m)
     assert valid >= 2
+
+
+def test_euclidean_inversion_model_is_exact_and_bounded():
+    """inv29.h's algorithm on Python integers and floats (pymodel.inv_euclid): the quotient estimates
+    never exceed the true quotient (asserted inside the model at every step), the result is the
+    inverse for random values and for values built to stress it — neighbours of powers of two,
+    consecutive-Fibonacci ratios (all quotients 1: the longest chains), q / k (one huge first
+    quotient), values one apart from their partner after a step —, the irregular inputs are reported
+    as fall-backs (the device then runs Fermat), and the half-step count stays far below the cap."""
+    import random
+    rnd = random.Random(99)
+    q = M.Q
+    fib = [1, 2]
+    while fib[-1] < q:
+        fib.append(fib[-1] + fib[-2])
+    cases = [q - 1, q - 2, (q - 1) // 2, (q + 1) // 2, q // 3, fib[-2], fib[-3], q - fib[-3], (1 << 254) + 1]
+    cases += [(1 << k) + d for k in range(33, 255, 13) for d in (-1, 0, 1)]
+    cases += [q // k for k in (3, 5, 1000003, (1 << 30) + 7)]
+    random_cases = [rnd.randrange(1 << 230, q) for _ in range(3000)]
+    cases += random_cases + [rnd.randrange(1, 1 << rnd.randrange(40, 255)) for _ in range(1000)]
+    worst = 0
+    regular = set(random_cases)
+    for x in cases:
+        inv, steps, fell_back = M.inv_euclid(x)
+        assert inv * x % q == 1, x
+        worst = max(worst, steps)
+        if x in regular:             # a quotient beyond 31 bits has probability ~2^-31 per step
+            assert not fell_back, x
+    assert worst < 2 * 400           # ~1.44 * 255 division steps at most, twice that in half-steps
+    # irregular inputs: the device falls back to Fermat, the value is still the inverse (0 for 0)
+    for x in (0, 1, 2, 3, 1 << 31, (1 << 100) + 1):
+        inv, _, fell_back = M.inv_euclid(x)
+        assert fell_back and inv == (pow(x, -1, q) if x else 0)
+    # the scalar field works the same way (the model is generic in the modulus)
+    for _ in range(300):
+        x = rnd.randrange(1, M.R_ORDER)
+        assert M.inv_euclid(x, M.R_ORDER)[0] * x % M.R_ORDER == 1
