@@ -173,6 +173,41 @@ def _verify_batch_e2e_double(E, bd, cores):
                         "320 B, BlsScalar 32 B) -> vector<bool>; dsv_verify_double_mont_cols" % n}
 
 
+def _verify_batch_e2e_vargen(E, bv, cores):
+    """`verify_batch_var_gen` of the C++ mirror over the var-generator batch as typed objects
+    (SignatureVarGen 192 B, PublicKeyVarGen 320 B): five strided columns, 352 B gathered per item."""
+    import ctypes
+
+    lib_path = os.path.join(ROOT, "tools", "libvb_e2e.so")
+    if not os.path.exists(lib_path):
+        return None
+    L = ctypes.CDLL(lib_path)
+    h = {k: bv[k].cpu().numpy() for k in ("u", "R", "PK", "Gen", "m")}
+    expected = bv["expected"].cpu().numpy()
+    n = h["u"].shape[0]
+    p = lambda a: ctypes.c_void_p(a.ctypes.data)
+    bad = L.vb_e2e_prepare_vargen(p(h["u"]), p(h["R"]), p(h["PK"]), p(h["Gen"]), p(h["m"]), ctypes.c_size_t(n),
+                                  ctypes.c_int(max(1, min(cores, 16))))
+    ok = np.zeros(n, dtype=np.uint8)
+    ms = ctypes.c_double(0)
+    try:
+        times = []
+        for rep in range(6):
+            if L.vb_e2e_run_vargen(p(ok), ctypes.byref(ms)) != 0:
+                raise SystemExit("verify_batch_e2e (var-generator): engine error")
+            if rep:
+                times.append(ms.value)
+        if (ok != expected).any():
+            raise SystemExit("verify_batch_e2e (var-generator): verdicts differ from the expected pattern")
+    finally:
+        L.vb_e2e_release()
+    times.sort()
+    return {"value": n / (times[0] * 1e-3), "unit": "verifies/s", "items": n, "best_ms": times[0],
+            "median_ms": times[len(times) // 2], "objects_not_representable": int(bad),
+            "workload": "verify_batch_var_gen over %d typed objects (SignatureVarGen 192 B, PublicKeyVarGen "
+                        "320 B, BlsScalar 32 B) -> vector<bool>; dsv_verify_vargen_mont_cols" % n}
+
+
 def _verify_batch_e2e(E, hu, hR, hPK, hm, expected, cores):
     """Time `verify_batch(&[Signature], &[PublicKey], &[BlsScalar]) -> Vec<bool>` of the C++ mirror
     (include/dusk_schnorr.hpp) over the whole batch as typed objects: 1 copy thread and the default
@@ -835,6 +870,11 @@ def main():
                 if e2d:
                     e2d["vs_device_resident_double"] = e2d["value"] / out["double"]["value"]
                     e2e["double"] = e2d
+            if "vargen" in sample_checks:
+                e2v = _verify_batch_e2e_vargen(E, sample_checks["vargen"][0], cores)
+                if e2v:
+                    e2v["vs_device_resident_vargen"] = e2v["value"] / out["vargen"]["value"]
+                    e2e["vargen"] = e2v
     if small_batch:
         out["small_batch"] = small_batch
 
