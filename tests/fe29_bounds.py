@@ -424,3 +424,32 @@ def prove_decompress():
     un = sub(B([0] * NL), u, 2)                     # the other root
     canon_ok(mul(un, B([1] + [0] * (NL - 1))))
     return {"u": u, "num": num, "den": den}
+
+
+# ---- k_normalize_uvz with inv29.h, k_scalars_from_mont (k_misc.hip), r04 ------------------------
+def prove_normalize_and_limb_conversion():
+    """the straight-line field code around the r04 additions on worst-case inputs:
+    k_scalars_from_mont — fe_canon(fe_mul(plain words, 2^5)); k_normalize_uvz — the running product of
+    fe_to_mont(plain z) values, fe_invert_euclid of it (fe_from_mont in, fe_to_mont(plain cofactor)
+    and its negation out, or a Fermat power), the walk back down (inv * prefix, inv * z) and the
+    quotients plain coordinate x Montgomery 1/z, canonicalised"""
+    plain = canonical()                              # eight 32-bit words < q re-cut into 29-bit limbs
+    two5 = B([32] + [0] * (NL - 1))
+    canon_ok(mul(plain, two5))                       # m = M * 2^5 * 2^-261
+    r2 = const(_load("DSV_R2"))
+    z = mul(plain, r2)                               # fe_to_mont
+    acc = join(const(_load("DSV_ONE")), z)
+    acc = join(acc, mul(acc, z))                     # any running product
+    one_plain = B([1] + [0] * (NL - 1))
+    canon_ok(mul(acc, one_plain))                    # fe_from_mont(acc) inside fe_invert_euclid
+    m = mul(canonical(), r2)                         # the cofactor back in Montgomery form
+    inv = join(m, sub(B([0] * NL), m, 2))            # ... or its negation (fe_neg2)
+    power = mul(acc, acc)
+    inv = join(inv, join(power, sqr(power)))         # ... or the Fermat fallback: a product of powers
+    zinv = mul(inv, acc)                             # inv * prefix
+    inv2 = mul(inv, z)                               # inv * z for the next point
+    inv2 = join(inv2, mul(inv2, z))
+    zinv = join(zinv, mul(inv2, acc))
+    q = mul(plain, zinv)                             # plain coordinate x Montgomery 1/z
+    canon_ok(q)
+    return {"quotient": q, "inverse": inv}

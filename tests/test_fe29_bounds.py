@@ -40,3 +40,9 @@ def test_hades_permutation_cannot_overflow_with_the_shipped_constants():
 
 def test_point_decompression_field_code_cannot_overflow():
     FB.prove_decompress()
+
+
+def test_normalisation_and_limb_conversion_field_code_cannot_overflow():
+    """r04: k_scalars_from_mont and k_normalize_uvz with the Euclidean inversion (inv29.h)"""
+    out = FB.prove_normalize_and_limb_conversion()
+    assert out["quotient"].v < 3 * FB.Q
