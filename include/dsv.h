@@ -36,9 +36,9 @@
  *
  * Host entry points take HOST pointers (pageable is fine), stage through library-owned pinned
  * and device buffers in chunks of 2^15 .. 2^18 items (DSV_HOST_THREADS / dsv_set_host_threads copy
- * threads, default 4; four library-owned streams per device, the two that carry the kernels on
- * different priority levels so that they never share a hardware queue) and block until the verdicts
- * are in `ok`.  The *_dev entry points take DEVICE pointers (hipMalloc'd,
+ * threads per call, default 4; six library-owned streams per device, the two that carry the kernels
+ * on different priority levels so that they never share a hardware queue) and block until the
+ * verdicts are in `ok`.  The *_dev entry points take DEVICE pointers (hipMalloc'd,
  * 16-byte aligned) plus a hipStream_t passed as void*, enqueue only, and never synchronise —
  * they are what the bench times with inputs resident in HBM.
  *
@@ -50,11 +50,13 @@
  *     Callers on different streams get different internal sub-batch streams (up to 8 per device,
  *     shared beyond that), so they overlap on the GPU.
  *   - host entry points run on the calling thread's device: dsv_set_device(d) (thread-local), else
- *     the first device initialised.  Host calls on ONE device serialise on that device's lock;
- *     host calls on different devices run in parallel.
+ *     the first device initialised.  Up to dsv_max_in_flight() (2) verify calls run concurrently on
+ *     ONE device, each with its own staging, sharing the device's compute streams (a further call
+ *     waits its turn, first come first served); host calls on different devices run in parallel.
+ *     The small utility entry points (challenge, sign, decompress, debug) serialise on a lock.
  *   - dsv_verify_*_multi shard one host batch over ALL initialised devices (contiguous shards, one
  *     host thread per device, no collective).
- *   - dsv_shutdown[_device] waits for the host call in flight on that device, synchronises the
+ *   - dsv_shutdown[_device] waits for the host calls (and jobs) in flight on that device, synchronises the
  *     device and releases everything; the caller must not have *_dev work of its own still
  *     enqueued whose workspace it frees, and must not start new calls on that device until a
  *     later dsv_init.  Calls that arrive after shutdown return DSV_ERR_NOT_INITIALIZED.
@@ -176,6 +178,25 @@ typedef struct dsv_column {
 int dsv_verify_single_mont_cols(const dsv_column *cols /*[4]*/, size_t n, uint8_t *ok);
 int dsv_verify_double_mont_cols(const dsv_column *cols /*[6]*/, size_t n, uint8_t *ok);
 int dsv_verify_vargen_mont_cols(const dsv_column *cols /*[5]*/, size_t n, uint8_t *ok);
+/* ... asynchronous: `submit` validates the arguments, hands the batch to a library-owned driver
+ * thread and returns at once with a job; `dsv_job_wait` blocks until the verdicts are in `ok`, returns
+ * the status the blocking form would have returned (dsv_last_error() then holds its text) and
+ * releases the job — every submitted job must be waited for exactly once.  cols[] is copied; the
+ * objects the columns point into and `ok` must stay valid until the wait returns.
+ * Why: a single call pays a ramp (the GPU idles until the first chunk has been gathered and
+ * transferred, then runs small first chunks at low occupancy) and a tail.  With two batches in
+ * flight the second one's ramp runs under the first one's tail: each call in flight owns its own
+ * staging (dsv_max_in_flight() per device; a further job waits inside its driver thread), the
+ * compute streams are shared, so the GPU sees one queue of sub-batches.  The blocking host entry
+ * points may equally be called from several threads at once — same mechanism.
+ * Jobs start in submission order.  dsv_job_done: 1 finished / 0 running (does not release). */
+typedef struct dsv_job dsv_job;
+int dsv_verify_single_mont_cols_submit(const dsv_column *cols /*[4]*/, size_t n, uint8_t *ok, dsv_job **job);
+int dsv_verify_double_mont_cols_submit(const dsv_column *cols /*[6]*/, size_t n, uint8_t *ok, dsv_job **job);
+int dsv_verify_vargen_mont_cols_submit(const dsv_column *cols /*[5]*/, size_t n, uint8_t *ok, dsv_job **job);
+int dsv_job_wait(dsv_job *job);
+int dsv_job_done(const dsv_job *job);
+int dsv_max_in_flight(void);
 /* ... dense arrays (structure of arrays), this thread's device */
 int dsv_verify_single_mont(const uint8_t *u, const uint8_t *R_uvz, const uint8_t *PK_uvz,
                            const uint8_t *m, size_t n, uint8_t *ok);

@@ -41,6 +41,9 @@ SYMBOLS = [
     "dsv_verify_single_mont_cols", "dsv_verify_double_mont_cols", "dsv_verify_vargen_mont_cols",
     "dsv_mont_workspace_bytes", "dsv_verify_single_mont_dev", "dsv_verify_double_mont_dev",
     "dsv_verify_vargen_mont_dev", "dsv_set_host_threads",
+    # r05: asynchronous form of the column entry points (two batches in flight per device)
+    "dsv_verify_single_mont_cols_submit", "dsv_verify_double_mont_cols_submit",
+    "dsv_verify_vargen_mont_cols_submit", "dsv_job_wait", "dsv_job_done", "dsv_max_in_flight",
 ]
 _SIZE_T_FUNCS = ("dsv_workspace_bytes", "dsv_mixed_workspace_bytes", "dsv_split_scratch_bytes",
                  "dsv_ext_workspace_bytes", "dsv_wire_workspace_bytes", "dsv_mont_workspace_bytes")

@@ -31,6 +31,7 @@
 // 33 B of c/valid between the two kernels and the window-table workspace: the path is VALU-bound
 // by orders of magnitude, not HBM-bound.
 #include <hip/hip_runtime.h>
+#include <immintrin.h>
 
 #include <atomic>
 #include <chrono>
@@ -151,7 +152,8 @@ class CopyPool {
   bool quit_ = false;
 };
 
-constexpr int kPipeSlots = 3;
+constexpr int kPipeSlots = 8;   // chunks in flight per host call: at most (Context::pipe_slots are used)
+constexpr int kPipes = 2;       // host calls in flight per device (each owns a Pipe)
 constexpr int kMaxDevices = 16;
 constexpr int kSplitLanes = 8;
 
@@ -176,6 +178,26 @@ struct SplitLane {
   hipEvent_t fork = nullptr, join[2] = {nullptr, nullptr}, side_join = nullptr;
 };
 
+// One chunk in flight of a host call: staging on both sides, the events that chain its stages.
+struct PipeSlot {
+  hipEvent_t ev_in = nullptr;            // the chunk's transfer to the device is done
+  hipEvent_t ev_pre = nullptr;           // its whole-chunk preprocessing is done
+  hipEvent_t ev_lane[2] = {nullptr, nullptr};  // its sub-batches on compute lane k are done
+  hipEvent_t ev_done = nullptr;          // its verdicts are in the pinned block
+  uint8_t* prep = nullptr;               // what the preprocessing produced
+  size_t prep_bytes = 0;
+  uint8_t* stage = nullptr;              // device side: the input block, then the verdicts
+  size_t bytes = 0;
+  uint8_t* host = nullptr;               // pinned host side (inputs, then verdicts)
+  size_t host_bytes = 0;
+};
+// What ONE host call in flight owns.
+struct Pipe {
+  PipeSlot slot[kPipeSlots];
+  CopyPool copiers;
+  bool busy = false;
+};
+
 // Everything the library owns on one GPU.  One Context per device ordinal; several devices can be
 // initialised in one process (dsv_init(d) for each) and used concurrently from different host
 // threads: no state is shared between contexts.
@@ -196,23 +218,34 @@ struct Context {
   // sub-batch lanes of the device-pointer entry points (run_split)
   std::mutex lane_mu;
   SplitLane lanes[kSplitLanes];
-  // pipeline of the host verify entry points (run_pipelined): kPipeSlots chunks in flight, each with
-  // its own device and pinned host staging; FOUR streams in all — one for the transfers in, two
-  // compute lanes that every chunk's sub-batches alternate between, one for the verdicts out
-  hipStream_t pipe_in = nullptr, pipe_out = nullptr, pipe_lane[2] = {nullptr, nullptr};
+  // Pipeline of the host verify entry points (run_pipelined).  SIX streams per device, shared by every
+  // call: one for the transfers in, one for whole-chunk preprocessing, two compute lanes that all
+  // sub-batches of all calls alternate between, one for the verdicts out, one for small one-chunk
+  // calls.  What a call owns while it runs is a Pipe: kPipeSlots chunks in flight, each with its own
+  // device and pinned host staging, its events, and the call's copy threads.  kPipes calls can be in
+  // flight per device (r05; r01 - r04 held `mu` for the whole call): the second call's ramp — small
+  // first chunks, an idle GPU waiting for the first transfer — runs under the first call's tail.
+  std::mutex pipe_mu;                     // pipe acquisition (FIFO by ticket), shutdown
+  std::condition_variable pipe_cv;
+  uint64_t pipe_ticket_next = 0, pipe_ticket_serving = 0;
+  uint64_t turn_next = 0, turn_serving = 0;  // whose turn it is to enqueue compute (TurnTicket)
+  int pipes_busy = 0;
+  Pipe pipes[kPipes];
+  std::mutex enq_mu;                      // one chunk's enqueue onto the shared streams is atomic: the
+                                          // lanes' work areas below belong to the sub-batch being enqueued
+  bool pipe_made = false;                 // streams + events exist
+  bool pipe_failed = false;               // ... could not be created (reported on every later call)
+  hipStream_t pipe_in = nullptr, pipe_out = nullptr, pipe_lane[2] = {nullptr, nullptr}, pipe_pre = nullptr;
   hipStream_t pipe_small = nullptr;       // a call of one small chunk runs on this stream alone
-  hipEvent_t pipe_ev_pre[kPipeSlots] = {};  // a chunk's whole-chunk preprocessing (on one of the lanes) is done
-  uint8_t* pipe_prep[kPipeSlots] = {};      // per slot: what that preprocessing produced
-  size_t pipe_prep_bytes[kPipeSlots] = {};
-  hipEvent_t pipe_ev_in[kPipeSlots] = {}, pipe_ev_lane[kPipeSlots][2] = {}, pipe_ev_done[kPipeSlots] = {};
-  uint8_t* pipe_stage[kPipeSlots] = {};   // device side of a slot: the input block, then the verdicts
-  size_t pipe_bytes[kPipeSlots] = {};
-  uint8_t* pipe_host[kPipeSlots] = {};    // pinned host side of a slot (inputs, then verdicts)
-  size_t pipe_host_bytes[kPipeSlots] = {};
-  uint8_t* pipe_work[2] = {};             // per compute lane: verify workspace + scratch of one sub-batch
-  size_t pipe_work_bytes[2] = {};
+  uint8_t* pipe_work[3] = {};             // per compute lane (+ [2]: pipe_small): verify workspace + scratch of one sub-batch
+  size_t pipe_work_bytes[3] = {};
   uint64_t pipe_parts = 0;                // sub-batches enqueued so far: part p runs on lane p & 1
-  CopyPool copiers;
+  bool prep_stream = true;                // DSV_PIPE_PREP_STREAM=0: whole-chunk preprocessing on a compute lane (r04)
+  size_t pipe_chunk = (size_t)1 << 18, pipe_first_chunk = (size_t)1 << 15;  // DSV_PIPE_CHUNK_LOG2 / DSV_PIPE_FIRST_LOG2
+  double pipe_growth = 2.0;               // DSV_PIPE_GROWTH (percent): chunk k + 1 = growth x chunk k up to pipe_chunk
+  int pipe_slots = 3;                     // DSV_PIPE_SLOTS: chunks in flight per call (<= kPipeSlots)
+  int pipe_plan[16] = {};                 // DSV_PIPE_PLAN="15,15,16,...": log2 chunk sizes of a call that finds the GPU idle
+  int pipe_plan_len = 0;
 };
 Context g_ctx[kMaxDevices];
 std::mutex g_init_mu;               // dsv_init / dsv_shutdown
@@ -256,66 +289,141 @@ int ensure_stage(Context& ctx, size_t bytes) {
   return DSV_OK;
 }
 
+void destroy_pipe_streams(Context& ctx) {
+  for (auto& pipe : ctx.pipes)
+    for (auto& sl : pipe.slot) {
+      hipEvent_t* evs[5] = {&sl.ev_in, &sl.ev_pre, &sl.ev_lane[0], &sl.ev_lane[1], &sl.ev_done};
+      for (hipEvent_t* e : evs) {
+        if (*e) (void)hipEventDestroy(*e);
+        *e = nullptr;
+      }
+    }
+  hipStream_t* streams[6] = {&ctx.pipe_lane[0], &ctx.pipe_lane[1], &ctx.pipe_pre, &ctx.pipe_in, &ctx.pipe_out, &ctx.pipe_small};
+  for (hipStream_t* st : streams) {
+    if (*st) (void)hipStreamDestroy(*st);
+    *st = nullptr;
+  }
+  ctx.pipe_made = false;
+}
+// (called under enq_mu)
 int ensure_pipe_streams(Context& ctx) {
-  if (ctx.pipe_ev_done[kPipeSlots - 1]) return DSV_OK;  // (the last thing created below)
-  if (ctx.pipe_lane[0]) return fail(DSV_ERR_HIP, "the host pipeline's streams could not be created earlier");
+  if (ctx.pipe_made) return DSV_OK;
   // The two compute lanes MUST sit on different hardware queues: ROCm multiplexes streams onto
   // GPU_MAX_HW_QUEUES (default 4) hardware queues per priority level, and two streams that land on one
   // queue run strictly one after the other — measured: both lanes on queue 4, no overlap at all, every
   // host path 10 - 20 % slower (profiles/r04/host_pipeline_streams.txt).  Which queue a stream gets
-  // depends on every stream the process created before; the priority level does not: streams of
-  // different priorities never share a queue.  So lane 0 is created at the highest priority, lane 1
-  // at the middle one, the two transfer streams (no kernels but a 2 us verdict copy) at the lowest.
-  // The lanes carry alternating sub-batches of equal work, so the priority only decides whose waves
-  // are dispatched first.
-  int least = 0, greatest = 0;
-  HIP_TRY(hipDeviceGetStreamPriorityRange(&least, &greatest));
-  HIP_TRY(hipStreamCreateWithPriority(&ctx.pipe_lane[0], hipStreamNonBlocking, greatest));
-  HIP_TRY(hipStreamCreateWithPriority(&ctx.pipe_lane[1], hipStreamNonBlocking, (least + greatest) / 2));
-  HIP_TRY(hipStreamCreateWithPriority(&ctx.pipe_in, hipStreamNonBlocking, least));
-  HIP_TRY(hipStreamCreateWithPriority(&ctx.pipe_out, hipStreamNonBlocking, least));
-  HIP_TRY(hipStreamCreateWithFlags(&ctx.pipe_small, hipStreamNonBlocking));
-  for (int sl = 0; sl < kPipeSlots; sl++) {
-    HIP_TRY(hipEventCreateWithFlags(&ctx.pipe_ev_in[sl], hipEventDisableTiming));
-    HIP_TRY(hipEventCreateWithFlags(&ctx.pipe_ev_pre[sl], hipEventDisableTiming));
-    HIP_TRY(hipEventCreateWithFlags(&ctx.pipe_ev_done[sl], hipEventDisableTiming));
-    for (int k = 0; k < 2; k++) HIP_TRY(hipEventCreateWithFlags(&ctx.pipe_ev_lane[sl][k], hipEventDisableTiming));
+  // depends on every stream the process created before at that level (each level hands out its first
+  // four queues one per stream, then shares them); the level itself does not: streams of different
+  // priorities never share a queue.  So lane 0 is created at the highest priority, lane 1 at the middle
+  // one, the two transfer streams (no kernels but a 2 us verdict copy) at the lowest.  The lanes carry
+  // alternating sub-batches of equal work, so the priority only decides whose waves are dispatched first.
+  // r05: the preprocessing stream (whole-chunk normalisation / limb conversion: few waves, one
+  // inversion chain each) also sits at the HIGHEST level — r04 tried it at the lowest, where it came to
+  // share a queue with the verdict copies and waited behind them (host_pipeline_streams.txt 6.).  Only
+  // the library creates streams at that level (lane 0 here, one sub-batch stream per caller stream of
+  // the device-pointer entry points), so it gets a queue of its own unless more than two caller
+  // streams are in use; its chunk is needed a whole chunk (~3 ms) later, so its waves slot in at the
+  // lanes' next kernel boundary and neither lane runs the latency-bound kernel in its own order.
+  const int rc = [&]() -> int {
+    int least = 0, greatest = 0;
+    HIP_TRY(hipDeviceGetStreamPriorityRange(&least, &greatest));
+    HIP_TRY(hipStreamCreateWithPriority(&ctx.pipe_lane[0], hipStreamNonBlocking, greatest));
+    HIP_TRY(hipStreamCreateWithPriority(&ctx.pipe_pre, hipStreamNonBlocking, greatest));
+    HIP_TRY(hipStreamCreateWithPriority(&ctx.pipe_lane[1], hipStreamNonBlocking, (least + greatest) / 2));
+    HIP_TRY(hipStreamCreateWithPriority(&ctx.pipe_in, hipStreamNonBlocking, least));
+    HIP_TRY(hipStreamCreateWithPriority(&ctx.pipe_out, hipStreamNonBlocking, least));
+    HIP_TRY(hipStreamCreateWithFlags(&ctx.pipe_small, hipStreamNonBlocking));
+    for (auto& pipe : ctx.pipes)
+      for (auto& sl : pipe.slot) {
+        hipEvent_t* evs[5] = {&sl.ev_in, &sl.ev_pre, &sl.ev_lane[0], &sl.ev_lane[1], &sl.ev_done};
+        for (hipEvent_t* e : evs) HIP_TRY(hipEventCreateWithFlags(e, hipEventDisableTiming));
+      }
+    return DSV_OK;
+  }();
+  if (rc != DSV_OK) {  // nothing half-made stays behind: a later call starts from scratch
+    const std::string why = g_err;
+    destroy_pipe_streams(ctx);
+    g_err = why;
+    return rc;
   }
+  ctx.pipe_made = true;
   return DSV_OK;
 }
+// (called under enq_mu: no sub-batch is being enqueued; work already in flight on the area is waited
+//  for by hipFree itself, which synchronises the device)
 int ensure_pipe_work(Context& ctx, int lane, size_t bytes) {
   if (ctx.pipe_work_bytes[lane] >= bytes) return DSV_OK;
-  if (ctx.pipe_work[lane]) HIP_TRY(hipFree(ctx.pipe_work[lane]));
+  if (ctx.pipe_work[lane]) {
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipFree(ctx.pipe_work[lane]));
+  }
   ctx.pipe_work[lane] = nullptr;
   ctx.pipe_work_bytes[lane] = 0;
   HIP_TRY(hipMalloc(&ctx.pipe_work[lane], bytes));
   ctx.pipe_work_bytes[lane] = bytes;
   return DSV_OK;
 }
-int ensure_pipe_slot(Context& ctx, int slot, size_t dev_bytes, size_t host_bytes, size_t prep_bytes) {
-  if (ctx.pipe_prep_bytes[slot] < prep_bytes) {
-    if (ctx.pipe_prep[slot]) HIP_TRY(hipFree(ctx.pipe_prep[slot]));
-    ctx.pipe_prep[slot] = nullptr;
-    ctx.pipe_prep_bytes[slot] = 0;
-    HIP_TRY(hipMalloc(&ctx.pipe_prep[slot], prep_bytes));
-    ctx.pipe_prep_bytes[slot] = prep_bytes;
+int ensure_pipe_slot(PipeSlot& sl, size_t dev_bytes, size_t host_bytes, size_t prep_bytes) {
+  if (sl.prep_bytes < prep_bytes) {
+    if (sl.prep) HIP_TRY(hipFree(sl.prep));
+    sl.prep = nullptr;
+    sl.prep_bytes = 0;
+    HIP_TRY(hipMalloc(&sl.prep, prep_bytes));
+    sl.prep_bytes = prep_bytes;
   }
-  if (ctx.pipe_bytes[slot] < dev_bytes) {
-    if (ctx.pipe_stage[slot]) HIP_TRY(hipFree(ctx.pipe_stage[slot]));
-    ctx.pipe_stage[slot] = nullptr;
-    ctx.pipe_bytes[slot] = 0;
-    HIP_TRY(hipMalloc(&ctx.pipe_stage[slot], dev_bytes));
-    ctx.pipe_bytes[slot] = dev_bytes;
+  if (sl.bytes < dev_bytes) {
+    if (sl.stage) HIP_TRY(hipFree(sl.stage));
+    sl.stage = nullptr;
+    sl.bytes = 0;
+    HIP_TRY(hipMalloc(&sl.stage, dev_bytes));
+    sl.bytes = dev_bytes;
   }
-  if (ctx.pipe_host_bytes[slot] < host_bytes) {
-    if (ctx.pipe_host[slot]) HIP_TRY(hipHostFree(ctx.pipe_host[slot]));
-    ctx.pipe_host[slot] = nullptr;
-    ctx.pipe_host_bytes[slot] = 0;
-    HIP_TRY(hipHostMalloc(&ctx.pipe_host[slot], host_bytes, hipHostMallocDefault));
-    ctx.pipe_host_bytes[slot] = host_bytes;
+  if (sl.host_bytes < host_bytes) {
+    if (sl.host) HIP_TRY(hipHostFree(sl.host));
+    sl.host = nullptr;
+    sl.host_bytes = 0;
+    HIP_TRY(hipHostMalloc(&sl.host, host_bytes, hipHostMallocDefault));
+    sl.host_bytes = host_bytes;
   }
   return DSV_OK;
 }
+// A host call's lease on one of the device's pipes: FIFO by ticket, blocks while kPipes calls are in
+// flight; released (and the next waiter woken) on scope exit.
+struct PipeLease {
+  Context& ctx;
+  Pipe* pipe = nullptr;
+  bool alone = true;  // no other call held a pipe of this device when this one got its own
+  // want_turn (may be null): the call's place in the order in which calls enqueue compute, taken in
+  // the same critical section, so pipes and turns are handed out in one order
+  template <class Turn>
+  PipeLease(Context& c, Turn* want_turn) : ctx(c) {
+    std::unique_lock<std::mutex> lk(ctx.pipe_mu);
+    const uint64_t mine = ctx.pipe_ticket_next++;
+    ctx.pipe_cv.wait(lk, [&] { return ctx.pipe_ticket_serving == mine && ctx.pipes_busy < kPipes; });
+    ctx.pipe_ticket_serving++;
+    if (want_turn) want_turn->take(ctx.turn_next++);
+    for (auto& p : ctx.pipes)
+      if (!p.busy) {
+        pipe = &p;
+        break;
+      }
+    pipe->busy = true;
+    alone = ctx.pipes_busy == 0;
+    ctx.pipes_busy++;
+    lk.unlock();
+    ctx.pipe_cv.notify_all();  // the next ticket may find the other pipe free
+  }
+  ~PipeLease() {
+    {
+      std::lock_guard<std::mutex> lk(ctx.pipe_mu);
+      pipe->busy = false;
+      ctx.pipes_busy--;
+    }
+    ctx.pipe_cv.notify_all();
+  }
+  PipeLease(const PipeLease&) = delete;
+  PipeLease& operator=(const PipeLease&) = delete;
+};
 
 inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
@@ -521,44 +629,30 @@ void release_context(Context& ctx) {
     (void)hipEventDestroy(l.fork);
     l = SplitLane();
   }
-  for (int k = 0; k < kPipeSlots; k++) {
-    if (ctx.pipe_stage[k]) (void)hipFree(ctx.pipe_stage[k]);
-    if (ctx.pipe_host[k]) (void)hipHostFree(ctx.pipe_host[k]);
-    ctx.pipe_stage[k] = nullptr;
-    ctx.pipe_host[k] = nullptr;
-    ctx.pipe_bytes[k] = 0;
-    ctx.pipe_host_bytes[k] = 0;
-    if (ctx.pipe_ev_in[k]) (void)hipEventDestroy(ctx.pipe_ev_in[k]);
-    if (ctx.pipe_ev_pre[k]) (void)hipEventDestroy(ctx.pipe_ev_pre[k]);
-    if (ctx.pipe_ev_done[k]) (void)hipEventDestroy(ctx.pipe_ev_done[k]);
-    ctx.pipe_ev_in[k] = ctx.pipe_ev_pre[k] = ctx.pipe_ev_done[k] = nullptr;
-    if (ctx.pipe_prep[k]) (void)hipFree(ctx.pipe_prep[k]);
-    ctx.pipe_prep[k] = nullptr;
-    ctx.pipe_prep_bytes[k] = 0;
-    for (int j = 0; j < 2; j++) {
-      if (ctx.pipe_ev_lane[k][j]) (void)hipEventDestroy(ctx.pipe_ev_lane[k][j]);
-      ctx.pipe_ev_lane[k][j] = nullptr;
+  for (auto& pipe : ctx.pipes) {
+    for (auto& sl : pipe.slot) {
+      if (sl.stage) (void)hipFree(sl.stage);
+      if (sl.host) (void)hipHostFree(sl.host);
+      if (sl.prep) (void)hipFree(sl.prep);
+      sl.stage = sl.host = sl.prep = nullptr;
+      sl.bytes = sl.host_bytes = sl.prep_bytes = 0;
     }
+    pipe.copiers.stop();
   }
-  for (int k = 0; k < 2; k++) {
+  for (int k = 0; k < 3; k++) {
     if (ctx.pipe_work[k]) (void)hipFree(ctx.pipe_work[k]);
     ctx.pipe_work[k] = nullptr;
     ctx.pipe_work_bytes[k] = 0;
-    if (ctx.pipe_lane[k]) (void)hipStreamDestroy(ctx.pipe_lane[k]);
-    ctx.pipe_lane[k] = nullptr;
   }
-  if (ctx.pipe_in) (void)hipStreamDestroy(ctx.pipe_in);
-  if (ctx.pipe_out) (void)hipStreamDestroy(ctx.pipe_out);
-  if (ctx.pipe_small) (void)hipStreamDestroy(ctx.pipe_small);
-  ctx.pipe_in = ctx.pipe_out = ctx.pipe_small = nullptr;
-  ctx.copiers.stop();
+  destroy_pipe_streams(ctx);
+  ctx.pipe_failed = false;
 }
 
 }  // namespace
 
 extern "C" {
 
-const char* dsv_version(void) { return "dsv 0.4.0 (gfx950, fe29)"; }
+const char* dsv_version(void) { return "dsv 0.5.0 (gfx950, fe29)"; }
 const char* dsv_last_error(void) { return g_err.c_str(); }
 
 int dsv_device_count(void) {
@@ -607,6 +701,34 @@ int dsv_init(int device) {
   ctx.small_overlap = !(sov && strcmp(sov, "0") == 0);
   const char* fused = getenv("DSV_DOUBLE_FUSED");
   ctx.fuse_double = !(fused && strcmp(fused, "0") == 0);
+  const char* pre = getenv("DSV_PIPE_PREP_STREAM");
+  ctx.prep_stream = !(pre && strcmp(pre, "0") == 0);
+  auto log2_env = [](const char* name, int lo, int hi, int dflt) {
+    const char* e = getenv(name);
+    const int v = e ? atoi(e) : dflt;
+    return (size_t)1 << (v < lo ? lo : (v > hi ? hi : v));
+  };
+  ctx.pipe_chunk = log2_env("DSV_PIPE_CHUNK_LOG2", 16, 20, 18);        // chunk size of the host pipeline
+  ctx.pipe_first_chunk = log2_env("DSV_PIPE_FIRST_LOG2", 12, 18, 15);  // ... of a call's first chunk (doubling from there)
+  if (ctx.pipe_first_chunk > ctx.pipe_chunk) ctx.pipe_first_chunk = ctx.pipe_chunk;
+  ctx.pipe_plan_len = 0;
+  if (const char* e = getenv("DSV_PIPE_PLAN")) {
+    for (const char* q = e; *q && ctx.pipe_plan_len < 16;) {
+      char* end = nullptr;
+      const long v = strtol(q, &end, 10);
+      if (end == q) break;
+      ctx.pipe_plan[ctx.pipe_plan_len++] = v < 12 ? 12 : (v > 20 ? 20 : (int)v);
+      q = *end == ',' ? end + 1 : end;
+    }
+  }
+  if (const char* e = getenv("DSV_PIPE_SLOTS")) {
+    const int v = atoi(e);
+    ctx.pipe_slots = v < 2 ? 2 : (v > kPipeSlots ? kPipeSlots : v);
+  }
+  if (const char* e = getenv("DSV_PIPE_GROWTH")) {
+    const int pct = atoi(e);
+    ctx.pipe_growth = (pct < 110 ? 110 : (pct > 400 ? 400 : pct)) / 100.0;
+  }
   ctx.ready.store(true, std::memory_order_release);
   int none = -1;
   g_primary.compare_exchange_strong(none, device);
@@ -652,7 +774,12 @@ int dsv_shutdown_device(int device) {
   (void)hipGetDevice(&prev);
   ctx.ready.store(false);  // new calls are refused from here on
   {
-    std::lock_guard<std::mutex> hold(ctx.mu);  // a host call in flight finishes first
+    // host calls in flight finish first: the pipelined ones hold a pipe, the small ones `mu`
+    std::unique_lock<std::mutex> pl(ctx.pipe_mu);
+    ctx.pipe_cv.wait(pl, [&] { return ctx.pipes_busy == 0 && ctx.pipe_ticket_next == ctx.pipe_ticket_serving; });
+    pl.unlock();
+    std::lock_guard<std::mutex> hold(ctx.mu);
+    std::lock_guard<std::mutex> enq(ctx.enq_mu);
     release_context(ctx);
   }
   if (prev >= 0) (void)hipSetDevice(prev);
@@ -1025,7 +1152,7 @@ struct HostIn {
 };
 // `count` items of `bytes` bytes, `stride` apart, packed densely into dst (the typed objects of a
 // language binding: one field out of every struct)
-inline void copy_strided(uint8_t* dst, const uint8_t* src, size_t stride, size_t bytes, size_t count) {
+inline void copy_strided_plain(uint8_t* dst, const uint8_t* src, size_t stride, size_t bytes, size_t count) {
   switch (bytes) {  // constant sizes: the copies are inlined vector moves
     case 32:
       for (size_t i = 0; i < count; i++) memcpy(dst + 32 * i, src + stride * i, 32);
@@ -1037,15 +1164,47 @@ inline void copy_strided(uint8_t* dst, const uint8_t* src, size_t stride, size_t
       for (size_t i = 0; i < count; i++) memcpy(dst + bytes * i, src + stride * i, bytes);
   }
 }
+// The same with non-temporal stores (dst 32-byte aligned, bytes a multiple of 32): the pinned staging
+// block is written once and read by the DMA engine only — ordinary stores first READ every line they
+// are about to overwrite (read-for-ownership: 40 % of the gather's memory traffic) and push the
+// caller's objects out of the cache.
+__attribute__((target("avx2"))) inline void copy_strided_nt(uint8_t* dst, const uint8_t* src, size_t stride,
+                                                           size_t bytes, size_t count) {
+  if (bytes == 32) {
+    for (size_t i = 0; i < count; i++)
+      _mm256_stream_si256((__m256i*)(dst + 32 * i), _mm256_loadu_si256((const __m256i*)(src + stride * i)));
+  } else if (bytes == 96) {
+    for (size_t i = 0; i < count; i++) {
+      const __m256i a = _mm256_loadu_si256((const __m256i*)(src + stride * i));
+      const __m256i b = _mm256_loadu_si256((const __m256i*)(src + stride * i + 32));
+      const __m256i c = _mm256_loadu_si256((const __m256i*)(src + stride * i + 64));
+      _mm256_stream_si256((__m256i*)(dst + 96 * i), a);
+      _mm256_stream_si256((__m256i*)(dst + 96 * i + 32), b);
+      _mm256_stream_si256((__m256i*)(dst + 96 * i + 64), c);
+    }
+  } else {
+    for (size_t i = 0; i < count; i++)
+      for (size_t o = 0; o < bytes; o += 32)
+        _mm256_stream_si256((__m256i*)(dst + bytes * i + o), _mm256_loadu_si256((const __m256i*)(src + stride * i + o)));
+  }
+  _mm_sfence();  // the stores are globally visible before the transfer is enqueued
+}
+inline void copy_strided(uint8_t* dst, const uint8_t* src, size_t stride, size_t bytes, size_t count) {
+  static const bool nt = [] {
+    const char* e = getenv("DSV_GATHER_NT");  // 0: ordinary stores (A/B)
+    return !(e && strcmp(e, "0") == 0) && __builtin_cpu_supports("avx2");
+  }();
+  if (nt && (bytes & 31) == 0 && ((uintptr_t)dst & 31) == 0) copy_strided_nt(dst, src, stride, bytes, count);
+  else copy_strided_plain(dst, src, stride, bytes, count);
+}
 // Chunk sizes double from 2^15 up to 2^18 items: the GPU starts after ~0.3 ms of staging, every
 // gather runs under the previous (half as long) chunk's kernels, and from the fourth chunk on the
 // transfers are long enough to run near the link rate (r03, same box, 2^20 items: chunks
 // capped at 2^17 as in r02: 68.0 M/s affine / 59.6 projective; 2^18: 72.4 / 63.6; two, three or
 // four slots: equal; profiles/r03/host_paths.txt; r04: first chunk 2^16 / 2^17, a merged last chunk:
 // equal, profiles/r04/ab_host_chunk_policy.txt)
-constexpr size_t kPipeChunk = (size_t)1 << 18;
-constexpr size_t kPipeFirstChunk = (size_t)1 << 15;
 
+constexpr size_t kPipeSmallCall = (size_t)1 << 16;  // up to here a call is ONE chunk on one stream
 std::atomic<int> g_host_threads{0};  // dsv_set_host_threads; 0 = $DSV_HOST_THREADS, else 4
 inline int clamp_host_threads(int v) {
   const int hw = (int)std::thread::hardware_concurrency();
@@ -1079,54 +1238,152 @@ struct NoPrep {};
 //   part(staged, offset, count, dok, ws, extra, stream): one sub-batch; `extra`: scratch of
 //     extra_item_bytes per item behind the lane's verify workspace (the wire path decompresses per
 //     sub-batch: full-occupancy kernels, no reason to serialise a chunk's worth on one lane).
+// The chunks of one call: sizes double from the first-chunk size up to the pipeline chunk (the GPU
+// starts after ~0.3 ms of staging and every gather runs under the previous, half as long, chunk's
+// kernels); a remainder of at most one sub-batch is merged into the last chunk instead of trailing
+// behind it as a part of its own on ONE lane (r05: the lane that got it finished ~1 ms after the
+// other, profiles/r05/host_timeline_e2e.txt).
+inline std::vector<size_t> plan_chunks(const Context& ctx, size_t n, bool ramp) {
+  std::vector<size_t> out;
+  if (n <= kPipeSmallCall) {  // one small call: a single chunk
+    out.push_back(n);
+    return out;
+  }
+  size_t left = n;
+  double want_f = (double)ctx.pipe_first_chunk;
+  for (size_t c = 0; left; c++) {
+    // (a call that starts behind another one's kernels has no idle GPU to feed quickly: full chunks at once)
+    size_t want = ramp ? align_up((size_t)want_f, 4096) : ctx.pipe_chunk;
+    if (ramp && ctx.pipe_plan_len)  // DSV_PIPE_PLAN: explicit sizes, the last one repeats
+      want = (size_t)1 << ctx.pipe_plan[c < (size_t)ctx.pipe_plan_len ? c : (size_t)ctx.pipe_plan_len - 1];
+    if (want > ctx.pipe_chunk) want = ctx.pipe_chunk;
+    if (left <= want + kSplitItems / 2 || left <= want + want / 4) want = left;  // the rest rides along
+    out.push_back(want);
+    left -= want;
+    want_f *= ctx.pipe_growth;
+  }
+  return out;
+}
+// A chunk is cut into sub-batches of at most kSplitItems items — an EVEN number of equal ones once it
+// holds more than one, so that both compute lanes get the same work from every chunk and finish the
+// call together.
+inline size_t plan_parts(size_t cnt, bool one_part, size_t& part_items) {
+  if (one_part || cnt <= kSplitItems) {
+    part_items = cnt;
+    return 1;
+  }
+  size_t parts = (cnt + kSplitItems - 1) / kSplitItems;
+  parts += parts & 1;
+  part_items = align_up((cnt + parts - 1) / parts, 256);
+  return (cnt + part_items - 1) / part_items;
+}
+// Whose turn it is to enqueue compute on the device's lanes.  Calls in flight take turns in the order
+// they acquired their pipes: the holder enqueues ALL its chunks, then passes the turn on; the next
+// call meanwhile gathers and transfers its first chunks (up to its kPipeSlots slots) and enqueues them
+// the moment the turn arrives — behind the holder's last chunks in the lanes' queues, so its ramp runs
+// under the holder's tail.  (Without turns two calls in flight share the lanes chunk by chunk, advance
+// in lock-step and finish together: both ramps and both tails coincide — measured, r05.)
+struct TurnTicket {
+  Context& ctx;
+  uint64_t mine = 0;
+  bool taken = false, held = false, released = false;
+  explicit TurnTicket(Context& c) : ctx(c) {}
+  void take(uint64_t ticket) {
+    mine = ticket;
+    taken = true;
+  }
+  bool try_acquire() {
+    if (held) return true;
+    std::lock_guard<std::mutex> lk(ctx.pipe_mu);
+    held = ctx.turn_serving == mine;
+    return held;
+  }
+  void acquire() {
+    if (held) return;
+    std::unique_lock<std::mutex> lk(ctx.pipe_mu);
+    ctx.pipe_cv.wait(lk, [&] { return ctx.turn_serving == mine; });
+    held = true;
+  }
+  void release() {  // (also on error paths: the turn must reach the calls behind this one)
+    if (!taken || released) return;
+    acquire();
+    {
+      std::lock_guard<std::mutex> lk(ctx.pipe_mu);
+      ctx.turn_serving++;
+    }
+    released = true;
+    ctx.pipe_cv.notify_all();
+  }
+  ~TurnTicket() { release(); }
+};
+
 template <size_t NIN, class Prep, class Part>
 int run_pipelined(Context& ctx, const HostIn (&ins)[NIN], uint8_t* ok, size_t n, size_t prep_item_bytes,
                   size_t extra_item_bytes, Prep prep, Part part) {
   constexpr bool has_prep = !std::is_same<Prep, NoPrep>::value;
-  std::lock_guard<std::mutex> lk(ctx.mu);
+  const bool small = n <= kPipeSmallCall;  // transfer, kernels and verdicts on ONE stream, a work area of its own
+  TurnTicket turn(ctx);                    // (on an error path its destructor still passes the turn on, in order)
+  PipeLease lease(ctx, small ? nullptr : &turn);  // blocks while kPipes calls are in flight on this device
+  Pipe& pipe = *lease.pipe;
   if (!ctx.ready.load(std::memory_order_acquire))
     return fail(DSV_ERR_NOT_INITIALIZED, "device %d was shut down", ctx.device);
   DSV_ON_DEVICE(ctx);
-  if (int r = ensure_pipe_streams(ctx)) return r;
-  const size_t chunk = n < kPipeChunk ? n : kPipeChunk;
-  // slot capacity: offsets of a FULL chunk (a shorter chunk packs its arrays tighter, see below)
+  // nobody else in flight: the GPU is idle, so start small and grow; behind another call (it holds its
+  // pipe until its last verdicts are out): full chunks at once
+  const std::vector<size_t> chunks = plan_chunks(ctx, n, small || lease.alone);
+  const size_t nchunks = chunks.size();
+  size_t chunk = 0;  // the largest chunk: slot capacity
+  for (size_t c : chunks) chunk = c > chunk ? c : chunk;
+  // slot capacity: offsets of the LARGEST chunk (a shorter chunk packs its arrays tighter, see below)
   size_t cap_off = 0;
   for (size_t k = 0; k < NIN; k++) cap_off += align_up(chunk * ins[k].bytes, 256);
   const size_t host_need = cap_off + align_up(chunk, 256);
-  auto chunk_len = [&](size_t c, size_t left) {
-    size_t want = c < 4 ? kPipeFirstChunk << c : kPipeChunk;
-    if (want > kPipeChunk) want = kPipeChunk;
-    if (n <= 2 * kPipeFirstChunk) want = n;  // one small call: a single chunk
-    return left < want ? left : want;
-  };
-  size_t nchunks = 0;
-  for (size_t left = n; left; nchunks++) left -= chunk_len(nchunks, left);
-  const int nslots = nchunks < (size_t)kPipeSlots ? (int)nchunks : kPipeSlots;
+  const int kSlots = ctx.pipe_slots;
+  const int nslots = nchunks < (size_t)kSlots ? (int)nchunks : kSlots;
   const size_t prep_need = has_prep ? chunk * prep_item_bytes + 16 * 256 : 0;
-  for (int sl = 0; sl < nslots; sl++)
-    if (int r = ensure_pipe_slot(ctx, sl, host_need, host_need, prep_need)) return r;
-  // a sub-batch: kSplitItems items (run_split's unit), or the whole chunk when the split is off or the
-  // call is one small chunk; each compute lane owns the workspace + scratch of one sub-batch
-  const bool one_part = !ctx.split || nchunks == 1;
+  // a sub-batch: at most kSplitItems items (run_split's unit), or the whole chunk when the split is off
+  // or the call is one small chunk; each compute lane owns the workspace + scratch of one sub-batch
+  const bool one_part = !ctx.split || small;
   const size_t part_max = one_part ? chunk : (chunk < kSplitItems ? chunk : kSplitItems);
   const size_t ws_bytes = align_up(dsv_workspace_bytes(part_max), 256);
   const size_t work_need = ws_bytes + part_max * extra_item_bytes + 16 * 256;
-  const int nlanes = one_part && nchunks == 1 ? 1 : 2;
-  for (int k = 0; k < nlanes; k++)
-    if (int r = ensure_pipe_work(ctx, k, work_need)) return r;
-  size_t slot_first[kPipeSlots] = {}, slot_cnt[kPipeSlots] = {}, slot_ok_off[kPipeSlots] = {};
+  {
+    std::lock_guard<std::mutex> enq(ctx.enq_mu);
+    if (int r = ensure_pipe_streams(ctx)) return r;
+    if (small) {
+      if (int r = ensure_pipe_work(ctx, 2, work_need)) return r;
+    } else {
+      for (int k = 0; k < 2; k++)
+        if (int r = ensure_pipe_work(ctx, k, work_need)) return r;
+    }
+  }
+  for (int sl = 0; sl < nslots; sl++)
+    if (int r = ensure_pipe_slot(pipe.slot[sl], host_need, host_need, prep_need)) return r;
+  // whole-chunk preprocessing on the stream of its own, or (r04, DSV_PIPE_PREP_STREAM=0) on the lane
+  // that takes the chunk's first sub-batch
+  const bool pre_stream = has_prep && !small && ctx.prep_stream;
+  // what a slot currently holds: a chunk that is staged (gathered + on its way to the device), then
+  // enqueued (its kernels and verdict copy are in the streams), then drained (verdicts delivered)
+  struct Held {
+    size_t first = 0, cnt = 0, ok_off = 0;
+    size_t in_off[NIN + 1] = {};
+    bool enqueued = false;
+  } held[kPipeSlots];
   auto drain = [&](int sl) -> int {
-    if (!slot_cnt[sl]) return DSV_OK;
-    if (nchunks == 1) HIP_TRY(hipStreamSynchronize(ctx.pipe_small));  // (the one-stream path of a small call)
-    else HIP_TRY(hipEventSynchronize(ctx.pipe_ev_done[sl]));
-    memcpy(ok + slot_first[sl], ctx.pipe_host[sl] + slot_ok_off[sl], slot_cnt[sl]);
-    slot_cnt[sl] = 0;
+    Held& h = held[sl];
+    if (!h.cnt) return DSV_OK;
+    if (small) HIP_TRY(hipStreamSynchronize(ctx.pipe_small));  // (the one-stream path of a small call)
+    else HIP_TRY(hipEventSynchronize(pipe.slot[sl].ev_done));
+    memcpy(ok + h.first, pipe.slot[sl].host + h.ok_off, h.cnt);
+    h.cnt = 0;
     return DSV_OK;
   };
   // an error half-way: nothing of this call may still be in flight when the caller's buffers go away
+  // (the streams are shared: this waits for the other call in flight as well — errors are rare)
   auto bail = [&](int rc) {
     const std::string why = g_err;
     (void)hipStreamSynchronize(ctx.pipe_in);
+    (void)hipStreamSynchronize(ctx.pipe_pre);
     (void)hipStreamSynchronize(ctx.pipe_small);
     for (int k = 0; k < 2; k++) (void)hipStreamSynchronize(ctx.pipe_lane[k]);
     (void)hipStreamSynchronize(ctx.pipe_out);
@@ -1137,57 +1394,77 @@ int run_pipelined(Context& ctx, const HostIn (&ins)[NIN], uint8_t* ok, size_t n,
     explicit PartScope(bool on) { t_pipeline_part = on; }
     ~PartScope() { t_pipeline_part = false; }
   } part_scope(nchunks > 1);
-  size_t done = 0;
   // DSV_PIPE_TRACE=1: per call, where the host thread's time went (stderr)
   static const bool trace = getenv("DSV_PIPE_TRACE") != nullptr;
-  double t_drain = 0, t_copy = 0, t_enq = 0;
+  double t_drain = 0, t_copy = 0, t_enq = 0, t_turn = 0;
   auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
   const double t_begin = now();
-  for (size_t c = 0; done < n; c++) {
-    const int sl = (int)(c % kPipeSlots);
-    const size_t cnt = chunk_len(c, n - done);
+
+  // ---- stage chunk c into its slot: gather the caller's arrays into pinned memory, start the transfer ----
+  auto stage = [&](size_t c, size_t first) -> int {
+    const int sl = (int)(c % (size_t)kSlots);
+    PipeSlot& slot = pipe.slot[sl];
+    Held& h = held[sl];
+    const size_t cnt = chunks[c];
     const double t0 = now();
-    if (int r = drain(sl)) return bail(r);  // slot free again, its verdicts delivered
+    if (int r = drain(sl)) return r;  // slot free again, its verdicts delivered
     const double t1 = now();
     t_drain += t1 - t0;
-    uint8_t* host = ctx.pipe_host[sl];
-    uint8_t* dev = ctx.pipe_stage[sl];
-    size_t in_off[NIN + 1];  // offsets inside the slot for THIS chunk, the same on both sides
-    in_off[0] = 0;
-    for (size_t k = 0; k < NIN; k++) in_off[k + 1] = in_off[k] + align_up(cnt * ins[k].bytes, 256);
-    const size_t ok_off = in_off[NIN];
+    uint8_t* host = slot.host;
+    h.in_off[0] = 0;  // offsets inside the slot for THIS chunk, the same on both sides
+    for (size_t k = 0; k < NIN; k++) h.in_off[k + 1] = h.in_off[k] + align_up(cnt * ins[k].bytes, 256);
+    h.ok_off = h.in_off[NIN];
     size_t bytes = 0;
     for (size_t k = 0; k < NIN; k++) bytes += cnt * ins[k].bytes;
     const int T = bytes >= ((size_t)1 << 20) ? host_copy_threads() : 1;
-    ctx.copiers.run(T, [&](int t, int nt) {
+    pipe.copiers.run(T, [&](int t, int nt) {
       for (size_t k = 0; k < NIN; k++) {
         if (ins[k].stride && ins[k].stride != ins[k].bytes) {  // one field out of every object
           const size_t lo = cnt * (size_t)t / (size_t)nt, hi = cnt * (size_t)(t + 1) / (size_t)nt;
-          copy_strided(host + in_off[k] + lo * ins[k].bytes, ins[k].p + (done + lo) * ins[k].stride,
+          copy_strided(host + h.in_off[k] + lo * ins[k].bytes, ins[k].p + (first + lo) * ins[k].stride,
                        ins[k].stride, ins[k].bytes, hi - lo);
           continue;
         }
         const size_t len = cnt * ins[k].bytes;
         const size_t lo = len * (size_t)t / (size_t)nt / 64 * 64;
         const size_t hi = t + 1 == nt ? len : len * (size_t)(t + 1) / (size_t)nt / 64 * 64;
-        memcpy(host + in_off[k] + lo, ins[k].p + done * ins[k].bytes + lo, hi - lo);
+        memcpy(host + h.in_off[k] + lo, ins[k].p + first * ins[k].bytes + lo, hi - lo);
       }
     });
+    t_copy += now() - t1;
+    h.first = first;
+    h.cnt = cnt;
+    h.enqueued = false;
+    // the input block is contiguous on both sides (pad bytes ride along); a single small chunk goes
+    // with its kernels and verdicts on ONE stream (no event hop on the latency path of a
+    // 1024-signature call), everything else on the shared transfer stream
+    hipStream_t s_in = small ? ctx.pipe_small : ctx.pipe_in;
+    std::lock_guard<std::mutex> enq(ctx.enq_mu);  // (record + later waits on ev_in stay paired)
+    if (hipMemcpyAsync(slot.stage, host, h.in_off[NIN - 1] + cnt * ins[NIN - 1].bytes, hipMemcpyHostToDevice, s_in) != hipSuccess ||
+        (!small && hipEventRecord(slot.ev_in, s_in) != hipSuccess))
+      return fail(DSV_ERR_HIP, "transfer to the device failed: %s", hipGetErrorString(hipGetLastError()));
+    return DSV_OK;
+  };
+
+  // ---- enqueue chunk c's preprocessing, sub-batches and verdict copy ----
+  // From here to the verdict copy the chunk is enqueued as one unit: a lane's work area belongs to one
+  // sub-batch at a time (the lanes are in-order, so enqueue order = use order).
+  auto enqueue = [&](size_t c) -> int {
+    const int sl = (int)(c % (size_t)kSlots);
+    PipeSlot& slot = pipe.slot[sl];
+    Held& h = held[sl];
+    const size_t cnt = h.cnt;
     const double t2 = now();
-    t_copy += t2 - t1;
-    uint8_t* dok = dev + ok_off;
-    // a single small chunk: transfer, kernels and verdicts on ONE stream (no event hop on the
-    // latency path of a 1024-signature call); else the four-stream pipeline
-    hipStream_t s_in = nchunks == 1 ? ctx.pipe_small : ctx.pipe_in;
-    hipStream_t s_out = nchunks == 1 ? ctx.pipe_small : ctx.pipe_out;
-    // the input block is contiguous on both sides (pad bytes ride along)
-    if (hipMemcpyAsync(dev, host, in_off[NIN - 1] + cnt * ins[NIN - 1].bytes, hipMemcpyHostToDevice, s_in) != hipSuccess ||
-        (nchunks > 1 && hipEventRecord(ctx.pipe_ev_in[sl], s_in) != hipSuccess))
-      return bail(fail(DSV_ERR_HIP, "transfer to the device failed: %s", hipGetErrorString(hipGetLastError())));
+    uint8_t* dev = slot.stage;
+    uint8_t* dok = dev + h.ok_off;
+    std::lock_guard<std::mutex> enq(ctx.enq_mu);
+    hipStream_t s_out = small ? ctx.pipe_small : ctx.pipe_out;
     bool used[2] = {false, false};
-    auto lane_for = [&](int k) -> int {  // first use of a lane by this chunk: its inputs must have arrived
-      if (nchunks > 1 && !used[k]) {
-        if (hipStreamWaitEvent(ctx.pipe_lane[k], ctx.pipe_ev_in[sl], 0) != hipSuccess)
+    // first use of a lane by this chunk: its inputs must have arrived (and, with the preprocessing on
+    // its own stream, been preprocessed: ev_pre implies ev_in)
+    auto lane_for = [&](int k) -> int {
+      if (!small && !used[k]) {
+        if (hipStreamWaitEvent(ctx.pipe_lane[k], pre_stream ? slot.ev_pre : slot.ev_in, 0) != hipSuccess)
           return fail(DSV_ERR_HIP, "hipStreamWaitEvent failed");
         used[k] = true;
       }
@@ -1196,62 +1473,90 @@ int run_pipelined(Context& ctx, const HostIn (&ins)[NIN], uint8_t* ok, size_t n,
     Staged sg;
     int prep_lane = -1;
     if constexpr (has_prep) {
-      // on the lane that takes this chunk's first sub-batch (the counter is not advanced here)
-      prep_lane = nchunks == 1 ? 0 : (int)(ctx.pipe_parts & 1);
-      if (int r = lane_for(prep_lane)) return bail(r);
-      hipStream_t sp = nchunks == 1 ? ctx.pipe_small : ctx.pipe_lane[prep_lane];
+      hipStream_t sp;
+      if (small) {
+        sp = ctx.pipe_small;
+      } else {
+        if (!pre_stream) prep_lane = (int)(ctx.pipe_parts & 1);  // the lane of the chunk's first sub-batch (counter not advanced)
+        sp = pre_stream ? ctx.pipe_pre : ctx.pipe_lane[prep_lane];
+        if (hipStreamWaitEvent(sp, slot.ev_in, 0) != hipSuccess) return fail(DSV_ERR_HIP, "hipStreamWaitEvent failed");
+      }
       const void* dptr[NIN];
-      for (size_t j = 0; j < NIN; j++) dptr[j] = dev + in_off[j];
-      Stager scratch(ctx.pipe_prep[sl]);
-      if (int r = prep(dptr, cnt, scratch, sp, sg)) return bail(r);
-      if (nchunks > 1 && hipEventRecord(ctx.pipe_ev_pre[sl], sp) != hipSuccess)
-        return bail(fail(DSV_ERR_HIP, "hipEventRecord failed"));
+      for (size_t j = 0; j < NIN; j++) dptr[j] = dev + h.in_off[j];
+      Stager scratch(slot.prep);
+      if (int r = prep(dptr, cnt, scratch, sp, sg)) return r;
+      if (!small && hipEventRecord(slot.ev_pre, sp) != hipSuccess) return fail(DSV_ERR_HIP, "hipEventRecord failed");
+      if (prep_lane >= 0) used[prep_lane] = true;  // (in order behind the transfer already)
     } else {
       (void)prep;
       for (size_t j = 0; j < NIN; j++) {
-        sg.p[j] = dev + in_off[j];
+        sg.p[j] = dev + h.in_off[j];
         sg.bytes[j] = ins[j].bytes;
       }
     }
     bool waited_pre[2] = {false, false};
+    size_t part_items = 0;
+    (void)plan_parts(cnt, one_part, part_items);
     for (size_t off = 0; off < cnt;) {
-      const size_t pc = one_part ? cnt : (cnt - off < kSplitItems ? cnt - off : kSplitItems);
-      const int k = nchunks == 1 ? 0 : (int)(ctx.pipe_parts++ & 1);
-      hipStream_t st = nchunks == 1 ? ctx.pipe_small : ctx.pipe_lane[k];
-      if (int r = lane_for(k)) return bail(r);
-      if (has_prep && nchunks > 1 && k != prep_lane && !waited_pre[k]) {
-        if (hipStreamWaitEvent(st, ctx.pipe_ev_pre[sl], 0) != hipSuccess)
-          return bail(fail(DSV_ERR_HIP, "hipStreamWaitEvent failed"));
+      const size_t pc = cnt - off < part_items ? cnt - off : part_items;
+      const int k = small ? 0 : (int)(ctx.pipe_parts++ & 1);
+      hipStream_t st = small ? ctx.pipe_small : ctx.pipe_lane[k];
+      if (int r = lane_for(k)) return r;
+      if (prep_lane >= 0 && k != prep_lane && !waited_pre[k]) {
+        if (hipStreamWaitEvent(st, slot.ev_pre, 0) != hipSuccess) return fail(DSV_ERR_HIP, "hipStreamWaitEvent failed");
         waited_pre[k] = true;
       }
-      uint8_t* ws = ctx.pipe_work[k];
+      uint8_t* ws = ctx.pipe_work[small ? 2 : k];
       Stager extra(ws + ws_bytes);
-      if (int r = part(sg, off, pc, dok + off, ws, extra, st)) return bail(r);
+      if (int r = part(sg, off, pc, dok + off, ws, extra, st)) return r;
       off += pc;
     }
-    if (nchunks > 1) {
+    if (!small) {
       for (int k = 0; k < 2; k++)
         if (used[k]) {
-          if (hipEventRecord(ctx.pipe_ev_lane[sl][k], ctx.pipe_lane[k]) != hipSuccess ||
-              hipStreamWaitEvent(s_out, ctx.pipe_ev_lane[sl][k], 0) != hipSuccess)
-            return bail(fail(DSV_ERR_HIP, "event record / wait failed"));
+          if (hipEventRecord(slot.ev_lane[k], ctx.pipe_lane[k]) != hipSuccess ||
+              hipStreamWaitEvent(s_out, slot.ev_lane[k], 0) != hipSuccess)
+            return fail(DSV_ERR_HIP, "event record / wait failed");
         }
     }
-    if (hipMemcpyAsync(host + ok_off, dok, cnt, hipMemcpyDeviceToHost, s_out) != hipSuccess ||
-        (nchunks > 1 && hipEventRecord(ctx.pipe_ev_done[sl], s_out) != hipSuccess))
-      return bail(fail(DSV_ERR_HIP, "verdict copy failed: %s", hipGetErrorString(hipGetLastError())));
-    slot_first[sl] = done;
-    slot_cnt[sl] = cnt;
-    slot_ok_off[sl] = ok_off;
-    done += cnt;
+    if (hipMemcpyAsync(slot.host + h.ok_off, dok, cnt, hipMemcpyDeviceToHost, s_out) != hipSuccess ||
+        (!small && hipEventRecord(slot.ev_done, s_out) != hipSuccess))
+      return fail(DSV_ERR_HIP, "verdict copy failed: %s", hipGetErrorString(hipGetLastError()));
+    h.enqueued = true;
     t_enq += now() - t2;
+    return DSV_OK;
+  };
+
+  size_t staged = 0, enqueued = 0, first = 0;
+  while (enqueued < nchunks) {
+    // stage the next chunk if its slot can be had: free, or holding a chunk whose kernels are enqueued
+    // (drain then waits for them) — never one that is itself still waiting for the turn
+    if (staged < nchunks && staged - enqueued < (size_t)kSlots) {
+      if (int r = stage(staged, first)) return bail(r);
+      first += chunks[staged];
+      staged++;
+    }
+    if (!small && !turn.held) {
+      // not our turn yet: keep staging while slots are free, then wait
+      if (!turn.try_acquire()) {
+        if (staged < nchunks && staged - enqueued < (size_t)kSlots) continue;
+        const double tw = now();
+        turn.acquire();
+        t_turn += now() - tw;
+      }
+    }
+    while (enqueued < staged) {
+      if (int r = enqueue(enqueued)) return bail(r);
+      enqueued++;
+    }
+    if (enqueued == nchunks) turn.release();  // the next call's chunks go behind ours
   }
   const double t3 = now();
   for (int sl = 0; sl < nslots; sl++)
     if (int r = drain(sl)) return bail(r);
   if (trace)
-    fprintf(stderr, "[dsv pipe] n=%zu chunks=%zu total %.2f ms: gather %.2f, enqueue %.2f, waiting for slots %.2f, final drain %.2f\n",
-            n, nchunks, now() - t_begin, t_copy, t_enq, t_drain, now() - t3);
+    fprintf(stderr, "[dsv pipe] n=%zu chunks=%zu total %.2f ms: gather %.2f, enqueue %.2f, waiting for slots %.2f, for the turn %.2f, final drain %.2f\n",
+            n, nchunks, now() - t_begin, t_copy, t_enq, t_drain, t_turn, now() - t3);
   return DSV_OK;
 }
 }  // namespace
@@ -1702,6 +2007,79 @@ int dsv_set_host_threads(int n) {
   g_host_threads.store(n > 0 ? clamp_host_threads(n) : 0, std::memory_order_relaxed);
   return host_copy_threads();
 }
+
+// ---- asynchronous form: submit returns at once, the batch runs on a library-owned driver thread ----
+// What a caller with a stream of batches uses to keep the GPU busy across calls: while batch k's last
+// chunks are on the GPU, batch k + 1's driver already gathers, transfers and enqueues its first ones
+// (each call in flight owns a Pipe; the compute lanes are shared, so the GPU sees one FIFO of
+// sub-batches).  A third submit simply waits for a pipe inside its driver thread.
+struct dsv_job {
+  std::thread th;
+  std::mutex m;
+  std::condition_variable cv;
+  bool started = false;
+  std::atomic<bool> finished{false};
+  int rc = DSV_OK;
+  std::string err;
+  int kind = 0;
+  dsv_column cols[6] = {};
+  size_t n = 0;
+  uint8_t* ok = nullptr;
+};
+namespace {
+int submit_mont_cols(int kind, const dsv_column* cols, size_t n, uint8_t* ok, dsv_job** out) {
+  if (!out) return fail(DSV_ERR_INVALID_ARGUMENT, "null job pointer");
+  *out = nullptr;
+  if (int r = check_cols(kind, cols, n, ok)) return r;
+  if (g_primary.load(std::memory_order_acquire) < 0)
+    return fail(DSV_ERR_NOT_INITIALIZED, "dsv_init() has not been called");
+  dsv_job* j = new (std::nothrow) dsv_job;
+  if (!j) return fail(DSV_ERR_HIP, "out of host memory");
+  j->kind = kind;
+  j->n = n;
+  j->ok = ok;
+  for (int k = 0; n && k < kMontCols[kind]; k++) j->cols[k] = cols[k];
+  try {
+    j->th = std::thread([j] {
+      {
+        std::lock_guard<std::mutex> lk(j->m);
+        j->started = true;
+      }
+      j->cv.notify_all();
+      j->rc = verify_mont_cols(j->kind, j->cols, j->n, j->ok, true);
+      if (j->rc) j->err = g_err;  // the text lives in this thread's thread-local
+      j->finished.store(true, std::memory_order_release);
+    });
+  } catch (...) {
+    delete j;
+    return fail(DSV_ERR_HIP, "could not start the driver thread of the batch");
+  }
+  {
+    // jobs take their place in the device's queue in submission order: return once the driver runs
+    // (it queues for its pipe within microseconds; the next submit has a thread to start first)
+    std::unique_lock<std::mutex> lk(j->m);
+    j->cv.wait(lk, [j] { return j->started; });
+  }
+  *out = j;
+  return DSV_OK;
+}
+}  // namespace
+int dsv_verify_single_mont_cols_submit(const dsv_column* cols, size_t n, uint8_t* ok, dsv_job** job) { return submit_mont_cols(0, cols, n, ok, job); }
+int dsv_verify_double_mont_cols_submit(const dsv_column* cols, size_t n, uint8_t* ok, dsv_job** job) { return submit_mont_cols(1, cols, n, ok, job); }
+int dsv_verify_vargen_mont_cols_submit(const dsv_column* cols, size_t n, uint8_t* ok, dsv_job** job) { return submit_mont_cols(2, cols, n, ok, job); }
+int dsv_job_done(const dsv_job* job) {
+  if (!job) return fail(DSV_ERR_INVALID_ARGUMENT, "null job");
+  return job->finished.load(std::memory_order_acquire) ? 1 : 0;
+}
+int dsv_job_wait(dsv_job* job) {
+  if (!job) return fail(DSV_ERR_INVALID_ARGUMENT, "null job");
+  if (job->th.joinable()) job->th.join();
+  const int rc = job->rc;
+  if (rc) g_err = job->err;
+  delete job;
+  return rc;
+}
+int dsv_max_in_flight(void) { return kPipes; }
 
 int dsv_verify_single_mont_cols(const dsv_column* cols, size_t n, uint8_t* ok) { return verify_mont_cols(0, cols, n, ok, true); }
 int dsv_verify_double_mont_cols(const dsv_column* cols, size_t n, uint8_t* ok) { return verify_mont_cols(1, cols, n, ok, true); }

@@ -222,6 +222,49 @@ def verify_mont_cols(scheme, cols):
     return ok
 
 
+class MontColsJob:
+    """A batch in flight (dsv_verify_*_mont_cols_submit): `wait()` blocks until the verdicts are
+    there and returns them.  Keeps the column arrays alive until then."""
+
+    def __init__(self, scheme, cols):
+        name, widths = _MONT_COLS[scheme]
+        if len(cols) != len(widths):
+            raise ValueError("%s takes %d columns" % (name, len(widths)))
+        n = cols[0].shape[0]
+        arr = (_lib.Column * len(cols))()
+        for k, (c, w) in enumerate(zip(cols, widths)):
+            if c.dtype != np.uint8 or c.ndim != 2 or c.shape != (n, w) or (w > 1 and c.strides[1] != 1) \
+                    or c.strides[0] < w:
+                raise ValueError("column %d: expected uint8 [n, %d] rows with contiguous bytes" % (k, w))
+            arr[k].base = c.ctypes.data
+            arr[k].stride = c.strides[0]
+        self._cols = cols
+        self._ok = np.zeros(n, dtype=np.uint8)
+        self._job = ctypes.c_void_p()
+        _lib.check(getattr(_lib.load(), name + "_submit")(arr, ctypes.c_size_t(n), _p(self._ok),
+                                                          ctypes.byref(self._job)))
+
+    def done(self):
+        return self._job.value is None or _lib.load().dsv_job_done(self._job) == 1
+
+    def wait(self):
+        if self._job.value is not None:
+            job, self._job = self._job, ctypes.c_void_p()
+            _lib.check(_lib.load().dsv_job_wait(job))
+            self._cols = None
+        return self._ok
+
+
+def submit_mont_cols(scheme, cols):
+    """Asynchronous verify_mont_cols: returns a MontColsJob at once; up to max_in_flight() batches
+    per device overlap (the second one's ramp runs under the first one's tail)."""
+    return MontColsJob(scheme, cols)
+
+
+def max_in_flight():
+    return int(_lib.load().dsv_max_in_flight())
+
+
 def challenge_single(R, m):
     R, m = _arr(R, 64), _arr(m, 32)
     n = _same_n(R, m)

@@ -95,6 +95,27 @@ static void batch() {
     CHECK(ok[i] == want);
     CHECK(pks[i].verify(sigs[i], msgs[i]) == want);
   }
+  // batches in flight: three jobs over the same objects (one more than the engine keeps in flight),
+  // a job that is moved, one that is dropped unwaited; 200-verdict words through the 64-at-a-time packing
+  {
+    BatchJob a = verify_batch_submit(sigs, pks, msgs), b = verify_batch_submit(sigs, pks, msgs);
+    BatchJob c = verify_batch_submit(sigs, pks, msgs);
+    BatchJob moved = std::move(b);
+    CHECK(a.wait() == ok && moved.wait() == ok);
+    CHECK(c.done() || true);  // (dropped: its destructor waits)
+    std::vector<Signature> s2;
+    std::vector<PublicKey> p2;
+    std::vector<BlsScalar> m2;
+    for (size_t i = 0; i < 200; i++) {
+      s2.push_back(sigs[i % n]);
+      p2.push_back(pks[i % n]);
+      m2.push_back(msgs[i % n]);
+    }
+    const std::vector<bool> ok2 = verify_batch_submit(s2, p2, m2).wait();
+    CHECK(ok2.size() == 200);
+    for (size_t i = 0; i < 200; i++) CHECK(ok2[i] == ok[i % n]);
+    CHECK(verify_batch_submit(std::vector<Signature>{}, {}, {}).wait().empty());
+  }
   bool threw = false;
   try {
     msgs.pop_back();

@@ -1,8 +1,13 @@
 #!/usr/bin/env python3
-"""Timeline of ONE host-buffer call (affine | ext | wire | mont) from a rocprofv3 kernel trace.
+"""Timeline of ONE host-buffer call (affine | ext | wire | e2e-single | e2e-double | e2e-vargen |
+e2e-*-streamed) from a rocprofv3 kernel trace.
 
-    rocprofv3 --kernel-trace --output-format csv -d DIR -- python3 tools/host_timeline.py run wire
-    python3 tools/host_timeline.py report DIR
+    rocprofv3 --kernel-trace --memory-copy-trace --output-format csv -d DIR -- python3 tools/host_timeline.py run wire
+    python3 tools/host_timeline.py report DIR [rows]
+
+The e2e kinds run verify_batch* over typed objects (tools/libvb_e2e.so); `-streamed`: four batches, two
+in flight, as the measured call.  `report DIR rows` also lists every dispatch and copy of the measured
+call with its hardware queue and stream.
 
 `run` performs two warm calls, prints a wall-clock marker, then the measured call (DSV_PIPE_TRACE=1
 in the environment adds the pipeline's own per-call line on stderr).  `report` reads the kernel
@@ -25,10 +30,38 @@ def run(kind):
     from schnorr_amd import workload as W
     E.init(0)
     n = 1 << int(os.environ.get("LOG2N", "20"))
-    b = W.gen_single(n, seed=2321)
-    h = {k: b[k].cpu().numpy() for k in ("u", "R", "PK", "m")}
-    want = b["expected"].cpu().numpy()
-    if kind == "affine":
+    if not kind.startswith("e2e"):
+        b = W.gen_single(n, seed=2321)
+        h = {k: b[k].cpu().numpy() for k in ("u", "R", "PK", "m")}
+        want = b["expected"].cpu().numpy()
+    if kind.startswith("e2e"):
+        import ctypes
+        L = ctypes.CDLL(os.path.join(os.path.dirname(os.path.abspath(__file__)), "libvb_e2e.so"))
+        scheme = kind.split("-")[1]
+        streamed = kind.endswith("streamed")
+        if scheme == "vargen":
+            n = 1 << int(os.environ.get("LOG2N", "18"))
+        gen = {"single": W.gen_single, "double": W.gen_double, "vargen": W.gen_vargen}[scheme]
+        keys = {"single": ("u", "R", "PK", "m"), "double": ("u", "R", "Rp", "PK", "PKp", "m"),
+                "vargen": ("u", "R", "PK", "Gen", "m")}[scheme]
+        k = ("single", "double", "vargen").index(scheme)
+        b = gen(n, seed=2321)
+        want = b["expected"].cpu().numpy()
+        hh = [b[x].cpu().numpy() for x in keys]
+        p = lambda a: ctypes.c_void_p(a.ctypes.data)
+        prep = (L.vb_e2e_prepare, L.vb_e2e_prepare_double, L.vb_e2e_prepare_vargen)[k]
+        runf = (L.vb_e2e_run, L.vb_e2e_run_double, L.vb_e2e_run_vargen)[k]
+        prep(*([p(a) for a in hh] + [ctypes.c_size_t(n), ctypes.c_int(8)]))
+        ok = np.zeros(n, dtype=np.uint8)
+        ms = ctypes.c_double(0)
+
+        def fn():
+            if streamed:
+                assert L.vb_e2e_run_streamed(ctypes.c_int(k), ctypes.c_int(4), ctypes.c_int(2), p(ok), ctypes.byref(ms)) == 0
+            else:
+                assert runf(p(ok), ctypes.byref(ms)) == 0
+            return ok
+    elif kind == "affine":
         fn = lambda: E.verify_single(h["u"], h["R"], h["PK"], h["m"])
     elif kind == "wire":
         sig = np.ascontiguousarray(np.concatenate([h["u"], E.compress_points(h["R"])], axis=1))
@@ -53,11 +86,17 @@ def run(kind):
     print("%s host call, n = 2^%d: %.2f ms wall = %.2f M/s" % (kind, n.bit_length() - 1, dt * 1e3, n / dt / 1e6))
 
 
-def report(d):
-    rows = []
+def report(d, list_rows=False):
+    rows, copies, meta = [], [], {}
     for f in glob.glob(os.path.join(d, "**", "*kernel_trace.csv"), recursive=True):
         for r in csv.DictReader(open(f)):
-            rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]))
+            key = (int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"])
+            rows.append(key)
+            meta[key] = (r.get("Queue_Id", "-"), r.get("Stream_Id", "-"))
+    for f in glob.glob(os.path.join(d, "**", "*memory_copy_trace.csv"), recursive=True):
+        for r in csv.DictReader(open(f)):
+            copies.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), "COPY " + r.get("Direction", "?"),
+                           r.get("Stream_Id", "-")))
     rows.sort()
     # the measured call = everything after the last gap of > 30 ms between dispatches
     cut = 0
@@ -88,10 +127,16 @@ def report(d):
     print("GPU running a kernel %.3f ms, idle %.3f ms" % (busy / 1e6, (t1 - t0 - busy) / 1e6))
     for at, ln, a, b in idle_gaps:
         print("  idle %.3f ms at +%.3f ms  (after %s, before %s)" % (ln, at, a, b))
+    if list_rows:
+        allr = [(s_, e_, k.split("(")[0].replace("dsv::", "").replace("void ", "")[:34], meta[(s_, e_, k)][0], meta[(s_, e_, k)][1])
+                for s_, e_, k in call]
+        allr += [(s_, e_, k, "-", st) for s_, e_, k, st in copies if t0 - 2e6 <= s_ <= t1]
+        for s_, e_, k, q, st in sorted(allr):
+            print("%8.3f %8.3f %6.3f  %-34s q=%s st=%s" % ((s_ - t0) / 1e6, (e_ - t0) / 1e6, (e_ - s_) / 1e6, k, q, st))
 
 
 if __name__ == "__main__":
     if sys.argv[1] == "run":
         run(sys.argv[2])
     else:
-        report(sys.argv[2])
+        report(sys.argv[2], len(sys.argv) > 3 and sys.argv[3] == "rows")

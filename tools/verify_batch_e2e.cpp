@@ -55,8 +55,9 @@ int vb_e2e_prepare(const uint8_t* u, const uint8_t* R_uv, const uint8_t* PK_uv, 
       bool ok = us && ms;
       for (int k = 0; k < 4 && ok; k++)
         ok = BlsScalar::from_bytes((k < 2 ? R_uv : PK_uv) + 64 * i + 32 * (k & 1)).has_value();
-      if (!ok) {  // the harness's tamper classes include encodings the types cannot hold: keep the
-        bad[t]++;  // item as a default signature (it then simply does not verify)
+      if (!ok) {  // the harness's tamper classes include encodings the types cannot hold: such an item
+        bad[t]++;  // becomes u = 1, R = pk = identity — 1*G + c*O = G != O, false under every scheme
+        g_sigs[i].u_ = JubJubScalar::one();  // (a DEFAULT object, u = 0, would verify: 0*G + c*O == O)
         continue;
       }
       g_sigs[i].u_ = *us;
@@ -133,6 +134,7 @@ int vb_e2e_prepare_double(const uint8_t* u, const uint8_t* R_uv, const uint8_t* 
       for (int k = 0; k < 8 && ok; k++) ok = BlsScalar::from_bytes(pts[k >> 1] + 32 * (k & 1)).has_value();
       if (!ok) {
         bad[t]++;
+        g_dsigs[i].u_ = JubJubScalar::one();  // guaranteed invalid, see vb_e2e_prepare
         continue;
       }
       g_dsigs[i].u_ = *us;
@@ -184,6 +186,9 @@ int vb_e2e_prepare_vargen(const uint8_t* u, const uint8_t* R_uv, const uint8_t* 
       for (int k = 0; k < 6 && ok; k++) ok = BlsScalar::from_bytes(pts[k >> 1] + 32 * (k & 1)).has_value();
       if (!ok) {
         bad[t]++;
+        // guaranteed invalid: generator = pk = identity, so u*Gen + c*PK = O whatever u is; R = (0, -1),
+        // the point of order two, is not O
+        g_vsigs[i].R_ = JubJubExtended::from(JubJubAffine{BlsScalar(), -BlsScalar::one()});
         continue;
       }
       g_vsigs[i].u_ = *us;
@@ -210,6 +215,41 @@ int vb_e2e_run_vargen(uint8_t* ok, double* ms) {
     return 0;
   } catch (const std::exception& e) {
     std::fprintf(stderr, "vb_e2e_run_vargen: %s\n", e.what());
+    return -1;
+  }
+}
+
+// ---- streamed: `calls` batches over the same objects, `in_flight` of them in flight at any time
+// (verify_batch*_submit / BatchJob::wait; 1 = back-to-back blocking calls).  ms = wall time of the whole
+// sequence incl. every Vec<bool>; ok = the LAST batch's verdicts; every batch's result is compared
+// with the first one's (returns 1 on a mismatch, -1 on an engine error).  scheme: 0 single, 1 double,
+// 2 var-generator.
+int vb_e2e_run_streamed(int scheme, int calls, int in_flight, uint8_t* ok, double* ms) {
+  try {
+    if (calls < 1 || in_flight < 1) return -1;
+    auto submit = [&]() -> BatchJob {
+      if (scheme == 0) return verify_batch_submit(g_sigs, g_pks, g_msgs);
+      if (scheme == 1) return verify_batch_double_submit(g_dsigs, g_dpks, g_dmsgs);
+      return verify_batch_var_gen_submit(g_vsigs, g_vpks, g_vmsgs);
+    };
+    std::vector<BatchJob> jobs;
+    std::vector<bool> first, out;
+    int mismatches = 0;
+    const double t0 = now_ms();
+    int submitted = 0, waited = 0;
+    std::vector<BatchJob> ring((size_t)in_flight);
+    for (; submitted < calls && submitted < in_flight; submitted++) ring[(size_t)submitted] = submit();
+    for (; waited < calls; waited++) {
+      out = ring[(size_t)(waited % in_flight)].wait();
+      if (submitted < calls) ring[(size_t)(waited % in_flight)] = submit(), submitted++;
+      if (waited == 0) first = out;
+      else if (out != first) mismatches++;
+    }
+    *ms = now_ms() - t0;
+    for (size_t i = 0; i < out.size(); i++) ok[i] = out[i] ? 1 : 0;
+    return mismatches ? 1 : 0;
+  } catch (const std::exception& e) {
+    std::fprintf(stderr, "vb_e2e_run_streamed: %s\n", e.what());
     return -1;
   }
 }
