@@ -83,7 +83,10 @@ int fail(int code, const char* fmt, ...) {
 class CopyPool {
  public:
   ~CopyPool() { stop(); }
-  // fn(t, T) runs on T threads (t = 0 is the caller); returns when all are done
+  // fn(t, T) runs on T threads (t = 0 is the caller); returns when all are done.
+  // Between the chunks of one call the workers SPIN for a short while before they block: a chunk
+  // arrives every 0.3 - 1 ms, and a condition-variable wake-up (30 - 100 us, twice per chunk: start
+  // and completion) is a tenth of a first chunk's whole gather — on the path the GPU is waiting for.
   void run(int T, const std::function<void(int, int)>& fn) {
     if (T <= 1) {
       fn(0, 1);
@@ -97,20 +100,23 @@ class CopyPool {
       }
       job_ = &fn;
       job_threads_ = T;
-      pending_ = T - 1;
-      gen_++;
+      pending_.store(T - 1, std::memory_order_relaxed);
+      gen_.fetch_add(1, std::memory_order_release);
     }
     go_.notify_all();
     fn(0, T);
-    std::unique_lock<std::mutex> lk(m_);
-    done_.wait(lk, [this] { return pending_ == 0; });
+    for (int spin = 0; spin < kSpin && pending_.load(std::memory_order_acquire) != 0; spin++) cpu_relax();
+    if (pending_.load(std::memory_order_acquire) != 0) {
+      std::unique_lock<std::mutex> lk(m_);
+      done_.wait(lk, [this] { return pending_.load(std::memory_order_acquire) == 0; });
+    }
     job_ = nullptr;
   }
   void stop() {
     {
       std::unique_lock<std::mutex> lk(m_);
       quit_ = true;
-      gen_++;
+      gen_.fetch_add(1, std::memory_order_release);
     }
     go_.notify_all();
     for (auto& t : th_) t.join();
@@ -119,27 +125,28 @@ class CopyPool {
   }
 
  private:
+  static constexpr int kSpin = 20000;  // ~0.2 - 0.4 ms of pause instructions
+  static void cpu_relax() { __builtin_ia32_pause(); }
   void loop(int id) {
-    uint64_t seen = 0;
-    {
-      std::unique_lock<std::mutex> lk(m_);
-      seen = gen_ - 1;  // started while a job is being posted: take it
-    }
+    uint64_t seen = gen_.load(std::memory_order_acquire) - 1;  // started while a job is being posted: take it
     for (;;) {
+      for (int spin = 0; spin < kSpin && gen_.load(std::memory_order_acquire) == seen; spin++) cpu_relax();
       const std::function<void(int, int)>* job;
       int T;
       {
         std::unique_lock<std::mutex> lk(m_);
-        go_.wait(lk, [&] { return gen_ != seen; });
-        seen = gen_;
+        go_.wait(lk, [&] { return gen_.load(std::memory_order_acquire) != seen; });
+        seen = gen_.load(std::memory_order_acquire);
         if (quit_) return;
         job = job_;
         T = job_threads_;
       }
       if (job && id < T) {
         (*job)(id, T);
-        std::unique_lock<std::mutex> lk(m_);
-        if (--pending_ == 0) done_.notify_one();
+        if (pending_.fetch_sub(1, std::memory_order_acq_rel) == 1) {
+          std::unique_lock<std::mutex> lk(m_);  // (the waiter may be between its check and its wait)
+          done_.notify_one();
+        }
       }
     }
   }
@@ -147,8 +154,9 @@ class CopyPool {
   std::mutex m_;
   std::condition_variable go_, done_;
   const std::function<void(int, int)>* job_ = nullptr;
-  int job_threads_ = 0, pending_ = 0;
-  uint64_t gen_ = 0;
+  int job_threads_ = 0;
+  std::atomic<int> pending_{0};
+  std::atomic<uint64_t> gen_{0};
   bool quit_ = false;
 };
 
@@ -242,10 +250,11 @@ struct Context {
   uint64_t pipe_parts = 0;                // sub-batches enqueued so far: part p runs on lane p & 1
   bool prep_stream = true;                // DSV_PIPE_PREP_STREAM=0: whole-chunk preprocessing on a compute lane (r04)
   size_t pipe_chunk = (size_t)1 << 18, pipe_first_chunk = (size_t)1 << 15;  // DSV_PIPE_CHUNK_LOG2 / DSV_PIPE_FIRST_LOG2
-  double pipe_growth = 2.0;               // DSV_PIPE_GROWTH (percent): chunk k + 1 = growth x chunk k up to pipe_chunk
-  int pipe_slots = 3;                     // DSV_PIPE_SLOTS: chunks in flight per call (<= kPipeSlots)
+  double pipe_growth = 0;                 // DSV_PIPE_GROWTH (percent; A/B): chunk k + 1 = growth x chunk k up to pipe_chunk
+  int pipe_slots = 0;                     // DSV_PIPE_SLOTS: chunks in flight per call (<= kPipeSlots); 0 = by chunk size
   int pipe_plan[16] = {};                 // DSV_PIPE_PLAN="15,15,16,...": log2 chunk sizes of a call that finds the GPU idle
   int pipe_plan_len = 0;
+  int norm_per_lane = 0, norm_block = 0;  // DSV_NORM_PER_LANE / DSV_NORM_BLOCK: shape of the pipeline's normalisation kernels
 };
 Context g_ctx[kMaxDevices];
 std::mutex g_init_mu;               // dsv_init / dsv_shutdown
@@ -721,6 +730,10 @@ int dsv_init(int device) {
       q = *end == ',' ? end + 1 : end;
     }
   }
+  ctx.pipe_slots = 0;
+  ctx.pipe_growth = 0;
+  ctx.norm_per_lane = getenv("DSV_NORM_PER_LANE") ? atoi(getenv("DSV_NORM_PER_LANE")) : 0;
+  ctx.norm_block = getenv("DSV_NORM_BLOCK") ? atoi(getenv("DSV_NORM_BLOCK")) : 0;
   if (const char* e = getenv("DSV_PIPE_SLOTS")) {
     const int v = atoi(e);
     ctx.pipe_slots = v < 2 ? 2 : (v > kPipeSlots ? kPipeSlots : v);
@@ -1238,41 +1251,54 @@ struct NoPrep {};
 //   part(staged, offset, count, dok, ws, extra, stream): one sub-batch; `extra`: scratch of
 //     extra_item_bytes per item behind the lane's verify workspace (the wire path decompresses per
 //     sub-batch: full-occupancy kernels, no reason to serialise a chunk's worth on one lane).
-// The chunks of one call: sizes double from the first-chunk size up to the pipeline chunk (the GPU
-// starts after ~0.3 ms of staging and every gather runs under the previous, half as long, chunk's
-// kernels); a remainder of at most one sub-batch is merged into the last chunk instead of trailing
-// behind it as a part of its own on ONE lane (r05: the lane that got it finished ~1 ms after the
-// other, profiles/r05/host_timeline_e2e.txt).
-inline std::vector<size_t> plan_chunks(const Context& ctx, size_t n, bool ramp) {
+// The chunks of one call.
+//   ramp (the call found the GPU idle): a first chunk of 2^15 items so that the GPU starts after ~0.5 ms
+//     of staging, then chunks of ONE sub-batch (2^16 items) — growing only with what is already staged
+//     (an eighth of it: 2^17 from 2^20 items on, 2^18 from 2^21).  A chunk is gathered, transferred and
+//     preprocessed as a unit, ~12 ns per item before its first kernel can start against ~12 ns per item
+//     of GPU work, so a chunk must stay well below the backlog the GPU still has: with the r01 - r04
+//     doubling (2^15 .. 2^18) the fourth chunk arrived ~1 ms after the GPU had run dry
+//     (profiles/r05/ab_chunk_plans.txt; the same box, one-shot calls: 16.6 -> 15.8 ms per 2^20).
+//   flat (behind another call in flight): full chunks at once — there is no idle GPU to feed quickly
+//     and whole chunks cost fewer launches (two in flight: 14.2 against 14.9 ms per 2^20 with 2^16).
+// A remainder of at most a quarter chunk (or half a sub-batch) is merged into the last chunk instead of
+// trailing behind it as a part of its own on ONE lane.
+inline std::vector<size_t> plan_chunks(const Context& ctx, size_t n, bool ramp, size_t unit = kSplitItems) {
   std::vector<size_t> out;
   if (n <= kPipeSmallCall) {  // one small call: a single chunk
     out.push_back(n);
     return out;
   }
-  size_t left = n;
+  size_t left = n, staged = 0;
   double want_f = (double)ctx.pipe_first_chunk;
   for (size_t c = 0; left; c++) {
-    // (a call that starts behind another one's kernels has no idle GPU to feed quickly: full chunks at once)
-    size_t want = ramp ? align_up((size_t)want_f, 4096) : ctx.pipe_chunk;
-    if (ramp && ctx.pipe_plan_len)  // DSV_PIPE_PLAN: explicit sizes, the last one repeats
+    size_t want = ctx.pipe_chunk;
+    if (ramp && ctx.pipe_plan_len) {  // DSV_PIPE_PLAN: explicit sizes, the last one repeats
       want = (size_t)1 << ctx.pipe_plan[c < (size_t)ctx.pipe_plan_len ? c : (size_t)ctx.pipe_plan_len - 1];
+    } else if (ramp && ctx.pipe_growth > 0) {  // DSV_PIPE_GROWTH: geometric from the first chunk
+      want = align_up((size_t)want_f, 4096);
+      want_f *= ctx.pipe_growth;
+    } else if (ramp) {
+      want = c == 0 ? (ctx.pipe_first_chunk < unit ? ctx.pipe_first_chunk : unit) : unit;  // one sub-batch
+      while (want * 2 <= staged / 8) want *= 2;
+    }
     if (want > ctx.pipe_chunk) want = ctx.pipe_chunk;
-    if (left <= want + kSplitItems / 2 || left <= want + want / 4) want = left;  // the rest rides along
+    if (left <= want + unit / 2 || left <= want + want / 4) want = left;  // the rest rides along
     out.push_back(want);
     left -= want;
-    want_f *= ctx.pipe_growth;
+    staged += want;
   }
   return out;
 }
 // A chunk is cut into sub-batches of at most kSplitItems items — an EVEN number of equal ones once it
 // holds more than one, so that both compute lanes get the same work from every chunk and finish the
 // call together.
-inline size_t plan_parts(size_t cnt, bool one_part, size_t& part_items) {
-  if (one_part || cnt <= kSplitItems) {
+inline size_t plan_parts(size_t cnt, bool one_part, size_t cap, size_t& part_items) {
+  if (one_part || cnt <= cap) {
     part_items = cnt;
     return 1;
   }
-  size_t parts = (cnt + kSplitItems - 1) / kSplitItems;
+  size_t parts = (cnt + cap - 1) / cap;
   parts += parts & 1;
   part_items = align_up((cnt + parts - 1) / parts, 256);
   return (cnt + part_items - 1) / part_items;
@@ -1330,7 +1356,8 @@ int run_pipelined(Context& ctx, const HostIn (&ins)[NIN], uint8_t* ok, size_t n,
   DSV_ON_DEVICE(ctx);
   // nobody else in flight: the GPU is idle, so start small and grow; behind another call (it holds its
   // pipe until its last verdicts are out): full chunks at once
-  const std::vector<size_t> chunks = plan_chunks(ctx, n, small || lease.alone);
+  const size_t part_cap = kSplitItems;
+  const std::vector<size_t> chunks = plan_chunks(ctx, n, small || lease.alone, part_cap);
   const size_t nchunks = chunks.size();
   size_t chunk = 0;  // the largest chunk: slot capacity
   for (size_t c : chunks) chunk = c > chunk ? c : chunk;
@@ -1338,9 +1365,12 @@ int run_pipelined(Context& ctx, const HostIn (&ins)[NIN], uint8_t* ok, size_t n,
   size_t cap_off = 0;
   for (size_t k = 0; k < NIN; k++) cap_off += align_up(chunk * ins[k].bytes, 256);
   const size_t host_need = cap_off + align_up(chunk, 256);
-  const int kSlots = ctx.pipe_slots;
+  // chunks in flight: three (r05, one-shot calls of 2^16-item chunks: six slots are ~1 ms per 2^20
+  // SLOWER than three — with the host far ahead every chunk's preprocessing kernel is resident at the
+  // lanes' kernel boundaries; profiles/r05/ab_chunk_plans.txt)
+  const int kSlots = ctx.pipe_slots ? ctx.pipe_slots : 3;
   const int nslots = nchunks < (size_t)kSlots ? (int)nchunks : kSlots;
-  const size_t prep_need = has_prep ? chunk * prep_item_bytes + 16 * 256 : 0;
+  const size_t prep_need = has_prep ? chunk * prep_item_bytes + 64 * 256 : 0;
   // a sub-batch: at most kSplitItems items (run_split's unit), or the whole chunk when the split is off
   // or the call is one small chunk; each compute lane owns the workspace + scratch of one sub-batch
   const bool one_part = !ctx.split || small;
@@ -1496,7 +1526,7 @@ int run_pipelined(Context& ctx, const HostIn (&ins)[NIN], uint8_t* ok, size_t n,
     }
     bool waited_pre[2] = {false, false};
     size_t part_items = 0;
-    (void)plan_parts(cnt, one_part, part_items);
+    (void)plan_parts(cnt, one_part, part_cap, part_items);
     for (size_t off = 0; off < cnt;) {
       const size_t pc = cnt - off < part_items ? cnt - off : part_items;
       const int k = small ? 0 : (int)(ctx.pipe_parts++ & 1);
@@ -1765,7 +1795,7 @@ int verify_ext_on(Context& ctx, int kind, const void* u, const void* const* pts_
 constexpr size_t kExtItemBytes = 4 * 64 + 1 + 4 * kLimbs * 4 + 1;
 // whole-chunk `to_hash_inputs` of the scheme's points (d: u, points..., m; [u_alt, m_alt]: converted
 // scalars to use instead of d's); fills the staged view of the affine path
-int prep_normalize(int kind, const void* const* d, size_t cnt, Stager& x, hipStream_t st, Staged& g,
+int prep_normalize(const Context& ctx, int kind, const void* const* d, size_t cnt, Stager& x, hipStream_t st, Staged& g,
                    const uint8_t* u_alt = nullptr, const uint8_t* m_alt = nullptr) {
   const int np = kind == 0 ? 2 : (kind == 1 ? 4 : 3);
   NormalizeArgs a = {};
@@ -1777,7 +1807,7 @@ int prep_normalize(int kind, const void* const* d, size_t cnt, Stager& x, hipStr
   }
   uint8_t* valid = x.take(cnt);
   u32* prefix = reinterpret_cast<u32*>(x.take(normalize_prefix_bytes(cnt, np)));
-  launch_normalize_uvz(a, np, cnt, valid, prefix, st);
+  launch_normalize_uvz(a, np, cnt, valid, prefix, st, ctx.norm_per_lane, ctx.norm_block);
   HIP_TRY(hipGetLastError());
   g.p[0] = u_alt ? u_alt : (const uint8_t*)d[0];
   g.p[1 + np] = m_alt ? m_alt : (const uint8_t*)d[1 + np];
@@ -1789,8 +1819,8 @@ template <size_t NIN>
 int verify_ext_host(Context& ctx, int kind, const HostIn (&ins)[NIN], size_t n, uint8_t* ok) {
   Context* cp = &ctx;
   return run_pipelined(ctx, ins, ok, n, kExtItemBytes, 0,
-                       [kind](const void* const* d, size_t cnt, Stager& x, hipStream_t st, Staged& g) {
-                         return prep_normalize(kind, d, cnt, x, st, g);
+                       [kind, cp](const void* const* d, size_t cnt, Stager& x, hipStream_t st, Staged& g) {
+                         return prep_normalize(*cp, kind, d, cnt, x, st, g);
                        },
                        DSV_PART(kind));
 }
@@ -1947,11 +1977,11 @@ template <size_t NIN>
 int verify_mont_host(Context& ctx, int kind, const HostIn (&ins)[NIN], size_t n, uint8_t* ok) {
   Context* cp = &ctx;
   return run_pipelined(ctx, ins, ok, n, kMontItemBytes, 0,
-                       [kind](const void* const* d, size_t cnt, Stager& x, hipStream_t st, Staged& g) {
+                       [kind, cp](const void* const* d, size_t cnt, Stager& x, hipStream_t st, Staged& g) {
                          const int np = kind == 0 ? 2 : (kind == 1 ? 4 : 3);
                          uint8_t *cu = x.take(cnt * 32), *cm = x.take(cnt * 32);
-                         launch_scalars_from_mont((const uint8_t*)d[0], (const uint8_t*)d[1 + np], cnt, cu, cm, st);
-                         return prep_normalize(kind, d, cnt, x, st, g, cu, cm);
+                         launch_scalars_from_mont((const uint8_t*)d[0], (const uint8_t*)d[1 + np], cnt, cu, cm, st, cp->norm_block);
+                         return prep_normalize(*cp, kind, d, cnt, x, st, g, cu, cm);
                        },
                        DSV_PART(kind));
 }

@@ -497,10 +497,11 @@ void launch_fixed_base_points(const uint8_t* scalar, const uint32_t* table, size
   hipLaunchKernelGGL(k_fixed_base_points, dim3(grid_for(n)), dim3(256), 0, s, scalar, table, n, out_uv);
 }
 void launch_normalize_uvz(const NormalizeArgs& a, int npoints, size_t n, uint8_t* valid,
-                          uint32_t* prefix, hipStream_t s) {
+                          uint32_t* prefix, hipStream_t s, int want_per_lane, int block_threads) {
   int per_lane;
-  const size_t lanes = normalize_lanes(n, per_lane);
-  const dim3 grid(grid_for(lanes)), block(256);
+  const size_t lanes = normalize_lanes(n, per_lane, want_per_lane);
+  const unsigned bt = block_threads > 0 ? (unsigned)block_threads : 256u;
+  const dim3 grid(grid_for(lanes, bt)), block(bt);
   switch (npoints) {
     case 1: hipLaunchKernelGGL(k_normalize_uvz<1>, grid, block, 0, s, a, n, lanes, per_lane, valid, prefix); break;
     case 2: hipLaunchKernelGGL(k_normalize_uvz<2>, grid, block, 0, s, a, n, lanes, per_lane, valid, prefix); break;
@@ -509,8 +510,9 @@ void launch_normalize_uvz(const NormalizeArgs& a, int npoints, size_t n, uint8_t
   }
 }
 void launch_scalars_from_mont(const uint8_t* u_mont, const uint8_t* m_mont, size_t n, uint8_t* u_out,
-                              uint8_t* m_out, hipStream_t s) {
-  hipLaunchKernelGGL(k_scalars_from_mont, dim3(grid_for(n)), dim3(256), 0, s, u_mont, m_mont, n, u_out, m_out);
+                              uint8_t* m_out, hipStream_t s, int block_threads) {
+  const unsigned bt = block_threads > 0 ? (unsigned)block_threads : 256u;
+  hipLaunchKernelGGL(k_scalars_from_mont, dim3(grid_for(n, bt)), dim3(bt), 0, s, u_mont, m_mont, n, u_out, m_out);
 }
 void launch_and_bytes(uint8_t* ok, const uint8_t* valid, size_t n, hipStream_t s) {
   hipLaunchKernelGGL(k_and_bytes, dim3(grid_for(n)), dim3(256), 0, s, ok, valid, n);

@@ -93,23 +93,25 @@ struct NormalizeArgs {
   const uint8_t* in[4];
   uint8_t* out[4];
 };
-constexpr int kNormalizePerLane = 16;  // at most (the kernel keeps one validity bit per item in a u32)
-inline size_t normalize_lanes(size_t n, int& per_lane) {
+constexpr int kNormalizePerLane = 32;  // at most (the kernel keeps one validity bit per item in a u32)
+inline size_t normalize_lanes(size_t n, int& per_lane, int want_per_lane = 0) {
   // items that share one inversion: more of them = less work, fewer lanes = longer latency
   per_lane = n >= ((size_t)1 << 19) ? 16 : (n >= ((size_t)1 << 15) ? 8 : 1);
+  if (want_per_lane > 0) per_lane = want_per_lane > kNormalizePerLane ? kNormalizePerLane : want_per_lane;
   return (n + per_lane - 1) / per_lane;
 }
 inline size_t normalize_prefix_bytes(size_t n, int npoints) {
-  int per_lane;
-  const size_t lanes = normalize_lanes(n, per_lane);
-  return (size_t)per_lane * npoints * lanes * kLimbs * 4;
+  // per_lane * lanes < n + per_lane slots of npoints running products (any per_lane up to the maximum)
+  return (size_t)npoints * (n + kNormalizePerLane) * kLimbs * 4;
 }
+// want_per_lane / block: 0 = the defaults above / 256 threads (the host pipeline asks for few,
+// single-wave workgroups: DESIGN.md §3 "Host pipeline")
 void launch_normalize_uvz(const NormalizeArgs& a, int npoints, size_t n, uint8_t* valid,
-                          uint32_t* prefix, hipStream_t s);
+                          uint32_t* prefix, hipStream_t s, int want_per_lane = 0, int block = 0);
 // JubJubScalar u and BlsScalar m from the reference's in-memory Montgomery limbs (R = 2^256) to the
 // canonical bytes every other kernel reads; limbs >= the modulus are poisoned (verdict 0)
 void launch_scalars_from_mont(const uint8_t* u_mont, const uint8_t* m_mont, size_t n, uint8_t* u_out,
-                              uint8_t* m_out, hipStream_t s);
+                              uint8_t* m_out, hipStream_t s, int block = 0);
 void launch_and_bytes(uint8_t* ok, const uint8_t* valid, size_t n, hipStream_t s);
 void launch_sign_finish(const uint8_t* r, const uint8_t* c, const uint8_t* sk, size_t n, uint8_t* u_out,
                         hipStream_t s);
