@@ -599,8 +599,22 @@ def main():
         pmc = _pmc()
         traffic = clock = valu_busy = None
         pmc_source = None
+        evidence = None
         if pmc:
-            pmc_source = {"file": "profiles/pmc_latest.json", "live": False,
+            # r05: the recorded counters are valid for ONE build of the kernel — the sha256 of
+            # k_verify.hip and every header it includes is stored with them; a mismatch marks every
+            # replayed figure stale (the library file's own hash is informational: it is rebuilt per box)
+            try:
+                from schnorr_amd import build as B
+                now_h = B.evidence_hashes()
+            except Exception:  # noqa: BLE001
+                now_h = {}
+            rec_h = pmc.get("evidence") or {}
+            evidence = {"recorded": rec_h, "this_build": now_h,
+                        "stale": not rec_h or rec_h.get("k_verify_sources_sha256") != now_h.get("k_verify_sources_sha256"),
+                        "same_library_file": bool(rec_h.get("libdsv_sha256")) and
+                        rec_h.get("libdsv_sha256") == now_h.get("libdsv_sha256")}
+            pmc_source = {"file": "profiles/pmc_latest.json", "live": False, "stale": evidence["stale"],
                           "captured": pmc.get("captured"), "commit": pmc.get("commit"),
                           "command": pmc.get("command"), "box_clock_held_ghz": pmc.get("clock_held_ghz"),
                           "note": "rocprofv3 --pmc passes cannot run inside the timed process: traffic and "
@@ -633,7 +647,10 @@ def main():
             "limit": "power (held clock) x issue slots spent on non-MAD instructions; neither HBM nor MFMA",
             "traffic": traffic,          # HBM / fabric bytes per launch, REPLAYED (pmc_source)
             "pmc_source": pmc_source,
-            "recorded": {"traffic_ratio": traffic / algo if traffic else None,
+            "evidence": evidence,
+            "recorded": {"stale": evidence["stale"] if evidence else None,
+                         "cache": (pmc or {}).get("cache"),
+                         "traffic_ratio": traffic / algo if traffic else None,
                          "clock_held_ghz": clock,
                          "frac_at_held_clock": dom["mad_frac"] * (CLOCK_HZ / 1e9) / clock if clock else None,
                          "valu_busy": valu_busy},

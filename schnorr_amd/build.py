@@ -121,6 +121,45 @@ def build_variant(name, force=False, verbose=False):
     return build(force=force, verbose=verbose, out=out, unit_flags=VARIANTS[name])
 
 
+def _includes(path, seen):
+    """the translation unit and every local header it includes, transitively"""
+    import re
+    path = os.path.normpath(path)
+    if path in seen or not os.path.exists(path):
+        return
+    seen.add(path)
+    with open(path, errors="replace") as f:
+        for m in re.finditer(r'^\s*#\s*include\s+"([^"]+)"', f.read(), re.M):
+            _includes(os.path.join(os.path.dirname(path), m.group(1)), seen)
+
+
+def unit_sources_sha256(unit):
+    """sha256 over a kernel translation unit and the local headers it includes: what a recorded
+    profile of that unit's kernels is valid for (profiles/pmc_latest.json, bench.py roofline.evidence)"""
+    seen = set()
+    _includes(os.path.join(CSRC, unit), seen)
+    h = hashlib.sha256()
+    for p in sorted(seen):
+        h.update(os.path.relpath(p, ROOT).encode() + b"\0")
+        with open(p, "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()
+
+
+def evidence_hashes():
+    """identity of the build a profile was taken from: kernel sources (authoritative: the library is
+    rebuilt per box and need not be byte-identical) and the library file itself"""
+    out = {"k_verify_sources_sha256": unit_sources_sha256("k_verify.hip"),
+           "k_hash_sources_sha256": unit_sources_sha256("k_hash.hip")}
+    if os.path.exists(LIB):
+        h = hashlib.sha256()
+        with open(LIB, "rb") as f:
+            for blk in iter(lambda: f.read(1 << 20), b""):
+                h.update(blk)
+        out["libdsv_sha256"] = h.hexdigest()
+    return out
+
+
 if __name__ == "__main__":
     flags = [a for a in sys.argv[1:] if a.startswith("-D")]
     names = [a.split("=", 1)[1] for a in sys.argv[1:] if a.startswith("--variant=")]

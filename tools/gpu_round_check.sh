@@ -3,14 +3,15 @@
 # (kernel trace + stats, then PMC passes on their own), summaries for profiles/<round>/, final bench
 # line.  Everything lands under gpurun_out/ (progress lines on stdout as it goes).
 #   tools/gpu_round_check.sh r03
+#   (a failing or timed-out step ends the run: no further GPU step is started after it)
 R=${1:-r03}
 mkdir -p gpurun_out
 echo "[final] tests"
-timeout -k 10 900 python3 -m pytest tests -m gpu -x -q --timeout 300 > gpurun_out/${R}_round_tests.log 2>&1
+timeout -k 10 900 python3 -m pytest tests -m gpu -x -q --timeout 300 > gpurun_out/${R}_round_tests.log 2>&1 || { tail -15 gpurun_out/${R}_round_tests.log; exit 1; }
 tail -3 gpurun_out/${R}_round_tests.log
 echo "[final] profiles"
 rm -rf gpurun_out/prof_round
-bash tools/profile_bench.sh gpurun_out/prof_round 2>&1 | grep "profile_bench"
+bash tools/profile_bench.sh gpurun_out/prof_round 2>&1 | grep "profile_bench" || exit 1
 python3 tools/summarize_prof.py gpurun_out/prof_round gpurun_out/${R}_final > gpurun_out/${R}_round_sum.log 2>&1 || tail -5 gpurun_out/${R}_round_sum.log
 cp profiles/pmc_latest.json gpurun_out/${R}_pmc_latest.json
 find gpurun_out/prof_round -name "*.db" -delete 2>/dev/null

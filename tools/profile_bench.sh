@@ -25,6 +25,13 @@ step "rocprofv3 --pmc FETCH_SIZE"
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -- python3 $ARGS > $OUT/pmc_fetch.log 2>&1
 step "rocprofv3 --pmc WRITE_SIZE"
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -- python3 $ARGS > $OUT/pmc_write.log 2>&1
+# where the fetched bytes are served from (r05): L2 hit rate, requests that leave the L2 for the fabric
+# (Infinity Cache / HBM) and their average latency (RDREQ_LEVEL / RDREQ: ~350 cycles = Infinity Cache,
+# ~700 = HBM on an idle chip, /opt/skills/guides/MI355X_MICROARCH.md) — four TCC slots per pass
+step "rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_LEVEL_sum"
+rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_LEVEL_sum --kernel-trace --output-format csv -d $OUT/pmc_tcc -- python3 $ARGS > $OUT/pmc_tcc.log 2>&1 || true
+step "rocprofv3 --pmc TCC_EA0_RDREQ_32B_sum TCC_EA0_RDREQ_DRAM_sum TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum"
+rocprofv3 --pmc TCC_EA0_RDREQ_32B_sum TCC_EA0_RDREQ_DRAM_sum TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum --kernel-trace --output-format csv -d $OUT/pmc_tcc2 -- python3 $ARGS > $OUT/pmc_tcc2.log 2>&1 || true
 # the fused double kernel (roofline_double.traffic): the same two counters over a run that includes the double leg
 ARGS2="bench.py --steps 2 --warmup 1 --no-cpu-baseline"
 step "rocprofv3 --pmc FETCH_SIZE (double leg)"

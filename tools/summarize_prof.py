@@ -106,6 +106,26 @@ def main():
         for c in ("SQ_INSTS_VALU", "SQ_WAVE_CYCLES", "GRBM_GUI_ACTIVE"):
             if c in d:
                 latest[c] = d[c]["avg_per_launch"]
+        # r05: what the recorded figures are valid for — bench.py marks them stale when the kernel's
+        # sources (k_verify.hip and every header it includes) differ from these
+        sys.path.insert(0, ROOT)
+        from schnorr_amd import build as B
+        latest["evidence"] = B.evidence_hashes()
+        # r05: where the fetched bytes are served from
+        tcc = {c: d[c]["avg_per_launch"] for c in ("TCC_HIT_sum", "TCC_MISS_sum", "TCC_EA0_RDREQ_sum",
+                                                   "TCC_EA0_RDREQ_LEVEL_sum", "TCC_EA0_RDREQ_32B_sum",
+                                                   "TCC_EA0_RDREQ_DRAM_sum", "TCC_EA0_WRREQ_sum",
+                                                   "TCC_EA0_WRREQ_64B_sum") if c in d}
+        if "TCC_HIT_sum" in tcc and "TCC_MISS_sum" in tcc:
+            tcc["l2_hit_rate"] = tcc["TCC_HIT_sum"] / max(1.0, tcc["TCC_HIT_sum"] + tcc["TCC_MISS_sum"])
+        if tcc.get("TCC_EA0_RDREQ_sum"):
+            if "TCC_EA0_RDREQ_LEVEL_sum" in tcc:
+                tcc["avg_fabric_read_latency_cycles"] = tcc["TCC_EA0_RDREQ_LEVEL_sum"] / tcc["TCC_EA0_RDREQ_sum"]
+            if "TCC_EA0_RDREQ_32B_sum" in tcc:
+                r32 = tcc["TCC_EA0_RDREQ_32B_sum"]
+                tcc["fabric_read_bytes"] = 32.0 * r32 + 64.0 * (tcc["TCC_EA0_RDREQ_sum"] - r32)
+        if tcc:
+            latest["cache"] = tcc
         latest["avg_duration_ns_under_pmc"] = d["avg_duration_ns_under_pmc"]
         if "clock_held_ghz" in d:
             latest["clock_held_ghz"] = d["clock_held_ghz"]
