@@ -328,6 +328,13 @@ def main():
     ap.add_argument("--config", choices=("single", "mixed"), default="single")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-double", action="store_true", help="skip the secondary figures")
+    ap.add_argument("--dump-inputs", metavar="DIR",
+                    help="write the timed batches (single, double, var-generator) as the reference's wire records "
+                         "+ the GPU verdicts into DIR: the input of rust/dusk-schnorr-gpu/src/bin/bench_ref.rs, "
+                         "which times the REAL crate's pk.verify(&sig, m) over them")
+    ap.add_argument("--cpu-baseline-file", metavar="JSON",
+                    help="output of bench_ref (the real dusk-schnorr crate on this box's host cores): becomes "
+                         "cpu_baseline with kind \"crate\"; the oracle's figures stay beside it as `port`")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -800,6 +807,32 @@ def main():
         mres, _ = run_mixed(max(1, args.steps // 2), 1)
         out["mixed"] = mres
 
+    # ---- the timed batches as the reference's wire records, for the real crate's CPU loop (bench_ref.rs)
+    if rank == 0 and world == 1 and args.dump_inputs:
+        os.makedirs(args.dump_inputs, exist_ok=True)
+        cat = lambda *a: np.ascontiguousarray(np.concatenate(a, axis=1))
+        comp = lambda t: E.compress_points(t.cpu().numpy())     # JubJubAffine::to_bytes
+        hn = lambda t: t.cpu().numpy()
+
+        def dump(name, sig, pk, m, verdicts):
+            for suffix, a in (("sig", sig), ("pk", pk), ("m", hn(m)), ("expected", hn(verdicts))):
+                np.ascontiguousarray(a).tofile(os.path.join(args.dump_inputs, "%s_%s.bin" % (name, suffix)))
+            return int(sig.shape[0])
+
+        meta = {"single": dump("single", cat(hn(batch["u"]), comp(batch["R"])), comp(batch["PK"]), batch["m"], ok)}
+        if "double" in sample_checks:
+            bd, got = sample_checks["double"]
+            meta["double"] = dump("double", cat(hn(bd["u"]), comp(bd["R"]), comp(bd["Rp"])),
+                                  cat(comp(bd["PK"]), comp(bd["PKp"])), bd["m"], got)
+        if "vargen" in sample_checks:
+            bv, got = sample_checks["vargen"]
+            meta["vargen"] = dump("vargen", cat(hn(bv["u"]), comp(bv["R"])), cat(comp(bv["PK"]), comp(bv["Gen"])),
+                                  bv["m"], got)
+        with open(os.path.join(args.dump_inputs, "meta.json"), "w") as f:
+            json.dump(meta, f)
+        out["dumped_inputs"] = {"dir": args.dump_inputs, "items": meta,
+                                "next": "DSV_NO_LINK=1 cargo run --release --bin bench_ref -- %s" % args.dump_inputs}
+
     # ---- CPU baseline: the oracle (port of the reference algorithm) on the host cores
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -874,6 +907,26 @@ def main():
             checked.append("wire")
         out["cpu_baseline"]["oracle_samples"] = "first %d items of: single (%d), %s" % (
             k, sample, ", ".join(checked))
+        if args.cpu_baseline_file:
+            # the reference itself (rust/dusk-schnorr-gpu/src/bin/bench_ref.rs): pk.verify(&sig, m) of the
+            # real crate over the batches --dump-inputs wrote, all cores and one thread
+            with open(args.cpu_baseline_file) as f:
+                ref = json.load(f)
+            if ref.get("kind") != "crate" or "single" not in ref:
+                raise SystemExit("--cpu-baseline-file: not a bench_ref output")
+            port = out["cpu_baseline"]
+            sg = ref["single"]
+            out["cpu_baseline"] = {
+                "value": sg["threads_all"]["value"], "unit": "verifies/s", "cores": ref.get("cores"),
+                "kind": "crate", "cpu": ref.get("cpu"),
+                "sample": "%s: pk.verify(&sig, m) over all %d items of the dumped single batch on %s threads "
+                          "(%.1f s); 1 thread: %.0f verifies/s on %d items; verdicts differing from the GPU's: %d"
+                          % (ref.get("crate"), sg["items"], sg["threads_all"].get("threads", ref.get("cores")),
+                             sg["threads_all"]["seconds"], sg["threads_1"]["value"], sg["threads_1"]["items"],
+                             sg["mismatches_vs_gpu"]),
+                "crate": {k_: ref[k_] for k_ in ("single", "double", "vargen") if k_ in ref},
+                "port": port,
+            }
         # host-buffer path of the C ABI (PCIe-inclusive), never the headline value
         hu, hR, hPK, hm = (h(batch[x], n) for x in ("u", "R", "PK", "m"))
         def host_best(fn, reps=3):
@@ -900,6 +953,19 @@ def main():
             out["host_path_ext"] = {"value": n / te, "unit": "verifies/s",
                                     "note": "dsv_verify_single_ext on %d host-resident items (u, v, z "
                                             "points: 256 B per item) incl. PCIe staging" % n}
+            # the same with z = 1 in every point — what deserialised keys / signatures and this library's
+            # own sign / keygen outputs hold: every lane's inversion is 1/1 (inv29.h answers it at once;
+            # before r05 such lanes paid a failed Euclid attempt plus the whole Fermat chain)
+            one = np.zeros((n, 32), dtype=np.uint8)
+            one[:, 0] = 1
+            z1 = lambda a: np.ascontiguousarray(np.concatenate([a, one], axis=1))
+            hR_z1, hPK_z1 = z1(hR), z1(hPK)
+            tz, got = host_best(lambda: E.verify_single_ext(hu, hR_z1, hPK_z1, hm))
+            if (got != batch["expected"].cpu().numpy()).any():
+                raise SystemExit("host projective-input (z = 1) verdicts differ from the expected pattern")
+            out["host_path_ext"]["z_equals_1"] = {"value": n / tz, "unit": "verifies/s",
+                                                  "note": "every point with z = 1 (affine-lifted input)"}
+            del hR_z1, hPK_z1
             tw, got = host_best(lambda: E.verify_single_wire(hsig, hpk, hm))
             if (got != batch["expected"].cpu().numpy()).any():
                 raise SystemExit("host wire-format verdicts differ from the expected pattern")

@@ -309,7 +309,10 @@ int dsv_challenge_double_dev(const void *R_uv, const void *Rp_uv, const void *m,
  * inside sign()).  Outputs: u (32 B), R_uv / Rp_uv (64 B).  gen_uv == NULL means the standard
  * generator G;  for the var-generator scheme pass the per-key generator (variable base).
  * NOT A PRODUCTION SIGNER: unlike dusk-jubjub's constant-time multiplication, these kernels index
- * global-memory tables with digits of sk and of the nonce (memory addresses depend on secrets).
+ * global-memory tables with digits of sk and of the nonce (memory addresses depend on secrets), and
+ * they normalise r*G / sk*G with a VARIABLE-TIME inversion of the projective z (extended Euclid,
+ * inv29.h: its step count, and whether it falls back to Fermat, depend on z — a value derived from
+ * the secret scalar; projective coordinates are known to leak scalar bits).
  * The host entry points zero their device staging of sk / nonce before returning (and the
  * library zeroes staging it releases); the *_dev forms work in the caller's buffers only.
  * A scalar that is not canonical (>= r): host entry points return DSV_ERR_INVALID_ARGUMENT; the

@@ -3,6 +3,11 @@
 //! `verify()` stay as they are; this crate adds
 //! `verify_batch(&[Signature], &[PublicKey], &[BlsScalar]) -> Vec<bool>` (+ `_double`, `_var_gen`)
 //! with `out[i] == pks[i].verify(&sigs[i], msgs[i])`, computed by libdsv.so on an MI355X.
+//! `verify` is infallible in the reference, so `verify_batch*` return the verdicts directly and PANIC
+//! if the engine itself fails (no GPU, HIP error) — `try_verify_batch*` return that as
+//! `Err(EngineError)` instead.  `verify_batch*_submit` start a batch and return a `BatchJob`; with
+//! two batches in flight per GPU the second one's ramp runs under the first one's tail
+//! (include/dsv.h: `dsv_verify_*_mont_cols_submit`; bench.py `verify_batch_e2e.streamed`).
 //!
 //! Replaces, batch-wise: `PublicKey::verify` (dusk-schnorr src/keys/public.rs:121-130),
 //! `PublicKeyDouble::verify` (:222-244), `PublicKeyVarGen::verify` (:401-415).
@@ -20,7 +25,8 @@
 //! path.
 //!
 //! The only thing this relies on beyond the public API is the in-memory layout of two upstream
-//! types, checked once at start-up by `layout_ok()` against values computed through the public API:
+//! types, checked once at RUN time by `layout_ok()` (sizes and field order, through a byte view)
+//! against values computed through the public API:
 //!   * `JubJubScalar` is its four limbs (a one-field tuple struct),
 //!   * `JubJubExtended` starts with the limbs of u, v, z in this order (`{u, v, z, t1, t2}`).
 //! If the probe fails (a future dusk-jubjub reorders fields) the crate falls back to copying the
@@ -56,6 +62,12 @@ extern "C" {
     fn dsv_verify_single_mont_cols(cols: *const Column, n: usize, ok: *mut u8) -> c_int;
     fn dsv_verify_double_mont_cols(cols: *const Column, n: usize, ok: *mut u8) -> c_int;
     fn dsv_verify_vargen_mont_cols(cols: *const Column, n: usize, ok: *mut u8) -> c_int;
+    // asynchronous forms: `submit` copies cols[], starts the batch on a library-owned driver thread and
+    // returns a job; `dsv_job_wait` blocks, returns the batch's status and releases the job
+    fn dsv_verify_single_mont_cols_submit(cols: *const Column, n: usize, ok: *mut u8, job: *mut *mut c_void) -> c_int;
+    fn dsv_verify_double_mont_cols_submit(cols: *const Column, n: usize, ok: *mut u8, job: *mut *mut c_void) -> c_int;
+    fn dsv_verify_vargen_mont_cols_submit(cols: *const Column, n: usize, ok: *mut u8, job: *mut *mut c_void) -> c_int;
+    fn dsv_job_wait(job: *mut c_void) -> c_int;
 }
 
 /// Engine failure (no GPU, HIP error).  Never a verdict.
@@ -87,21 +99,32 @@ pub fn init_all() -> Result<usize, EngineError> {
     Ok(n as usize)
 }
 
-const _: () = assert!(core::mem::size_of::<JubJubScalar>() == 32);
-const _: () = assert!(core::mem::size_of::<BlsScalar>() == 32);
-const _: () = assert!(core::mem::size_of::<JubJubExtended>() == 160);
-
-/// The two layout facts the zero-copy path rests on, checked against the public API.
+/// The layout facts the zero-copy path rests on, checked AT RUN TIME against values computed through
+/// the public API: a dusk-jubjub that changes a size or reorders fields makes this return false and
+/// selects the accessor-copy path below — it never breaks the build and never reads past an object
+/// (the former compile-time size asserts + `transmute` turned a layout change into a hard
+/// build failure, not a fallback).
 fn layout_ok() -> bool {
     static OK: OnceLock<bool> = OnceLock::new();
     *OK.get_or_init(|| {
+        use core::mem::size_of;
+        if size_of::<JubJubScalar>() != 32 || size_of::<BlsScalar>() != 32 || size_of::<JubJubExtended>() != 160 {
+            return false;
+        }
+        // limb k of a value, read through a byte view (no alignment or size assumption beyond the checks above)
+        fn limbs<T, const K: usize>(v: &T) -> [u64; K] {
+            assert!(size_of::<T>() >= 8 * K);
+            let p = v as *const T as *const u8;
+            core::array::from_fn(|k| unsafe { core::ptr::read_unaligned(p.add(8 * k) as *const u64) })
+        }
         // JubJubScalar::one() must read as R mod r
-        let one: [u64; 4] = unsafe { core::mem::transmute(JubJubScalar::one()) };
         let r_mod_r = [0x25f8_0bb3_b996_07d9u64, 0xf315_d62f_66b6_e750, 0x9325_14ee_eb88_14f4,
                        0x09a6_fc6f_4791_55c6];
+        let one: [u64; 4] = limbs(&JubJubScalar::one());
         // a point with three distinct, non-trivial coordinates
         let p = GENERATOR_EXTENDED * JubJubScalar::from(7u64);
-        let raw: [u64; 20] = unsafe { core::mem::transmute(p) };
+        let raw: [u64; 12] = limbs(&p);
+        // the three schemes' structs: the accessors must point INTO the objects handed to the engine
         one == r_mod_r
             && raw[0..4] == p.get_u().0
             && raw[4..8] == p.get_v().0
@@ -117,7 +140,21 @@ fn verdicts(ok: Vec<u8>) -> Vec<bool> {
     ok.into_iter().map(|b| b == 1).collect()
 }
 
-pub fn verify_batch(sigs: &[Signature], pks: &[PublicKey], msgs: &[BlsScalar])
+/// `out[i] == pks[i].verify(&sigs[i], msgs[i])` (dusk-schnorr src/keys/public.rs:121-130) — the entry
+/// point `north_star` names.  Panics if the slices differ in length or the engine fails.
+pub fn verify_batch(sigs: &[Signature], pks: &[PublicKey], msgs: &[BlsScalar]) -> Vec<bool> {
+    try_verify_batch(sigs, pks, msgs).expect("dusk-schnorr-gpu: engine failure")
+}
+/// ... `PublicKeyDouble::verify` (src/keys/public.rs:222-244)
+pub fn verify_batch_double(sigs: &[SignatureDouble], pks: &[PublicKeyDouble], msgs: &[BlsScalar]) -> Vec<bool> {
+    try_verify_batch_double(sigs, pks, msgs).expect("dusk-schnorr-gpu: engine failure")
+}
+/// ... `PublicKeyVarGen::verify` (src/keys/public.rs:401-415)
+pub fn verify_batch_var_gen(sigs: &[SignatureVarGen], pks: &[PublicKeyVarGen], msgs: &[BlsScalar]) -> Vec<bool> {
+    try_verify_batch_var_gen(sigs, pks, msgs).expect("dusk-schnorr-gpu: engine failure")
+}
+
+pub fn try_verify_batch(sigs: &[Signature], pks: &[PublicKey], msgs: &[BlsScalar])
     -> Result<Vec<bool>, EngineError> {
     assert!(sigs.len() == pks.len() && sigs.len() == msgs.len());
     let n = sigs.len();
@@ -138,7 +175,7 @@ pub fn verify_batch(sigs: &[Signature], pks: &[PublicKey], msgs: &[BlsScalar])
     Ok(verdicts(ok))
 }
 
-pub fn verify_batch_double(sigs: &[SignatureDouble], pks: &[PublicKeyDouble], msgs: &[BlsScalar])
+pub fn try_verify_batch_double(sigs: &[SignatureDouble], pks: &[PublicKeyDouble], msgs: &[BlsScalar])
     -> Result<Vec<bool>, EngineError> {
     assert!(sigs.len() == pks.len() && sigs.len() == msgs.len());
     let n = sigs.len();
@@ -159,7 +196,7 @@ pub fn verify_batch_double(sigs: &[SignatureDouble], pks: &[PublicKeyDouble], ms
     Ok(verdicts(ok))
 }
 
-pub fn verify_batch_var_gen(sigs: &[SignatureVarGen], pks: &[PublicKeyVarGen], msgs: &[BlsScalar])
+pub fn try_verify_batch_var_gen(sigs: &[SignatureVarGen], pks: &[PublicKeyVarGen], msgs: &[BlsScalar])
     -> Result<Vec<bool>, EngineError> {
     assert!(sigs.len() == pks.len() && sigs.len() == msgs.len());
     let n = sigs.len();
@@ -178,6 +215,96 @@ pub fn verify_batch_var_gen(sigs: &[SignatureVarGen], pks: &[PublicKeyVarGen], m
         check(unsafe { dsv_verify_vargen_mont_cols(soa.cols().as_ptr(), n, ok.as_mut_ptr()) })?;
     }
     Ok(verdicts(ok))
+}
+
+/// A batch in flight.  Borrows the slices it was started from (the engine reads the objects in place
+/// until `wait` returns); dropping it unwaited waits.
+pub struct BatchJob<'a> {
+    job: *mut c_void,
+    ok: Vec<u8>,
+    _soa: Option<Box<dyn core::any::Any>>, // the dense copies of the layout-agnostic path, if taken (owned arrays)
+    _borrow: core::marker::PhantomData<&'a ()>,
+}
+impl<'a> BatchJob<'a> {
+    /// Blocks until the verdicts are there: `out[i] == pks[i].verify(&sigs[i], msgs[i])`.
+    pub fn wait(mut self) -> Result<Vec<bool>, EngineError> {
+        let job = core::mem::replace(&mut self.job, core::ptr::null_mut());
+        if !job.is_null() {
+            check(unsafe { dsv_job_wait(job) })?;
+        }
+        Ok(verdicts(core::mem::take(&mut self.ok)))
+    }
+}
+impl<'a> Drop for BatchJob<'a> {
+    fn drop(&mut self) {
+        if !self.job.is_null() {
+            unsafe { dsv_job_wait(self.job) };
+        }
+    }
+}
+type SubmitFn = unsafe extern "C" fn(*const Column, usize, *mut u8, *mut *mut c_void) -> c_int;
+fn submit<'a>(f: SubmitFn, cols: &[Column], n: usize, soa: Option<Box<dyn core::any::Any>>)
+    -> Result<BatchJob<'a>, EngineError> {
+    let mut j = BatchJob { job: core::ptr::null_mut(), ok: vec![0u8; n], _soa: soa, _borrow: core::marker::PhantomData };
+    if n != 0 {
+        init_all()?;
+        check(unsafe { f(cols.as_ptr(), n, j.ok.as_mut_ptr(), &mut j.job) })?;
+    }
+    Ok(j)
+}
+/// Start `verify_batch` and return at once.  Keep two in flight per GPU:
+/// `let a = submit(b0); let b = submit(b1); a.wait(); let c = submit(b2); b.wait(); ...`
+pub fn verify_batch_submit<'a>(sigs: &'a [Signature], pks: &'a [PublicKey], msgs: &'a [BlsScalar])
+    -> Result<BatchJob<'a>, EngineError> {
+    assert!(sigs.len() == pks.len() && sigs.len() == msgs.len());
+    let n = sigs.len();
+    if n == 0 {
+        return submit(dsv_verify_single_mont_cols_submit, &[], 0, None);
+    }
+    if layout_ok() {
+        let cols = [col(sigs[0].u(), sigs), col(sigs[0].R(), sigs), col(pks[0].as_ref(), pks), col(&msgs[0], msgs)];
+        submit(dsv_verify_single_mont_cols_submit, &cols, n, None)
+    } else {
+        let soa = Box::new(fallback::Soa::gather(n, |i| sigs[i].u(), |i| [sigs[i].R(), pks[i].as_ref()], |i| &msgs[i]));
+        let cols = soa.cols(); // (pointers into the boxed arrays: they do not move with the box)
+        submit(dsv_verify_single_mont_cols_submit, &cols, n, Some(soa as Box<dyn core::any::Any>))
+    }
+}
+pub fn verify_batch_double_submit<'a>(sigs: &'a [SignatureDouble], pks: &'a [PublicKeyDouble], msgs: &'a [BlsScalar])
+    -> Result<BatchJob<'a>, EngineError> {
+    assert!(sigs.len() == pks.len() && sigs.len() == msgs.len());
+    let n = sigs.len();
+    if n == 0 {
+        return submit(dsv_verify_double_mont_cols_submit, &[], 0, None);
+    }
+    if layout_ok() {
+        let cols = [col(sigs[0].u(), sigs), col(sigs[0].R(), sigs), col(sigs[0].R_prime(), sigs),
+                    col(pks[0].pk(), pks), col(pks[0].pk_prime(), pks), col(&msgs[0], msgs)];
+        submit(dsv_verify_double_mont_cols_submit, &cols, n, None)
+    } else {
+        let soa = Box::new(fallback::Soa::gather(n, |i| sigs[i].u(),
+            |i| [sigs[i].R(), sigs[i].R_prime(), pks[i].pk(), pks[i].pk_prime()], |i| &msgs[i]));
+        let cols = soa.cols();
+        submit(dsv_verify_double_mont_cols_submit, &cols, n, Some(soa as Box<dyn core::any::Any>))
+    }
+}
+pub fn verify_batch_var_gen_submit<'a>(sigs: &'a [SignatureVarGen], pks: &'a [PublicKeyVarGen], msgs: &'a [BlsScalar])
+    -> Result<BatchJob<'a>, EngineError> {
+    assert!(sigs.len() == pks.len() && sigs.len() == msgs.len());
+    let n = sigs.len();
+    if n == 0 {
+        return submit(dsv_verify_vargen_mont_cols_submit, &[], 0, None);
+    }
+    if layout_ok() {
+        let cols = [col(sigs[0].u(), sigs), col(sigs[0].R(), sigs), col(pks[0].public_key(), pks),
+                    col(pks[0].generator(), pks), col(&msgs[0], msgs)];
+        submit(dsv_verify_vargen_mont_cols_submit, &cols, n, None)
+    } else {
+        let soa = Box::new(fallback::Soa::gather(n, |i| sigs[i].u(),
+            |i| [sigs[i].R(), pks[i].public_key(), pks[i].generator()], |i| &msgs[i]));
+        let cols = soa.cols();
+        submit(dsv_verify_vargen_mont_cols_submit, &cols, n, Some(soa as Box<dyn core::any::Any>))
+    }
 }
 
 /// Layout-agnostic path: limb COPIES through the public accessors (`get_u().0`: a field read, no
@@ -272,7 +399,13 @@ mod tests {
             msgs.push(m);
         }
         pks.swap(3, 4); // two wrong keys
-        let gpu = verify_batch(&sigs, &pks, &msgs).expect("engine");
+        let gpu = verify_batch(&sigs, &pks, &msgs);
+        assert_eq!(try_verify_batch(&sigs, &pks, &msgs).expect("engine"), gpu);
+        // two batches in flight give the same verdicts
+        let (a, b) = (verify_batch_submit(&sigs, &pks, &msgs).expect("engine"),
+                      verify_batch_submit(&sigs, &pks, &msgs).expect("engine"));
+        assert_eq!(a.wait().expect("engine"), gpu);
+        assert_eq!(b.wait().expect("engine"), gpu);
         for i in 0..sigs.len() {
             assert_eq!(gpu[i], pks[i].verify(&sigs[i], msgs[i]), "item {i}");
         }

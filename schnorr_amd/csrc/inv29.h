@@ -14,8 +14,8 @@
 // one side is 0; the other then holds gcd(q, x) = 1 (q is prime, x != 0) and its cofactor is +-1/x.
 // Exactness does not rest on the floating-point arithmetic: an estimate is only ever too SMALL, a
 // too-small quotient leaves a valid (longer) Euclidean pair, and the result is checked —
-// r == 1 — before it is used; anything else (x = 0, a quotient above 2^31 - 1 such as for x = 1, the
-// iteration cap) falls back to Fermat.  Tests: test_inversion_edge_values_through_to_hash_inputs
+// r == 1 — before it is used; x = 1 is answered at once, anything else (x = 0, a quotient above
+// 2^31 - 1 such as for x = 2, the iteration cap) falls back to Fermat.  Tests: test_inversion_edge_values_through_to_hash_inputs
 // (tests/test_gpu_r04.py) against Python integers; every projective / limb parity test and soak runs
 // through it.
 #pragma once
@@ -61,6 +61,11 @@ DSV_DEV bool is_one8(const u32 (&x)[8]) { return x[0] == 1 && (x[1] | x[2] | x[3
 DSV_DEV Fe fe_invert_euclid(const Fe& z) {
   u32 A[8], B[8], tA[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tB[8] = {1, 0, 0, 0, 0, 0, 0, 0};
   fe_to_words_plain(B, fe_from_mont(z));  // canonical plain value, < q
+  // x = 1: the product of a lane's z's whenever every point of the lane has z = 1 — the most common
+  // real input (deserialised keys and signatures, this library's own sign / keygen outputs).  The
+  // first quotient would be q itself (> 31 bits) and the lane would pay a failed attempt PLUS the whole
+  // Fermat chain; 1/1 needs neither.
+  if (is_one8(B)) return fe_one();
 #pragma unroll
   for (int i = 0; i < 8; i++) A[i] = kQ32[i];
   double dA = to_double8(A), dB = to_double8(B);
