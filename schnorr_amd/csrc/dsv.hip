@@ -50,6 +50,7 @@
 #define DSV_HOST_TABLES 1
 #include "dsv_constants.h"
 #include "launch.h"
+#include "host_sync.h"
 
 
 // ==========================================================================================
@@ -78,90 +79,7 @@ int fail(int code, const char* fmt, ...) {
                   __LINE__);                                                                  \
   } while (0)
 
-// Copy threads of the host path: the caller's (pageable) arrays are gathered into pinned staging
-// by several threads at once, so the DMA engine is fed faster than one memcpy stream can.
-class CopyPool {
- public:
-  ~CopyPool() { stop(); }
-  // fn(t, T) runs on T threads (t = 0 is the caller); returns when all are done.
-  // Between the chunks of one call the workers SPIN for a short while before they block: a chunk
-  // arrives every 0.3 - 1 ms, and a condition-variable wake-up (30 - 100 us, twice per chunk: start
-  // and completion) is a tenth of a first chunk's whole gather — on the path the GPU is waiting for.
-  void run(int T, const std::function<void(int, int)>& fn) {
-    if (T <= 1) {
-      fn(0, 1);
-      return;
-    }
-    {
-      std::unique_lock<std::mutex> lk(m_);
-      while ((int)th_.size() < T - 1) {
-        const int id = (int)th_.size() + 1;
-        th_.emplace_back([this, id] { loop(id); });
-      }
-      job_ = &fn;
-      job_threads_ = T;
-      pending_.store(T - 1, std::memory_order_relaxed);
-      gen_.fetch_add(1, std::memory_order_release);
-    }
-    go_.notify_all();
-    fn(0, T);
-    for (int spin = 0; spin < kSpin && pending_.load(std::memory_order_acquire) != 0; spin++) cpu_relax();
-    if (pending_.load(std::memory_order_acquire) != 0) {
-      std::unique_lock<std::mutex> lk(m_);
-      done_.wait(lk, [this] { return pending_.load(std::memory_order_acquire) == 0; });
-    }
-    job_ = nullptr;
-  }
-  void stop() {
-    {
-      std::unique_lock<std::mutex> lk(m_);
-      quit_ = true;
-      gen_.fetch_add(1, std::memory_order_release);
-    }
-    go_.notify_all();
-    for (auto& t : th_) t.join();
-    th_.clear();
-    quit_ = false;
-  }
-
- private:
-  static constexpr int kSpin = 20000;  // ~0.2 - 0.4 ms of pause instructions
-  static void cpu_relax() { __builtin_ia32_pause(); }
-  void loop(int id) {
-    uint64_t seen = gen_.load(std::memory_order_acquire) - 1;  // started while a job is being posted: take it
-    for (;;) {
-      for (int spin = 0; spin < kSpin && gen_.load(std::memory_order_acquire) == seen; spin++) cpu_relax();
-      const std::function<void(int, int)>* job;
-      int T;
-      {
-        std::unique_lock<std::mutex> lk(m_);
-        go_.wait(lk, [&] { return gen_.load(std::memory_order_acquire) != seen; });
-        seen = gen_.load(std::memory_order_acquire);
-        if (quit_) return;
-        job = job_;
-        T = job_threads_;
-      }
-      if (job && id < T) {
-        (*job)(id, T);
-        if (pending_.fetch_sub(1, std::memory_order_acq_rel) == 1) {
-          std::unique_lock<std::mutex> lk(m_);  // (the waiter may be between its check and its wait)
-          done_.notify_one();
-        }
-      }
-    }
-  }
-  std::vector<std::thread> th_;
-  std::mutex m_;
-  std::condition_variable go_, done_;
-  const std::function<void(int, int)>* job_ = nullptr;
-  int job_threads_ = 0;
-  std::atomic<int> pending_{0};
-  std::atomic<uint64_t> gen_{0};
-  bool quit_ = false;
-};
-
 constexpr int kPipeSlots = 8;   // chunks in flight per host call: at most (Context::pipe_slots are used)
-constexpr int kPipes = 2;       // host calls in flight per device (each owns a Pipe)
 constexpr int kMaxDevices = 16;
 constexpr int kSplitLanes = 8;
 
@@ -203,7 +121,6 @@ struct PipeSlot {
 struct Pipe {
   PipeSlot slot[kPipeSlots];
   CopyPool copiers;
-  bool busy = false;
 };
 
 // Everything the library owns on one GPU.  One Context per device ordinal; several devices can be
@@ -233,11 +150,7 @@ struct Context {
   // device and pinned host staging, its events, and the call's copy threads.  kPipes calls can be in
   // flight per device (r05; r01 - r04 held `mu` for the whole call): the second call's ramp — small
   // first chunks, an idle GPU waiting for the first transfer — runs under the first call's tail.
-  std::mutex pipe_mu;                     // pipe acquisition (FIFO by ticket), shutdown
-  std::condition_variable pipe_cv;
-  uint64_t pipe_ticket_next = 0, pipe_ticket_serving = 0;
-  uint64_t turn_next = 0, turn_serving = 0;  // whose turn it is to enqueue compute (TurnTicket)
-  int pipes_busy = 0;
+  PipeSync pipe_sync;                     // pipe acquisition (FIFO by ticket), compute turns, shutdown (host_sync.h)
   Pipe pipes[kPipes];
   std::mutex enq_mu;                      // one chunk's enqueue onto the shared streams is atomic: the
                                           // lanes' work areas below belong to the sub-batch being enqueued
@@ -249,11 +162,8 @@ struct Context {
   size_t pipe_work_bytes[3] = {};
   uint64_t pipe_parts = 0;                // sub-batches enqueued so far: part p runs on lane p & 1
   bool prep_stream = true;                // DSV_PIPE_PREP_STREAM=0: whole-chunk preprocessing on a compute lane (r04)
-  size_t pipe_chunk = (size_t)1 << 18, pipe_first_chunk = (size_t)1 << 15;  // DSV_PIPE_CHUNK_LOG2 / DSV_PIPE_FIRST_LOG2
-  double pipe_growth = 0;                 // DSV_PIPE_GROWTH (percent; A/B): chunk k + 1 = growth x chunk k up to pipe_chunk
-  int pipe_slots = 0;                     // DSV_PIPE_SLOTS: chunks in flight per call (<= kPipeSlots); 0 = by chunk size
-  int pipe_plan[16] = {};                 // DSV_PIPE_PLAN="15,15,16,...": log2 chunk sizes of a call that finds the GPU idle
-  int pipe_plan_len = 0;
+  PlanParams plan;                        // chunk plan of a call (host_sync.h; DSV_PIPE_CHUNK_LOG2 / _FIRST_LOG2 / _GROWTH / _PLAN)
+  int pipe_slots = 0;                     // DSV_PIPE_SLOTS: chunks in flight per call (<= kPipeSlots); 0 = three
   int norm_per_lane = 0, norm_block = 0;  // DSV_NORM_PER_LANE / DSV_NORM_BLOCK: shape of the pipeline's normalisation kernels
 };
 Context g_ctx[kMaxDevices];
@@ -396,45 +306,6 @@ int ensure_pipe_slot(PipeSlot& sl, size_t dev_bytes, size_t host_bytes, size_t p
   }
   return DSV_OK;
 }
-// A host call's lease on one of the device's pipes: FIFO by ticket, blocks while kPipes calls are in
-// flight; released (and the next waiter woken) on scope exit.
-struct PipeLease {
-  Context& ctx;
-  Pipe* pipe = nullptr;
-  bool alone = true;  // no other call held a pipe of this device when this one got its own
-  // want_turn (may be null): the call's place in the order in which calls enqueue compute, taken in
-  // the same critical section, so pipes and turns are handed out in one order
-  template <class Turn>
-  PipeLease(Context& c, Turn* want_turn) : ctx(c) {
-    std::unique_lock<std::mutex> lk(ctx.pipe_mu);
-    const uint64_t mine = ctx.pipe_ticket_next++;
-    ctx.pipe_cv.wait(lk, [&] { return ctx.pipe_ticket_serving == mine && ctx.pipes_busy < kPipes; });
-    ctx.pipe_ticket_serving++;
-    if (want_turn) want_turn->take(ctx.turn_next++);
-    for (auto& p : ctx.pipes)
-      if (!p.busy) {
-        pipe = &p;
-        break;
-      }
-    pipe->busy = true;
-    alone = ctx.pipes_busy == 0;
-    ctx.pipes_busy++;
-    lk.unlock();
-    ctx.pipe_cv.notify_all();  // the next ticket may find the other pipe free
-  }
-  ~PipeLease() {
-    {
-      std::lock_guard<std::mutex> lk(ctx.pipe_mu);
-      pipe->busy = false;
-      ctx.pipes_busy--;
-    }
-    ctx.pipe_cv.notify_all();
-  }
-  PipeLease(const PipeLease&) = delete;
-  PipeLease& operator=(const PipeLease&) = delete;
-};
-
-inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
 int check_n(size_t n) {
   if (n > DSV_MAX_BATCH) return fail(DSV_ERR_TOO_LARGE, "batch of %zu exceeds DSV_MAX_BATCH", n);
@@ -540,7 +411,6 @@ void launch_verify_fixed_double(const Context& ctx, const void* u, const void* c
 // on every SIMD — hash next to scalar multiplication, table build next to window loop — and
 // leaves no gap between kernels: +6 % on 2^20, same-box A/B (probe: tools/overlap_probe.py).  The caller's stream is
 // forked / joined with events, so the call still behaves as one enqueue on that stream.
-constexpr size_t kSplitItems = (size_t)1 << 16;
 
 int acquire_lane(Context& ctx, hipStream_t user, SplitLane*& out) {
   std::lock_guard<std::mutex> lk(ctx.lane_mu);
@@ -717,21 +587,21 @@ int dsv_init(int device) {
     const int v = e ? atoi(e) : dflt;
     return (size_t)1 << (v < lo ? lo : (v > hi ? hi : v));
   };
-  ctx.pipe_chunk = log2_env("DSV_PIPE_CHUNK_LOG2", 16, 20, 18);        // chunk size of the host pipeline
-  ctx.pipe_first_chunk = log2_env("DSV_PIPE_FIRST_LOG2", 12, 18, 15);  // ... of a call's first chunk (doubling from there)
-  if (ctx.pipe_first_chunk > ctx.pipe_chunk) ctx.pipe_first_chunk = ctx.pipe_chunk;
-  ctx.pipe_plan_len = 0;
+  ctx.plan.chunk = log2_env("DSV_PIPE_CHUNK_LOG2", 16, 20, 18);        // chunk size of the host pipeline
+  ctx.plan.first_chunk = log2_env("DSV_PIPE_FIRST_LOG2", 12, 18, 15);  // ... of a call's first chunk (doubling from there)
+  if (ctx.plan.first_chunk > ctx.plan.chunk) ctx.plan.first_chunk = ctx.plan.chunk;
+  ctx.plan.plan_len = 0;
   if (const char* e = getenv("DSV_PIPE_PLAN")) {
-    for (const char* q = e; *q && ctx.pipe_plan_len < 16;) {
+    for (const char* q = e; *q && ctx.plan.plan_len < 16;) {
       char* end = nullptr;
       const long v = strtol(q, &end, 10);
       if (end == q) break;
-      ctx.pipe_plan[ctx.pipe_plan_len++] = v < 12 ? 12 : (v > 20 ? 20 : (int)v);
+      ctx.plan.plan[ctx.plan.plan_len++] = v < 12 ? 12 : (v > 20 ? 20 : (int)v);
       q = *end == ',' ? end + 1 : end;
     }
   }
   ctx.pipe_slots = 0;
-  ctx.pipe_growth = 0;
+  ctx.plan.growth = 0;
   ctx.norm_per_lane = getenv("DSV_NORM_PER_LANE") ? atoi(getenv("DSV_NORM_PER_LANE")) : 0;
   ctx.norm_block = getenv("DSV_NORM_BLOCK") ? atoi(getenv("DSV_NORM_BLOCK")) : 0;
   if (const char* e = getenv("DSV_PIPE_SLOTS")) {
@@ -740,7 +610,7 @@ int dsv_init(int device) {
   }
   if (const char* e = getenv("DSV_PIPE_GROWTH")) {
     const int pct = atoi(e);
-    ctx.pipe_growth = (pct < 110 ? 110 : (pct > 400 ? 400 : pct)) / 100.0;
+    ctx.plan.growth = (pct < 110 ? 110 : (pct > 400 ? 400 : pct)) / 100.0;
   }
   ctx.ready.store(true, std::memory_order_release);
   int none = -1;
@@ -788,8 +658,8 @@ int dsv_shutdown_device(int device) {
   ctx.ready.store(false);  // new calls are refused from here on
   {
     // host calls in flight finish first: the pipelined ones hold a pipe, the small ones `mu`
-    std::unique_lock<std::mutex> pl(ctx.pipe_mu);
-    ctx.pipe_cv.wait(pl, [&] { return ctx.pipes_busy == 0 && ctx.pipe_ticket_next == ctx.pipe_ticket_serving; });
+    std::unique_lock<std::mutex> pl(ctx.pipe_sync.mu);
+    ctx.pipe_sync.cv.wait(pl, [&] { return ctx.pipe_sync.idle(); });
     pl.unlock();
     std::lock_guard<std::mutex> hold(ctx.mu);
     std::lock_guard<std::mutex> enq(ctx.enq_mu);
@@ -1217,7 +1087,6 @@ inline void copy_strided(uint8_t* dst, const uint8_t* src, size_t stride, size_t
 // four slots: equal; profiles/r03/host_paths.txt; r04: first chunk 2^16 / 2^17, a merged last chunk:
 // equal, profiles/r04/ab_host_chunk_policy.txt)
 
-constexpr size_t kPipeSmallCall = (size_t)1 << 16;  // up to here a call is ONE chunk on one stream
 std::atomic<int> g_host_threads{0};  // dsv_set_host_threads; 0 = $DSV_HOST_THREADS, else 4
 inline int clamp_host_threads(int v) {
   const int hw = (int)std::thread::hardware_concurrency();
@@ -1251,115 +1120,21 @@ struct NoPrep {};
 //   part(staged, offset, count, dok, ws, extra, stream): one sub-batch; `extra`: scratch of
 //     extra_item_bytes per item behind the lane's verify workspace (the wire path decompresses per
 //     sub-batch: full-occupancy kernels, no reason to serialise a chunk's worth on one lane).
-// The chunks of one call.
-//   ramp (the call found the GPU idle): a first chunk of 2^15 items so that the GPU starts after ~0.5 ms
-//     of staging, then chunks of ONE sub-batch (2^16 items) — growing only with what is already staged
-//     (an eighth of it: 2^17 from 2^20 items on, 2^18 from 2^21).  A chunk is gathered, transferred and
-//     preprocessed as a unit, ~12 ns per item before its first kernel can start against ~12 ns per item
-//     of GPU work, so a chunk must stay well below the backlog the GPU still has: with the r01 - r04
-//     doubling (2^15 .. 2^18) the fourth chunk arrived ~1 ms after the GPU had run dry
-//     (profiles/r05/ab_chunk_plans.txt; the same box, one-shot calls: 16.6 -> 15.8 ms per 2^20).
-//   flat (behind another call in flight): full chunks at once — there is no idle GPU to feed quickly
-//     and whole chunks cost fewer launches (two in flight: 14.2 against 14.9 ms per 2^20 with 2^16).
-// A remainder of at most a quarter chunk (or half a sub-batch) is merged into the last chunk instead of
-// trailing behind it as a part of its own on ONE lane.
-inline std::vector<size_t> plan_chunks(const Context& ctx, size_t n, bool ramp, size_t unit = kSplitItems) {
-  std::vector<size_t> out;
-  if (n <= kPipeSmallCall) {  // one small call: a single chunk
-    out.push_back(n);
-    return out;
-  }
-  size_t left = n, staged = 0;
-  double want_f = (double)ctx.pipe_first_chunk;
-  for (size_t c = 0; left; c++) {
-    size_t want = ctx.pipe_chunk;
-    if (ramp && ctx.pipe_plan_len) {  // DSV_PIPE_PLAN: explicit sizes, the last one repeats
-      want = (size_t)1 << ctx.pipe_plan[c < (size_t)ctx.pipe_plan_len ? c : (size_t)ctx.pipe_plan_len - 1];
-    } else if (ramp && ctx.pipe_growth > 0) {  // DSV_PIPE_GROWTH: geometric from the first chunk
-      want = align_up((size_t)want_f, 4096);
-      want_f *= ctx.pipe_growth;
-    } else if (ramp) {
-      // (chunks of TWO sub-batches, one per lane at a time, from a first chunk of 2 x 2^15: 17.3 against
-      //  15.8 ms per 2^20 one-shot, same box — the staging latency of the larger chunks outweighs it)
-      want = c == 0 ? (ctx.pipe_first_chunk < unit ? ctx.pipe_first_chunk : unit) : unit;  // one sub-batch
-      while (want * 2 <= staged / 8) want *= 2;
-    }
-    if (want > ctx.pipe_chunk) want = ctx.pipe_chunk;
-    if (left <= want + unit / 2 || left <= want + want / 4) want = left;  // the rest rides along
-    out.push_back(want);
-    left -= want;
-    staged += want;
-  }
-  return out;
-}
-// A chunk is cut into sub-batches of at most kSplitItems items — an EVEN number of equal ones once it
-// holds more than one, so that both compute lanes get the same work from every chunk and finish the
-// call together.
-inline size_t plan_parts(size_t cnt, bool one_part, size_t cap, size_t& part_items) {
-  if (one_part || cnt <= cap) {
-    part_items = cnt;
-    return 1;
-  }
-  size_t parts = (cnt + cap - 1) / cap;
-  parts += parts & 1;
-  part_items = align_up((cnt + parts - 1) / parts, 256);
-  return (cnt + part_items - 1) / part_items;
-}
-// Whose turn it is to enqueue compute on the device's lanes.  Calls in flight take turns in the order
-// they acquired their pipes: the holder enqueues ALL its chunks, then passes the turn on; the next
-// call meanwhile gathers and transfers its first chunks (up to its kPipeSlots slots) and enqueues them
-// the moment the turn arrives — behind the holder's last chunks in the lanes' queues, so its ramp runs
-// under the holder's tail.  (Without turns two calls in flight share the lanes chunk by chunk, advance
-// in lock-step and finish together: both ramps and both tails coincide — measured, r05.)
-struct TurnTicket {
-  Context& ctx;
-  uint64_t mine = 0;
-  bool taken = false, held = false, released = false;
-  explicit TurnTicket(Context& c) : ctx(c) {}
-  void take(uint64_t ticket) {
-    mine = ticket;
-    taken = true;
-  }
-  bool try_acquire() {
-    if (held) return true;
-    std::lock_guard<std::mutex> lk(ctx.pipe_mu);
-    held = ctx.turn_serving == mine;
-    return held;
-  }
-  void acquire() {
-    if (held) return;
-    std::unique_lock<std::mutex> lk(ctx.pipe_mu);
-    ctx.pipe_cv.wait(lk, [&] { return ctx.turn_serving == mine; });
-    held = true;
-  }
-  void release() {  // (also on error paths: the turn must reach the calls behind this one)
-    if (!taken || released) return;
-    acquire();
-    {
-      std::lock_guard<std::mutex> lk(ctx.pipe_mu);
-      ctx.turn_serving++;
-    }
-    released = true;
-    ctx.pipe_cv.notify_all();
-  }
-  ~TurnTicket() { release(); }
-};
-
 template <size_t NIN, class Prep, class Part>
 int run_pipelined(Context& ctx, const HostIn (&ins)[NIN], uint8_t* ok, size_t n, size_t prep_item_bytes,
                   size_t extra_item_bytes, Prep prep, Part part) {
   constexpr bool has_prep = !std::is_same<Prep, NoPrep>::value;
   const bool small = n <= kPipeSmallCall;  // transfer, kernels and verdicts on ONE stream, a work area of its own
-  TurnTicket turn(ctx);                    // (on an error path its destructor still passes the turn on, in order)
-  PipeLease lease(ctx, small ? nullptr : &turn);  // blocks while kPipes calls are in flight on this device
-  Pipe& pipe = *lease.pipe;
+  TurnTicket turn(ctx.pipe_sync);          // (on an error path its destructor still passes the turn on, in order)
+  PipeLease lease(ctx.pipe_sync, small ? nullptr : &turn);  // blocks while kPipes calls are in flight on this device
+  Pipe& pipe = ctx.pipes[lease.index];
   if (!ctx.ready.load(std::memory_order_acquire))
     return fail(DSV_ERR_NOT_INITIALIZED, "device %d was shut down", ctx.device);
   DSV_ON_DEVICE(ctx);
   // nobody else in flight: the GPU is idle, so start small and grow; behind another call (it holds its
   // pipe until its last verdicts are out): full chunks at once
   const size_t part_cap = kSplitItems;
-  const std::vector<size_t> chunks = plan_chunks(ctx, n, small || lease.alone, part_cap);
+  const std::vector<size_t> chunks = plan_chunks(ctx.plan, n, small || lease.alone, part_cap);
   const size_t nchunks = chunks.size();
   size_t chunk = 0;  // the largest chunk: slot capacity
   for (size_t c : chunks) chunk = c > chunk ? c : chunk;
