@@ -762,8 +762,10 @@ hipEvent_t prep_tables_beside_hash(Context& ctx, const void* PK_uv, const void* 
   }
   return lane->side_join;
 }
+// valid_in (may be null): per-item validity found by an earlier stage (normalisation, decompression);
+// the hash kernel folds it into the validity the verify kernel starts from
 int verify_single_on(Context& ctx, const void* u, const void* R_uv, const void* PK_uv, const void* m,
-                     size_t n, void* ok, void* workspace, hipStream_t stream) {
+                     size_t n, void* ok, void* workspace, hipStream_t stream, const uint8_t* valid_in = nullptr) {
   const uint8_t *pu = (const uint8_t*)u, *pR = (const uint8_t*)R_uv, *pPK = (const uint8_t*)PK_uv,
                 *pm = (const uint8_t*)m;
   uint8_t* pok = (uint8_t*)ok;
@@ -774,7 +776,8 @@ int verify_single_on(Context& ctx, const void* u, const void* R_uv, const void* 
     //  except for a short last part, which simply builds its tables in the kernel)
     hipEvent_t ready = cnt == n ? prep_tables_beside_hash(*cp, pPK + 64 * off, pR + 64 * off, cnt, w.tables, s)
                                 : nullptr;
-    launch_challenge(false, pR + 64 * off, (const uint8_t*)nullptr, pm + 32 * off, cnt, w.c, w.valid, s);
+    launch_challenge(false, pR + 64 * off, (const uint8_t*)nullptr, pm + 32 * off, cnt, w.c, w.valid, s,
+                     valid_in ? valid_in + off : nullptr);
     if (ready && hipStreamWaitEvent(s, ready, 0) != hipSuccess) return;  // (surfaces through hipGetLastError)
     launch_verify_fixed(*cp, false, pu + 32 * off, w.c, pPK + 64 * off, pR + 64 * off, 0, w.valid,
                         cnt, pok + off, w.tables, s, ready != nullptr);
@@ -782,7 +785,7 @@ int verify_single_on(Context& ctx, const void* u, const void* R_uv, const void* 
 }
 int verify_double_on(Context& ctx, const void* u, const void* R_uv, const void* Rp_uv,
                      const void* PK_uv, const void* PKp_uv, const void* m, size_t n, void* ok,
-                     void* workspace, hipStream_t stream) {
+                     void* workspace, hipStream_t stream, const uint8_t* valid_in = nullptr) {
   const uint8_t *pu = (const uint8_t*)u, *pR = (const uint8_t*)R_uv, *pRp = (const uint8_t*)Rp_uv,
                 *pPK = (const uint8_t*)PK_uv, *pPKp = (const uint8_t*)PKp_uv, *pm = (const uint8_t*)m;
   uint8_t* pok = (uint8_t*)ok;
@@ -793,7 +796,8 @@ int verify_double_on(Context& ctx, const void* u, const void* R_uv, const void* 
     //  except for a short last part, which simply builds its tables in the kernel)
     hipEvent_t ready = cnt == n ? prep_tables_beside_hash(*cp, pPK + 64 * off, pR + 64 * off, cnt, w.tables, s)
                                 : nullptr;
-    launch_challenge(true, pR + 64 * off, pRp + 64 * off, pm + 32 * off, cnt, w.c, w.valid, s);
+    launch_challenge(true, pR + 64 * off, pRp + 64 * off, pm + 32 * off, cnt, w.c, w.valid, s,
+                     valid_in ? valid_in + off : nullptr);
     if (ready && hipStreamWaitEvent(s, ready, 0) != hipSuccess) return;
     launch_verify_fixed_double(*cp, pu + 32 * off, w.c, pPK + 64 * off, pR + 64 * off,
                                pPKp + 64 * off, pRp + 64 * off, w.valid, cnt, pok + off, w.tables, s,
@@ -802,13 +806,14 @@ int verify_double_on(Context& ctx, const void* u, const void* R_uv, const void* 
 }
 int verify_vargen_on(Context& ctx, const void* u, const void* R_uv, const void* PK_uv,
                      const void* Gen_uv, const void* m, size_t n, void* ok, void* workspace,
-                     hipStream_t stream) {
+                     hipStream_t stream, const uint8_t* valid_in = nullptr) {
   const uint8_t *pu = (const uint8_t*)u, *pR = (const uint8_t*)R_uv, *pPK = (const uint8_t*)PK_uv,
                 *pG = (const uint8_t*)Gen_uv, *pm = (const uint8_t*)m;
   uint8_t* pok = (uint8_t*)ok;
   return run_split(ctx, n, workspace, stream,
                    [=](size_t off, size_t cnt, const Workspace& w, hipStream_t s) {
-    launch_challenge(false, pR + 64 * off, (const uint8_t*)nullptr, pm + 32 * off, cnt, w.c, w.valid, s);
+    launch_challenge(false, pR + 64 * off, (const uint8_t*)nullptr, pm + 32 * off, cnt, w.c, w.valid, s,
+                     valid_in ? valid_in + off : nullptr);
     launch_verify_var(pu + 32 * off, (const uint8_t*)w.c, pPK + 64 * off, pG + 64 * off, pR + 64 * off, (const uint8_t*)w.valid, cnt, pok + off, w.tables, s);
   });
 }
@@ -1390,11 +1395,11 @@ int part_verify(Context& ctx, int kind, const Staged& g, size_t off, size_t cnt,
                 hipStream_t st) {
   auto at = [&](int k) { return g.p[k] + off * g.bytes[k]; };
   int rc;
-  if (kind == 0) rc = verify_single_on(ctx, at(0), at(1), at(2), at(3), cnt, dok, ws, st);
-  else if (kind == 1) rc = verify_double_on(ctx, at(0), at(1), at(2), at(3), at(4), at(5), cnt, dok, ws, st);
-  else rc = verify_vargen_on(ctx, at(0), at(1), at(2), at(3), at(4), cnt, dok, ws, st);
+  const uint8_t* vin = g.valid ? g.valid + off : nullptr;  // (the chunk-level preprocessing's verdict on the items)
+  if (kind == 0) rc = verify_single_on(ctx, at(0), at(1), at(2), at(3), cnt, dok, ws, st, vin);
+  else if (kind == 1) rc = verify_double_on(ctx, at(0), at(1), at(2), at(3), at(4), at(5), cnt, dok, ws, st, vin);
+  else rc = verify_vargen_on(ctx, at(0), at(1), at(2), at(3), at(4), cnt, dok, ws, st, vin);
   if (rc) return rc;
-  if (g.valid) launch_and_bytes((uint8_t*)dok, g.valid + off, cnt, st);
   HIP_TRY(hipGetLastError());
   return DSV_OK;
 }
@@ -1559,11 +1564,10 @@ int verify_ext_on(Context& ctx, int kind, const void* u, const void* const* pts_
   }
   launch_normalize_uvz(a, np, n, w.valid, w.prefix, s);
   int rc;
-  if (kind == 0) rc = verify_single_on(ctx, u, w.pts[0], w.pts[1], m, n, ok, w.vws, s);
-  else if (kind == 1) rc = verify_double_on(ctx, u, w.pts[0], w.pts[1], w.pts[2], w.pts[3], m, n, ok, w.vws, s);
-  else rc = verify_vargen_on(ctx, u, w.pts[0], w.pts[1], w.pts[2], m, n, ok, w.vws, s);
+  if (kind == 0) rc = verify_single_on(ctx, u, w.pts[0], w.pts[1], m, n, ok, w.vws, s, w.valid);
+  else if (kind == 1) rc = verify_double_on(ctx, u, w.pts[0], w.pts[1], w.pts[2], w.pts[3], m, n, ok, w.vws, s, w.valid);
+  else rc = verify_vargen_on(ctx, u, w.pts[0], w.pts[1], w.pts[2], m, n, ok, w.vws, s, w.valid);
   if (rc) return rc;
-  launch_and_bytes((uint8_t*)ok, w.valid, n, s);
   HIP_TRY(hipGetLastError());
   return DSV_OK;
 }
@@ -2228,11 +2232,10 @@ int verify_wire_on(Context& ctx, int kind, const uint8_t* dsig, const uint8_t* d
   if (kind != 0)
     if (int r = decompress_on(ctx, dpk + 32, pk_bytes, cnt, x.P1, x.valid, 1, st)) return r;
   int rc;
-  if (kind == 0) rc = verify_single_on(ctx, x.u, x.R, x.P0, dm, cnt, dok, vws, st);
-  else if (kind == 1) rc = verify_double_on(ctx, x.u, x.R, x.Rp, x.P0, x.P1, dm, cnt, dok, vws, st);
-  else rc = verify_vargen_on(ctx, x.u, x.R, x.P0, x.P1, dm, cnt, dok, vws, st);
+  if (kind == 0) rc = verify_single_on(ctx, x.u, x.R, x.P0, dm, cnt, dok, vws, st, x.valid);
+  else if (kind == 1) rc = verify_double_on(ctx, x.u, x.R, x.Rp, x.P0, x.P1, dm, cnt, dok, vws, st, x.valid);
+  else rc = verify_vargen_on(ctx, x.u, x.R, x.P0, x.P1, dm, cnt, dok, vws, st, x.valid);
   if (rc) return rc;
-  launch_and_bytes((uint8_t*)dok, x.valid, cnt, st);
   HIP_TRY(hipGetLastError());
   return DSV_OK;
 }

@@ -19,7 +19,7 @@ template <bool DOUBLE>
 __global__ void __launch_bounds__(256, kWavesHash)
 k_challenge(const uint8_t* __restrict__ R_uv, const uint8_t* __restrict__ Rp_uv,
             const uint8_t* __restrict__ m, size_t n, uint8_t* __restrict__ c_out,
-            uint8_t* __restrict__ valid) {
+            uint8_t* __restrict__ valid, const uint8_t* __restrict__ valid_in) {
   // the hashes of a wave cooperate through the matrix cores: every lane runs, spare lanes redo
   // the last item and skip the stores
   hades_mfma_load_table();
@@ -52,7 +52,10 @@ k_challenge(const uint8_t* __restrict__ R_uv, const uint8_t* __restrict__ Rp_uv,
   poseidon_truncate(c, s[1]);
   if (!live) return;
   store_words8(c_out, i, c);
-  if (valid) valid[i] = ok ? 1 : 0;
+  // valid_in (may be null): what an earlier stage found out about the item — the normalisation of
+  // projective input (z = 0, a coordinate >= q), point decompression — folded in here instead of a
+  // kernel of its own AND-ing the verdicts afterwards (r05: one launch less per sub-batch)
+  if (valid) valid[i] = (ok && (!valid_in || valid_in[i] != 0)) ? 1 : 0;
 }
 
 hipError_t hash_upload_constants() {
@@ -63,11 +66,11 @@ hipError_t hash_upload_constants() {
 }
 
 void launch_challenge(bool dbl, const uint8_t* R_uv, const uint8_t* Rp_uv, const uint8_t* m, size_t n,
-                      uint8_t* c, uint8_t* valid, hipStream_t s) {
+                      uint8_t* c, uint8_t* valid, hipStream_t s, const uint8_t* valid_in) {
   if (dbl)
-    hipLaunchKernelGGL(k_challenge<true>, dim3(grid_for(n)), dim3(256), 0, s, R_uv, Rp_uv, m, n, c, valid);
+    hipLaunchKernelGGL(k_challenge<true>, dim3(grid_for(n)), dim3(256), 0, s, R_uv, Rp_uv, m, n, c, valid, valid_in);
   else
-    hipLaunchKernelGGL(k_challenge<false>, dim3(grid_for(n)), dim3(256), 0, s, R_uv, Rp_uv, m, n, c, valid);
+    hipLaunchKernelGGL(k_challenge<false>, dim3(grid_for(n)), dim3(256), 0, s, R_uv, Rp_uv, m, n, c, valid, valid_in);
 }
 
 }  // namespace dsv

@@ -139,11 +139,6 @@ k_normalize_uvz(NormalizeArgs a, size_t n, size_t lanes, int per_lane, uint8_t* 
     valid[i] = ok ? 1 : 0;
   }
 }
-__global__ void k_and_bytes(uint8_t* __restrict__ ok, const uint8_t* __restrict__ valid, size_t n) {
-  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) ok[i] = ok[i] & valid[i];
-}
-
 // ------------------------------------------------------------------------------------------
 // The reference's in-memory scalars.  `BlsScalar` (dusk-bls12_381 0.13) and `JubJubScalar`
 // (dusk-jubjub 0.14; /root/reference/Cargo.toml:25-26) hold `[u64; 4]` MONTGOMERY limbs, R = 2^256:
@@ -513,9 +508,6 @@ void launch_scalars_from_mont(const uint8_t* u_mont, const uint8_t* m_mont, size
                               uint8_t* m_out, hipStream_t s, int block_threads) {
   const unsigned bt = block_threads > 0 ? (unsigned)block_threads : 256u;
   hipLaunchKernelGGL(k_scalars_from_mont, dim3(grid_for(n, bt)), dim3(bt), 0, s, u_mont, m_mont, n, u_out, m_out);
-}
-void launch_and_bytes(uint8_t* ok, const uint8_t* valid, size_t n, hipStream_t s) {
-  hipLaunchKernelGGL(k_and_bytes, dim3(grid_for(n)), dim3(256), 0, s, ok, valid, n);
 }
 void launch_sign_finish(const uint8_t* r, const uint8_t* c, const uint8_t* sk, size_t n, uint8_t* u_out,
                         hipStream_t s) {

@@ -58,8 +58,9 @@ struct ChaChaKey {
 
 // ---- k_hash.hip ------------------------------------------------------------------------------
 hipError_t hash_upload_constants();  // the selected device's __constant__ round constants
+// valid_in (may be null): per-item bytes of an earlier stage, AND-ed into `valid`
 void launch_challenge(bool dbl, const uint8_t* R_uv, const uint8_t* Rp_uv, const uint8_t* m, size_t n,
-                      uint8_t* c, uint8_t* valid, hipStream_t s);
+                      uint8_t* c, uint8_t* valid, hipStream_t s, const uint8_t* valid_in = nullptr);
 // ---- k_verify.hip: ok[i] = (accumulate ? ok[i] : valid[i]) & [every chain's equation holds] ----
 void launch_verify_half(int nchain, bool accumulate, const uint8_t* u, const uint8_t* c,
                         ChainOperands op0, ChainOperands op1, const uint8_t* valid, size_t n,
@@ -112,7 +113,6 @@ void launch_normalize_uvz(const NormalizeArgs& a, int npoints, size_t n, uint8_t
 // canonical bytes every other kernel reads; limbs >= the modulus are poisoned (verdict 0)
 void launch_scalars_from_mont(const uint8_t* u_mont, const uint8_t* m_mont, size_t n, uint8_t* u_out,
                               uint8_t* m_out, hipStream_t s, int block = 0);
-void launch_and_bytes(uint8_t* ok, const uint8_t* valid, size_t n, hipStream_t s);
 void launch_sign_finish(const uint8_t* r, const uint8_t* c, const uint8_t* sk, size_t n, uint8_t* u_out,
                         hipStream_t s);
 void launch_decompress(const uint8_t* in, size_t in_stride, size_t n, uint8_t* out_uv, uint8_t* ok,
