@@ -204,8 +204,8 @@ struct PlanParams {
   int plan_len = 0;
 };
 // The chunks of one call.
-//   ramp (the call found the GPU idle): a first chunk of 2^15 items so that the GPU starts after ~0.5 ms
-//     of staging, then chunks of ONE sub-batch (2^16 items) — growing only with what is already staged
+//   ramp (the call found the GPU idle): two first chunks of 2^15 items (the GPU starts after ~0.5 ms of
+//     staging, the second lane half a millisecond later), then chunks of ONE sub-batch (2^16 items) — growing only with what is already staged
 //     (an eighth of it: 2^17 from 2^20 items on, 2^18 from 2^21).  A chunk is gathered, transferred and
 //     preprocessed as a unit, ~12 ns per item before its first kernel can start against ~12 ns per item
 //     of GPU work, so a chunk must stay well below the backlog the GPU still has: with the r01 - r04
@@ -233,7 +233,8 @@ inline std::vector<size_t> plan_chunks(const PlanParams& p, size_t n, bool ramp,
     } else if (ramp) {
       // (chunks of TWO sub-batches, one per lane at a time, from a first chunk of 2 x 2^15: 17.3 against
       //  15.8 ms per 2^20 one-shot, same box — the staging latency of the larger chunks outweighs it)
-      want = c == 0 ? (p.first_chunk < unit ? p.first_chunk : unit) : unit;  // one sub-batch
+      // two first chunks of 2^15, one per lane, then one sub-batch per chunk
+      want = c < 2 ? (p.first_chunk < unit ? p.first_chunk : unit) : unit;
       while (want * 2 <= staged / 8) want *= 2;
     }
     if (want > p.chunk) want = p.chunk;

@@ -161,7 +161,7 @@ static void plans() {
       if (n <= kPipeSmallCall) CHECK(chunks.size() == 1);
       if (!ramp && n > kPipeSmallCall)  // behind another call: full chunks from the start
         for (size_t k = 0; k + 1 < chunks.size(); k++) CHECK(chunks[k] == p.chunk);
-      if (ramp && n > 4 * kSplitItems && !p.plan_len) CHECK(chunks[0] == std::min(p.first_chunk, kSplitItems));
+      if (ramp && n > 4 * kSplitItems && !p.plan_len) CHECK(chunks[0] == std::min(p.first_chunk, kSplitItems) && chunks[1] == chunks[0]);
     }
   }
 }
