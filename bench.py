@@ -256,7 +256,7 @@ def _verify_batch_e2e(E, hu, hR, hPK, hm, expected, cores):
     res = {"unit": "verifies/s", "items": n, "objects_not_representable": int(bad),
            "workload": "verify_batch over %d typed objects (Signature 192 B, PublicKey 160 B, BlsScalar "
                        "32 B; Montgomery limbs, random z per point) -> vector<bool>: field gather by the "
-                       "engine's copy threads (dsv_verify_single_mont_cols), PCIe, k_scalars_from_mont + "
+                       "engine's copy threads (dsv_verify_single_mont_cols), PCIe, "
                        "k_normalize_uvz + the affine path, verdict packing; no host field arithmetic" % n}
     try:
         for label, threads in (("threads_1", 1), ("threads_default", 0)):

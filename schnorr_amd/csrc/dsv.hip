@@ -1553,14 +1553,23 @@ ExtWs carve_ext(void* ws, size_t n) {
   return w;
 }
 // kind 0: pts = {R, PK}; 1: {R, R', PK, PK'}; 2: {R, PK, Gen} — each n x 96 B (u || v || z)
+// u_mont / m_mont (both or neither): the scalars as Montgomery limbs, converted INTO u / m by the
+// normalisation kernel (dsv_verify_*_mont_dev)
 int verify_ext_on(Context& ctx, int kind, const void* u, const void* const* pts_uvz, const void* m,
-                  size_t n, void* ok, void* workspace, hipStream_t s) {
+                  size_t n, void* ok, void* workspace, hipStream_t s, const uint8_t* u_mont = nullptr,
+                  const uint8_t* m_mont = nullptr) {
   const int np = kind == 0 ? 2 : (kind == 1 ? 4 : 3);
   const ExtWs w = carve_ext(workspace, n);
   NormalizeArgs a = {};
   for (int k = 0; k < np; k++) {
     a.in[k] = (const uint8_t*)pts_uvz[k];
     a.out[k] = w.pts[k];
+  }
+  if (u_mont) {
+    a.u_mont = u_mont;
+    a.m_mont = m_mont;
+    a.u_out = (uint8_t*)const_cast<void*>(u);
+    a.m_out = (uint8_t*)const_cast<void*>(m);
   }
   launch_normalize_uvz(a, np, n, w.valid, w.prefix, s);
   int rc;
@@ -1576,8 +1585,9 @@ int verify_ext_on(Context& ctx, int kind, const void* u, const void* const* pts_
 constexpr size_t kExtItemBytes = 4 * 64 + 1 + 4 * kLimbs * 4 + 1;
 // whole-chunk `to_hash_inputs` of the scheme's points (d: u, points..., m; [u_alt, m_alt]: converted
 // scalars to use instead of d's); fills the staged view of the affine path
+// mont: the scalars d[0] / d[1 + np] are Montgomery limbs — the same kernel converts them into (u_alt, m_alt)
 int prep_normalize(const Context& ctx, int kind, const void* const* d, size_t cnt, Stager& x, hipStream_t st, Staged& g,
-                   const uint8_t* u_alt = nullptr, const uint8_t* m_alt = nullptr) {
+                   uint8_t* u_alt = nullptr, uint8_t* m_alt = nullptr, bool mont = false) {
   const int np = kind == 0 ? 2 : (kind == 1 ? 4 : 3);
   NormalizeArgs a = {};
   for (int k = 0; k < np; k++) {
@@ -1588,6 +1598,12 @@ int prep_normalize(const Context& ctx, int kind, const void* const* d, size_t cn
   }
   uint8_t* valid = x.take(cnt);
   u32* prefix = reinterpret_cast<u32*>(x.take(normalize_prefix_bytes(cnt, np)));
+  if (mont) {
+    a.u_mont = (const uint8_t*)d[0];
+    a.m_mont = (const uint8_t*)d[1 + np];
+    a.u_out = u_alt;
+    a.m_out = m_alt;
+  }
   launch_normalize_uvz(a, np, cnt, valid, prefix, st, ctx.norm_per_lane, ctx.norm_block);
   HIP_TRY(hipGetLastError());
   g.p[0] = u_alt ? u_alt : (const uint8_t*)d[0];
@@ -1738,7 +1754,7 @@ int dsv_verify_vargen_ext_dev(const void* u, const void* R_uvz, const void* PK_u
 // element — eight per single signature, fourteen per double one — on ONE host thread: ~30x below the
 // engine.  The *_mont entry points take the limbs as they lie in memory:
 //   points  (u R, v R, z R) : straight into k_normalize_uvz — a quotient does not see the common factor
-//   u, m                    : k_scalars_from_mont (two reductions per signature, on the device)
+//   u, m                    : two reductions per signature inside the same kernel (scalars_from_mont_item)
 // so a binding copies bytes and nothing else; the *_mont_cols forms even take the typed objects
 // where they lie (one strided column per field) and gather them into the pinned staging with the
 // pipeline's copy threads — no intermediate structure of arrays on the host.
@@ -1749,8 +1765,7 @@ int verify_mont_on(Context& ctx, int kind, const void* u, const void* const* pts
                    size_t n, void* ok, void* workspace, hipStream_t s) {
   Stager st(static_cast<uint8_t*>(workspace));
   uint8_t *cu = st.take(n * 32), *cm = st.take(n * 32);
-  launch_scalars_from_mont((const uint8_t*)u, (const uint8_t*)m, n, cu, cm, s);
-  return verify_ext_on(ctx, kind, cu, pts_uvz, cm, n, ok, st.take(0), s);
+  return verify_ext_on(ctx, kind, cu, pts_uvz, cm, n, ok, st.take(0), s, (const uint8_t*)u, (const uint8_t*)m);
 }
 constexpr size_t kMontItemBytes = kExtItemBytes + 64;
 // ins: u, points..., m — dense arrays or strided columns of typed objects
@@ -1761,8 +1776,8 @@ int verify_mont_host(Context& ctx, int kind, const HostIn (&ins)[NIN], size_t n,
                        [kind, cp](const void* const* d, size_t cnt, Stager& x, hipStream_t st, Staged& g) {
                          const int np = kind == 0 ? 2 : (kind == 1 ? 4 : 3);
                          uint8_t *cu = x.take(cnt * 32), *cm = x.take(cnt * 32);
-                         launch_scalars_from_mont((const uint8_t*)d[0], (const uint8_t*)d[1 + np], cnt, cu, cm, st, cp->norm_block);
-                         return prep_normalize(*cp, kind, d, cnt, x, st, g, cu, cm);
+                         (void)np;
+                         return prep_normalize(*cp, kind, d, cnt, x, st, g, cu, cm, true);  // ONE launch
                        },
                        DSV_PART(kind));
 }

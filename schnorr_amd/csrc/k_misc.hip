@@ -85,6 +85,40 @@ DSV_DEV Fe load_z_for_product(const uint8_t* in, size_t i, bool& ok) {
   const Fe z = fe_to_mont(fe_from_words_plain(w));
   return fe_select(usable, z, fe_one());
 }
+// ------------------------------------------------------------------------------------------
+// The reference's in-memory scalars.  `BlsScalar` (dusk-bls12_381 0.13) and `JubJubScalar`
+// (dusk-jubjub 0.14; /root/reference/Cargo.toml:25-26) hold `[u64; 4]` MONTGOMERY limbs, R = 2^256:
+// the `u` of a Signature (/root/reference/src/signatures.rs:58-61) is u * 2^256 mod r, the message
+// handed to verify (/root/reference/src/keys/public.rs:121) is m * 2^256 mod q.  The *_mont entry
+// points take those limbs as they lie in memory — the caller runs no `to_bytes()`, i.e. no Montgomery
+// reduction, on the host — and the device performs the two reductions: u by one CIOS pass against 1
+// (fr.h), m as the fe29 product M * 2^5 * 2^-261.  Limbs that are not below the modulus (the Rust types
+// cannot hold them) are poisoned, so the verify kernels give the item verdict 0.  The POINTS of such a
+// caller need no conversion: (u R, v R, z R) normalises to the same (u/z, v/z), so they go into
+// k_normalize_uvz unchanged.  r04 ran this as a kernel of its own (k_scalars_from_mont: 1024 trivially
+// short waves per 2^16 items); r05 calls it from k_normalize_uvz — the host pipeline's preprocessing is
+// one launch of few waves.
+// ------------------------------------------------------------------------------------------
+__device__ constexpr u32 kTwo5[NL] = {32, 0, 0, 0, 0, 0, 0, 0, 0};
+DSV_DEV void scalars_from_mont_item(const uint8_t* __restrict__ u_mont, const uint8_t* __restrict__ m_mont, size_t i,
+                                    uint8_t* __restrict__ u_out, uint8_t* __restrict__ m_out) {
+  u32 w[8], o[8];
+  load_words8(w, u_mont, i);
+  if (words_lt(w, kR32)) {
+    const u32 one[8] = {1, 0, 0, 0, 0, 0, 0, 0};
+    fr_mont_mul(o, w, one);
+    store_words8(u_out, i, o);
+  } else {
+    store_poison(u_out, i);
+  }
+  load_words8(w, m_mont, i);
+  if (words_lt(w, kQ32)) {
+    fe_to_words_plain(o, fe_canon(fe_mul(fe_from_words_plain(w), fe_const(kTwo5))));
+    store_words8(m_out, i, o);
+  } else {
+    store_poison(m_out, i);
+  }
+}
 template <int NP>
 __global__ void __launch_bounds__(256)
 k_normalize_uvz(NormalizeArgs a, size_t n, size_t lanes, int per_lane, uint8_t* __restrict__ valid,
@@ -108,6 +142,7 @@ k_normalize_uvz(NormalizeArgs a, size_t n, size_t lanes, int per_lane, uint8_t* 
     if (NP > 2) up(2);
     if (NP > 3) up(3);
     okmask |= (ok ? 1u : 0u) << k;
+    if (a.u_mont) scalars_from_mont_item(a.u_mont, a.m_mont, i, a.u_out, a.m_out);  // (wave-uniform branch)
   }
   Fe inv = fe_invert_euclid(acc);  // the lane's one dependent chain: Euclid, ~4x shorter than Fermat (inv29.h)
 #pragma unroll 1
@@ -139,42 +174,6 @@ k_normalize_uvz(NormalizeArgs a, size_t n, size_t lanes, int per_lane, uint8_t* 
     valid[i] = ok ? 1 : 0;
   }
 }
-// ------------------------------------------------------------------------------------------
-// The reference's in-memory scalars.  `BlsScalar` (dusk-bls12_381 0.13) and `JubJubScalar`
-// (dusk-jubjub 0.14; /root/reference/Cargo.toml:25-26) hold `[u64; 4]` MONTGOMERY limbs, R = 2^256:
-// the `u` of a Signature (/root/reference/src/signatures.rs:58-61) is u * 2^256 mod r, the message
-// handed to verify (/root/reference/src/keys/public.rs:121) is m * 2^256 mod q.  The *_mont entry
-// points take those limbs as they lie in memory — the caller runs no `to_bytes()`, i.e. no Montgomery
-// reduction, on the host — and this kernel performs the two reductions: u by one CIOS pass against
-// 1 (fr.h), m as the fe29 product M * 2^5 * 2^-261.  Limbs that are not below the modulus (the Rust
-// types cannot hold them) are poisoned, so the verify kernels give the item verdict 0.  The POINTS of
-// such a caller need no kernel of their own: (u R, v R, z R) normalises to the same (u/z, v/z), so
-// they go into k_normalize_uvz unchanged.
-// ------------------------------------------------------------------------------------------
-__device__ constexpr u32 kTwo5[NL] = {32, 0, 0, 0, 0, 0, 0, 0, 0};
-__global__ void __launch_bounds__(256)
-k_scalars_from_mont(const uint8_t* __restrict__ u_mont, const uint8_t* __restrict__ m_mont, size_t n,
-                    uint8_t* __restrict__ u_out, uint8_t* __restrict__ m_out) {
-  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  u32 w[8], o[8];
-  load_words8(w, u_mont, i);
-  if (words_lt(w, kR32)) {
-    const u32 one[8] = {1, 0, 0, 0, 0, 0, 0, 0};
-    fr_mont_mul(o, w, one);
-    store_words8(u_out, i, o);
-  } else {
-    store_poison(u_out, i);
-  }
-  load_words8(w, m_mont, i);
-  if (words_lt(w, kQ32)) {
-    fe_to_words_plain(o, fe_canon(fe_mul(fe_from_words_plain(w), fe_const(kTwo5))));
-    store_words8(m_out, i, o);
-  } else {
-    store_poison(m_out, i);
-  }
-}
-
 // ------------------------------------------------------------------------------------------
 // signing / key derivation ("next" row of the scope table: the step that precedes verify)
 // ------------------------------------------------------------------------------------------
@@ -503,11 +502,6 @@ void launch_normalize_uvz(const NormalizeArgs& a, int npoints, size_t n, uint8_t
     case 3: hipLaunchKernelGGL(k_normalize_uvz<3>, grid, block, 0, s, a, n, lanes, per_lane, valid, prefix); break;
     default: hipLaunchKernelGGL(k_normalize_uvz<4>, grid, block, 0, s, a, n, lanes, per_lane, valid, prefix); break;
   }
-}
-void launch_scalars_from_mont(const uint8_t* u_mont, const uint8_t* m_mont, size_t n, uint8_t* u_out,
-                              uint8_t* m_out, hipStream_t s, int block_threads) {
-  const unsigned bt = block_threads > 0 ? (unsigned)block_threads : 256u;
-  hipLaunchKernelGGL(k_scalars_from_mont, dim3(grid_for(n, bt)), dim3(bt), 0, s, u_mont, m_mont, n, u_out, m_out);
 }
 void launch_sign_finish(const uint8_t* r, const uint8_t* c, const uint8_t* sk, size_t n, uint8_t* u_out,
                         hipStream_t s) {

@@ -93,6 +93,15 @@ void launch_fixed_base_points(const uint8_t* scalar, const uint32_t* table, size
 struct NormalizeArgs {
   const uint8_t* in[4];
   uint8_t* out[4];
+  // r05, optional (all four or none): the item's two scalars in the reference's in-memory form
+  // (Montgomery limbs, R = 2^256) converted to canonical bytes BY THE SAME KERNEL — the host pipeline's
+  // preprocessing is then one launch of few waves instead of two (k_scalars_from_mont alone is 1024
+  // trivially short waves per 2^16 items, each waiting for a wave slot next to the resident verify waves:
+  // 0.16 - 0.37 ms of a chunk's staging chain, profiles/r05/host_timeline_e2e.txt)
+  const uint8_t* u_mont = nullptr;
+  const uint8_t* m_mont = nullptr;
+  uint8_t* u_out = nullptr;
+  uint8_t* m_out = nullptr;
 };
 constexpr int kNormalizePerLane = 32;  // at most (the kernel keeps one validity bit per item in a u32)
 inline size_t normalize_lanes(size_t n, int& per_lane, int want_per_lane = 0) {
@@ -109,10 +118,6 @@ inline size_t normalize_prefix_bytes(size_t n, int npoints) {
 // single-wave workgroups: DESIGN.md §3 "Host pipeline")
 void launch_normalize_uvz(const NormalizeArgs& a, int npoints, size_t n, uint8_t* valid,
                           uint32_t* prefix, hipStream_t s, int want_per_lane = 0, int block = 0);
-// JubJubScalar u and BlsScalar m from the reference's in-memory Montgomery limbs (R = 2^256) to the
-// canonical bytes every other kernel reads; limbs >= the modulus are poisoned (verdict 0)
-void launch_scalars_from_mont(const uint8_t* u_mont, const uint8_t* m_mont, size_t n, uint8_t* u_out,
-                              uint8_t* m_out, hipStream_t s, int block = 0);
 void launch_sign_finish(const uint8_t* r, const uint8_t* c, const uint8_t* sk, size_t n, uint8_t* u_out,
                         hipStream_t s);
 void launch_decompress(const uint8_t* in, size_t in_stride, size_t n, uint8_t* out_uv, uint8_t* ok,
