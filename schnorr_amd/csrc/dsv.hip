@@ -160,8 +160,9 @@ struct Context {
   hipStream_t pipe_small = nullptr;       // a call of one small chunk runs on this stream alone
   uint8_t* pipe_work[3] = {};             // per compute lane (+ [2]: pipe_small): verify workspace + scratch of one sub-batch
   size_t pipe_work_bytes[3] = {};
-  uint64_t pipe_parts = 0;                // sub-batches enqueued so far: part p runs on lane p & 1
-  bool prep_stream = true;                // DSV_PIPE_PREP_STREAM=0: whole-chunk preprocessing on a compute lane (r04)
+  uint64_t pipe_parts = 0;                // sub-batches enqueued so far (ties between the lanes alternate by it)
+  long lane_load[2] = {0, 0};             // sub-batches enqueued on a lane and not yet known to be done (under enq_mu)
+  bool prep_stream = false;               // DSV_PIPE_PREP_STREAM=1: whole-chunk preprocessing on a stream of its own (A/B)
   PlanParams plan;                        // chunk plan of a call (host_sync.h; DSV_PIPE_CHUNK_LOG2 / _FIRST_LOG2 / _GROWTH / _PLAN)
   int pipe_slots = 0;                     // DSV_PIPE_SLOTS: chunks in flight per call (<= kPipeSlots); 0 = three
   int norm_per_lane = 0, norm_block = 0;  // DSV_NORM_PER_LANE / DSV_NORM_BLOCK: shape of the pipeline's normalisation kernels
@@ -581,7 +582,7 @@ int dsv_init(int device) {
   const char* fused = getenv("DSV_DOUBLE_FUSED");
   ctx.fuse_double = !(fused && strcmp(fused, "0") == 0);
   const char* pre = getenv("DSV_PIPE_PREP_STREAM");
-  ctx.prep_stream = !(pre && strcmp(pre, "0") == 0);
+  ctx.prep_stream = pre && strcmp(pre, "1") == 0;
   auto log2_env = [](const char* name, int lo, int hi, int dflt) {
     const char* e = getenv(name);
     const int v = e ? atoi(e) : dflt;
@@ -602,7 +603,9 @@ int dsv_init(int device) {
   }
   ctx.pipe_slots = 0;
   ctx.plan.growth = 0;
-  ctx.norm_per_lane = getenv("DSV_NORM_PER_LANE") ? atoi(getenv("DSV_NORM_PER_LANE")) : 0;
+  // items that share one inversion in the PIPELINE's normalisation: 4 (the device-resident entry points keep
+  // 8 - 16: there the kernel runs once, alone; here it sits in a compute lane's order, where its length counts)
+  ctx.norm_per_lane = getenv("DSV_NORM_PER_LANE") ? atoi(getenv("DSV_NORM_PER_LANE")) : 4;
   ctx.norm_block = getenv("DSV_NORM_BLOCK") ? atoi(getenv("DSV_NORM_BLOCK")) : 0;
   if (const char* e = getenv("DSV_PIPE_SLOTS")) {
     const int v = atoi(e);
@@ -1171,8 +1174,18 @@ int run_pipelined(Context& ctx, const HostIn (&ins)[NIN], uint8_t* ok, size_t n,
   }
   for (int sl = 0; sl < nslots; sl++)
     if (int r = ensure_pipe_slot(pipe.slot[sl], host_need, host_need, prep_need)) return r;
-  // whole-chunk preprocessing on the stream of its own, or (r04, DSV_PIPE_PREP_STREAM=0) on the lane
-  // that takes the chunk's first sub-batch
+  // Whole-chunk preprocessing (normalisation / limb conversion: few waves, one inversion chain each) runs
+  // ON the lane that takes the chunk's first sub-batch, in that lane's order; the other lane waits for its
+  // event.  r05 tried it on a high-priority stream of its own (DSV_PIPE_PREP_STREAM=1): the two lane
+  // kernels resident at any time fill every wave slot of the chip exactly (1024 + 1024 waves, two slots on
+  // each of 1024 SIMDs), so a third kernel's waves only ever start where a lane kernel has just ended, the
+  // lane's next kernel starts that many waves short, and an in-order lane cannot go on before those
+  // stragglers are done: a small kernel beside the lanes costs ~10 x its work (profiles/r05/squat_probe.txt).
+  // With random z the side stream still came out 0.7 ms ahead for a one-shot call (its inversions are long
+  // enough to be worth taking off the lane), with z = 1 everywhere — deserialised keys and signatures — it
+  // fell into a mode 2 - 3 ms slower every other call; in a lane's order the preprocessing gets that lane's
+  // own slots, nothing depends on when the host issued it, and two calls in flight are faster as well
+  // (0.95 against 0.92 x the device-resident rate).  profiles/r05/ab_prep_placement.txt.
   const bool pre_stream = has_prep && !small && ctx.prep_stream;
   // what a slot currently holds: a chunk that is staged (gathered + on its way to the device), then
   // enqueued (its kernels and verdict copy are in the streams), then drained (verdicts delivered)
@@ -1180,7 +1193,9 @@ int run_pipelined(Context& ctx, const HostIn (&ins)[NIN], uint8_t* ok, size_t n,
     size_t first = 0, cnt = 0, ok_off = 0;
     size_t in_off[NIN + 1] = {};
     bool enqueued = false;
+    int parts_on[2] = {0, 0};  // its sub-batches per compute lane
   } held[kPipeSlots];
+  int slot_of[kPipeSlots + 1] = {};  // ring: slot of chunk c at slot_of[c % (kPipeSlots + 1)] (staged .. enqueued)
   auto drain = [&](int sl) -> int {
     Held& h = held[sl];
     if (!h.cnt) return DSV_OK;
@@ -1188,7 +1203,43 @@ int run_pipelined(Context& ctx, const HostIn (&ins)[NIN], uint8_t* ok, size_t n,
     else HIP_TRY(hipEventSynchronize(pipe.slot[sl].ev_done));
     memcpy(ok + h.first, pipe.slot[sl].host + h.ok_off, h.cnt);
     h.cnt = 0;
+    if (h.parts_on[0] | h.parts_on[1]) {
+      std::lock_guard<std::mutex> enq(ctx.enq_mu);
+      for (int k = 0; k < 2; k++) {
+        ctx.lane_load[k] -= h.parts_on[k];
+        h.parts_on[k] = 0;
+      }
+    }
     return DSV_OK;
+  };
+  // A slot for the next chunk: a free one, else one whose chunk is DONE — in completion order, not in
+  // chunk order: when one lane runs slower than the other (its kernels shared the SIMDs with the
+  // preprocessing, or simply the higher-priority lane's), the chunk the host would wait for in order is the
+  // slow lane's while the fast lane's later chunk finished long ago — and the fast lane starves behind a
+  // slot that is free (r05: host calls whose preprocessing is quick, all points with z = 1, fell into that
+  // mode every other call: 15.8 against 18.5 ms).  Else wait for the oldest enqueued chunk.
+  auto free_slot = [&](int& out) -> int {
+    for (int sl = 0; sl < nslots; sl++)
+      if (!held[sl].cnt) {
+        out = sl;
+        return DSV_OK;
+      }
+    if (!small)
+      for (int sl = 0; sl < nslots; sl++)
+        if (held[sl].enqueued) {
+          const hipError_t q = hipEventQuery(pipe.slot[sl].ev_done);
+          if (q == hipSuccess) {
+            out = sl;
+            return drain(sl);
+          }
+          if (q != hipErrorNotReady) return fail(DSV_ERR_HIP, "hipEventQuery failed: %s", hipGetErrorString(q));
+        }
+    int oldest = -1;
+    for (int sl = 0; sl < nslots; sl++)
+      if (held[sl].enqueued && (oldest < 0 || held[sl].first < held[oldest].first)) oldest = sl;
+    if (oldest < 0) return fail(DSV_ERR_HIP, "host pipeline: no slot to wait for");  // (cannot happen: see the loop)
+    out = oldest;
+    return drain(oldest);
   };
   // an error half-way: nothing of this call may still be in flight when the caller's buffers go away
   // (the streams are shared: this waits for the other call in flight as well — errors are rare)
@@ -1199,6 +1250,14 @@ int run_pipelined(Context& ctx, const HostIn (&ins)[NIN], uint8_t* ok, size_t n,
     (void)hipStreamSynchronize(ctx.pipe_small);
     for (int k = 0; k < 2; k++) (void)hipStreamSynchronize(ctx.pipe_lane[k]);
     (void)hipStreamSynchronize(ctx.pipe_out);
+    {  // what this call had outstanding on the lanes is gone
+      std::lock_guard<std::mutex> enq(ctx.enq_mu);
+      for (auto& h : held)
+        for (int k = 0; k < 2; k++) {
+          ctx.lane_load[k] -= h.parts_on[k];
+          h.parts_on[k] = 0;
+        }
+    }
     g_err = why;
     return rc;
   };
@@ -1214,12 +1273,13 @@ int run_pipelined(Context& ctx, const HostIn (&ins)[NIN], uint8_t* ok, size_t n,
 
   // ---- stage chunk c into its slot: gather the caller's arrays into pinned memory, start the transfer ----
   auto stage = [&](size_t c, size_t first) -> int {
-    const int sl = (int)(c % (size_t)kSlots);
-    PipeSlot& slot = pipe.slot[sl];
-    Held& h = held[sl];
     const size_t cnt = chunks[c];
     const double t0 = now();
-    if (int r = drain(sl)) return r;  // slot free again, its verdicts delivered
+    int sl = -1;
+    if (int r = free_slot(sl)) return r;  // a slot that is free (again), its verdicts delivered
+    slot_of[c % (size_t)(kPipeSlots + 1)] = sl;
+    PipeSlot& slot = pipe.slot[sl];
+    Held& h = held[sl];
     const double t1 = now();
     t_drain += t1 - t0;
     uint8_t* host = slot.host;
@@ -1262,7 +1322,7 @@ int run_pipelined(Context& ctx, const HostIn (&ins)[NIN], uint8_t* ok, size_t n,
   // From here to the verdict copy the chunk is enqueued as one unit: a lane's work area belongs to one
   // sub-batch at a time (the lanes are in-order, so enqueue order = use order).
   auto enqueue = [&](size_t c) -> int {
-    const int sl = (int)(c % (size_t)kSlots);
+    const int sl = slot_of[c % (size_t)(kPipeSlots + 1)];
     PipeSlot& slot = pipe.slot[sl];
     Held& h = held[sl];
     const size_t cnt = h.cnt;
@@ -1282,6 +1342,11 @@ int run_pipelined(Context& ctx, const HostIn (&ins)[NIN], uint8_t* ok, size_t n,
       }
       return DSV_OK;
     };
+    // the lane with fewer sub-batches outstanding; a tie alternates
+    auto next_lane = [&]() -> int {
+      if (ctx.lane_load[0] != ctx.lane_load[1]) return ctx.lane_load[0] < ctx.lane_load[1] ? 0 : 1;
+      return (int)(ctx.pipe_parts & 1);
+    };
     Staged sg;
     int prep_lane = -1;
     if constexpr (has_prep) {
@@ -1289,7 +1354,7 @@ int run_pipelined(Context& ctx, const HostIn (&ins)[NIN], uint8_t* ok, size_t n,
       if (small) {
         sp = ctx.pipe_small;
       } else {
-        if (!pre_stream) prep_lane = (int)(ctx.pipe_parts & 1);  // the lane of the chunk's first sub-batch (counter not advanced)
+        if (!pre_stream) prep_lane = next_lane();  // the lane of the chunk's first sub-batch (nothing advanced)
         sp = pre_stream ? ctx.pipe_pre : ctx.pipe_lane[prep_lane];
         if (hipStreamWaitEvent(sp, slot.ev_in, 0) != hipSuccess) return fail(DSV_ERR_HIP, "hipStreamWaitEvent failed");
       }
@@ -1311,7 +1376,12 @@ int run_pipelined(Context& ctx, const HostIn (&ins)[NIN], uint8_t* ok, size_t n,
     (void)plan_parts(cnt, one_part, part_cap, part_items);
     for (size_t off = 0; off < cnt;) {
       const size_t pc = cnt - off < part_items ? cnt - off : part_items;
-      const int k = small ? 0 : (int)(ctx.pipe_parts++ & 1);
+      const int k = small ? 0 : next_lane();
+      if (!small) {
+        ctx.pipe_parts++;
+        ctx.lane_load[k]++;
+        h.parts_on[k]++;
+      }
       hipStream_t st = small ? ctx.pipe_small : ctx.pipe_lane[k];
       if (int r = lane_for(k)) return r;
       if (prep_lane >= 0 && k != prep_lane && !waited_pre[k]) {
