@@ -4,10 +4,14 @@
 // ThreadSanitizer (tests/cpp/test_host_sync.cpp, run by tests/test_host_sync.py): GPU sanitizers are
 // not available on this pool, and this is exactly the code where a data race would hide.
 #pragma once
+#include <immintrin.h>
+
 #include <atomic>
 #include <condition_variable>
 #include <cstddef>
 #include <cstdint>
+#include <cstdlib>
+#include <cstring>
 #include <functional>
 #include <mutex>
 #include <thread>
@@ -102,6 +106,55 @@ class CopyPool {
   bool quit_ = false;
 };
 
+
+// ---- the strided gather ----------------------------------------------------------------------
+// `count` items of `bytes` bytes, `stride` apart, packed densely into dst (the typed objects of a
+// language binding: one field out of every struct)
+inline void copy_strided_plain(uint8_t* dst, const uint8_t* src, size_t stride, size_t bytes, size_t count) {
+  switch (bytes) {  // constant sizes: the copies are inlined vector moves
+    case 32:
+      for (size_t i = 0; i < count; i++) memcpy(dst + 32 * i, src + stride * i, 32);
+      break;
+    case 96:
+      for (size_t i = 0; i < count; i++) memcpy(dst + 96 * i, src + stride * i, 96);
+      break;
+    default:
+      for (size_t i = 0; i < count; i++) memcpy(dst + bytes * i, src + stride * i, bytes);
+  }
+}
+// The same with non-temporal stores (dst 32-byte aligned, bytes a multiple of 32): the pinned staging
+// block is written once and read by the DMA engine only — ordinary stores first READ every line they
+// are about to overwrite (read-for-ownership: 40 % of the gather's memory traffic) and push the
+// caller's objects out of the cache.
+__attribute__((target("avx2"))) inline void copy_strided_nt(uint8_t* dst, const uint8_t* src, size_t stride,
+                                                           size_t bytes, size_t count) {
+  if (bytes == 32) {
+    for (size_t i = 0; i < count; i++)
+      _mm256_stream_si256((__m256i*)(dst + 32 * i), _mm256_loadu_si256((const __m256i*)(src + stride * i)));
+  } else if (bytes == 96) {
+    for (size_t i = 0; i < count; i++) {
+      const __m256i a = _mm256_loadu_si256((const __m256i*)(src + stride * i));
+      const __m256i b = _mm256_loadu_si256((const __m256i*)(src + stride * i + 32));
+      const __m256i c = _mm256_loadu_si256((const __m256i*)(src + stride * i + 64));
+      _mm256_stream_si256((__m256i*)(dst + 96 * i), a);
+      _mm256_stream_si256((__m256i*)(dst + 96 * i + 32), b);
+      _mm256_stream_si256((__m256i*)(dst + 96 * i + 64), c);
+    }
+  } else {
+    for (size_t i = 0; i < count; i++)
+      for (size_t o = 0; o < bytes; o += 32)
+        _mm256_stream_si256((__m256i*)(dst + bytes * i + o), _mm256_loadu_si256((const __m256i*)(src + stride * i + o)));
+  }
+  _mm_sfence();  // the stores are globally visible before the transfer is enqueued
+}
+inline void copy_strided(uint8_t* dst, const uint8_t* src, size_t stride, size_t bytes, size_t count) {
+  static const bool nt = [] {
+    const char* e = getenv("DSV_GATHER_NT");  // 0: ordinary stores (A/B)
+    return !(e && strcmp(e, "0") == 0) && __builtin_cpu_supports("avx2");
+  }();
+  if (nt && (bytes & 31) == 0 && ((uintptr_t)dst & 31) == 0) copy_strided_nt(dst, src, stride, bytes, count);
+  else copy_strided_plain(dst, src, stride, bytes, count);
+}
 
 // ---- who runs when ---------------------------------------------------------------------------
 // One per device.  Calls take a ticket; a pipe is handed out first come first served while fewer than

@@ -9,6 +9,7 @@
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <random>
 
 #include "../../schnorr_amd/csrc/host_sync.h"
@@ -166,7 +167,31 @@ static void plans() {
   }
 }
 
+// the strided gather: non-temporal and plain stores give the same bytes for every width, stride,
+// source misalignment and count the pipeline uses (and for the widths that fall back to plain stores)
+static void gather() {
+  std::mt19937 rng(11);
+  std::vector<uint8_t> src(1 << 20), a(1 << 19), b(1 << 19);
+  for (auto& x : src) x = (uint8_t)rng();
+  const size_t widths[] = {32, 96, 64, 128, 48, 1};
+  for (size_t bytes : widths)
+    for (int iter = 0; iter < 40; iter++) {
+      const size_t stride = bytes + (rng() % 5) * 32 + (iter & 1 ? rng() % 17 : 0);  // 160, 192, 320, 352 ... and odd ones
+      const size_t count = 1 + rng() % 1500, off = rng() % 64;
+      if (off + stride * count > src.size() || bytes * count + 64 > a.size()) continue;
+      uint8_t* da = a.data() + ((64 - (uintptr_t)a.data() % 64) % 64);  // 64-byte aligned, as the slots are
+      uint8_t* db = b.data() + ((64 - (uintptr_t)b.data() % 64) % 64);
+      std::fill(a.begin(), a.end(), 0xAA);
+      std::fill(b.begin(), b.end(), 0xAA);
+      copy_strided(da, src.data() + off, stride, bytes, count);
+      copy_strided_plain(db, src.data() + off, stride, bytes, count);
+      CHECK(std::memcmp(da, db, bytes * count + 64) == 0);  // (incl. nothing written behind the block)
+      for (size_t i = 0; i < count; i += 97) CHECK(std::memcmp(da + bytes * i, src.data() + off + stride * i, bytes) == 0);
+    }
+}
+
 int main() {
+  gather();
   plans();
   copy_pool();
   leases_and_turns();
