@@ -244,6 +244,14 @@ class MontColsJob:
         _lib.check(getattr(_lib.load(), name + "_submit")(arr, ctypes.c_size_t(n), _p(self._ok),
                                                           ctypes.byref(self._job)))
 
+    def __del__(self):
+        # a job dropped unwaited still reads the columns and writes the verdicts: wait before they go
+        try:
+            if getattr(self, "_job", None) is not None and self._job.value is not None:
+                self.wait()
+        except Exception:  # noqa: BLE001
+            pass
+
     def done(self):
         return self._job.value is None or _lib.load().dsv_job_done(self._job) == 1
 
