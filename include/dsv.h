@@ -189,7 +189,10 @@ int dsv_verify_vargen_mont_cols(const dsv_column *cols /*[5]*/, size_t n, uint8_
  * staging (dsv_max_in_flight() per device; a further job waits inside its driver thread), the
  * compute streams are shared, so the GPU sees one queue of sub-batches.  The blocking host entry
  * points may equally be called from several threads at once — same mechanism.
- * Jobs start in submission order.  dsv_job_done: 1 finished / 0 running (does not release). */
+ * Jobs start in submission order.  dsv_job_done: 1 finished / 0 running (does not release).
+ * dsv_shutdown* first lets every job submitted so far (and every blocking call that already owns
+ * its staging) run to its verdicts; a submit racing with the shutdown may fail with
+ * DSV_ERR_NOT_INITIALIZED at its wait. */
 typedef struct dsv_job dsv_job;
 int dsv_verify_single_mont_cols_submit(const dsv_column *cols /*[4]*/, size_t n, uint8_t *ok, dsv_job **job);
 int dsv_verify_double_mont_cols_submit(const dsv_column *cols /*[6]*/, size_t n, uint8_t *ok, dsv_job **job);

@@ -170,6 +170,11 @@ Context g_ctx[kMaxDevices];
 std::mutex g_init_mu;               // dsv_init / dsv_shutdown
 std::atomic<int> g_primary{-1};     // first device initialised: default of the host entry points
 thread_local int t_device = -1;     // dsv_set_device: this thread's choice for host entry points
+// jobs submitted and not finished (dsv_*_submit): dsv_shutdown lets them run to their verdicts first —
+// a job's driver may not have queued for its pipe yet when the shutdown arrives
+std::mutex g_jobs_mu;
+std::condition_variable g_jobs_cv;
+int g_jobs = 0;
 
 // the calling thread's current HIP device is restored on scope exit: the library must not leave a
 // caller's thread on another GPU
@@ -655,6 +660,10 @@ int dsv_shutdown_device(int device) {
   if (device < 0 || device >= kMaxDevices) return fail(DSV_ERR_INVALID_ARGUMENT, "bad device %d", device);
   Context& ctx = g_ctx[device];
   if (!ctx.ready.load()) return DSV_OK;
+  {
+    std::unique_lock<std::mutex> jl(g_jobs_mu);
+    g_jobs_cv.wait(jl, [] { return g_jobs == 0; });
+  }
   int prev = -1;
   (void)hipGetDevice(&prev);
   ctx.ready.store(false);  // new calls are refused from here on
@@ -1887,8 +1896,14 @@ int submit_mont_cols(int kind, const dsv_column* cols, size_t n, uint8_t* ok, ds
   j->n = n;
   j->ok = ok;
   for (int k = 0; n && k < kMontCols[kind]; k++) j->cols[k] = cols[k];
+  auto job_count = [](int d) {
+    std::lock_guard<std::mutex> lk(g_jobs_mu);
+    g_jobs += d;
+    if (g_jobs == 0) g_jobs_cv.notify_all();
+  };
+  job_count(+1);
   try {
-    j->th = std::thread([j] {
+    j->th = std::thread([j, job_count] {
       {
         std::lock_guard<std::mutex> lk(j->m);
         j->started = true;
@@ -1897,8 +1912,10 @@ int submit_mont_cols(int kind, const dsv_column* cols, size_t n, uint8_t* ok, ds
       j->rc = verify_mont_cols(j->kind, j->cols, j->n, j->ok, true);
       if (j->rc) j->err = g_err;  // the text lives in this thread's thread-local
       j->finished.store(true, std::memory_order_release);
+      job_count(-1);
     });
   } catch (...) {
+    job_count(-1);
     delete j;
     return fail(DSV_ERR_HIP, "could not start the driver thread of the batch");
   }

@@ -118,3 +118,29 @@ def test_submit_validates_like_the_blocking_form(engine):
     assert rc == 0 and job.value is not None
     assert L.dsv_job_wait(job) == 0
     assert L.dsv_job_wait(None) == -2
+
+
+def test_shutdown_waits_for_the_calls_in_flight(engine):
+    """dsv_shutdown while three jobs are in flight (two own a pipe, one waits for one): it returns only
+    after all of them have delivered the oracle's verdicts; calls after it fail loudly; dsv_init brings the
+    engine back."""
+    from schnorr_amd import _lib
+    cases = []
+    for scheme, n, seed in (("single", (1 << 17) + 99, 81), ("vargen", 1 << 16, 82), ("double", (1 << 16) + 2000, 83)):
+        tcols, want = _tiled_case(scheme, 199, n, seed, period=4)
+        cases.append((scheme, C.as_records(scheme, tcols)[3], want))
+    jobs = [engine.submit_mont_cols(scheme, views) for scheme, views, _ in cases]
+    done = {}
+    th = threading.Thread(target=lambda: done.setdefault("rc", engine.shutdown()))
+    th.start()
+    th.join(timeout=120)
+    assert not th.is_alive(), "dsv_shutdown did not return"
+    try:
+        for (scheme, _, want), job in zip(cases, jobs):
+            assert job.done()                                  # shutdown has waited for every one of them
+            assert np.array_equal(job.wait(), want), scheme
+        with pytest.raises(_lib.DsvError):
+            engine.verify_mont_cols(cases[0][0], cases[0][1])  # not initialised any more
+    finally:
+        engine.init(0)
+    assert np.array_equal(engine.verify_mont_cols(cases[0][0], cases[0][1]), cases[0][2])
