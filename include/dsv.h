@@ -256,6 +256,28 @@ int dsv_verify_double_dev(const void *u, const void *R_uv, const void *Rp_uv, co
 int dsv_verify_vargen_dev(const void *u, const void *R_uv, const void *PK_uv, const void *Gen_uv,
                           const void *m, size_t n, void *ok, void *workspace, void *stream);
 
+/* ---- optional fast accept: random-linear-combination batch verification ----
+ * Same inputs and the same verdict vector as dsv_verify_single_dev — what differs is the time.  Per
+ * group of up to 2^22 items the call first runs ONE aggregate test (schnorr_amd/csrc/k_rlc.hip):
+ *   every PK_i and R_i lies in the prime-order subgroup, and
+ *   (sum z_i u_i) G + sum (z_i c_i) PK_i - sum z_i R_i == O   for secret 128-bit z_i drawn per call
+ * (getrandom).  If it holds, every well-formed item's verdict is `true`, exactly as
+ * `PublicKey::verify` (/root/reference/src/keys/public.rs:121-130) would say one by one — up to an
+ * error probability <= 2^-112 of accepting a batch that holds a wrong signature, where the
+ * per-signature path has none.  If it does not hold (one wrong signature, one point with a
+ * small-order component — the reference's types can hold those and its equation is cofactorless —
+ * or a point off the curve), the group is verified by dsv_verify_single_dev's kernels and gets their
+ * verdicts: nothing is ever decided by the aggregate except "all true".  Worth it where batches are
+ * expected to be entirely valid (~2.7x less arithmetic then; a batch that fails pays both paths).
+ * window_bits: 0 = chosen from n, else an even number in 4..16 (bucket windows; tests).
+ * *accepted (may be NULL): 1 if every group took the fast path.
+ * Unlike the other *_dev calls this one BLOCKS on `stream` (the decision is taken on the host).
+ * workspace: dsv_rlc_workspace_bytes(n, window_bits) device bytes, 256-byte aligned. */
+size_t dsv_rlc_workspace_bytes(size_t n, int window_bits);
+int dsv_verify_single_rlc_dev(const void *u, const void *R_uv, const void *PK_uv, const void *m,
+                              size_t n, void *ok, void *workspace, void *stream, int window_bits,
+                              int *accepted);
+
 /* second stage alone: ok[i] = (accumulate ? ok[i] : valid[i]) & [u*Gen + c*PK == R], Gen = G
  * (which = 0) or G' (which = 1); c and valid as produced by dsv_challenge_*_dev */
 int dsv_verify_core_dev(const void *u, const void *c, const void *valid, const void *PK_uv,

@@ -44,9 +44,12 @@ SYMBOLS = [
     # r05: asynchronous form of the column entry points (two batches in flight per device)
     "dsv_verify_single_mont_cols_submit", "dsv_verify_double_mont_cols_submit",
     "dsv_verify_vargen_mont_cols_submit", "dsv_job_wait", "dsv_job_done", "dsv_max_in_flight",
+    # r05: random-linear-combination fast accept in front of the per-signature kernels
+    "dsv_rlc_workspace_bytes", "dsv_verify_single_rlc_dev",
 ]
 _SIZE_T_FUNCS = ("dsv_workspace_bytes", "dsv_mixed_workspace_bytes", "dsv_split_scratch_bytes",
-                 "dsv_ext_workspace_bytes", "dsv_wire_workspace_bytes", "dsv_mont_workspace_bytes")
+                 "dsv_ext_workspace_bytes", "dsv_wire_workspace_bytes", "dsv_mont_workspace_bytes",
+                 "dsv_rlc_workspace_bytes")
 
 
 class Column(ctypes.Structure):
@@ -88,7 +91,7 @@ def load():
     L.dsv_last_error.restype = ctypes.c_char_p
     for name in _SIZE_T_FUNCS:
         getattr(L, name).restype = ctypes.c_size_t
-        getattr(L, name).argtypes = [ctypes.c_size_t]
+        getattr(L, name).argtypes = [ctypes.c_size_t] + ([ctypes.c_int] if name == "dsv_rlc_workspace_bytes" else [])
     for name in SYMBOLS:
         fn = getattr(L, name)  # AttributeError if a declared symbol is not exported
         if name not in ("dsv_version", "dsv_last_error") + _SIZE_T_FUNCS:

@@ -18,7 +18,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libdsv.so")
-UNITS = ["dsv.hip", "k_hash.hip", "k_verify.hip", "k_quad.hip", "k_vargen.hip", "k_misc.hip"]
+UNITS = ["dsv.hip", "k_hash.hip", "k_verify.hip", "k_quad.hip", "k_vargen.hip", "k_misc.hip", "k_rlc.hip"]
 ARCH = "gfx950"
 FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wextra"]
 

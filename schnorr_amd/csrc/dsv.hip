@@ -45,10 +45,14 @@
 #include <type_traits>
 #include <vector>
 
+#include <errno.h>
+#include <sys/random.h>
+
 #include "../../include/dsv.h"
 #define DSV_HOST_TABLES 1
 #include "dsv_constants.h"
 #include "launch.h"
+#include "rlc.h"
 #include "host_sync.h"
 
 
@@ -844,6 +848,98 @@ int dsv_verify_single_dev(const void* u, const void* R_uv, const void* PK_uv, co
     return fail(DSV_ERR_INVALID_ARGUMENT, "null pointer");
   DSV_DEV_PROLOGUE(n, ok);
   return verify_single_on(ctx, u, R_uv, PK_uv, m, n, ok, workspace, (hipStream_t)stream);
+}
+
+// ---- random-linear-combination fast accept in front of the per-signature path ----
+// Per group of at most kRlcMaxGroup items: hash, then one aggregate test (k_rlc.hip: every key and
+// nonce point in the prime-order subgroup AND the z-weighted sum of the equations is the identity,
+// z_i secret, fresh per call).  Accepted: every well-formed item's verdict is `true`, as the
+// reference's (error <= 2^-112).  Rejected — one wrong signature, one point with a small-order
+// component or off the curve — the group goes through dsv_verify_single_dev's kernels and gets
+// THEIR verdicts.  The call blocks on `stream` once per group (the decision is taken on the host).
+extern "C++" {
+namespace {
+struct RlcCarve {
+  Workspace w;  // the per-signature path's own workspace comes first: the fallback uses it as it is
+  RlcBuffers b;
+  size_t bytes;
+};
+RlcCarve carve_rlc(void* ws, size_t n, const RlcPlan& p) {
+  RlcCarve r;
+  r.w = carve(ws, n);
+  Stager st(static_cast<uint8_t*>(ws) + align_up(dsv_workspace_bytes(n), 256));
+  auto words = [&](size_t count) { return reinterpret_cast<u32*>(st.take(count * 4)); };
+  r.b.pts = words(2 * n * 32);
+  r.b.fsc = words(n * 8);
+  r.b.fpart = words((size_t)kRlcFsumBlocks * 8);
+  r.b.fsum = words(8);
+  for (int k = 0; k < 2; k++) r.b.keys[k] = words(p.entries), r.b.vals[k] = words(p.entries);
+  r.b.buckets = words(p.buckets * 36);
+  for (int k = 0; k < 2; k++) r.b.tmp[k] = words(rlc_tmp_points(p, k) * 36);
+  r.b.flags = words(4);
+  r.b.sort_temp_bytes = rlc_sort_temp_bytes(p);
+  r.b.sort_temp = st.take(r.b.sort_temp_bytes);
+  r.bytes = align_up(dsv_workspace_bytes(n), 256) + st.off;
+  return r;
+}
+size_t rlc_group_items(size_t n) { return n < kRlcMaxGroup ? n : kRlcMaxGroup; }
+int rlc_random_key(ChaChaKey& key) {
+  uint8_t* p = reinterpret_cast<uint8_t*>(key.w);
+  size_t have = 0;
+  while (have < sizeof key.w) {
+    const ssize_t got = getrandom(p + have, sizeof key.w - have, 0);
+    if (got < 0) {
+      if (errno == EINTR) continue;
+      return fail(DSV_ERR_HIP, "getrandom: %s (the batch weights must be unpredictable)", strerror(errno));
+    }
+    have += (size_t)got;
+  }
+  return DSV_OK;
+}
+}  // namespace
+}  // extern "C++"
+size_t dsv_rlc_workspace_bytes(size_t n, int window_bits) {
+  const size_t g = rlc_group_items(n);
+  if (g == 0) return 256;
+  const int c = window_bits ? window_bits : rlc_default_bits(g);
+  if (!rlc_bits_ok(c)) return 0;
+  return carve_rlc(reinterpret_cast<void*>((uintptr_t)4096), g, rlc_plan(g, c)).bytes + 256;
+}
+int dsv_verify_single_rlc_dev(const void* u, const void* R_uv, const void* PK_uv, const void* m, size_t n,
+                              void* ok, void* workspace, void* stream, int window_bits, int* accepted) {
+  if (accepted) *accepted = 0;
+  if (n && (!u || !R_uv || !PK_uv || !m || !ok || !workspace))
+    return fail(DSV_ERR_INVALID_ARGUMENT, "null pointer");
+  if (window_bits && !rlc_bits_ok(window_bits))
+    return fail(DSV_ERR_INVALID_ARGUMENT, "window_bits must be 0 (automatic) or an even number in 4..16");
+  DSV_DEV_PROLOGUE(n, ok);
+  const hipStream_t s = (hipStream_t)stream;
+  const uint8_t *pu = (const uint8_t*)u, *pR = (const uint8_t*)R_uv, *pPK = (const uint8_t*)PK_uv,
+                *pm = (const uint8_t*)m;
+  uint8_t* pok = (uint8_t*)ok;
+  const size_t group = rlc_group_items(n);
+  bool all = true;
+  for (size_t off = 0; off < n; off += group) {
+    const size_t cnt = n - off < group ? n - off : group;
+    const RlcPlan plan = rlc_plan(cnt, window_bits ? window_bits : rlc_default_bits(cnt));
+    const RlcCarve cv = carve_rlc(workspace, cnt, plan);
+    ChaChaKey key;
+    if (int r = rlc_random_key(key)) return r;
+    launch_challenge(false, pR + 64 * off, (const uint8_t*)nullptr, pm + 32 * off, cnt, cv.w.c, cv.w.valid, s);
+    launch_rlc(plan, cv.b, pu + 32 * off, cv.w.c, pPK + 64 * off, pR + 64 * off, cv.w.valid, key, ctx.table[0],
+               pok + off, s);
+    HIP_TRY(hipGetLastError());
+    u32 flags[4] = {~0u, 0, 0, 0};
+    HIP_TRY(hipMemcpyAsync(flags, cv.b.flags, sizeof flags, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    if (flags[0] == 0 && flags[1] == 1) continue;  // ok[] = "well-formed" is the verdict vector
+    all = false;
+    if (int r = verify_single_on(ctx, pu + 32 * off, pR + 64 * off, pPK + 64 * off, pm + 32 * off, cnt, pok + off,
+                                 workspace, s))
+      return r;
+  }
+  if (accepted) *accepted = all ? 1 : 0;
+  return DSV_OK;
 }
 
 // second stage alone (c and valid already computed): lets callers time / profile the dominant

@@ -1,0 +1,435 @@
+// k_rlc.hip — SURVEY.md §8(f)-4: random-linear-combination batch verification of
+// `PublicKey::verify` (/root/reference/src/keys/public.rs:121-130) as an OPTIONAL fast-accept path
+// in front of the per-signature kernels (k_verify.hip), behind the same bool-vector boundary.
+//
+// The reference's equation is cofactorless, u*G + c*PK == R, and its types hold points with a
+// small-order component (`from_bytes` checks the curve equation only, src/keys/public.rs:94-100), so
+// a plain  sum z_i (u_i G + c_i PK_i - R_i) == O  is NOT the reference's verdict: torsion defects
+// cancel.  What this path accepts instead is the conjunction of
+//   (1) every PK_i and R_i that enters the sum lies in the prime-order subgroup, and
+//   (2) (sum z_i u_i) G + sum (z_i c_i) PK_i - sum z_i R_i == O     with secret random 128-bit z_i,
+// under which every per-signature verdict is `true` (error <= 2^-112: see below).  If either fails
+// the caller (dsv.hip) runs the per-signature kernels and returns THEIR verdicts, so the bool vector
+// is the reference's in every case; only the time differs.
+//
+// Both come out of ONE bucket pass.  With c-bit unsigned windows, (2) is Pippenger: bucket (w, d)
+// sums the points whose scalar has digit d in window w.  Seen as a 2^(c/2) x 2^(c/2) matrix per
+// window, the buckets' row and column sums give, for every BIT p of the scalars,
+//   S_p = sum over { i : bit p of scalar_i is set } of P_i,
+// and sum_i scalar_i P_i = sum_p 2^p S_p.  The S_p are also 252 + 128 independent random-subset sums
+// of the inputs: if some PK_i0 (R_i0) has a torsion component t != 0, then "r * S_p == O for every
+// p" pins every bit of z_i0 c_i0 mod r (of z_i0) to one value — probability 2^-128 over z_i0 (the
+// map z -> z c mod r is injective for c != 0; for c == 0 the key does not enter the equation, in the
+// reference's either).  PK and R scalars use SEPARATE windows so the two arguments stay independent.
+// Cost per signature at c = 16: 16 + 8 mixed additions (7 multiplications each) against ~1900
+// multiplications of the half-gcd chain, plus a sort of 24 (key, index) pairs.
+//
+// Kernels (launch order; every stage reads what the previous one wrote, same stream):
+//   k_rlc_prep        per item: z_i = ChaCha12(key, i), e_i = z_i c_i, f_i = z_i u_i (mod r), range and
+//                     curve checks, the points as affine niels (PK_i, -R_i), (bucket, index) pairs
+//   k_rlc_fsum[2]     sum f_i mod r
+//   (hipcub radix sort of the pairs by bucket)
+//   k_rlc_accumulate  one lane per bucket: binary search of its run, mixed additions
+//   k_rlc_sum<0..3>   row / column sums, then the per-bit subset sums S_p        (short chains)
+//   k_rlc_scale       lanes A: r * S_p == O ?      lanes B: 2^p * S_p
+//   k_rlc_sum<4>, k_rlc_final   sum of the scaled S_p, + (sum f_i) * G, identity test -> flags
+#include <hipcub/hipcub.hpp>
+
+#include "common.h"
+#include "rlc.h"
+#include "stdrng.h"
+
+namespace dsv {
+
+namespace {
+constexpr int kPtWords = 32;     // affine niels (v+u, v-u, 2d*uv): 27 words, padded to one 128-byte line
+constexpr int kNielsWords = 36;  // (v+u, v-u, z, 2d*t)
+
+// signed binary expansion of r (non-adjacent form, 85 non-zero digits, top digit +2^252):
+// r = kRNafPos - kRNafNeg, checked at compile time below
+__device__ constexpr u32 kRNafPos[8] = {0x00004100u, 0x10a01080u, 0x11081084u, 0xa8882094u,
+                                        0x01444000u, 0x08884001u, 0x85440029u, 0x1080050au};
+__device__ constexpr u32 kRNafNeg[8] = {0x29091449u, 0x40090221u, 0x44400001u, 0x02200000u,
+                                        0x00100500u, 0x02210500u, 0x20105080u, 0x02025020u};
+constexpr u32 kRWords[8] = DSV_R32;
+constexpr bool naf_is_r() {
+  const u32 pos[8] = {0x00004100u, 0x10a01080u, 0x11081084u, 0xa8882094u, 0x01444000u, 0x08884001u, 0x85440029u, 0x1080050au};
+  const u32 neg[8] = {0x29091449u, 0x40090221u, 0x44400001u, 0x02200000u, 0x00100500u, 0x02210500u, 0x20105080u, 0x02025020u};
+  u64 borrow = 0;
+  for (int i = 0; i < 8; i++) {
+    const u64 d = (u64)pos[i] - neg[i] - borrow;
+    if ((u32)d != kRWords[i]) return false;
+    borrow = (d >> 63) & 1;
+    if (pos[i] & neg[i]) return false;
+  }
+  return borrow == 0;
+}
+static_assert(naf_is_r(), "kRNafPos - kRNafNeg must be the subgroup order r");
+
+DSV_DEV void fr_add(u32 (&out)[8], const u32 (&a)[8], const u32 (&b)[8]) {  // a + b mod r (a, b < r)
+  u32 s[8], d[8];
+  u32 carry = 0, borrow = 0;
+#pragma unroll
+  for (int j = 0; j < 8; j++) {
+    const u64 y = (u64)a[j] + b[j] + carry;
+    s[j] = (u32)y;
+    carry = (u32)(y >> 32);
+  }
+#pragma unroll
+  for (int j = 0; j < 8; j++) {
+    const u64 y = (u64)s[j] - kR32[j] - borrow;
+    d[j] = (u32)y;
+    borrow = (u32)(y >> 63);
+  }
+  const bool ge = borrow == 0;  // (r < 2^252: a + b never carries out of 256 bits)
+#pragma unroll
+  for (int j = 0; j < 8; j++) out[j] = ge ? d[j] : s[j];
+}
+
+DSV_DEV void store_pt(u32* p, const ANiels& n) {
+  uint4* q = reinterpret_cast<uint4*>(p);
+  u32 w[28];
+#pragma unroll
+  for (int i = 0; i < NL; i++) {
+    w[i] = n.vpu.l[i];
+    w[NL + i] = n.vmu.l[i];
+    w[2 * NL + i] = n.t2d.l[i];
+  }
+  w[27] = 0;
+#pragma unroll
+  for (int k = 0; k < 7; k++) q[k] = make_uint4(w[4 * k], w[4 * k + 1], w[4 * k + 2], w[4 * k + 3]);
+}
+DSV_DEV ANiels load_pt(const u32* p) {
+  const uint4* q = reinterpret_cast<const uint4*>(p);
+  u32 w[28];
+#pragma unroll
+  for (int k = 0; k < 7; k++) {
+    const uint4 x = q[k];
+    w[4 * k] = x.x, w[4 * k + 1] = x.y, w[4 * k + 2] = x.z, w[4 * k + 3] = x.w;
+  }
+  ANiels n;
+#pragma unroll
+  for (int i = 0; i < NL; i++) {
+    n.vpu.l[i] = w[i];
+    n.vmu.l[i] = w[NL + i];
+    n.t2d.l[i] = w[2 * NL + i];
+  }
+  return n;
+}
+DSV_DEV void store_niels(u32* p, const Niels& n) {
+  uint4* q = reinterpret_cast<uint4*>(p);
+  u32 w[kNielsWords];
+#pragma unroll
+  for (int i = 0; i < NL; i++) {
+    w[i] = n.vpu.l[i];
+    w[NL + i] = n.vmu.l[i];
+    w[2 * NL + i] = n.z.l[i];
+    w[3 * NL + i] = n.t2d.l[i];
+  }
+#pragma unroll
+  for (int k = 0; k < 9; k++) q[k] = make_uint4(w[4 * k], w[4 * k + 1], w[4 * k + 2], w[4 * k + 3]);
+}
+DSV_DEV Niels load_niels(const u32* p) {
+  const uint4* q = reinterpret_cast<const uint4*>(p);
+  u32 w[kNielsWords];
+#pragma unroll
+  for (int k = 0; k < 9; k++) {
+    const uint4 x = q[k];
+    w[4 * k] = x.x, w[4 * k + 1] = x.y, w[4 * k + 2] = x.z, w[4 * k + 3] = x.w;
+  }
+  Niels n;
+#pragma unroll
+  for (int i = 0; i < NL; i++) {
+    n.vpu.l[i] = w[i];
+    n.vmu.l[i] = w[NL + i];
+    n.z.l[i] = w[2 * NL + i];
+    n.t2d.l[i] = w[3 * NL + i];
+  }
+  return n;
+}
+DSV_DEV Niels niels_neg(const Niels& n) {
+  Niels r;
+  r.vpu = n.vmu;
+  r.vmu = n.vpu;
+  r.z = n.z;
+  r.t2d = fe_neg2(n.t2d);
+  return r;
+}
+DSV_DEV bool ext_is_identity(const Ext& p) {  // u == 0 and v == z (z != 0 on the curve: complete formulas)
+  return (bool)((int)fe_equal(p.u, fe_zero()) & (int)fe_equal(p.v, p.z));
+}
+
+// -u^2 + v^2 == 1 + d u^2 v^2, as 2 v^2 == 2 u^2 + 2 + (2d) u^2 v^2 (u, v: fe_mul outputs)
+DSV_DEV bool on_curve(const Fe& u, const Fe& v) {
+  const Fe uu = fe_sqr(u), vv = fe_sqr(v);
+  const Fe rhs = fe_mul(fe_mul(uu, vv), fe_const(kD2));
+  const Fe a = fe_carry(fe_dbl(vv));                                           // < 3q
+  const Fe b0 = fe_carry(fe_add(fe_dbl(uu), fe_dbl(fe_one())));                // < 5q
+  const Fe b = fe_carry(fe_add(b0, rhs));                                      // < 6.5q, limbs < 2^29 + 8
+  return fe_equal(a, b);
+}
+// (v+u, v-u, 2d*uv) of (u, v), or of (-u, v) — forms as ext_to_niels stores them
+DSV_DEV ANiels affine_niels(const Fe& u, const Fe& v, bool negate) {
+  ANiels n;
+  const Fe s = fe_carry(fe_add(v, u)), d = fe_sub2(v, u);
+  const Fe t = fe_mul(fe_mul(u, v), fe_const(kD2));
+  n.vpu = negate ? d : s;
+  n.vmu = negate ? s : d;
+  n.t2d = negate ? fe_neg2(t) : t;
+  return n;
+}
+}  // namespace
+
+// ---- per item ---------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+k_rlc_prep(const uint8_t* __restrict__ u, const uint8_t* __restrict__ c, const uint8_t* __restrict__ PK_uv,
+           const uint8_t* __restrict__ R_uv, const uint8_t* __restrict__ valid, ChaChaKey key, RlcPlan p,
+           uint8_t* __restrict__ ok, u32* __restrict__ pts, u32* __restrict__ fsc, u32* __restrict__ keys,
+           u32* __restrict__ vals, u32* __restrict__ flags) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= p.n) return;
+  bool good = valid[i] != 0;
+  u32 us[8], cs[8];
+  load_words8(us, u, i);
+  load_words8(cs, c, i);
+  good &= words_lt(us, kR32);
+  {
+    Fe pu, pv, ru, rv;
+    good &= load_fq(pu, PK_uv, 2 * i);
+    good &= load_fq(pv, PK_uv, 2 * i + 1);
+    good &= load_fq(ru, R_uv, 2 * i);
+    good &= load_fq(rv, R_uv, 2 * i + 1);
+    // a point off the curve has no place in a group sum: the per-signature kernels decide the batch
+    if (good && !((int)on_curve(pu, pv) & (int)on_curve(ru, rv))) atomicOr(&flags[0], kRlcOffCurve);
+    store_pt(pts + i * kPtWords, affine_niels(pu, pv, false));
+    store_pt(pts + ((size_t)p.n + i) * kPtWords, affine_niels(ru, rv, true));
+  }
+  ok[i] = good ? 1 : 0;
+  u32 z[8] = {0, 0, 0, 0, 0, 0, 0, 0}, e[8], f[8];
+  {
+    u32 blk[16];
+    chacha12_block(blk, key.w, (u64)i);
+#pragma unroll
+    for (int k = 0; k < 4; k++) z[k] = good ? blk[k] : 0u;  // an item with verdict `false` stays out of the sum
+  }
+  if (!good) {
+    us[7] &= 0x0fffffffu;  // keep fr_mul's inputs in range; the products are 0 anyway
+    cs[7] &= 0x0fffffffu;
+  }
+  fr_mul(e, z, cs);
+  fr_mul(f, z, us);
+  store_words8(reinterpret_cast<uint8_t*>(fsc), i, f);
+  const u32 mask = (1u << p.c) - 1u, none = (u32)p.windows << p.c;
+#pragma unroll 1
+  for (int w = 0; w < p.wpk; w++) {
+    const u32 d = e[0] & mask;
+#pragma unroll
+    for (int k = 0; k < 7; k++) e[k] = __funnelshift_r(e[k], e[k + 1], p.c);
+    e[7] >>= p.c;
+    keys[(size_t)w * p.n + i] = d ? (((u32)w << p.c) | d) : none;
+    vals[(size_t)w * p.n + i] = (u32)i;
+  }
+#pragma unroll 1
+  for (int w = 0; w < p.wr; w++) {
+    const u32 d = z[0] & mask;
+#pragma unroll
+    for (int k = 0; k < 3; k++) z[k] = __funnelshift_r(z[k], z[k + 1], p.c);
+    z[3] >>= p.c;
+    keys[(size_t)(p.wpk + w) * p.n + i] = d ? (((u32)(p.wpk + w) << p.c) | d) : none;
+    vals[(size_t)(p.wpk + w) * p.n + i] = (u32)(p.n + i);
+  }
+}
+
+// sum of n scalars mod r: stage 0 -> kRlcFsumBlocks partial sums, stage 1 (one workgroup) -> out
+__global__ void __launch_bounds__(256) k_rlc_fsum(const u32* __restrict__ in, size_t n, u32* __restrict__ out) {
+  __shared__ u32 sh[256][8];
+  u32 acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+    u32 x[8], t[8];
+    load_words8(x, reinterpret_cast<const uint8_t*>(in), i);
+    fr_add(t, acc, x);
+#pragma unroll
+    for (int k = 0; k < 8; k++) acc[k] = t[k];
+  }
+#pragma unroll
+  for (int k = 0; k < 8; k++) sh[threadIdx.x][k] = acc[k];
+  __syncthreads();
+  for (int step = 128; step > 0; step >>= 1) {
+    if ((int)threadIdx.x < step) {
+      u32 a[8], b[8], t[8];
+#pragma unroll
+      for (int k = 0; k < 8; k++) a[k] = sh[threadIdx.x][k], b[k] = sh[threadIdx.x + step][k];
+      fr_add(t, a, b);
+#pragma unroll
+      for (int k = 0; k < 8; k++) sh[threadIdx.x][k] = t[k];
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    u32 t[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) t[k] = sh[0][k];
+    store_words8(reinterpret_cast<uint8_t*>(out), blockIdx.x, t);
+  }
+}
+
+// ---- buckets ----------------------------------------------------------------------------------
+DSV_DEV size_t lower_bound_u32(const u32* __restrict__ a, size_t n, u32 key) {
+  size_t lo = 0, hi = n;
+  while (lo < hi) {
+    const size_t mid = lo + ((hi - lo) >> 1);
+    if (a[mid] < key) lo = mid + 1;
+    else hi = mid;
+  }
+  return lo;
+}
+__global__ void __launch_bounds__(64)
+k_rlc_accumulate(const u32* __restrict__ keys, const u32* __restrict__ vals, const u32* __restrict__ pts,
+                 RlcPlan p, u32* __restrict__ buckets) {
+  const size_t b = (size_t)blockIdx.x * 64 + threadIdx.x;
+  if (b >= p.buckets) return;
+  size_t lo = 0, hi = 0;
+  if (b & ((1u << p.c) - 1u)) {  // digit 0 enters no sum
+    lo = lower_bound_u32(keys, p.entries, (u32)b);
+    hi = lower_bound_u32(keys, p.entries, (u32)b + 1u);
+  }
+  Ext acc = ext_identity();
+#pragma unroll 1
+  for (size_t j = lo; j < hi; j++) {
+    const u32 id = vals[j];
+    if (id >= 2u * p.n) continue;  // (cannot happen: the sort moves what prep wrote)
+    acc = ext_add_aniels(acc, load_pt(pts + (size_t)id * kPtWords));
+  }
+  store_niels(buckets + b * kNielsWords, ext_to_niels(acc));
+}
+
+// ---- short sums of stored points: out[o] = sum_k in[addr(o, k)] ------------------------------------
+//   MODE 0  buckets -> segments of the row (kind 1) / column (kind 0) sums of each window's bucket matrix
+//   MODE 1  segments -> row / column sums ("lines")
+//   MODE 2  lines -> segments of: sum of the lines whose index has bit j set
+//   MODE 3  segments -> S[w * c + kind * half + j], the subset sum of bit (kind * half + j) of window w
+//   MODE 4  scaled S -> one sum per window
+template <int MODE>
+__global__ void __launch_bounds__(64)
+k_rlc_sum(const u32* __restrict__ in, RlcPlan p, u32* __restrict__ out) {
+  const u32 o = blockIdx.x * 64 + threadIdx.x;
+  const u32 side = 1u << p.half;
+  u32 total, count;
+  if (MODE == 0) total = (u32)p.windows * 2 * side * p.nseg, count = side / p.nseg;
+  else if (MODE == 1) total = (u32)p.windows * 2 * side, count = p.nseg;
+  else if (MODE == 2) total = (u32)p.windows * 2 * p.half * p.nseg2, count = side / 2 / p.nseg2;
+  else if (MODE == 3) total = (u32)p.windows * 2 * p.half, count = p.nseg2;
+  else total = (u32)p.windows, count = p.c;
+  if (o >= total) return;
+  u32 base = 0, step = 1, j = 0, first = 0;
+  if (MODE == 0) {
+    const u32 seg = o % p.nseg, line = o / p.nseg, idx = line % side, wk = line / side, kind = wk & 1, w = wk >> 1;
+    const u32 e0 = seg * count;
+    if (kind) base = (w << p.c) | (idx << p.half) | e0, step = 1;           // row idx: the low half runs
+    else base = (w << p.c) | (e0 << p.half) | idx, step = side;              // column idx: the high half runs
+  } else if (MODE == 1 || MODE == 3 || MODE == 4) {
+    base = o * count;
+  } else {
+    const u32 s = o % p.nseg2, t = o / p.nseg2;
+    j = t % p.half;
+    base = (t / p.half) * side;  // (w * 2 + kind) * side
+    first = s * count;
+  }
+  Ext acc = ext_identity();
+#pragma unroll 1
+  for (u32 k = 0; k < count; k++) {
+    u32 a;
+    if (MODE == 2) {
+      const u32 m = first + k;  // the m-th index with bit j set
+      a = base + ((((m >> j) << 1) | 1u) << j | (m & ((1u << j) - 1u)));
+    } else {
+      a = base + k * step;
+    }
+    acc = ext_add_niels(acc, load_niels(in + (size_t)a * kNielsWords));
+  }
+  // (MODE 3: o = (w * 2 + kind) * half + j is w * c + kind * half + j, the bit's place in window w)
+  store_niels(out + (size_t)o * kNielsWords, ext_to_niels(acc));
+}
+
+// ---- the subset sums: subgroup test and weights -----------------------------------------------------
+// lane l < windows * c.  Workgroups [0, g): flags |= kRlcTorsion unless r * S_l == O.
+// Workgroups [g, 2g): W_l = 2^pos(l) * S_l, pos = bit position inside the scalar the window belongs to.
+__global__ void __launch_bounds__(64)
+k_rlc_scale(const u32* __restrict__ S, RlcPlan p, u32* __restrict__ W, u32* __restrict__ flags) {
+  const u32 lanes = (u32)p.windows * p.c, g = (lanes + 63) / 64;
+  const bool weigh = blockIdx.x >= g;
+  const u32 l = (blockIdx.x - (weigh ? g : 0)) * 64 + threadIdx.x;
+  if (l >= lanes) return;
+  const Niels s = load_niels(S + (size_t)l * kNielsWords);
+  Ext acc = ext_from_niels(s);
+  if (weigh) {
+    const u32 w = l / p.c, bit = l % p.c;
+    const u32 pos = (w < (u32)p.wpk ? w : w - p.wpk) * p.c + bit;
+#pragma unroll 1
+    for (u32 k = 0; k < pos; k++) acc = ext_double(acc);
+    // (pos == 0: acc is ext_from_niels' output, whose t1 * t2 is outside ext_to_niels' proven range:
+    //  one doubling-free pass through the addition formulas instead)
+    if (pos == 0) acc = ext_add_niels(ext_identity(), s);
+    store_niels(W + (size_t)l * kNielsWords, ext_to_niels(acc));
+    return;
+  }
+  const Niels sn = niels_neg(s);
+#pragma unroll 1
+  for (int k = 251; k >= 0; k--) {  // digit 252 is the +1 acc starts from
+    acc = ext_double(acc);
+    const u32 pb = (kRNafPos[k >> 5] >> (k & 31)) & 1u, nb = (kRNafNeg[k >> 5] >> (k & 31)) & 1u;
+    if (pb) acc = ext_add_niels(acc, s);
+    if (nb) acc = ext_add_niels(acc, sn);
+  }
+  if (!ext_is_identity(acc)) atomicOr(&flags[0], kRlcTorsion);
+}
+
+// sum of the windows' weighted sums + (sum f_i) * G == O ?
+__global__ void __launch_bounds__(64)
+k_rlc_final(const u32* __restrict__ T, const u32* __restrict__ fsum, const u32* __restrict__ tableG, RlcPlan p,
+            u32* __restrict__ flags) {
+  if (blockIdx.x || threadIdx.x) return;
+  Ext acc = ext_identity();
+#pragma unroll 1
+  for (int w = 0; w < p.windows; w++) acc = ext_add_niels(acc, load_niels(T + (size_t)w * kNielsWords));
+  u32 f[8];
+  load_words8(f, reinterpret_cast<const uint8_t*>(fsum), 0);
+  const bool holds = fixed_base_accumulate_is_identity(acc, f, tableG);
+  if (!holds) atomicOr(&flags[0], kRlcSum);
+  flags[1] = 1;  // the chain of kernels ran to its end
+}
+
+// ---- host side ----------------------------------------------------------------------------------------
+size_t rlc_sort_temp_bytes(const RlcPlan& p) {
+  size_t bytes = 0;
+  const u32* k = nullptr;
+  u32* ko = nullptr;
+  (void)hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, k, ko, k, ko, p.entries, 0, p.key_bits, (hipStream_t) nullptr);
+  return bytes;
+}
+
+void launch_rlc(const RlcPlan& p, const RlcBuffers& b, const uint8_t* u, const uint8_t* c, const uint8_t* PK_uv,
+                const uint8_t* R_uv, const uint8_t* valid, ChaChaKey key, const uint32_t* tableG, uint8_t* ok,
+                hipStream_t s) {
+  (void)hipMemsetAsync(b.flags, 0, 16, s);
+  hipLaunchKernelGGL(k_rlc_prep, dim3(grid_for(p.n)), dim3(256), 0, s, u, c, PK_uv, R_uv, valid, key, p, ok, b.pts,
+                     b.fsc, b.keys[0], b.vals[0], b.flags);
+  hipLaunchKernelGGL(k_rlc_fsum, dim3(kRlcFsumBlocks), dim3(256), 0, s, b.fsc, (size_t)p.n, b.fpart);
+  hipLaunchKernelGGL(k_rlc_fsum, dim3(1), dim3(256), 0, s, b.fpart, (size_t)kRlcFsumBlocks, b.fsum);
+  size_t temp = b.sort_temp_bytes;
+  (void)hipcub::DeviceRadixSort::SortPairs(b.sort_temp, temp, b.keys[0], b.keys[1], b.vals[0], b.vals[1], p.entries, 0,
+                                           p.key_bits, s);
+  hipLaunchKernelGGL(k_rlc_accumulate, dim3(grid_for(p.buckets, 64)), dim3(64), 0, s, b.keys[1], b.vals[1], b.pts, p,
+                     b.buckets);
+  const unsigned side = 1u << p.half;
+  hipLaunchKernelGGL(k_rlc_sum<0>, dim3(grid_for((size_t)p.windows * 2 * side * p.nseg, 64)), dim3(64), 0, s, b.buckets, p, b.tmp[0]);
+  hipLaunchKernelGGL(k_rlc_sum<1>, dim3(grid_for((size_t)p.windows * 2 * side, 64)), dim3(64), 0, s, b.tmp[0], p, b.tmp[1]);
+  hipLaunchKernelGGL(k_rlc_sum<2>, dim3(grid_for((size_t)p.windows * 2 * p.half * p.nseg2, 64)), dim3(64), 0, s, b.tmp[1], p, b.tmp[0]);
+  hipLaunchKernelGGL(k_rlc_sum<3>, dim3(grid_for((size_t)p.windows * 2 * p.half, 64)), dim3(64), 0, s, b.tmp[0], p, b.tmp[1]);
+  const unsigned lanes = (unsigned)p.windows * p.c, g = (lanes + 63) / 64;
+  hipLaunchKernelGGL(k_rlc_scale, dim3(2 * g), dim3(64), 0, s, b.tmp[1], p, b.tmp[0], b.flags);
+  hipLaunchKernelGGL(k_rlc_sum<4>, dim3(grid_for((size_t)p.windows, 64)), dim3(64), 0, s, b.tmp[0], p, b.tmp[1]);
+  hipLaunchKernelGGL(k_rlc_final, dim3(1), dim3(64), 0, s, b.tmp[1], b.fsum, tableG, p, b.flags);
+}
+
+}  // namespace dsv

@@ -1,0 +1,72 @@
+// rlc.h — geometry and launcher of k_rlc.hip (random-linear-combination fast accept, SURVEY.md
+// §8(f)-4), shared with the host side (dsv.hip).  Kept out of launch.h: that header is part of the
+// dominant kernel's translation unit, whose sources are what the recorded roofline evidence is
+// valid for (schnorr_amd/build.py: unit_sources_sha256).
+#pragma once
+#include "launch.h"
+
+namespace dsv {
+
+// One group of n items, c-bit unsigned windows: wpk windows over the 252-bit scalars z_i c_i of the
+// keys, wr windows over the 128-bit z_i of the nonce points (separate buckets: k_rlc.hip says why).
+// A window's 2^c buckets are a 2^half x 2^half matrix; row / column sums run in nseg segments, the
+// per-bit subset sums over them in nseg2 segments, so that no serial chain exceeds ~32 additions.
+struct RlcPlan {
+  uint32_t n;
+  int c, half, wpk, wr, windows, nseg, nseg2, key_bits;
+  size_t entries;  // n * windows (key, index) pairs
+  size_t buckets;  // windows << c
+};
+constexpr size_t kRlcMaxGroup = (size_t)1 << 22;  // n * windows and 2 n must fit 32 bits with room to spare
+constexpr int kRlcFsumBlocks = 64;
+enum : uint32_t { kRlcOffCurve = 1, kRlcTorsion = 2, kRlcSum = 4 };  // flags[0]; flags[1] = 1: chain complete
+inline int rlc_default_bits(size_t n) {
+  return n >= ((size_t)1 << 19) ? 16 : n >= ((size_t)1 << 17) ? 14 : n >= ((size_t)1 << 15) ? 12 : n >= ((size_t)1 << 12) ? 10 : 8;
+}
+inline bool rlc_bits_ok(int c) { return c >= 4 && c <= 16 && (c & 1) == 0; }
+inline RlcPlan rlc_plan(size_t n, int c) {
+  RlcPlan p;
+  p.n = (uint32_t)n;
+  p.c = c;
+  p.half = c / 2;
+  p.wpk = (252 + c - 1) / c;
+  p.wr = (128 + c - 1) / c;
+  p.windows = p.wpk + p.wr;
+  const int side = 1 << p.half;
+  p.nseg = side >= 64 ? side / 32 : 1;
+  p.nseg2 = side >= 128 ? side / 64 : 1;
+  p.key_bits = c;
+  for (int w = p.windows; w; w >>= 1) p.key_bits++;
+  p.entries = n * (size_t)p.windows;
+  p.buckets = (size_t)p.windows << c;
+  return p;
+}
+struct RlcBuffers {
+  uint32_t* pts;      // 2 n x 32 words: PK_i, then -R_i, as affine niels
+  uint32_t* fsc;      // n x 8 words: z_i u_i mod r
+  uint32_t* fpart;    // kRlcFsumBlocks x 8
+  uint32_t* fsum;     // 8
+  uint32_t* keys[2];  // entries each (unsorted / sorted)
+  uint32_t* vals[2];
+  uint32_t* buckets;  // buckets x 36 words (extended niels)
+  uint32_t* tmp[2];   // rlc_tmp_points(p, k) x 36 words
+  uint32_t* flags;    // 4 words
+  void* sort_temp;
+  size_t sort_temp_bytes;
+};
+inline size_t rlc_tmp_points(const RlcPlan& p, int k) {
+  const size_t side = (size_t)1 << p.half, w = (size_t)p.windows;
+  if (k == 0) {
+    size_t a = w * 2 * side * p.nseg, b = w * 2 * p.half * p.nseg2, c = w * p.c;
+    return a > b ? (a > c ? a : c) : (b > c ? b : c);
+  }
+  const size_t a = w * 2 * side, b = w * p.c;
+  return a > b ? a : b;
+}
+size_t rlc_sort_temp_bytes(const RlcPlan& p);
+// hash output c / valid of the group in, ok[i] = "item i is well-formed" and flags out; never synchronises
+void launch_rlc(const RlcPlan& p, const RlcBuffers& b, const uint8_t* u, const uint8_t* c, const uint8_t* PK_uv,
+                const uint8_t* R_uv, const uint8_t* valid, ChaChaKey key, const uint32_t* tableG, uint8_t* ok,
+                hipStream_t s);
+
+}  // namespace dsv

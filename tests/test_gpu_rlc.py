@@ -1,0 +1,198 @@
+"""GPU tests of the random-linear-combination fast accept (include/dsv.h:
+dsv_verify_single_rlc_dev; schnorr_amd/csrc/k_rlc.hip).
+
+The contract: the verdict vector of `PublicKey::verify` (/root/reference/src/keys/public.rs:121-130)
+item by item — i.e. the ORACLE's — on every input; `accepted` says whether the aggregate decided.
+An all-valid batch of prime-order points must be accepted (if the bucket sums, the per-bit subset
+sums or the weights were wrong the aggregate would not be the identity), and a batch holding one
+wrong signature, one point with a small-order component or one point off the curve must not be.
+"""
+import numpy as np
+import pytest
+import torch
+
+import harness as H
+import oracle_lib as O
+import pymodel as M
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _run(engine, a, window_bits=0):
+    n = len(a["u"])
+    t = {k: torch.from_numpy(np.ascontiguousarray(a[k])).to(DEV) for k in ("u", "R", "PK", "m")}
+    ok = torch.full((n,), 7, dtype=torch.uint8, device=DEV)
+    ws = torch.empty(engine.rlc_workspace_bytes(n, window_bits), dtype=torch.uint8, device=DEV)
+    accepted = engine.verify_single_rlc_dev(t["u"], t["R"], t["PK"], t["m"], ok, ws, window_bits=window_bits)
+    torch.cuda.synchronize()
+    return accepted, ok.cpu().numpy()
+
+
+def _signed(n, seed):
+    d = O.keygen_sign_single(n, seed, nthreads=8)
+    return {k: d[k] for k in ("u", "R", "PK", "m")}
+
+
+@pytest.mark.parametrize("bits", [4, 8, 10, 12, 14, 16, 0])
+def test_all_valid_batch_is_accepted_by_the_aggregate(engine, bits):
+    n = 1500 if bits else 4500
+    d = _signed(n, 900 + bits)
+    accepted, ok = _run(engine, d, bits)
+    assert accepted and ok.all()
+
+
+@pytest.mark.parametrize("bits", [8, 12, 0])
+def test_one_wrong_signature_sends_the_batch_to_the_per_signature_kernels(engine, bits):
+    n = 2000
+    d = _signed(n, 910 + bits)
+    for victim, field in ((0, "u"), (n - 1, "m"), (n // 2, "PK"), (777, "R")):
+        a = {k: v.copy() for k, v in d.items()}
+        if field in ("u", "m"):
+            a[field][victim, 3] ^= 0x10
+        else:  # another point of the subgroup
+            a[field][victim] = d[field][(victim + 1) % n]
+        want = O.verify_single(a["u"], a["R"], a["PK"], a["m"], nthreads=8)
+        assert want.sum() == n - 1 and not want[victim]
+        accepted, ok = _run(engine, a, bits)
+        assert not accepted
+        assert np.array_equal(ok, want)
+
+
+def test_tampered_batch_matches_the_oracle(engine):
+    n = 6000
+    d = _signed(n, 920)
+    H.tamper(d, period=16)
+    want = O.verify_single(d["u"], d["R"], d["PK"], d["m"], nthreads=8)
+    assert 0 < want.sum() < n
+    accepted, ok = _run(engine, d)
+    assert not accepted and np.array_equal(ok, want)
+
+
+def test_malformed_items_stay_out_of_the_sum(engine):
+    """u >= r, a coordinate >= q, m >= q: verdict false by the encoding alone (the reference's types
+    cannot hold them); the other items are all valid and the aggregate accepts them."""
+    n = 1200
+    d = _signed(n, 930)
+    top = np.frombuffer(b"\xff" * 32, np.uint8)
+    d["u"][5] = top
+    d["R"][60, 32:] = top
+    d["PK"][700, :32] = top
+    d["m"][1100] = top
+    want = O.verify_single(d["u"], d["R"], d["PK"], d["m"], nthreads=8)
+    assert want.sum() == n - 4
+    accepted, ok = _run(engine, d, 8)
+    assert np.array_equal(ok, want)
+    assert accepted
+
+
+def _torsion_rows(t8, rnd, count, cancel):
+    """signatures whose key and nonce point carry order-8 components; `cancel`: c*k1 == k2 (mod 8),
+    i.e. VALID under the reference's cofactorless equation"""
+    rows = {"u": [], "R": [], "PK": [], "m": []}
+    while len(rows["u"]) < count:
+        sk, m, rr = rnd.randrange(1, M.R_ORDER), rnd.randrange(M.Q), rnd.randrange(1, M.R_ORDER)
+        k1, k2 = rnd.randrange(1, 8), rnd.randrange(8)
+        pk = M.padd(M.pmul(M.GEN, sk), M.pmul(t8, k1))
+        R = M.padd(M.pmul(M.GEN, rr), M.pmul(t8, k2))
+        c = M.challenge(R, m)
+        if ((c * k1 - k2) % 8 == 0) != cancel:
+            continue
+        rows["u"].append(np.frombuffer(M.le32((rr - c * sk) % M.R_ORDER), np.uint8))
+        rows["R"].append(np.frombuffer(M.point_bytes(R), np.uint8))
+        rows["PK"].append(np.frombuffer(M.point_bytes(pk), np.uint8))
+        rows["m"].append(np.frombuffer(M.le32(m), np.uint8))
+    return {k: np.stack(v) for k, v in rows.items()}
+
+
+def test_small_order_components_are_never_decided_by_the_aggregate(engine):
+    """The reference's equation is cofactorless: a key / nonce point with an order-8 component verifies
+    exactly when the torsion parts cancel.  Whatever they do, a batch holding such a point must fall back
+    — also when all its items are VALID (the aggregate's subgroup test is about the inputs, not the
+    verdicts), and when two order-2 defects would cancel in a plain sum of the equations."""
+    import test_halfgcd as TH
+    t8, rnd = TH.order8_point(), TH.rnd
+    n = 900
+    base = _signed(n, 940)
+    for cancel, count in ((True, 1), (False, 1), (True, 3), (False, 2)):
+        rows = _torsion_rows(t8, rnd, count, cancel)
+        a = {k: v.copy() for k, v in base.items()}
+        for j in range(count):
+            for k in rows:
+                a[k][100 + 250 * j] = rows[k][j]
+        want = O.verify_single(a["u"], a["R"], a["PK"], a["m"], nthreads=8)
+        assert want.sum() == (n if cancel else n - count)
+        accepted, ok = _run(engine, a, 8)
+        assert not accepted, (cancel, count)
+        assert np.array_equal(ok, want)
+    # two items with the SAME order-2 defect: R + T2 signed as if it were R (T2 = (0, -1), so R + T2 =
+    # (-u, -v)); z_a D + z_b D vanishes in a plain weighted sum whenever z_a + z_b is even
+    t2 = M.pmul(t8, 4)
+    assert t2 == (0, M.Q - 1)
+    a = {k: v.copy() for k, v in base.items()}
+    for i in (10, 20):
+        sk, m, rr = rnd.randrange(1, M.R_ORDER), rnd.randrange(M.Q), rnd.randrange(1, M.R_ORDER)
+        R = M.padd(M.pmul(M.GEN, rr), t2)
+        c = M.challenge(R, m)
+        a["u"][i] = np.frombuffer(M.le32((rr - c * sk) % M.R_ORDER), np.uint8)
+        a["R"][i] = np.frombuffer(M.point_bytes(R), np.uint8)
+        a["PK"][i] = np.frombuffer(M.point_bytes(M.pmul(M.GEN, sk)), np.uint8)
+        a["m"][i] = np.frombuffer(M.le32(m), np.uint8)
+    want = O.verify_single(a["u"], a["R"], a["PK"], a["m"], nthreads=8)
+    assert want.sum() == n - 2
+    for _ in range(6):  # fresh weights every call
+        accepted, ok = _run(engine, a, 8)
+        assert not accepted and np.array_equal(ok, want)
+
+
+def test_point_off_the_curve_takes_the_per_signature_path(engine):
+    n = 800
+    d = _signed(n, 950)
+    d["PK"][33, 0] ^= 1  # canonical coordinates, not on the curve (the reference's types cannot hold it)
+    t = {k: torch.from_numpy(d[k]).to(DEV) for k in ("u", "R", "PK", "m")}
+    ok0 = torch.zeros(n, dtype=torch.uint8, device=DEV)
+    ws0 = torch.empty(engine.workspace_bytes(n), dtype=torch.uint8, device=DEV)
+    engine.verify_single_dev(t["u"], t["R"], t["PK"], t["m"], ok0, ws0)
+    torch.cuda.synchronize()
+    accepted, ok = _run(engine, d, 8)
+    assert not accepted
+    assert np.array_equal(ok, ok0.cpu().numpy())
+
+
+def test_argument_checks(engine):
+    from schnorr_amd import _lib
+    d = _signed(16, 960)
+    with pytest.raises(ValueError):
+        engine.rlc_workspace_bytes(16, 7)
+    t = {k: torch.from_numpy(d[k]).to(DEV) for k in ("u", "R", "PK", "m")}
+    ok = torch.zeros(16, dtype=torch.uint8, device=DEV)
+    ws = torch.empty(engine.rlc_workspace_bytes(16), dtype=torch.uint8, device=DEV)
+    import ctypes
+    L = _lib.load()
+    rc = L.dsv_verify_single_rlc_dev(ctypes.c_void_p(t["u"].data_ptr()), ctypes.c_void_p(t["R"].data_ptr()),
+                                     ctypes.c_void_p(t["PK"].data_ptr()), ctypes.c_void_p(t["m"].data_ptr()),
+                                     ctypes.c_size_t(16), ctypes.c_void_p(ok.data_ptr()), ctypes.c_void_p(ws.data_ptr()),
+                                     None, ctypes.c_int(18), None)
+    assert rc == -2
+    accepted, got = _run(engine, d)  # tiny batch, default bits
+    assert accepted and got.all()
+    acc0 = ctypes.c_int(5)
+    rc = L.dsv_verify_single_rlc_dev(None, None, None, None, ctypes.c_size_t(0), None, None, None, ctypes.c_int(0),
+                                     ctypes.byref(acc0))
+    assert rc == 0
+
+
+def test_full_size_batches(engine):
+    """2^20 signatures (BASELINE configs[1]'s size): all valid -> accepted; the graded workload (1/16
+    tampered) -> the per-signature kernels' verdicts, equal to the construction-time pattern."""
+    from schnorr_amd import workload as W
+    n = 1 << 20
+    ws = torch.empty(engine.rlc_workspace_bytes(n), dtype=torch.uint8, device=DEV)
+    ok = torch.zeros(n, dtype=torch.uint8, device=DEV)
+    b = W.gen_single(n, seed=2321, tamper=False)
+    assert engine.verify_single_rlc_dev(b["u"], b["R"], b["PK"], b["m"], ok, ws)
+    assert bool(ok.all())
+    b = W.gen_single(n, seed=2321)
+    ok.zero_()
+    assert not engine.verify_single_rlc_dev(b["u"], b["R"], b["PK"], b["m"], ok, ws)
+    assert torch.equal(ok, b["expected"])
