@@ -269,7 +269,7 @@ int dsv_verify_vargen_dev(const void *u, const void *R_uv, const void *PK_uv, co
  * or a point off the curve), the group is verified by dsv_verify_single_dev's kernels and gets their
  * verdicts: nothing is ever decided by the aggregate except "all true".  Worth it where batches are
  * expected to be entirely valid (~2.7x less arithmetic then; a batch that fails pays both paths).
- * window_bits: 0 = chosen from n, else an even number in 4..16 (bucket windows; tests).
+ * window_bits: 0 = chosen from n, else one of 4, 6, 8, 12, 14, 16 (bucket windows; tests).
  * *accepted (may be NULL): 1 if every group took the fast path.
  * Unlike the other *_dev calls this one BLOCKS on `stream` (the decision is taken on the host).
  * workspace: dsv_rlc_workspace_bytes(n, window_bits) device bytes, 256-byte aligned. */

@@ -874,6 +874,8 @@ RlcCarve carve_rlc(void* ws, size_t n, const RlcPlan& p) {
   r.b.fpart = words((size_t)kRlcFsumBlocks * 8);
   r.b.fsum = words(8);
   for (int k = 0; k < 2; k++) r.b.keys[k] = words(p.entries), r.b.vals[k] = words(p.entries);
+  r.b.start = words(p.buckets + 1);
+  for (int k = 0; k < 2; k++) r.b.cnt[k] = words(p.buckets), r.b.order[k] = words(p.buckets);
   r.b.buckets = words(p.buckets * 36);
   for (int k = 0; k < 2; k++) r.b.tmp[k] = words(rlc_tmp_points(p, k) * 36);
   r.b.flags = words(4);
@@ -911,7 +913,7 @@ int dsv_verify_single_rlc_dev(const void* u, const void* R_uv, const void* PK_uv
   if (n && (!u || !R_uv || !PK_uv || !m || !ok || !workspace))
     return fail(DSV_ERR_INVALID_ARGUMENT, "null pointer");
   if (window_bits && !rlc_bits_ok(window_bits))
-    return fail(DSV_ERR_INVALID_ARGUMENT, "window_bits must be 0 (automatic) or an even number in 4..16");
+    return fail(DSV_ERR_INVALID_ARGUMENT, "window_bits must be 0 (automatic) or one of 4, 6, 8, 12, 14, 16");
   DSV_DEV_PROLOGUE(n, ok);
   const hipStream_t s = (hipStream_t)stream;
   const uint8_t *pu = (const uint8_t*)u, *pR = (const uint8_t*)R_uv, *pPK = (const uint8_t*)PK_uv,

@@ -29,10 +29,12 @@
 //                     curve checks, the points as affine niels (PK_i, -R_i), (bucket, index) pairs
 //   k_rlc_fsum[2]     sum f_i mod r
 //   (hipcub radix sort of the pairs by bucket)
-//   k_rlc_accumulate  one lane per bucket: binary search of its run, mixed additions
+//   k_rlc_starts      where each bucket's run of the sorted pairs begins
+//   k_rlc_counts      run lengths; (hipcub sort of the bucket numbers by run length)
+//   k_rlc_accumulate  one lane per bucket: mixed additions over its run
 //   k_rlc_sum<0..3>   row / column sums, then the per-bit subset sums S_p        (short chains)
-//   k_rlc_scale       lanes A: r * S_p == O ?      lanes B: 2^p * S_p
-//   k_rlc_sum<4>, k_rlc_final   sum of the scaled S_p, + (sum f_i) * G, identity test -> flags
+//   k_rlc_scale       lanes A: r * S_p == O ?    lanes B: 2^p * S_p    one more lane: (sum f_i) * G
+//   k_rlc_final       sum of all of lanes B's and that lane's results, identity test -> flags
 #include <hipcub/hipcub.hpp>
 
 #include "common.h"
@@ -206,11 +208,20 @@ k_rlc_prep(const uint8_t* __restrict__ u, const uint8_t* __restrict__ c, const u
   }
   ok[i] = good ? 1 : 0;
   u32 z[8] = {0, 0, 0, 0, 0, 0, 0, 0}, e[8], f[8];
+  u32 kr;
   {
     u32 blk[16];
     chacha12_block(blk, key.w, (u64)i);
+    // z_i: wr * c >= 128 random bits — every window of it is uniform; an item with verdict `false`
+    // stays out of the sum (z = 0)
+    const int zbits = p.wr * p.c;
 #pragma unroll
-    for (int k = 0; k < 4; k++) z[k] = good ? blk[k] : 0u;  // an item with verdict `false` stays out of the sum
+    for (int k = 0; k < 5; k++) {
+      const int left = zbits - 32 * k;
+      const u32 m = left >= 32 ? ~0u : (left > 0 ? (1u << left) - 1u : 0u);
+      z[k] = good ? (blk[k] & m) : 0u;
+    }
+    kr = good ? blk[8] % p.kmul : 0u;
   }
   if (!good) {
     us[7] &= 0x0fffffffu;  // keep fr_mul's inputs in range; the products are 0 anyway
@@ -218,6 +229,19 @@ k_rlc_prep(const uint8_t* __restrict__ u, const uint8_t* __restrict__ c, const u
   }
   fr_mul(e, z, cs);
   fr_mul(f, z, us);
+  {
+    // e' = e + k r, k uniform below floor(2^(wpk c) / r): the same multiple of a point of the prime-order
+    // subgroup (any other point fails the subgroup test anyway), but uniform over ALL wpk * c bits —
+    // without it the top window of a 252-bit scalar has a few thousand (c = 16: 2^12) digits only, and
+    // its buckets get runs 16 times as long as the others: a lane per bucket would wait for those
+    u64 carry = 0;
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+      const u64 t = (u64)kR32[k] * kr + e[k] + carry;
+      e[k] = (u32)t;
+      carry = t >> 32;
+    }
+  }
   store_words8(reinterpret_cast<uint8_t*>(fsc), i, f);
   const u32 mask = (1u << p.c) - 1u, none = (u32)p.windows << p.c;
 #pragma unroll 1
@@ -233,8 +257,8 @@ k_rlc_prep(const uint8_t* __restrict__ u, const uint8_t* __restrict__ c, const u
   for (int w = 0; w < p.wr; w++) {
     const u32 d = z[0] & mask;
 #pragma unroll
-    for (int k = 0; k < 3; k++) z[k] = __funnelshift_r(z[k], z[k + 1], p.c);
-    z[3] >>= p.c;
+    for (int k = 0; k < 4; k++) z[k] = __funnelshift_r(z[k], z[k + 1], p.c);
+    z[4] >>= p.c;
     keys[(size_t)(p.wpk + w) * p.n + i] = d ? (((u32)(p.wpk + w) << p.c) | d) : none;
     vals[(size_t)(p.wpk + w) * p.n + i] = (u32)(p.n + i);
   }
@@ -274,33 +298,56 @@ __global__ void __launch_bounds__(256) k_rlc_fsum(const u32* __restrict__ in, si
 }
 
 // ---- buckets ----------------------------------------------------------------------------------
-DSV_DEV size_t lower_bound_u32(const u32* __restrict__ a, size_t n, u32 key) {
-  size_t lo = 0, hi = n;
-  while (lo < hi) {
-    const size_t mid = lo + ((hi - lo) >> 1);
-    if (a[mid] < key) lo = mid + 1;
-    else hi = mid;
-  }
-  return lo;
+// start[b] = first sorted entry with key >= b, for b = 0 .. buckets (entries with digit 0 carry the key
+// `buckets` and sort behind everything): every entry fills in the keys between its predecessor's and
+// its own, so empty buckets get their (empty) range too
+__global__ void __launch_bounds__(256)
+k_rlc_starts(const u32* __restrict__ keys, RlcPlan p, u32* __restrict__ start) {
+  const size_t j = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (j > p.entries) return;
+  const u32 last = (u32)p.buckets;
+  u32 lo = j ? keys[j - 1] + 1u : 0u, hi = j < p.entries ? keys[j] : last;
+  if (hi > last) hi = last;  // (cannot happen)
+  for (u32 k = lo; k <= hi && j < p.entries; k++) start[k] = (u32)j;
+  if (j == p.entries)
+    for (u32 k = lo; k <= last; k++) start[k] = (u32)j;
 }
-__global__ void __launch_bounds__(64)
-k_rlc_accumulate(const u32* __restrict__ keys, const u32* __restrict__ vals, const u32* __restrict__ pts,
-                 RlcPlan p, u32* __restrict__ buckets) {
-  const size_t b = (size_t)blockIdx.x * 64 + threadIdx.x;
+// run lengths (clipped to 8 bits) and the identity permutation: sorted by length, longest first, they
+// give every wave of the accumulation 64 runs of (nearly) the same length — with buckets in their
+// natural order a wave waits for its longest run (Poisson, mean 16: the maximum of 64 is ~26)
+__global__ void __launch_bounds__(256)
+k_rlc_counts(const u32* __restrict__ start, RlcPlan p, u32* __restrict__ cnt, u32* __restrict__ ids) {
+  const size_t b = (size_t)blockIdx.x * 256 + threadIdx.x;
   if (b >= p.buckets) return;
-  size_t lo = 0, hi = 0;
-  if (b & ((1u << p.c) - 1u)) {  // digit 0 enters no sum
-    lo = lower_bound_u32(keys, p.entries, (u32)b);
-    hi = lower_bound_u32(keys, p.entries, (u32)b + 1u);
-  }
+  u32 len = (b & ((1u << p.c) - 1u)) ? start[b + 1] - start[b] : 0u;  // digit 0 enters no sum
+  cnt[b] = len < 255u ? len : 255u;
+  ids[b] = (u32)b;
+}
+// one lane per bucket (in the order of `order`): its run of the sorted pairs, one mixed addition per
+// entry; the next entry's point is loaded while the current one is added
+__global__ void __launch_bounds__(64)
+k_rlc_accumulate(const u32* __restrict__ order, const u32* __restrict__ start, const u32* __restrict__ vals,
+                 const u32* __restrict__ pts, RlcPlan p, u32* __restrict__ buckets) {
+  const size_t t = (size_t)blockIdx.x * 64 + threadIdx.x;
+  if (t >= p.buckets) return;
+  const u32 b = order[t];
+  if (b >= p.buckets) return;  // (cannot happen: the sort moves what k_rlc_counts wrote)
+  u32 lo = 0, hi = 0;
+  if (b & ((1u << p.c) - 1u)) lo = start[b], hi = start[b + 1];
+  const u32 last_pt = 2u * p.n - 1u;
   Ext acc = ext_identity();
+  if (lo < hi) {
+    u32 id = vals[lo];
+    ANiels cur = load_pt(pts + (size_t)(id < last_pt ? id : last_pt) * kPtWords);
 #pragma unroll 1
-  for (size_t j = lo; j < hi; j++) {
-    const u32 id = vals[j];
-    if (id >= 2u * p.n) continue;  // (cannot happen: the sort moves what prep wrote)
-    acc = ext_add_aniels(acc, load_pt(pts + (size_t)id * kPtWords));
+    for (u32 j = lo; j < hi; j++) {
+      id = vals[j + 1 < hi ? j + 1 : j];
+      const ANiels nxt = load_pt(pts + (size_t)(id < last_pt ? id : last_pt) * kPtWords);
+      acc = ext_add_aniels(acc, cur);
+      cur = nxt;
+    }
   }
-  store_niels(buckets + b * kNielsWords, ext_to_niels(acc));
+  store_niels(buckets + (size_t)b * kNielsWords, ext_to_niels(acc));
 }
 
 // ---- short sums of stored points: out[o] = sum_k in[addr(o, k)] ------------------------------------
@@ -308,7 +355,6 @@ k_rlc_accumulate(const u32* __restrict__ keys, const u32* __restrict__ vals, con
 //   MODE 1  segments -> row / column sums ("lines")
 //   MODE 2  lines -> segments of: sum of the lines whose index has bit j set
 //   MODE 3  segments -> S[w * c + kind * half + j], the subset sum of bit (kind * half + j) of window w
-//   MODE 4  scaled S -> one sum per window
 template <int MODE>
 __global__ void __launch_bounds__(64)
 k_rlc_sum(const u32* __restrict__ in, RlcPlan p, u32* __restrict__ out) {
@@ -318,8 +364,7 @@ k_rlc_sum(const u32* __restrict__ in, RlcPlan p, u32* __restrict__ out) {
   if (MODE == 0) total = (u32)p.windows * 2 * side * p.nseg, count = side / p.nseg;
   else if (MODE == 1) total = (u32)p.windows * 2 * side, count = p.nseg;
   else if (MODE == 2) total = (u32)p.windows * 2 * p.half * p.nseg2, count = side / 2 / p.nseg2;
-  else if (MODE == 3) total = (u32)p.windows * 2 * p.half, count = p.nseg2;
-  else total = (u32)p.windows, count = p.c;
+  else total = (u32)p.windows * 2 * p.half, count = p.nseg2;
   if (o >= total) return;
   u32 base = 0, step = 1, j = 0, first = 0;
   if (MODE == 0) {
@@ -327,7 +372,7 @@ k_rlc_sum(const u32* __restrict__ in, RlcPlan p, u32* __restrict__ out) {
     const u32 e0 = seg * count;
     if (kind) base = (w << p.c) | (idx << p.half) | e0, step = 1;           // row idx: the low half runs
     else base = (w << p.c) | (e0 << p.half) | idx, step = side;              // column idx: the high half runs
-  } else if (MODE == 1 || MODE == 3 || MODE == 4) {
+  } else if (MODE == 1 || MODE == 3) {
     base = o * count;
   } else {
     const u32 s = o % p.nseg2, t = o / p.nseg2;
@@ -335,17 +380,20 @@ k_rlc_sum(const u32* __restrict__ in, RlcPlan p, u32* __restrict__ out) {
     base = (t / p.half) * side;  // (w * 2 + kind) * side
     first = s * count;
   }
-  Ext acc = ext_identity();
-#pragma unroll 1
-  for (u32 k = 0; k < count; k++) {
-    u32 a;
+  auto addr = [&](u32 k) -> size_t {
     if (MODE == 2) {
       const u32 m = first + k;  // the m-th index with bit j set
-      a = base + ((((m >> j) << 1) | 1u) << j | (m & ((1u << j) - 1u)));
-    } else {
-      a = base + k * step;
+      return (size_t)(base + ((((m >> j) << 1) | 1u) << j | (m & ((1u << j) - 1u)))) * kNielsWords;
     }
-    acc = ext_add_niels(acc, load_niels(in + (size_t)a * kNielsWords));
+    return (size_t)(base + k * step) * kNielsWords;
+  };
+  Ext acc = ext_identity();
+  Niels cur = load_niels(in + addr(0));
+#pragma unroll 1
+  for (u32 k = 0; k < count; k++) {
+    const Niels nxt = load_niels(in + addr(k + 1 < count ? k + 1 : k));
+    acc = ext_add_niels(acc, cur);
+    cur = nxt;
   }
   // (MODE 3: o = (w * 2 + kind) * half + j is w * c + kind * half + j, the bit's place in window w)
   store_niels(out + (size_t)o * kNielsWords, ext_to_niels(acc));
@@ -354,9 +402,19 @@ k_rlc_sum(const u32* __restrict__ in, RlcPlan p, u32* __restrict__ out) {
 // ---- the subset sums: subgroup test and weights -----------------------------------------------------
 // lane l < windows * c.  Workgroups [0, g): flags |= kRlcTorsion unless r * S_l == O.
 // Workgroups [g, 2g): W_l = 2^pos(l) * S_l, pos = bit position inside the scalar the window belongs to.
+// Workgroup 2g: W_lanes = (sum f_i) * G from the fixed-base table.
 __global__ void __launch_bounds__(64)
-k_rlc_scale(const u32* __restrict__ S, RlcPlan p, u32* __restrict__ W, u32* __restrict__ flags) {
+k_rlc_scale(const u32* __restrict__ S, const u32* __restrict__ fsum, const u32* __restrict__ tableG, RlcPlan p,
+            u32* __restrict__ W, u32* __restrict__ flags) {
   const u32 lanes = (u32)p.windows * p.c, g = (lanes + 63) / 64;
+  if (blockIdx.x == 2 * g) {
+    if (threadIdx.x) return;
+    u32 f[8];
+    load_words8(f, reinterpret_cast<const uint8_t*>(fsum), 0);
+    const Ext fg = fixed_base_accumulate(ext_identity(), f, tableG);
+    store_niels(W + (size_t)lanes * kNielsWords, ext_to_niels(fg));
+    return;
+  }
   const bool weigh = blockIdx.x >= g;
   const u32 l = (blockIdx.x - (weigh ? g : 0)) * 64 + threadIdx.x;
   if (l >= lanes) return;
@@ -384,19 +442,26 @@ k_rlc_scale(const u32* __restrict__ S, RlcPlan p, u32* __restrict__ W, u32* __re
   if (!ext_is_identity(acc)) atomicOr(&flags[0], kRlcTorsion);
 }
 
-// sum of the windows' weighted sums + (sum f_i) * G == O ?
+// sum of the windows * c weighted subset sums and of (sum f_i) * G == O ?  One wave: a strided pass,
+// then a tree through LDS.
 __global__ void __launch_bounds__(64)
-k_rlc_final(const u32* __restrict__ T, const u32* __restrict__ fsum, const u32* __restrict__ tableG, RlcPlan p,
-            u32* __restrict__ flags) {
-  if (blockIdx.x || threadIdx.x) return;
+k_rlc_final(const u32* __restrict__ W, RlcPlan p, u32* __restrict__ flags) {
+  __shared__ __attribute__((aligned(16))) u32 sh[64 * kNielsWords];
+  const u32 count = (u32)p.windows * p.c + 1u, t = threadIdx.x;
   Ext acc = ext_identity();
 #pragma unroll 1
-  for (int w = 0; w < p.windows; w++) acc = ext_add_niels(acc, load_niels(T + (size_t)w * kNielsWords));
-  u32 f[8];
-  load_words8(f, reinterpret_cast<const uint8_t*>(fsum), 0);
-  const bool holds = fixed_base_accumulate_is_identity(acc, f, tableG);
-  if (!holds) atomicOr(&flags[0], kRlcSum);
-  flags[1] = 1;  // the chain of kernels ran to its end
+  for (u32 k = t; k < count; k += 64) acc = ext_add_niels(acc, load_niels(W + (size_t)k * kNielsWords));
+#pragma unroll 1
+  for (u32 step = 32; step > 0; step >>= 1) {
+    if (t >= step && t < 2 * step) store_niels(sh + t * kNielsWords, ext_to_niels(acc));
+    __syncthreads();
+    if (t < step) acc = ext_add_niels(acc, load_niels(sh + (t + step) * kNielsWords));
+    __syncthreads();
+  }
+  if (t == 0) {
+    if (!ext_is_identity(acc)) atomicOr(&flags[0], kRlcSum);
+    flags[1] = 1;  // the chain of kernels ran to its end
+  }
 }
 
 // ---- host side ----------------------------------------------------------------------------------------
@@ -405,7 +470,9 @@ size_t rlc_sort_temp_bytes(const RlcPlan& p) {
   const u32* k = nullptr;
   u32* ko = nullptr;
   (void)hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, k, ko, k, ko, p.entries, 0, p.key_bits, (hipStream_t) nullptr);
-  return bytes;
+  size_t bytes2 = 0;
+  (void)hipcub::DeviceRadixSort::SortPairsDescending(nullptr, bytes2, k, ko, k, ko, p.buckets, 0, 8, (hipStream_t) nullptr);
+  return bytes > bytes2 ? bytes : bytes2;
 }
 
 void launch_rlc(const RlcPlan& p, const RlcBuffers& b, const uint8_t* u, const uint8_t* c, const uint8_t* PK_uv,
@@ -419,17 +486,21 @@ void launch_rlc(const RlcPlan& p, const RlcBuffers& b, const uint8_t* u, const u
   size_t temp = b.sort_temp_bytes;
   (void)hipcub::DeviceRadixSort::SortPairs(b.sort_temp, temp, b.keys[0], b.keys[1], b.vals[0], b.vals[1], p.entries, 0,
                                            p.key_bits, s);
-  hipLaunchKernelGGL(k_rlc_accumulate, dim3(grid_for(p.buckets, 64)), dim3(64), 0, s, b.keys[1], b.vals[1], b.pts, p,
-                     b.buckets);
+  hipLaunchKernelGGL(k_rlc_starts, dim3(grid_for(p.entries + 1)), dim3(256), 0, s, b.keys[1], p, b.start);
+  hipLaunchKernelGGL(k_rlc_counts, dim3(grid_for(p.buckets)), dim3(256), 0, s, b.start, p, b.cnt[0], b.order[0]);
+  temp = b.sort_temp_bytes;
+  (void)hipcub::DeviceRadixSort::SortPairsDescending(b.sort_temp, temp, b.cnt[0], b.cnt[1], b.order[0], b.order[1],
+                                                     p.buckets, 0, 8, s);
+  hipLaunchKernelGGL(k_rlc_accumulate, dim3(grid_for(p.buckets, 64)), dim3(64), 0, s, b.order[1], b.start, b.vals[1],
+                     b.pts, p, b.buckets);
   const unsigned side = 1u << p.half;
   hipLaunchKernelGGL(k_rlc_sum<0>, dim3(grid_for((size_t)p.windows * 2 * side * p.nseg, 64)), dim3(64), 0, s, b.buckets, p, b.tmp[0]);
   hipLaunchKernelGGL(k_rlc_sum<1>, dim3(grid_for((size_t)p.windows * 2 * side, 64)), dim3(64), 0, s, b.tmp[0], p, b.tmp[1]);
   hipLaunchKernelGGL(k_rlc_sum<2>, dim3(grid_for((size_t)p.windows * 2 * p.half * p.nseg2, 64)), dim3(64), 0, s, b.tmp[1], p, b.tmp[0]);
   hipLaunchKernelGGL(k_rlc_sum<3>, dim3(grid_for((size_t)p.windows * 2 * p.half, 64)), dim3(64), 0, s, b.tmp[0], p, b.tmp[1]);
   const unsigned lanes = (unsigned)p.windows * p.c, g = (lanes + 63) / 64;
-  hipLaunchKernelGGL(k_rlc_scale, dim3(2 * g), dim3(64), 0, s, b.tmp[1], p, b.tmp[0], b.flags);
-  hipLaunchKernelGGL(k_rlc_sum<4>, dim3(grid_for((size_t)p.windows, 64)), dim3(64), 0, s, b.tmp[0], p, b.tmp[1]);
-  hipLaunchKernelGGL(k_rlc_final, dim3(1), dim3(64), 0, s, b.tmp[1], b.fsum, tableG, p, b.flags);
+  hipLaunchKernelGGL(k_rlc_scale, dim3(2 * g + 1), dim3(64), 0, s, b.tmp[1], b.fsum, tableG, p, b.tmp[0], b.flags);
+  hipLaunchKernelGGL(k_rlc_final, dim3(1), dim3(64), 0, s, b.tmp[0], p, b.flags);
 }
 
 }  // namespace dsv

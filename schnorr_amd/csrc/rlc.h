@@ -14,6 +14,7 @@ namespace dsv {
 struct RlcPlan {
   uint32_t n;
   int c, half, wpk, wr, windows, nseg, nseg2, key_bits;
+  uint32_t kmul;   // floor(2^(wpk c) / r): the keys' scalars get a random multiple of r below it added
   size_t entries;  // n * windows (key, index) pairs
   size_t buckets;  // windows << c
 };
@@ -21,9 +22,10 @@ constexpr size_t kRlcMaxGroup = (size_t)1 << 22;  // n * windows and 2 n must fi
 constexpr int kRlcFsumBlocks = 64;
 enum : uint32_t { kRlcOffCurve = 1, kRlcTorsion = 2, kRlcSum = 4 };  // flags[0]; flags[1] = 1: chain complete
 inline int rlc_default_bits(size_t n) {
-  return n >= ((size_t)1 << 19) ? 16 : n >= ((size_t)1 << 17) ? 14 : n >= ((size_t)1 << 15) ? 12 : n >= ((size_t)1 << 12) ? 10 : 8;
+  return n >= ((size_t)1 << 19) ? 16 : n >= ((size_t)1 << 17) ? 14 : n >= ((size_t)1 << 14) ? 12 : 8;
 }
-inline bool rlc_bits_ok(int c) { return c >= 4 && c <= 16 && (c & 1) == 0; }
+// even, and the keys' windows cover 252 or 256 bits exactly (10 would need 260: a ninth scalar word)
+inline bool rlc_bits_ok(int c) { return c == 4 || c == 6 || c == 8 || c == 12 || c == 14 || c == 16; }
 inline RlcPlan rlc_plan(size_t n, int c) {
   RlcPlan p;
   p.n = (uint32_t)n;
@@ -33,8 +35,9 @@ inline RlcPlan rlc_plan(size_t n, int c) {
   p.wr = (128 + c - 1) / c;
   p.windows = p.wpk + p.wr;
   const int side = 1 << p.half;
-  p.nseg = side >= 64 ? side / 32 : 1;
-  p.nseg2 = side >= 128 ? side / 64 : 1;
+  p.nseg = side >= 32 ? side / 16 : 1;
+  p.nseg2 = side >= 64 ? side / 32 : 1;
+  p.kmul = p.wpk * c == 256 ? 17u : 1u;  // floor(2^256 / r) = 17, floor(2^252 / r) = 1
   p.key_bits = c;
   for (int w = p.windows; w; w >>= 1) p.key_bits++;
   p.entries = n * (size_t)p.windows;
@@ -48,6 +51,9 @@ struct RlcBuffers {
   uint32_t* fsum;     // 8
   uint32_t* keys[2];  // entries each (unsorted / sorted)
   uint32_t* vals[2];
+  uint32_t* start;    // buckets + 1: first sorted pair of every bucket
+  uint32_t* cnt[2];   // buckets each: run lengths (unsorted / sorted, longest first)
+  uint32_t* order[2]; // buckets each: bucket numbers (identity / in the order of the sorted lengths)
   uint32_t* buckets;  // buckets x 36 words (extended niels)
   uint32_t* tmp[2];   // rlc_tmp_points(p, k) x 36 words
   uint32_t* flags;    // 4 words
@@ -57,7 +63,7 @@ struct RlcBuffers {
 inline size_t rlc_tmp_points(const RlcPlan& p, int k) {
   const size_t side = (size_t)1 << p.half, w = (size_t)p.windows;
   if (k == 0) {
-    size_t a = w * 2 * side * p.nseg, b = w * 2 * p.half * p.nseg2, c = w * p.c;
+    size_t a = w * 2 * side * p.nseg, b = w * 2 * p.half * p.nseg2, c = w * p.c + 1;
     return a > b ? (a > c ? a : c) : (b > c ? b : c);
   }
   const size_t a = w * 2 * side, b = w * p.c;

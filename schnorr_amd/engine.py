@@ -521,7 +521,7 @@ def verify_single_dev(u, R, PK, m, ok, workspace, stream=None):
 def rlc_workspace_bytes(n, window_bits=0):
     b = int(_lib.load().dsv_rlc_workspace_bytes(ctypes.c_size_t(n), ctypes.c_int(window_bits)))
     if b == 0:
-        raise ValueError("window_bits must be 0 or an even number in 4..16")
+        raise ValueError("window_bits must be 0 or one of 4, 6, 8, 12, 14, 16")
     return b
 
 
