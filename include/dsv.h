@@ -277,6 +277,16 @@ size_t dsv_rlc_workspace_bytes(size_t n, int window_bits);
 int dsv_verify_single_rlc_dev(const void *u, const void *R_uv, const void *PK_uv, const void *m,
                               size_t n, void *ok, void *workspace, void *stream, int window_bits,
                               int *accepted);
+/* the same in front of dsv_verify_double_dev (`PublicKeyDouble::verify`, src/keys/public.rs:222-244:
+ * both equations of an item enter the sum, each with a weight of its own) and of
+ * dsv_verify_vargen_dev (`PublicKeyVarGen::verify`, :401-415: the generator is a third variable
+ * point, its scalar z_i u_i) */
+int dsv_verify_double_rlc_dev(const void *u, const void *R_uv, const void *Rp_uv, const void *PK_uv,
+                              const void *PKp_uv, const void *m, size_t n, void *ok, void *workspace,
+                              void *stream, int window_bits, int *accepted);
+int dsv_verify_vargen_rlc_dev(const void *u, const void *R_uv, const void *PK_uv, const void *Gen_uv,
+                              const void *m, size_t n, void *ok, void *workspace, void *stream,
+                              int window_bits, int *accepted);
 
 /* second stage alone: ok[i] = (accumulate ? ok[i] : valid[i]) & [u*Gen + c*PK == R], Gen = G
  * (which = 0) or G' (which = 1); c and valid as produced by dsv_challenge_*_dev */

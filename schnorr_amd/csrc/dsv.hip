@@ -869,10 +869,10 @@ RlcCarve carve_rlc(void* ws, size_t n, const RlcPlan& p) {
   r.w = carve(ws, n);
   Stager st(static_cast<uint8_t*>(ws) + align_up(dsv_workspace_bytes(n), 256));
   auto words = [&](size_t count) { return reinterpret_cast<u32*>(st.take(count * 4)); };
-  r.b.pts = words(2 * n * 32);
-  r.b.fsc = words(n * 8);
+  r.b.pts = words((size_t)(p.lpts + p.spts) * n * 32);
+  r.b.fsc = words((size_t)(p.fixed ? p.fixed : 1) * n * 8);
   r.b.fpart = words((size_t)kRlcFsumBlocks * 8);
-  r.b.fsum = words(8);
+  r.b.fsum = words(16);
   for (int k = 0; k < 2; k++) r.b.keys[k] = words(p.entries), r.b.vals[k] = words(p.entries);
   r.b.start = words(p.buckets + 1);
   for (int k = 0; k < 2; k++) r.b.cnt[k] = words(p.buckets), r.b.order[k] = words(p.buckets);
@@ -898,6 +898,50 @@ int rlc_random_key(ChaChaKey& key) {
   }
   return DSV_OK;
 }
+// scheme 0 single (R, PK), 1 double (R, R', PK, PK'), 2 var-generator (R, PK, Gen): unused pointers null
+int verify_rlc_on(Context& ctx, int scheme, const void* u, const void* R_uv, const void* Rp_uv, const void* PK_uv,
+                  const void* PKp_uv, const void* Gen_uv, const void* m, size_t n, void* ok, void* workspace,
+                  hipStream_t s, int window_bits, int* accepted) {
+  const uint8_t *pu = (const uint8_t*)u, *pR = (const uint8_t*)R_uv, *pRp = (const uint8_t*)Rp_uv,
+                *pPK = (const uint8_t*)PK_uv, *pPKp = (const uint8_t*)PKp_uv, *pG = (const uint8_t*)Gen_uv,
+                *pm = (const uint8_t*)m;
+  uint8_t* pok = (uint8_t*)ok;
+  const size_t group = rlc_group_items(n);
+  bool all = true;
+  for (size_t off = 0; off < n; off += group) {
+    const size_t cnt = n - off < group ? n - off : group;
+    const RlcPlan plan = rlc_plan(scheme, cnt, window_bits ? window_bits : rlc_default_bits(cnt));
+    const RlcCarve cv = carve_rlc(workspace, cnt, plan);
+    ChaChaKey key;
+    if (int r = rlc_random_key(key)) return r;
+    launch_challenge(scheme == 1, pR + 64 * off, scheme == 1 ? pRp + 64 * off : (const uint8_t*)nullptr, pm + 32 * off,
+                     cnt, cv.w.c, cv.w.valid, s);
+    RlcInputs in = {};
+    in.u = pu + 32 * off, in.c = cv.w.c, in.valid = cv.w.valid;
+    in.pk[0] = pPK + 64 * off, in.r[0] = pR + 64 * off;
+    if (scheme == 1) in.pk[1] = pPKp + 64 * off, in.r[1] = pRp + 64 * off;
+    if (scheme == 2) in.gen = pG + 64 * off;
+    launch_rlc(scheme, plan, cv.b, in, key, ctx.table[0], ctx.table[1], pok + off, s);
+    HIP_TRY(hipGetLastError());
+    u32 flags[4] = {~0u, 0, 0, 0};
+    HIP_TRY(hipMemcpyAsync(flags, cv.b.flags, sizeof flags, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    if (flags[0] == 0 && flags[1] == 1) continue;  // ok[] = "well-formed" is the verdict vector
+    all = false;
+    int r;
+    if (scheme == 0)
+      r = verify_single_on(ctx, pu + 32 * off, pR + 64 * off, pPK + 64 * off, pm + 32 * off, cnt, pok + off, workspace, s);
+    else if (scheme == 1)
+      r = verify_double_on(ctx, pu + 32 * off, pR + 64 * off, pRp + 64 * off, pPK + 64 * off, pPKp + 64 * off,
+                           pm + 32 * off, cnt, pok + off, workspace, s);
+    else
+      r = verify_vargen_on(ctx, pu + 32 * off, pR + 64 * off, pPK + 64 * off, pG + 64 * off, pm + 32 * off, cnt,
+                           pok + off, workspace, s);
+    if (r) return r;
+  }
+  if (accepted) *accepted = all ? 1 : 0;
+  return DSV_OK;
+}
 }  // namespace
 }  // extern "C++"
 size_t dsv_rlc_workspace_bytes(size_t n, int window_bits) {
@@ -905,43 +949,33 @@ size_t dsv_rlc_workspace_bytes(size_t n, int window_bits) {
   if (g == 0) return 256;
   const int c = window_bits ? window_bits : rlc_default_bits(g);
   if (!rlc_bits_ok(c)) return 0;
-  return carve_rlc(reinterpret_cast<void*>((uintptr_t)4096), g, rlc_plan(g, c)).bytes + 256;
+  // the double scheme's needs: four points per item, two fixed-base terms (the others fit inside)
+  return carve_rlc(reinterpret_cast<void*>((uintptr_t)4096), g, rlc_plan(1, g, c)).bytes + 256;
 }
+#define DSV_RLC_PROLOGUE(nullcheck)                                                              \
+  if (accepted) *accepted = 0;                                                                   \
+  if (n && (nullcheck)) return fail(DSV_ERR_INVALID_ARGUMENT, "null pointer");                   \
+  if (window_bits && !rlc_bits_ok(window_bits))                                                  \
+    return fail(DSV_ERR_INVALID_ARGUMENT, "window_bits must be 0 (automatic) or one of 4, 6, 8, 12, 14, 16"); \
+  DSV_DEV_PROLOGUE(n, ok)
 int dsv_verify_single_rlc_dev(const void* u, const void* R_uv, const void* PK_uv, const void* m, size_t n,
                               void* ok, void* workspace, void* stream, int window_bits, int* accepted) {
-  if (accepted) *accepted = 0;
-  if (n && (!u || !R_uv || !PK_uv || !m || !ok || !workspace))
-    return fail(DSV_ERR_INVALID_ARGUMENT, "null pointer");
-  if (window_bits && !rlc_bits_ok(window_bits))
-    return fail(DSV_ERR_INVALID_ARGUMENT, "window_bits must be 0 (automatic) or one of 4, 6, 8, 12, 14, 16");
-  DSV_DEV_PROLOGUE(n, ok);
-  const hipStream_t s = (hipStream_t)stream;
-  const uint8_t *pu = (const uint8_t*)u, *pR = (const uint8_t*)R_uv, *pPK = (const uint8_t*)PK_uv,
-                *pm = (const uint8_t*)m;
-  uint8_t* pok = (uint8_t*)ok;
-  const size_t group = rlc_group_items(n);
-  bool all = true;
-  for (size_t off = 0; off < n; off += group) {
-    const size_t cnt = n - off < group ? n - off : group;
-    const RlcPlan plan = rlc_plan(cnt, window_bits ? window_bits : rlc_default_bits(cnt));
-    const RlcCarve cv = carve_rlc(workspace, cnt, plan);
-    ChaChaKey key;
-    if (int r = rlc_random_key(key)) return r;
-    launch_challenge(false, pR + 64 * off, (const uint8_t*)nullptr, pm + 32 * off, cnt, cv.w.c, cv.w.valid, s);
-    launch_rlc(plan, cv.b, pu + 32 * off, cv.w.c, pPK + 64 * off, pR + 64 * off, cv.w.valid, key, ctx.table[0],
-               pok + off, s);
-    HIP_TRY(hipGetLastError());
-    u32 flags[4] = {~0u, 0, 0, 0};
-    HIP_TRY(hipMemcpyAsync(flags, cv.b.flags, sizeof flags, hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipStreamSynchronize(s));
-    if (flags[0] == 0 && flags[1] == 1) continue;  // ok[] = "well-formed" is the verdict vector
-    all = false;
-    if (int r = verify_single_on(ctx, pu + 32 * off, pR + 64 * off, pPK + 64 * off, pm + 32 * off, cnt, pok + off,
-                                 workspace, s))
-      return r;
-  }
-  if (accepted) *accepted = all ? 1 : 0;
-  return DSV_OK;
+  DSV_RLC_PROLOGUE(!u || !R_uv || !PK_uv || !m || !ok || !workspace);
+  return verify_rlc_on(ctx, 0, u, R_uv, nullptr, PK_uv, nullptr, nullptr, m, n, ok, workspace, (hipStream_t)stream,
+                       window_bits, accepted);
+}
+int dsv_verify_double_rlc_dev(const void* u, const void* R_uv, const void* Rp_uv, const void* PK_uv,
+                              const void* PKp_uv, const void* m, size_t n, void* ok, void* workspace, void* stream,
+                              int window_bits, int* accepted) {
+  DSV_RLC_PROLOGUE(!u || !R_uv || !Rp_uv || !PK_uv || !PKp_uv || !m || !ok || !workspace);
+  return verify_rlc_on(ctx, 1, u, R_uv, Rp_uv, PK_uv, PKp_uv, nullptr, m, n, ok, workspace, (hipStream_t)stream,
+                       window_bits, accepted);
+}
+int dsv_verify_vargen_rlc_dev(const void* u, const void* R_uv, const void* PK_uv, const void* Gen_uv, const void* m,
+                              size_t n, void* ok, void* workspace, void* stream, int window_bits, int* accepted) {
+  DSV_RLC_PROLOGUE(!u || !R_uv || !PK_uv || !Gen_uv || !m || !ok || !workspace);
+  return verify_rlc_on(ctx, 2, u, R_uv, nullptr, PK_uv, nullptr, Gen_uv, m, n, ok, workspace, (hipStream_t)stream,
+                       window_bits, accepted);
 }
 
 // second stage alone (c and valid already computed): lets callers time / profile the dominant

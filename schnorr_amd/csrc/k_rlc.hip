@@ -183,66 +183,42 @@ DSV_DEV ANiels affine_niels(const Fe& u, const Fe& v, bool negate) {
 }  // namespace
 
 // ---- per item ---------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256)
-k_rlc_prep(const uint8_t* __restrict__ u, const uint8_t* __restrict__ c, const uint8_t* __restrict__ PK_uv,
-           const uint8_t* __restrict__ R_uv, const uint8_t* __restrict__ valid, ChaChaKey key, RlcPlan p,
-           uint8_t* __restrict__ ok, u32* __restrict__ pts, u32* __restrict__ fsc, u32* __restrict__ keys,
-           u32* __restrict__ vals, u32* __restrict__ flags) {
-  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-  if (i >= p.n) return;
-  bool good = valid[i] != 0;
-  u32 us[8], cs[8];
-  load_words8(us, u, i);
-  load_words8(cs, c, i);
-  good &= words_lt(us, kR32);
-  {
-    Fe pu, pv, ru, rv;
-    good &= load_fq(pu, PK_uv, 2 * i);
-    good &= load_fq(pv, PK_uv, 2 * i + 1);
-    good &= load_fq(ru, R_uv, 2 * i);
-    good &= load_fq(rv, R_uv, 2 * i + 1);
-    // a point off the curve has no place in a group sum: the per-signature kernels decide the batch
-    if (good && !((int)on_curve(pu, pv) & (int)on_curve(ru, rv))) atomicOr(&flags[0], kRlcOffCurve);
-    store_pt(pts + i * kPtWords, affine_niels(pu, pv, false));
-    store_pt(pts + ((size_t)p.n + i) * kPtWords, affine_niels(ru, rv, true));
-  }
-  ok[i] = good ? 1 : 0;
-  u32 z[8] = {0, 0, 0, 0, 0, 0, 0, 0}, e[8], f[8];
-  u32 kr;
-  {
-    u32 blk[16];
-    chacha12_block(blk, key.w, (u64)i);
-    // z_i: wr * c >= 128 random bits — every window of it is uniform; an item with verdict `false`
-    // stays out of the sum (z = 0)
-    const int zbits = p.wr * p.c;
+// What an item contributes (SCHEME 0 single, 1 double, 2 var-generator; p.lpts "long" points with
+// 252-bit scalars, p.spts "short" ones with the z themselves, p.fixed fixed-base terms):
+//   single  u G  + c PK      - R        : long { PK: z c },            short { -R: z },          fixed { G: z u }
+//   double  ... and u G' + c PK' - R'   : long { PK: z c, PK': z' c }, short { -R: z, -R': z' }, fixed { G: z u, G': z' u }
+//   vargen  u Gen + c PK - R            : long { PK: z c, Gen: z u },  short { -R: z },          fixed { }
+// (/root/reference/src/keys/public.rs:121-130, :222-244, :401-415), z and z' independent.
+namespace {
+struct PrepOut {
+  size_t i;
+  const RlcPlan& p;
+  u32* pts;
+  u32* keys;
+  u32* vals;
+};
+// loads one point, folds its range check into `good`, returns "is on the curve", stores it as affine niels
+DSV_DEV bool prep_point(const PrepOut& o, const uint8_t* __restrict__ uv, int slot, bool negate, bool& good) {
+  Fe pu, pv;
+  good &= load_fq(pu, uv, 2 * o.i);
+  good &= load_fq(pv, uv, 2 * o.i + 1);
+  store_pt(o.pts + ((size_t)slot * o.p.n + o.i) * kPtWords, affine_niels(pu, pv, negate));
+  return on_curve(pu, pv);
+}
+// e' = e + k r, k uniform below floor(2^(wpk c) / r): the same multiple of a point of the prime-order
+// subgroup (any other point fails the subgroup test anyway), but uniform over ALL wpk * c bits —
+// without it the top window of a 252-bit scalar has a few thousand (c = 16: 2^12) digits only, and
+// its buckets get runs 16 times as long as the others: a lane per bucket would wait for those.
+// Then one (bucket, point) pair per window.
+DSV_DEV void emit_long(const PrepOut& o, u32 (&e)[8], u32 kr, int slot) {
+  const RlcPlan& p = o.p;
+  u64 carry = 0;
 #pragma unroll
-    for (int k = 0; k < 5; k++) {
-      const int left = zbits - 32 * k;
-      const u32 m = left >= 32 ? ~0u : (left > 0 ? (1u << left) - 1u : 0u);
-      z[k] = good ? (blk[k] & m) : 0u;
-    }
-    kr = good ? blk[8] % p.kmul : 0u;
+  for (int k = 0; k < 8; k++) {
+    const u64 t = (u64)kR32[k] * kr + e[k] + carry;
+    e[k] = (u32)t;
+    carry = t >> 32;
   }
-  if (!good) {
-    us[7] &= 0x0fffffffu;  // keep fr_mul's inputs in range; the products are 0 anyway
-    cs[7] &= 0x0fffffffu;
-  }
-  fr_mul(e, z, cs);
-  fr_mul(f, z, us);
-  {
-    // e' = e + k r, k uniform below floor(2^(wpk c) / r): the same multiple of a point of the prime-order
-    // subgroup (any other point fails the subgroup test anyway), but uniform over ALL wpk * c bits —
-    // without it the top window of a 252-bit scalar has a few thousand (c = 16: 2^12) digits only, and
-    // its buckets get runs 16 times as long as the others: a lane per bucket would wait for those
-    u64 carry = 0;
-#pragma unroll
-    for (int k = 0; k < 8; k++) {
-      const u64 t = (u64)kR32[k] * kr + e[k] + carry;
-      e[k] = (u32)t;
-      carry = t >> 32;
-    }
-  }
-  store_words8(reinterpret_cast<uint8_t*>(fsc), i, f);
   const u32 mask = (1u << p.c) - 1u, none = (u32)p.windows << p.c;
 #pragma unroll 1
   for (int w = 0; w < p.wpk; w++) {
@@ -250,17 +226,76 @@ k_rlc_prep(const uint8_t* __restrict__ u, const uint8_t* __restrict__ c, const u
 #pragma unroll
     for (int k = 0; k < 7; k++) e[k] = __funnelshift_r(e[k], e[k + 1], p.c);
     e[7] >>= p.c;
-    keys[(size_t)w * p.n + i] = d ? (((u32)w << p.c) | d) : none;
-    vals[(size_t)w * p.n + i] = (u32)i;
+    const size_t at = ((size_t)w * p.lpts + slot) * p.n + o.i;
+    o.keys[at] = d ? (((u32)w << p.c) | d) : none;
+    o.vals[at] = (u32)((size_t)slot * p.n + o.i);
   }
+}
+DSV_DEV void emit_short(const PrepOut& o, const u32 (&zz)[8], int slot) {
+  const RlcPlan& p = o.p;
+  u32 z[5] = {zz[0], zz[1], zz[2], zz[3], zz[4]};
+  const u32 mask = (1u << p.c) - 1u, none = (u32)p.windows << p.c;
+  const size_t first = (size_t)p.wpk * p.lpts * p.n;
 #pragma unroll 1
   for (int w = 0; w < p.wr; w++) {
     const u32 d = z[0] & mask;
 #pragma unroll
     for (int k = 0; k < 4; k++) z[k] = __funnelshift_r(z[k], z[k + 1], p.c);
     z[4] >>= p.c;
-    keys[(size_t)(p.wpk + w) * p.n + i] = d ? (((u32)(p.wpk + w) << p.c) | d) : none;
-    vals[(size_t)(p.wpk + w) * p.n + i] = (u32)(p.n + i);
+    const size_t at = first + ((size_t)w * p.spts + slot) * p.n + o.i;
+    o.keys[at] = d ? (((u32)(p.wpk + w) << p.c) | d) : none;
+    o.vals[at] = (u32)((size_t)(p.lpts + slot) * p.n + o.i);
+  }
+}
+// wr * c >= 128 random bits from five keystream words: every window of z is uniform
+DSV_DEV void draw_z(u32 (&z)[8], const u32* blk, int zbits, bool good) {
+#pragma unroll
+  for (int k = 0; k < 8; k++) {
+    const int left = zbits - 32 * k;
+    const u32 m = left >= 32 ? ~0u : (left > 0 ? (1u << left) - 1u : 0u);
+    z[k] = (good && k < 5) ? (blk[k] & m) : 0u;
+  }
+}
+}  // namespace
+
+template <int SCHEME>
+__global__ void __launch_bounds__(256)
+k_rlc_prep(RlcInputs in, ChaChaKey key, RlcPlan p, uint8_t* __restrict__ ok, u32* __restrict__ pts,
+           u32* __restrict__ fsc, u32* __restrict__ keys, u32* __restrict__ vals, u32* __restrict__ flags) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= p.n) return;
+  const PrepOut o{i, p, pts, keys, vals};
+  bool good = in.valid[i] != 0;
+  u32 us[8], cs[8];
+  load_words8(us, in.u, i);
+  load_words8(cs, in.c, i);
+  good &= words_lt(us, kR32);
+  // slots: long points first (PK, then PK' / Gen), then the short ones (-R, -R')
+  bool curve = prep_point(o, in.pk[0], 0, false, good);
+  if (SCHEME == 1) curve &= prep_point(o, in.pk[1], 1, false, good);
+  if (SCHEME == 2) curve &= prep_point(o, in.gen, 1, false, good);
+  curve &= prep_point(o, in.r[0], p.lpts, true, good);
+  if (SCHEME == 1) curve &= prep_point(o, in.r[1], p.lpts + 1, true, good);
+  // a point off the curve has no place in a group sum: the per-signature kernels decide the batch
+  if (good && !curve) atomicOr(&flags[0], kRlcOffCurve);
+  ok[i] = good ? 1 : 0;
+  u32 blk[16];
+  chacha12_block(blk, key.w, (u64)i);
+  if (!good) {
+    us[7] &= 0x0fffffffu;  // keep fr_mul's inputs in range; the products are 0 anyway
+    cs[7] &= 0x0fffffffu;
+  }
+  // an item with verdict `false` stays out of every sum (z = 0)
+#pragma unroll
+  for (int eq = 0; eq < (SCHEME == 1 ? 2 : 1); eq++) {
+    u32 z[8], e[8];
+    draw_z(z, blk + 8 * eq, p.wr * p.c, good);
+    fr_mul(e, z, cs);
+    emit_long(o, e, good ? blk[8 * eq + 5] % p.kmul : 0u, eq);
+    fr_mul(e, z, us);
+    if (SCHEME == 2) emit_long(o, e, good ? blk[6] % p.kmul : 0u, 1);
+    else store_words8(reinterpret_cast<uint8_t*>(fsc), (size_t)eq * p.n + i, e);
+    emit_short(o, z, eq);
   }
 }
 
@@ -334,7 +369,7 @@ k_rlc_accumulate(const u32* __restrict__ order, const u32* __restrict__ start, c
   if (b >= p.buckets) return;  // (cannot happen: the sort moves what k_rlc_counts wrote)
   u32 lo = 0, hi = 0;
   if (b & ((1u << p.c) - 1u)) lo = start[b], hi = start[b + 1];
-  const u32 last_pt = 2u * p.n - 1u;
+  const u32 last_pt = (u32)(p.lpts + p.spts) * p.n - 1u;
   Ext acc = ext_identity();
   if (lo < hi) {
     u32 id = vals[lo];
@@ -402,16 +437,20 @@ k_rlc_sum(const u32* __restrict__ in, RlcPlan p, u32* __restrict__ out) {
 // ---- the subset sums: subgroup test and weights -----------------------------------------------------
 // lane l < windows * c.  Workgroups [0, g): flags |= kRlcTorsion unless r * S_l == O.
 // Workgroups [g, 2g): W_l = 2^pos(l) * S_l, pos = bit position inside the scalar the window belongs to.
-// Workgroup 2g: W_lanes = (sum f_i) * G from the fixed-base table.
+// Workgroup 2g: W_lanes = (sum f_i) * G (+ (sum f'_i) * G') from the fixed-base tables.
 __global__ void __launch_bounds__(64)
-k_rlc_scale(const u32* __restrict__ S, const u32* __restrict__ fsum, const u32* __restrict__ tableG, RlcPlan p,
-            u32* __restrict__ W, u32* __restrict__ flags) {
+k_rlc_scale(const u32* __restrict__ S, const u32* __restrict__ fsum, const u32* __restrict__ tableG,
+            const u32* __restrict__ tableG2, RlcPlan p, u32* __restrict__ W, u32* __restrict__ flags) {
   const u32 lanes = (u32)p.windows * p.c, g = (lanes + 63) / 64;
   if (blockIdx.x == 2 * g) {
     if (threadIdx.x) return;
-    u32 f[8];
-    load_words8(f, reinterpret_cast<const uint8_t*>(fsum), 0);
-    const Ext fg = fixed_base_accumulate(ext_identity(), f, tableG);
+    Ext fg = ext_identity();
+#pragma unroll 1
+    for (int k = 0; k < p.fixed; k++) {
+      u32 f[8];
+      load_words8(f, reinterpret_cast<const uint8_t*>(fsum), k);
+      fg = fixed_base_accumulate(fg, f, k ? tableG2 : tableG);
+    }
     store_niels(W + (size_t)lanes * kNielsWords, ext_to_niels(fg));
     return;
   }
@@ -475,14 +514,20 @@ size_t rlc_sort_temp_bytes(const RlcPlan& p) {
   return bytes > bytes2 ? bytes : bytes2;
 }
 
-void launch_rlc(const RlcPlan& p, const RlcBuffers& b, const uint8_t* u, const uint8_t* c, const uint8_t* PK_uv,
-                const uint8_t* R_uv, const uint8_t* valid, ChaChaKey key, const uint32_t* tableG, uint8_t* ok,
-                hipStream_t s) {
+void launch_rlc(int scheme, const RlcPlan& p, const RlcBuffers& b, const RlcInputs& in, ChaChaKey key,
+                const uint32_t* tableG, const uint32_t* tableG2, uint8_t* ok, hipStream_t s) {
   (void)hipMemsetAsync(b.flags, 0, 16, s);
-  hipLaunchKernelGGL(k_rlc_prep, dim3(grid_for(p.n)), dim3(256), 0, s, u, c, PK_uv, R_uv, valid, key, p, ok, b.pts,
-                     b.fsc, b.keys[0], b.vals[0], b.flags);
-  hipLaunchKernelGGL(k_rlc_fsum, dim3(kRlcFsumBlocks), dim3(256), 0, s, b.fsc, (size_t)p.n, b.fpart);
-  hipLaunchKernelGGL(k_rlc_fsum, dim3(1), dim3(256), 0, s, b.fpart, (size_t)kRlcFsumBlocks, b.fsum);
+  const dim3 grid(grid_for(p.n)), block(256);
+  if (scheme == 0)
+    hipLaunchKernelGGL(k_rlc_prep<0>, grid, block, 0, s, in, key, p, ok, b.pts, b.fsc, b.keys[0], b.vals[0], b.flags);
+  else if (scheme == 1)
+    hipLaunchKernelGGL(k_rlc_prep<1>, grid, block, 0, s, in, key, p, ok, b.pts, b.fsc, b.keys[0], b.vals[0], b.flags);
+  else
+    hipLaunchKernelGGL(k_rlc_prep<2>, grid, block, 0, s, in, key, p, ok, b.pts, b.fsc, b.keys[0], b.vals[0], b.flags);
+  for (int k = 0; k < p.fixed; k++) {
+    hipLaunchKernelGGL(k_rlc_fsum, dim3(kRlcFsumBlocks), dim3(256), 0, s, b.fsc + (size_t)k * p.n * 8, (size_t)p.n, b.fpart);
+    hipLaunchKernelGGL(k_rlc_fsum, dim3(1), dim3(256), 0, s, b.fpart, (size_t)kRlcFsumBlocks, b.fsum + 8 * k);
+  }
   size_t temp = b.sort_temp_bytes;
   (void)hipcub::DeviceRadixSort::SortPairs(b.sort_temp, temp, b.keys[0], b.keys[1], b.vals[0], b.vals[1], p.entries, 0,
                                            p.key_bits, s);
@@ -499,7 +544,7 @@ void launch_rlc(const RlcPlan& p, const RlcBuffers& b, const uint8_t* u, const u
   hipLaunchKernelGGL(k_rlc_sum<2>, dim3(grid_for((size_t)p.windows * 2 * p.half * p.nseg2, 64)), dim3(64), 0, s, b.tmp[1], p, b.tmp[0]);
   hipLaunchKernelGGL(k_rlc_sum<3>, dim3(grid_for((size_t)p.windows * 2 * p.half, 64)), dim3(64), 0, s, b.tmp[0], p, b.tmp[1]);
   const unsigned lanes = (unsigned)p.windows * p.c, g = (lanes + 63) / 64;
-  hipLaunchKernelGGL(k_rlc_scale, dim3(2 * g + 1), dim3(64), 0, s, b.tmp[1], b.fsum, tableG, p, b.tmp[0], b.flags);
+  hipLaunchKernelGGL(k_rlc_scale, dim3(2 * g + 1), dim3(64), 0, s, b.tmp[1], b.fsum, tableG, tableG2, p, b.tmp[0], b.flags);
   hipLaunchKernelGGL(k_rlc_final, dim3(1), dim3(64), 0, s, b.tmp[0], p, b.flags);
 }
 

@@ -13,12 +13,13 @@ namespace dsv {
 // per-bit subset sums over them in nseg2 segments, so that no serial chain exceeds ~32 additions.
 struct RlcPlan {
   uint32_t n;
+  int lpts, spts, fixed;  // per item: points with 252-bit scalars, points with the z themselves, fixed-base terms
   int c, half, wpk, wr, windows, nseg, nseg2, key_bits;
   uint32_t kmul;   // floor(2^(wpk c) / r): the keys' scalars get a random multiple of r below it added
-  size_t entries;  // n * windows (key, index) pairs
+  size_t entries;  // n * (wpk * lpts + wr * spts) (key, index) pairs
   size_t buckets;  // windows << c
 };
-constexpr size_t kRlcMaxGroup = (size_t)1 << 22;  // n * windows and 2 n must fit 32 bits with room to spare
+constexpr size_t kRlcMaxGroup = (size_t)1 << 22;  // the pair count (at most 48 n) must fit 32 bits with room to spare
 constexpr int kRlcFsumBlocks = 64;
 enum : uint32_t { kRlcOffCurve = 1, kRlcTorsion = 2, kRlcSum = 4 };  // flags[0]; flags[1] = 1: chain complete
 inline int rlc_default_bits(size_t n) {
@@ -26,9 +27,13 @@ inline int rlc_default_bits(size_t n) {
 }
 // even, and the keys' windows cover 252 or 256 bits exactly (10 would need 260: a ninth scalar word)
 inline bool rlc_bits_ok(int c) { return c == 4 || c == 6 || c == 8 || c == 12 || c == 14 || c == 16; }
-inline RlcPlan rlc_plan(size_t n, int c) {
+// scheme: 0 single, 1 double, 2 var-generator (k_rlc.hip: k_rlc_prep says which point gets which scalar)
+inline RlcPlan rlc_plan(int scheme, size_t n, int c) {
   RlcPlan p;
   p.n = (uint32_t)n;
+  p.lpts = scheme == 0 ? 1 : 2;
+  p.spts = scheme == 1 ? 2 : 1;
+  p.fixed = scheme == 0 ? 1 : (scheme == 1 ? 2 : 0);
   p.c = c;
   p.half = c / 2;
   p.wpk = (252 + c - 1) / c;
@@ -40,15 +45,23 @@ inline RlcPlan rlc_plan(size_t n, int c) {
   p.kmul = p.wpk * c == 256 ? 17u : 1u;  // floor(2^256 / r) = 17, floor(2^252 / r) = 1
   p.key_bits = c;
   for (int w = p.windows; w; w >>= 1) p.key_bits++;
-  p.entries = n * (size_t)p.windows;
+  p.entries = n * ((size_t)p.wpk * p.lpts + (size_t)p.wr * p.spts);
   p.buckets = (size_t)p.windows << c;
   return p;
 }
+struct RlcInputs {
+  const uint8_t* u;
+  const uint8_t* c;      // k_challenge's output for the group
+  const uint8_t* valid;  // ... and its validity bytes
+  const uint8_t* pk[2];  // PK, PK' (double)
+  const uint8_t* r[2];   // R, R' (double)
+  const uint8_t* gen;    // Gen (var-generator)
+};
 struct RlcBuffers {
-  uint32_t* pts;      // 2 n x 32 words: PK_i, then -R_i, as affine niels
-  uint32_t* fsc;      // n x 8 words: z_i u_i mod r
+  uint32_t* pts;      // (lpts + spts) n x 32 words: the long points, then the negated short ones, as affine niels
+  uint32_t* fsc;      // fixed x n x 8 words: z_i u_i mod r (z'_i u_i)
   uint32_t* fpart;    // kRlcFsumBlocks x 8
-  uint32_t* fsum;     // 8
+  uint32_t* fsum;     // 2 x 8
   uint32_t* keys[2];  // entries each (unsorted / sorted)
   uint32_t* vals[2];
   uint32_t* start;    // buckets + 1: first sorted pair of every bucket
@@ -71,8 +84,7 @@ inline size_t rlc_tmp_points(const RlcPlan& p, int k) {
 }
 size_t rlc_sort_temp_bytes(const RlcPlan& p);
 // hash output c / valid of the group in, ok[i] = "item i is well-formed" and flags out; never synchronises
-void launch_rlc(const RlcPlan& p, const RlcBuffers& b, const uint8_t* u, const uint8_t* c, const uint8_t* PK_uv,
-                const uint8_t* R_uv, const uint8_t* valid, ChaChaKey key, const uint32_t* tableG, uint8_t* ok,
-                hipStream_t s);
+void launch_rlc(int scheme, const RlcPlan& p, const RlcBuffers& b, const RlcInputs& in, ChaChaKey key,
+                const uint32_t* tableG, const uint32_t* tableG2, uint8_t* ok, hipStream_t s);
 
 }  // namespace dsv

@@ -525,18 +525,32 @@ def rlc_workspace_bytes(n, window_bits=0):
     return b
 
 
+def _rlc(name, cols, ok, workspace, stream, window_bits):
+    n, dev = _rows(*cols)
+    accepted = ctypes.c_int(0)
+    _lib.check(getattr(_lib.load(), name)(
+        *[_tp(t, w) for t, w, _ in cols], ctypes.c_size_t(n), _bytes_out(ok, n, dev, "ok"),
+        _bytes_out(workspace, rlc_workspace_bytes(n, window_bits), dev, "workspace"),
+        _stream_ptr(stream, dev), ctypes.c_int(window_bits), ctypes.byref(accepted)))
+    return bool(accepted.value)
+
+
 def verify_single_rlc_dev(u, R, PK, m, ok, workspace, stream=None, window_bits=0):
     """dsv_verify_single_rlc_dev: the verdict vector of verify_single_dev, through one aggregate test
     per group when the whole group is valid.  Blocks on `stream`.  Returns True if every group was
     accepted by its aggregate (else the per-signature kernels decided)."""
-    n, dev = _rows((u, 32, "u"), (R, 64, "R"), (PK, 64, "PK"), (m, 32, "m"))
-    accepted = ctypes.c_int(0)
-    _lib.check(_lib.load().dsv_verify_single_rlc_dev(
-        _tp(u, 32), _tp(R, 64), _tp(PK, 64), _tp(m, 32), ctypes.c_size_t(n),
-        _bytes_out(ok, n, dev, "ok"),
-        _bytes_out(workspace, rlc_workspace_bytes(n, window_bits), dev, "workspace"),
-        _stream_ptr(stream, dev), ctypes.c_int(window_bits), ctypes.byref(accepted)))
-    return bool(accepted.value)
+    return _rlc("dsv_verify_single_rlc_dev", ((u, 32, "u"), (R, 64, "R"), (PK, 64, "PK"), (m, 32, "m")),
+                ok, workspace, stream, window_bits)
+
+
+def verify_double_rlc_dev(u, R, Rp, PK, PKp, m, ok, workspace, stream=None, window_bits=0):
+    return _rlc("dsv_verify_double_rlc_dev", ((u, 32, "u"), (R, 64, "R"), (Rp, 64, "Rp"), (PK, 64, "PK"),
+                                               (PKp, 64, "PKp"), (m, 32, "m")), ok, workspace, stream, window_bits)
+
+
+def verify_vargen_rlc_dev(u, R, PK, Gen, m, ok, workspace, stream=None, window_bits=0):
+    return _rlc("dsv_verify_vargen_rlc_dev", ((u, 32, "u"), (R, 64, "R"), (PK, 64, "PK"), (Gen, 64, "Gen"),
+                                               (m, 32, "m")), ok, workspace, stream, window_bits)
 
 
 def verify_double_dev(u, R, Rp, PK, PKp, m, ok, workspace, stream=None):

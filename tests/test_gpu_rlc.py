@@ -19,19 +19,73 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 
 
+COLS = {"single": ("u", "R", "PK", "m"), "double": ("u", "R", "Rp", "PK", "PKp", "m"),
+        "vargen": ("u", "R", "PK", "Gen", "m")}
+
+
+def _scheme_of(a):
+    return "double" if "Rp" in a else ("vargen" if "Gen" in a else "single")
+
+
 def _run(engine, a, window_bits=0):
+    scheme = _scheme_of(a)
     n = len(a["u"])
-    t = {k: torch.from_numpy(np.ascontiguousarray(a[k])).to(DEV) for k in ("u", "R", "PK", "m")}
+    t = [torch.from_numpy(np.ascontiguousarray(a[k])).to(DEV) for k in COLS[scheme]]
     ok = torch.full((n,), 7, dtype=torch.uint8, device=DEV)
     ws = torch.empty(engine.rlc_workspace_bytes(n, window_bits), dtype=torch.uint8, device=DEV)
-    accepted = engine.verify_single_rlc_dev(t["u"], t["R"], t["PK"], t["m"], ok, ws, window_bits=window_bits)
+    accepted = getattr(engine, "verify_%s_rlc_dev" % scheme)(*t, ok, ws, window_bits=window_bits)
     torch.cuda.synchronize()
     return accepted, ok.cpu().numpy()
 
 
-def _signed(n, seed):
-    d = O.keygen_sign_single(n, seed, nthreads=8)
-    return {k: d[k] for k in ("u", "R", "PK", "m")}
+def _oracle(a):
+    scheme = _scheme_of(a)
+    return getattr(O, "verify_" + scheme)(*[a[k] for k in COLS[scheme]], nthreads=8)
+
+
+def _signed(n, seed, scheme="single"):
+    d = getattr(O, "keygen_sign_" + scheme)(n, seed, nthreads=8)
+    return {k: d[k] for k in COLS[scheme]}
+
+
+@pytest.mark.parametrize("scheme", ["double", "vargen"])
+def test_double_and_var_generator_schemes(engine, scheme):
+    """`PublicKeyDouble::verify` / `PublicKeyVarGen::verify` (src/keys/public.rs:222-244, :401-415) through
+    the aggregate: all valid -> accepted; one wrong field anywhere -> the per-signature kernels' (= the
+    oracle's) verdicts; the harness's tamper classes; a key / generator with a small-order component."""
+    n = 1800
+    d = _signed(n, 970 + len(scheme), scheme)
+    for bits in (8, 12, 0):
+        accepted, ok = _run(engine, d, bits)
+        assert accepted and ok.all(), bits
+    points = [k for k in COLS[scheme] if k not in ("u", "m")]
+    for j, field in enumerate(COLS[scheme]):
+        a = {k: v.copy() for k, v in d.items()}
+        victim = 100 + 37 * j
+        if field in ("u", "m"):
+            a[field][victim, 2] ^= 0x04
+        else:
+            a[field][victim] = d[field][victim + 1]
+        want = _oracle(a)
+        assert want.sum() == n - 1 and not want[victim], field
+        accepted, ok = _run(engine, a, 8)
+        assert not accepted and np.array_equal(ok, want), field
+    a = {k: v.copy() for k, v in d.items()}
+    H.tamper(a, period=9)
+    want = _oracle(a)
+    assert 0 < want.sum() < n
+    accepted, ok = _run(engine, a)
+    assert not accepted and np.array_equal(ok, want)
+    # small-order component in ONE point of one item, for every point column: never decided by the aggregate
+    import test_halfgcd as TH
+    t8 = TH.order8_point()
+    for field in points:
+        a = {k: v.copy() for k, v in d.items()}
+        P = H.to_int_point(a[field][50])
+        a[field][50] = np.frombuffer(M.point_bytes(M.padd(P, M.pmul(t8, 4))), np.uint8)
+        want = _oracle(a)
+        accepted, ok = _run(engine, a, 8)
+        assert not accepted and np.array_equal(ok, want), field
 
 
 @pytest.mark.parametrize("bits", [4, 6, 8, 12, 14, 16, 0])
