@@ -733,6 +733,24 @@ def main():
                      algo_bytes=ALGO_BYTES["vargen"])
         sample_checks["vargen"] = (bv, okv.clone())
 
+        # ---- random-linear-combination fast accept (opt-in entry point, NOT the headline:
+        # `value` stays the per-signature path on the graded 1/16-tampered workload, where the aggregate
+        # always fails).  Same verdict vectors; what is reported is the time on an ALL-VALID batch (the
+        # aggregate decides) and on the graded batch (aggregate + per-signature kernels).
+        wsr = torch.empty(E.rlc_workspace_bytes(n), dtype=torch.uint8, device=dev)
+        okr = torch.zeros(n, dtype=torch.uint8, device=dev)
+        rlc = {"unit": "verifies/s", "entry_point": "dsv_verify_single_rlc_dev (blocks on the stream; weights from getrandom)"}
+        for label, b_ in (("all_valid", W.gen_single(n, seed=2321, device=dev, tamper=False)), ("graded_workload", batch)):
+            acc = []
+            f_ = lambda: acc.append(E.verify_single_rlc_dev(b_["u"], b_["R"], b_["PK"], b_["m"], okr, wsr))
+            t_ = timed(f_, reps, 1)
+            if int((okr != b_["expected"]).sum().item()) or any(a != (label == "all_valid") for a in acc):
+                raise SystemExit("rlc (%s): verdicts / acceptance differ from the expected pattern" % label)
+            rlc[label] = {"value": n * reps / t_, "ms_per_call": t_ / reps * 1e3, "accepted_by_aggregate": label == "all_valid",
+                          "vs_per_signature": (n * reps / t_) / value}
+        out["rlc"] = rlc
+        del wsr, okr
+
         # ---- projective inputs (what the reference's types hold): to_hash_inputs on the device
         zr = torch.randint(0, 256, (n, 32), dtype=torch.uint8, device=dev)
         zr[:, 31] = 0

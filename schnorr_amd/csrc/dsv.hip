@@ -928,15 +928,20 @@ int verify_rlc_on(Context& ctx, int scheme, const void* u, const void* R_uv, con
     HIP_TRY(hipStreamSynchronize(s));
     if (flags[0] == 0 && flags[1] == 1) continue;  // ok[] = "well-formed" is the verdict vector
     all = false;
-    int r;
-    if (scheme == 0)
-      r = verify_single_on(ctx, pu + 32 * off, pR + 64 * off, pPK + 64 * off, pm + 32 * off, cnt, pok + off, workspace, s);
-    else if (scheme == 1)
-      r = verify_double_on(ctx, pu + 32 * off, pR + 64 * off, pRp + 64 * off, pPK + 64 * off, pPKp + 64 * off,
-                           pm + 32 * off, cnt, pok + off, workspace, s);
-    else
-      r = verify_vargen_on(ctx, pu + 32 * off, pR + 64 * off, pPK + 64 * off, pG + 64 * off, pm + 32 * off, cnt,
-                           pok + off, workspace, s);
+    // the per-signature kernels, from the challenges already in the workspace (run_split carves it the same way)
+    Context* cp = &ctx;
+    const int r = run_split(ctx, cnt, workspace, s, [=](size_t o, size_t part, const Workspace& w, hipStream_t ps) {
+      const size_t at = off + o;
+      if (scheme == 0)
+        launch_verify_fixed(*cp, false, pu + 32 * at, w.c, pPK + 64 * at, pR + 64 * at, 0, w.valid, part, pok + at,
+                            w.tables, ps);
+      else if (scheme == 1)
+        launch_verify_fixed_double(*cp, pu + 32 * at, w.c, pPK + 64 * at, pR + 64 * at, pPKp + 64 * at,
+                                   pRp + 64 * at, w.valid, part, pok + at, w.tables, ps);
+      else
+        launch_verify_var(pu + 32 * at, (const uint8_t*)w.c, pPK + 64 * at, pG + 64 * at, pR + 64 * at,
+                          (const uint8_t*)w.valid, part, pok + at, w.tables, ps);
+    });
     if (r) return r;
   }
   if (accepted) *accepted = all ? 1 : 0;

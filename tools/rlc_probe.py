@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Time dsv_verify_single_rlc_dev beside dsv_verify_single_dev (device-resident inputs):
 
-    python tools/rlc_probe.py [log2n=20] [window_bits=0] [reps=10]
+    python tools/rlc_probe.py [log2n=20] [window_bits=0] [reps=10] [scheme=single|double|vargen]
 
 all-valid batch (the aggregate decides) and the graded workload (1/16 tampered: aggregate fails, the
 per-signature kernels decide).  Verdicts checked against the construction-time pattern."""
@@ -19,6 +19,11 @@ E.init(0)
 n = 1 << (int(sys.argv[1]) if len(sys.argv) > 1 else 20)
 bits = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 reps = int(sys.argv[3]) if len(sys.argv) > 3 else 10
+scheme = sys.argv[4] if len(sys.argv) > 4 else "single"
+COLS = {"single": ("u", "R", "PK", "m"), "double": ("u", "R", "Rp", "PK", "PKp", "m"), "vargen": ("u", "R", "PK", "Gen", "m")}[scheme]
+gen = getattr(W, "gen_" + scheme)
+rlc = getattr(E, "verify_%s_rlc_dev" % scheme)
+plain = getattr(E, "verify_%s_dev" % scheme)
 ws = torch.empty(E.rlc_workspace_bytes(n, bits), dtype=torch.uint8, device="cuda:0")
 ok = torch.zeros(n, dtype=torch.uint8, device="cuda:0")
 
@@ -37,12 +42,13 @@ def timed(fn):
 
 
 for label, tamper in (("all valid", False), ("1/16 tampered", True)):
-    b = W.gen_single(n, seed=2321, tamper=tamper)
+    b = gen(n, seed=2321, tamper=tamper)
+    cols = [b[k] for k in COLS]
     acc = []
-    best, med = timed(lambda: acc.append(E.verify_single_rlc_dev(b["u"], b["R"], b["PK"], b["m"], ok, ws, window_bits=bits)))
+    best, med = timed(lambda: acc.append(rlc(*cols, ok, ws, window_bits=bits)))
     assert torch.equal(ok, b["expected"]) and all(a == (not tamper) for a in acc)
     ok.zero_()
-    best0, med0 = timed(lambda: E.verify_single_dev(b["u"], b["R"], b["PK"], b["m"], ok, ws))
+    best0, med0 = timed(lambda: plain(*cols, ok, ws))
     assert torch.equal(ok, b["expected"])
-    print("n=2^%d bits=%d %-14s rlc %.3f ms (median %.3f) = %.1f M/s | per-signature %.3f ms (median %.3f) = %.1f M/s | x%.2f" % (
+    print(scheme + " n=2^%d bits=%d %-14s rlc %.3f ms (median %.3f) = %.1f M/s | per-signature %.3f ms (median %.3f) = %.1f M/s | x%.2f" % (
         n.bit_length() - 1, bits, label, best, med, n / best / 1e3, best0, med0, n / best0 / 1e3, best0 / best), flush=True)
