@@ -435,14 +435,83 @@ k_rlc_sum(const u32* __restrict__ in, RlcPlan p, u32* __restrict__ out) {
 }
 
 // ---- the subset sums: subgroup test and weights -----------------------------------------------------
-// lane l < windows * c.  Workgroups [0, g): flags |= kRlcTorsion unless r * S_l == O.
-// Workgroups [g, 2g): W_l = 2^pos(l) * S_l, pos = bit position inside the scalar the window belongs to.
-// Workgroup 2g: W_lanes = (sum f_i) * G (+ (sum f'_i) * G') from the fixed-base tables.
-__global__ void __launch_bounds__(64)
+// Both are ~250 dependent point operations per lane on a handful of lanes: pure latency (a wave
+// issues one multiplication's 190 instructions in ~860 cycles whatever its neighbours do).  So FOUR
+// waves share every point operation: a doubling and an addition are two rounds of at most four
+// independent field multiplications each — wave k does the k-th of them for all 64 points of the
+// workgroup and the results change hands through LDS (one barrier per round, two buffers).  The
+// running point is (u, v, z, tt) with tt = t1 t2 (the product the next addition needs) computed by
+// the wave that is idle in the second round; operand forms are exactly those of ext_double /
+// ext_add_niels / ext_to_niels (jubjub29.h), so their proven bounds carry over.
+namespace {
+struct Xp {
+  Fe u, v, z, tt;
+};
+struct Quad {  // the four waves' round results
+  Fe r[4];
+};
+DSV_DEV Quad exchange(u32* sh, int& buf, int wave, int lane, const Fe& mine) {
+  u32* b = sh + buf * (4 * NL * 64);
+#pragma unroll
+  for (int i = 0; i < NL; i++) b[(wave * NL + i) * 64 + lane] = mine.l[i];
+  __syncthreads();
+  Quad q;
+#pragma unroll
+  for (int w = 0; w < 4; w++)
+#pragma unroll
+    for (int i = 0; i < NL; i++) q.r[w].l[i] = b[(w * NL + i) * 64 + lane];
+  buf ^= 1;  // the next round writes the other buffer: nobody is still reading it (one barrier back)
+  return q;
+}
+// (limb by limb: a select between whole structs becomes an array in scratch memory indexed by `wave`)
+DSV_DEV Fe pick(int wave, const Fe& a, const Fe& b, const Fe& c, const Fe& d) {
+  return fe_select(wave < 2, fe_select(wave == 0, a, b), fe_select(wave == 2, c, d));
+}
+DSV_DEV Xp xp_finish(u32* sh, int& buf, int wave, int lane, const Fe& cu, const Fe& ct, const Fe& cv, const Fe& cz,
+                     const Fe& zl, const Fe& t2) {
+  // u = cu ct, v = cv cz, z = zl ct, tt = cu t2
+  const Fe x = pick(wave, cu, cv, zl, cu), y = pick(wave, ct, cz, ct, t2);
+  const Quad q = exchange(sh, buf, wave, lane, fe_mul(x, y));
+  Xp r;
+  r.u = q.r[0], r.v = q.r[1], r.z = q.r[2], r.tt = q.r[3];
+  return r;
+}
+DSV_DEV Xp xp_double(u32* sh, int& buf, int wave, int lane, const Xp& p) {
+  const Quad q = exchange(sh, buf, wave, lane, fe_sqr(pick(wave, p.u, p.v, p.z, fe_add(p.u, p.v))));
+  const Fe zz2 = fe_dbl(q.r[2]);
+  const Fe vpu = fe_add(q.r[1], q.r[0]);
+  const Fe cu = fe_sub4w(q.r[3], vpu);       // 2uv (ext_two_uv)
+  const Fe vmu = fe_sub2_raw(q.r[1], q.r[0]);
+  const Fe ct = fe_sub4w(zz2, vmu);
+  return xp_finish(sh, buf, wave, lane, cu, ct, vpu, vmu, vmu, vpu);  // (ext_double: u = cu ct, v = vpu vmu, z = vmu ct; t1 t2 = cu vpu)
+}
+DSV_DEV Xp xp_add(u32* sh, int& buf, int wave, int lane, const Xp& p, const Niels& n) {
+  const Fe x = pick(wave, fe_sub2_raw(p.v, p.u), fe_add(p.v, p.u), p.tt, p.z);
+  const Fe y = pick(wave, n.vmu, n.vpu, n.t2d, n.z);
+  const Quad q = exchange(sh, buf, wave, lane, fe_mul(x, y));  // a, b, c, z nz
+  const Fe d = fe_dbl(q.r[3]);
+  const Fe cu = fe_sub2_raw(q.r[1], q.r[0]), cv = fe_add(q.r[1], q.r[0]);
+  const Fe cz = fe_add(d, q.r[2]), ct = fe_sub2(d, q.r[2]);
+  return xp_finish(sh, buf, wave, lane, cu, ct, cv, cz, cz, cv);  // (ext_add_tail: u = cu ct, v = cv cz, z = cz ct; t1 t2 = cu cv)
+}
+DSV_DEV Xp xp_identity() {
+  Xp r;
+  r.u = fe_zero(), r.v = fe_one(), r.z = fe_one(), r.tt = fe_zero();
+  return r;
+}
+}  // namespace
+
+// 256 threads = 4 waves x 64 points.  Workgroups [0, g): flags |= kRlcTorsion unless r * S_l == O.
+// Workgroups [g, 2g): W_l = 2^pos(l) * S_l, pos = bit position inside the scalar the window belongs to
+// (every lane runs the workgroup's longest chain and keeps its own result once it is there).
+// Workgroup 2g: W_lanes = (sum f_i) * G (+ (sum f'_i) * G') from the fixed-base tables, one lane.
+__global__ void __launch_bounds__(256)
 k_rlc_scale(const u32* __restrict__ S, const u32* __restrict__ fsum, const u32* __restrict__ tableG,
             const u32* __restrict__ tableG2, RlcPlan p, u32* __restrict__ W, u32* __restrict__ flags) {
+  __shared__ u32 sh[2 * 4 * NL * 64];
+  __shared__ u32 sh_max;
   const u32 lanes = (u32)p.windows * p.c, g = (lanes + 63) / 64;
-  if (blockIdx.x == 2 * g) {
+  if (blockIdx.x == 2 * g) {  // (no barrier on this path)
     if (threadIdx.x) return;
     Ext fg = ext_identity();
 #pragma unroll 1
@@ -454,31 +523,50 @@ k_rlc_scale(const u32* __restrict__ S, const u32* __restrict__ fsum, const u32* 
     store_niels(W + (size_t)lanes * kNielsWords, ext_to_niels(fg));
     return;
   }
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const bool weigh = blockIdx.x >= g;
-  const u32 l = (blockIdx.x - (weigh ? g : 0)) * 64 + threadIdx.x;
-  if (l >= lanes) return;
-  const Niels s = load_niels(S + (size_t)l * kNielsWords);
-  Ext acc = ext_from_niels(s);
+  const u32 l = (blockIdx.x - (weigh ? g : 0)) * 64 + lane;
+  const bool live = l < lanes;  // the others keep step with the barriers on the identity
+  const Niels s = live ? load_niels(S + (size_t)l * kNielsWords) : niels_identity();
+  int buf = 0;
+  Xp acc = xp_add(sh, buf, wave, lane, xp_identity(), s);
   if (weigh) {
     const u32 w = l / p.c, bit = l % p.c;
-    const u32 pos = (w < (u32)p.wpk ? w : w - p.wpk) * p.c + bit;
+    const u32 pos = live ? (w < (u32)p.wpk ? w : w - p.wpk) * p.c + bit : 0u;
+    if (threadIdx.x == 0) sh_max = 0;
+    __syncthreads();
+    atomicMax(&sh_max, pos);
+    __syncthreads();
+    const u32 longest = sh_max;
 #pragma unroll 1
-    for (u32 k = 0; k < pos; k++) acc = ext_double(acc);
-    // (pos == 0: acc is ext_from_niels' output, whose t1 * t2 is outside ext_to_niels' proven range:
-    //  one doubling-free pass through the addition formulas instead)
-    if (pos == 0) acc = ext_add_niels(ext_identity(), s);
-    store_niels(W + (size_t)l * kNielsWords, ext_to_niels(acc));
+    for (u32 k = 0; k < longest; k++) {
+      const Xp d = xp_double(sh, buf, wave, lane, acc);
+      const bool take = k < pos;
+      acc.u = fe_select(take, d.u, acc.u), acc.v = fe_select(take, d.v, acc.v);
+      acc.z = fe_select(take, d.z, acc.z), acc.tt = fe_select(take, d.tt, acc.tt);
+    }
+    if (wave == 0 && live) {
+      Niels n;
+      n.vpu = fe_carry(fe_add(acc.v, acc.u));
+      n.vmu = fe_sub2(acc.v, acc.u);
+      n.z = acc.z;
+      n.t2d = fe_mul(acc.tt, fe_const(kD2));
+      store_niels(W + (size_t)l * kNielsWords, n);
+    }
     return;
   }
   const Niels sn = niels_neg(s);
 #pragma unroll 1
   for (int k = 251; k >= 0; k--) {  // digit 252 is the +1 acc starts from
-    acc = ext_double(acc);
+    acc = xp_double(sh, buf, wave, lane, acc);
     const u32 pb = (kRNafPos[k >> 5] >> (k & 31)) & 1u, nb = (kRNafNeg[k >> 5] >> (k & 31)) & 1u;
-    if (pb) acc = ext_add_niels(acc, s);
-    if (nb) acc = ext_add_niels(acc, sn);
+    if (pb) acc = xp_add(sh, buf, wave, lane, acc, s);   // (uniform: the digits are constants)
+    if (nb) acc = xp_add(sh, buf, wave, lane, acc, sn);
   }
-  if (!ext_is_identity(acc)) atomicOr(&flags[0], kRlcTorsion);
+  if (wave == 0 && live) {
+    const bool identity = (bool)((int)fe_equal(acc.u, fe_zero()) & (int)fe_equal(acc.v, acc.z));
+    if (!identity) atomicOr(&flags[0], kRlcTorsion);
+  }
 }
 
 // sum of the windows * c weighted subset sums and of (sum f_i) * G == O ?  One wave: a strided pass,
@@ -544,7 +632,7 @@ void launch_rlc(int scheme, const RlcPlan& p, const RlcBuffers& b, const RlcInpu
   hipLaunchKernelGGL(k_rlc_sum<2>, dim3(grid_for((size_t)p.windows * 2 * p.half * p.nseg2, 64)), dim3(64), 0, s, b.tmp[1], p, b.tmp[0]);
   hipLaunchKernelGGL(k_rlc_sum<3>, dim3(grid_for((size_t)p.windows * 2 * p.half, 64)), dim3(64), 0, s, b.tmp[0], p, b.tmp[1]);
   const unsigned lanes = (unsigned)p.windows * p.c, g = (lanes + 63) / 64;
-  hipLaunchKernelGGL(k_rlc_scale, dim3(2 * g + 1), dim3(64), 0, s, b.tmp[1], b.fsum, tableG, tableG2, p, b.tmp[0], b.flags);
+  hipLaunchKernelGGL(k_rlc_scale, dim3(2 * g + 1), dim3(256), 0, s, b.tmp[1], b.fsum, tableG, tableG2, p, b.tmp[0], b.flags);
   hipLaunchKernelGGL(k_rlc_final, dim3(1), dim3(64), 0, s, b.tmp[0], p, b.flags);
 }
 
