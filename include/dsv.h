@@ -274,6 +274,11 @@ int dsv_verify_vargen_dev(const void *u, const void *R_uv, const void *PK_uv, co
  * Unlike the other *_dev calls this one BLOCKS on `stream` (the decision is taken on the host).
  * workspace: dsv_rlc_workspace_bytes(n, window_bits) device bytes, 256-byte aligned. */
 size_t dsv_rlc_workspace_bytes(size_t n, int window_bits);
+/* geometry of one group's aggregate (tests, sizing; works without a GPU): scheme 0 single / 1 double /
+ * 2 var-generator; out[16] = window bits c, c/2, key windows, nonce windows, windows, row/column
+ * segments, bit-sum segments, sort key bits, multiples of r added to a key scalar, long / short
+ * points and fixed-base terms per item, (bucket, point) pairs, buckets, points of the two scratch areas */
+int dsv_rlc_plan_info(int scheme, size_t n, int window_bits, uint64_t *out /*[16]*/);
 int dsv_verify_single_rlc_dev(const void *u, const void *R_uv, const void *PK_uv, const void *m,
                               size_t n, void *ok, void *workspace, void *stream, int window_bits,
                               int *accepted);

@@ -46,7 +46,7 @@ SYMBOLS = [
     "dsv_verify_vargen_mont_cols_submit", "dsv_job_wait", "dsv_job_done", "dsv_max_in_flight",
     # r05: random-linear-combination fast accept in front of the per-signature kernels
     "dsv_rlc_workspace_bytes", "dsv_verify_single_rlc_dev", "dsv_verify_double_rlc_dev",
-    "dsv_verify_vargen_rlc_dev",
+    "dsv_verify_vargen_rlc_dev", "dsv_rlc_plan_info",
 ]
 _SIZE_T_FUNCS = ("dsv_workspace_bytes", "dsv_mixed_workspace_bytes", "dsv_split_scratch_bytes",
                  "dsv_ext_workspace_bytes", "dsv_wire_workspace_bytes", "dsv_mont_workspace_bytes",

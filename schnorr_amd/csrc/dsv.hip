@@ -957,6 +957,22 @@ size_t dsv_rlc_workspace_bytes(size_t n, int window_bits) {
   // the double scheme's needs: four points per item, two fixed-base terms (the others fit inside)
   return carve_rlc(reinterpret_cast<void*>((uintptr_t)4096), g, rlc_plan(1, g, c)).bytes + 256;
 }
+// the geometry of one group's aggregate, for tests and sizing (no GPU needed): out[0..15] =
+// c, half, wpk, wr, windows, nseg, nseg2, key_bits, kmul, lpts, spts, fixed, entries, buckets,
+// points of tmp[0], points of tmp[1]
+int dsv_rlc_plan_info(int scheme, size_t n, int window_bits, uint64_t* out) {
+  if (!out || scheme < 0 || scheme > 2 || n == 0 || n > kRlcMaxGroup)
+    return fail(DSV_ERR_INVALID_ARGUMENT, "bad argument");
+  const int c = window_bits ? window_bits : rlc_default_bits(n);
+  if (!rlc_bits_ok(c)) return fail(DSV_ERR_INVALID_ARGUMENT, "window_bits must be 0 (automatic) or one of 4, 6, 8, 12, 14, 16");
+  const RlcPlan p = rlc_plan(scheme, n, c);
+  const uint64_t v[16] = {(uint64_t)p.c, (uint64_t)p.half, (uint64_t)p.wpk, (uint64_t)p.wr, (uint64_t)p.windows,
+                          (uint64_t)p.nseg, (uint64_t)p.nseg2, (uint64_t)p.key_bits, p.kmul, (uint64_t)p.lpts,
+                          (uint64_t)p.spts, (uint64_t)p.fixed, p.entries, p.buckets, rlc_tmp_points(p, 0),
+                          rlc_tmp_points(p, 1)};
+  for (int k = 0; k < 16; k++) out[k] = v[k];
+  return DSV_OK;
+}
 #define DSV_RLC_PROLOGUE(nullcheck)                                                              \
   if (accepted) *accepted = 0;                                                                   \
   if (n && (nullcheck)) return fail(DSV_ERR_INVALID_ARGUMENT, "null pointer");                   \

@@ -525,6 +525,16 @@ def rlc_workspace_bytes(n, window_bits=0):
     return b
 
 
+def rlc_plan_info(scheme, n, window_bits=0):
+    """dsv_rlc_plan_info as a dict (no GPU needed)"""
+    out = (ctypes.c_uint64 * 16)()
+    _lib.check(_lib.load().dsv_rlc_plan_info(ctypes.c_int({"single": 0, "double": 1, "vargen": 2}[scheme]),
+                                             ctypes.c_size_t(n), ctypes.c_int(window_bits), out))
+    names = ("c", "half", "wpk", "wr", "windows", "nseg", "nseg2", "key_bits", "kmul", "lpts", "spts", "fixed",
+             "entries", "buckets", "tmp0", "tmp1")
+    return dict(zip(names, [int(x) for x in out]))
+
+
 def _rlc(name, cols, ok, workspace, stream, window_bits):
     n, dev = _rows(*cols)
     accepted = ctypes.c_int(0)

@@ -1,0 +1,98 @@
+#!/usr/bin/env python3
+"""Soak of the batch fast accept (dsv_verify_*_rlc_dev) against the oracle, bit for bit:
+
+    python tools/soak_rlc.py [rounds=60] [seed=1]
+
+Every round: one scheme, a size between 40 and 2^17 + change (so that every default window width and
+the group logic see ragged sizes), explicit or automatic window bits, and one of
+  clean      all valid                               -> must be ACCEPTED, all verdicts 1
+  one        one wrong field in one random item      -> must NOT be accepted
+  few        the harness's tamper classes, sparse    -> must NOT be accepted
+  torsion    an order-8 / order-4 / order-2 component added to one random point (the signature may
+             stay valid under the reference's cofactorless equation or not) -> must NOT be accepted
+  malformed  non-canonical encodings only            -> accepted, those items 0
+Verdicts always equal the oracle's (the oracle is test infrastructure; nothing here is timed)."""
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import torch  # noqa: E402
+
+import harness as H  # noqa: E402
+import oracle_lib as O  # noqa: E402
+import pymodel as M  # noqa: E402
+import test_halfgcd as TH  # noqa: E402
+from schnorr_amd import engine as E  # noqa: E402
+
+COLS = {"single": ("u", "R", "PK", "m"), "double": ("u", "R", "Rp", "PK", "PKp", "m"),
+        "vargen": ("u", "R", "PK", "Gen", "m")}
+rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 60
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+E.init(0)
+t8 = TH.order8_point()
+SIZES = [40, 700, 4097, (1 << 14) + 3, (1 << 15) - 1, 40000, (1 << 16) + 77, (1 << 17) + 1]
+total = bad = 0
+t0 = time.time()
+for rd in range(rounds):
+    scheme = ("single", "double", "vargen")[int(rng.integers(0, 3))]
+    n = int(SIZES[int(rng.integers(0, len(SIZES)))])
+    bits = int((0, 0, 0, 4, 6, 8, 12, 14, 16)[int(rng.integers(0, 9))])
+    if bits and bits < 8 and n > 5000:
+        bits = 8
+    kind = ("clean", "one", "few", "torsion", "malformed")[int(rng.integers(0, 5))]
+    base = min(n, 1500)
+    d = getattr(O, "keygen_sign_" + scheme)(base, int(rng.integers(1, 1 << 30)), nthreads=8)
+    d = {k: d[k] for k in COLS[scheme]}
+    points = [k for k in COLS[scheme] if k not in ("u", "m")]
+    if kind == "one":
+        f = COLS[scheme][int(rng.integers(0, len(COLS[scheme])))]
+        i = int(rng.integers(0, base))
+        if f in ("u", "m"):
+            d[f][i, int(rng.integers(0, 31))] ^= np.uint8(1 << int(rng.integers(0, 8)))
+        else:
+            d[f][i] = d[f][(i + 1) % base].copy()
+    elif kind == "few":
+        H.tamper(d, period=int(rng.integers(50, 400)))
+    elif kind == "torsion":
+        f = points[int(rng.integers(0, len(points)))]
+        i = int(rng.integers(0, base))
+        P = H.to_int_point(d[f][i])
+        d[f][i] = np.frombuffer(M.point_bytes(M.padd(P, M.pmul(t8, int(rng.integers(1, 8))))), np.uint8)
+    elif kind == "malformed":
+        top = np.frombuffer(b"\xff" * 32, np.uint8)
+        for _ in range(3):
+            f = COLS[scheme][int(rng.integers(0, len(COLS[scheme])))]
+            i = int(rng.integers(0, base))
+            if f in ("u", "m"):
+                d[f][i] = top
+            else:
+                d[f][i, 32 * int(rng.integers(0, 2)):][:32] = top
+    want = getattr(O, "verify_" + scheme)(*[d[k] for k in COLS[scheme]], nthreads=8)
+    # tile to n: items repeat, their weights do not (one z per item and call)
+    reps = -(-n // base)
+    a = [np.ascontiguousarray(np.tile(d[k], (reps, 1))[:n]) for k in COLS[scheme]]
+    twant = np.tile(want, reps)[:n]
+    t = [torch.from_numpy(x).to("cuda:0") for x in a]
+    ok = torch.full((n,), 9, dtype=torch.uint8, device="cuda:0")
+    ws = torch.empty(E.rlc_workspace_bytes(n, bits), dtype=torch.uint8, device="cuda:0")
+    accepted = getattr(E, "verify_%s_rlc_dev" % scheme)(*t, ok, ws, window_bits=bits)
+    got = ok.cpu().numpy()
+    expect_accept = kind in ("clean", "malformed")
+    if kind == "torsion" and False:
+        pass
+    diff = int((got != twant).sum())
+    wrong_accept = accepted != expect_accept
+    total += n
+    bad += diff + (1 if wrong_accept else 0)
+    print("round %d: %s n=%d bits=%d %-9s accepted=%d valid=%d/%d%s  (%.0f s)" % (
+        rd, scheme, n, bits, kind, accepted, int(twant.sum()), n,
+        "  DIFFERENT: %d verdicts%s" % (diff, ", acceptance" if wrong_accept else "") if diff or wrong_accept else "",
+        time.time() - t0), flush=True)
+    del ws, ok, t
+print("soak_rlc: %d verdicts compared with the oracle, %d different / wrongly accepted" % (total, bad))
+sys.exit(1 if bad else 0)
