@@ -47,6 +47,7 @@ SYMBOLS = [
     # r05: random-linear-combination fast accept in front of the per-signature kernels
     "dsv_rlc_workspace_bytes", "dsv_verify_single_rlc_dev", "dsv_verify_double_rlc_dev",
     "dsv_verify_vargen_rlc_dev", "dsv_rlc_plan_info",
+    "dsv_verify_single_mont_cols_rlc", "dsv_verify_double_mont_cols_rlc", "dsv_verify_vargen_mont_cols_rlc",
 ]
 _SIZE_T_FUNCS = ("dsv_workspace_bytes", "dsv_mixed_workspace_bytes", "dsv_split_scratch_bytes",
                  "dsv_ext_workspace_bytes", "dsv_wire_workspace_bytes", "dsv_mont_workspace_bytes",

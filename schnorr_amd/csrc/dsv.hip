@@ -169,6 +169,12 @@ struct Context {
   PlanParams plan;                        // chunk plan of a call (host_sync.h; DSV_PIPE_CHUNK_LOG2 / _FIRST_LOG2 / _GROWTH / _PLAN)
   int pipe_slots = 0;                     // DSV_PIPE_SLOTS: chunks in flight per call (<= kPipeSlots); 0 = three
   int norm_per_lane = 0, norm_block = 0;  // DSV_NORM_PER_LANE / DSV_NORM_BLOCK: shape of the pipeline's normalisation kernels
+  // batch fast accept from host memory (dsv_verify_*_mont_cols_rlc): the whole group's normalised inputs,
+  // its verdict bytes and the aggregate's workspace stay resident; one such call at a time per device
+  std::mutex rlc_mu;
+  uint8_t* rlc_arena = nullptr;
+  size_t rlc_arena_bytes = 0;
+  hipStream_t rlc_stream = nullptr;
 };
 Context g_ctx[kMaxDevices];
 std::mutex g_init_mu;               // dsv_init / dsv_shutdown
@@ -534,6 +540,11 @@ void release_context(Context& ctx) {
   }
   destroy_pipe_streams(ctx);
   ctx.pipe_failed = false;
+  if (ctx.rlc_arena) (void)hipFree(ctx.rlc_arena);
+  ctx.rlc_arena = nullptr;
+  ctx.rlc_arena_bytes = 0;
+  if (ctx.rlc_stream) (void)hipStreamDestroy(ctx.rlc_stream);
+  ctx.rlc_stream = nullptr;
 }
 
 }  // namespace
@@ -676,6 +687,7 @@ int dsv_shutdown_device(int device) {
     std::unique_lock<std::mutex> pl(ctx.pipe_sync.mu);
     ctx.pipe_sync.cv.wait(pl, [&] { return ctx.pipe_sync.idle(); });
     pl.unlock();
+    std::lock_guard<std::mutex> rlc(ctx.rlc_mu);  // a fast-accept host call past its pipeline phase finishes first
     std::lock_guard<std::mutex> hold(ctx.mu);
     std::lock_guard<std::mutex> enq(ctx.enq_mu);
     release_context(ctx);
@@ -759,6 +771,8 @@ namespace {
 // stream in front of the verify kernel.  nullptr: not a small batch (or the overlap is off, or no
 // lane could be had) — the verify kernel then builds its tables itself.
 thread_local bool t_pipeline_part = false;  // run_pipelined, several chunks: its four streams are all there is
+thread_local size_t t_chunk_first = 0;      // run_pipelined: first item of the chunk being enqueued (prep / part
+                                            // callbacks that place their output by item number: the fast accept)
 hipEvent_t prep_tables_beside_hash(Context& ctx, const void* PK_uv, const void* R_uv, size_t n,
                                    u32* tables, hipStream_t user) {
   if (!(ctx.quad && ctx.small_overlap && n <= kQuadMaxItems) || t_pipeline_part) return nullptr;
@@ -901,7 +915,7 @@ int rlc_random_key(ChaChaKey& key) {
 // scheme 0 single (R, PK), 1 double (R, R', PK, PK'), 2 var-generator (R, PK, Gen): unused pointers null
 int verify_rlc_on(Context& ctx, int scheme, const void* u, const void* R_uv, const void* Rp_uv, const void* PK_uv,
                   const void* PKp_uv, const void* Gen_uv, const void* m, size_t n, void* ok, void* workspace,
-                  hipStream_t s, int window_bits, int* accepted) {
+                  hipStream_t s, int window_bits, int* accepted, bool have_challenges = false) {
   const uint8_t *pu = (const uint8_t*)u, *pR = (const uint8_t*)R_uv, *pRp = (const uint8_t*)Rp_uv,
                 *pPK = (const uint8_t*)PK_uv, *pPKp = (const uint8_t*)PKp_uv, *pG = (const uint8_t*)Gen_uv,
                 *pm = (const uint8_t*)m;
@@ -914,8 +928,11 @@ int verify_rlc_on(Context& ctx, int scheme, const void* u, const void* R_uv, con
     const RlcCarve cv = carve_rlc(workspace, cnt, plan);
     ChaChaKey key;
     if (int r = rlc_random_key(key)) return r;
-    launch_challenge(scheme == 1, pR + 64 * off, scheme == 1 ? pRp + 64 * off : (const uint8_t*)nullptr, pm + 32 * off,
-                     cnt, cv.w.c, cv.w.valid, s);
+    // (have_challenges: one group whose c / valid are in the workspace already — the host form hashes
+    //  chunk by chunk while the transfers run)
+    if (!have_challenges)
+      launch_challenge(scheme == 1, pR + 64 * off, scheme == 1 ? pRp + 64 * off : (const uint8_t*)nullptr,
+                       pm + 32 * off, cnt, cv.w.c, cv.w.valid, s);
     RlcInputs in = {};
     in.u = pu + 32 * off, in.c = cv.w.c, in.valid = cv.w.valid;
     in.pk[0] = pPK + 64 * off, in.r[0] = pR + 64 * off;
@@ -1440,6 +1457,7 @@ int run_pipelined(Context& ctx, const HostIn (&ins)[NIN], uint8_t* ok, size_t n,
     PipeSlot& slot = pipe.slot[sl];
     Held& h = held[sl];
     const size_t cnt = h.cnt;
+    t_chunk_first = h.first;
     const double t2 = now();
     uint8_t* dev = slot.stage;
     uint8_t* dok = dev + h.ok_off;
@@ -2008,6 +2026,124 @@ int verify_mont_cols(int kind, const dsv_column* cols, size_t n, uint8_t* ok, bo
 }
 }  // namespace
 }  // extern "C++"
+
+// ---- batch fast accept over typed objects in host memory (SURVEY §8(f)-4 at the named entry point) ----
+// The aggregate needs its whole group resident, so this form splits the work differently from
+// verify_mont_host: the pipeline (gather, transfer, normalisation — and the challenge hash, chunk by
+// chunk, in the shadow of the transfers) only FILLS a per-device arena; one aggregate over the arena
+// follows, and only if it fails, the per-signature kernels on what is resident already.  One group
+// (n <= 2^22) on the calling thread's device; anything else takes the ordinary column path.
+extern "C++" {
+namespace {
+struct RlcArena {
+  uint8_t* u;
+  uint8_t* pts[4];
+  uint8_t* ok;
+  uint8_t* ws;
+  size_t bytes;
+};
+RlcArena carve_arena(uint8_t* base, int kind, size_t n) {
+  Stager st(base);
+  RlcArena a = {};
+  a.u = st.take(n * 32);
+  const int np = kind == 0 ? 2 : (kind == 1 ? 4 : 3);
+  for (int k = 0; k < np; k++) a.pts[k] = st.take(n * 64);
+  a.ok = st.take(n);
+  a.ws = st.take(dsv_rlc_workspace_bytes(n, 0));
+  a.bytes = st.off;
+  return a;
+}
+template <size_t NIN>
+int fill_arena(Context& ctx, int kind, const HostIn (&ins)[NIN], size_t n, uint8_t* ok, const RlcArena& a,
+               const Workspace& w) {
+  Context* cp = &ctx;
+  const int np = kind == 0 ? 2 : (kind == 1 ? 4 : 3);
+  return run_pipelined(
+      ctx, ins, ok, n, kMontItemBytes, 0,
+      [=](const void* const* d, size_t cnt, Stager& x, hipStream_t st, Staged& g) {
+        const size_t first = t_chunk_first;
+        NormalizeArgs na = {};
+        for (int k = 0; k < np; k++) {
+          na.in[k] = (const uint8_t*)d[1 + k];
+          na.out[k] = a.pts[k] + first * 64;
+          g.p[1 + k] = na.out[k];
+          g.bytes[1 + k] = 64;
+        }
+        uint8_t* valid = x.take(cnt);
+        uint8_t* cm = x.take(cnt * 32);  // the canonical message: only the hash reads it
+        u32* prefix = reinterpret_cast<u32*>(x.take(normalize_prefix_bytes(cnt, np)));
+        na.u_mont = (const uint8_t*)d[0];
+        na.m_mont = (const uint8_t*)d[1 + np];
+        na.u_out = a.u + first * 32;
+        na.m_out = cm;
+        launch_normalize_uvz(na, np, cnt, valid, prefix, st, cp->norm_per_lane, cp->norm_block);
+        HIP_TRY(hipGetLastError());
+        g.p[0] = na.u_out;
+        g.p[1 + np] = cm;
+        g.bytes[0] = g.bytes[1 + np] = 32;
+        g.valid = valid;
+        return (int)DSV_OK;
+      },
+      [=](const Staged& g, size_t off, size_t cnt, void*, void*, Stager&, hipStream_t st) {
+        const size_t at = t_chunk_first + off;
+        launch_challenge(kind == 1, g.p[1] + 64 * off, kind == 1 ? g.p[2] + 64 * off : (const uint8_t*)nullptr,
+                         g.p[1 + np] + 32 * off, cnt, w.c + 32 * at, w.valid + at, st, g.valid + off);
+        HIP_TRY(hipGetLastError());
+        return (int)DSV_OK;
+      });
+}
+int verify_mont_cols_rlc(int kind, const dsv_column* cols, size_t n, uint8_t* ok, int* accepted) {
+  if (accepted) *accepted = 0;
+  if (int r = check_cols(kind, cols, n, ok)) return r;
+  if (n == 0) return DSV_OK;
+  if (n > kRlcMaxGroup) return verify_mont_cols(kind, cols, n, ok, true);
+  Context* ctxp = nullptr;
+  if (int r = host_context(ctxp)) return r;
+  Context& ctx = *ctxp;
+  DSV_ON_DEVICE(ctx);
+  std::lock_guard<std::mutex> one(ctx.rlc_mu);
+  const size_t need = carve_arena(reinterpret_cast<uint8_t*>((uintptr_t)4096), kind, n).bytes + 256;
+  if (ctx.rlc_arena_bytes < need) {
+    if (ctx.rlc_arena) HIP_TRY(hipFree(ctx.rlc_arena));
+    ctx.rlc_arena = nullptr;
+    ctx.rlc_arena_bytes = 0;
+    HIP_TRY(hipMalloc(&ctx.rlc_arena, need + need / 8));
+    ctx.rlc_arena_bytes = need + need / 8;
+  }
+  if (!ctx.rlc_stream) HIP_TRY(hipStreamCreateWithFlags(&ctx.rlc_stream, hipStreamNonBlocking));
+  const RlcArena a = carve_arena(ctx.rlc_arena, kind, n);
+  const Workspace w = carve(a.ws, n);  // where the aggregate (and the per-signature kernels) expect c / valid
+  auto in = [&](int k, size_t width) {
+    return HostIn{static_cast<const uint8_t*>(cols[k].base), width, cols[k].stride};
+  };
+  int rc;
+  if (kind == 0) {
+    const HostIn ins[4] = {in(0, 32), in(1, 96), in(2, 96), in(3, 32)};
+    rc = fill_arena(ctx, 0, ins, n, ok, a, w);
+  } else if (kind == 1) {
+    const HostIn ins[6] = {in(0, 32), in(1, 96), in(2, 96), in(3, 96), in(4, 96), in(5, 32)};
+    rc = fill_arena(ctx, 1, ins, n, ok, a, w);
+  } else {
+    const HostIn ins[5] = {in(0, 32), in(1, 96), in(2, 96), in(3, 96), in(4, 32)};
+    rc = fill_arena(ctx, 2, ins, n, ok, a, w);
+  }
+  if (rc) return rc;
+  // (run_pipelined returned: every chunk's kernels are done.)  Columns: single u R PK m, double u R R' PK
+  // PK' m, var-generator u R PK Gen m
+  const uint8_t *R = a.pts[0], *Rp = kind == 1 ? a.pts[1] : nullptr, *PK = a.pts[kind == 1 ? 2 : 1],
+                *PKp = kind == 1 ? a.pts[3] : nullptr, *Gen = kind == 2 ? a.pts[2] : nullptr;
+  if (int r = verify_rlc_on(ctx, kind, a.u, R, Rp, PK, PKp, Gen, /*m: hashed already*/ a.u, n, a.ok, a.ws,
+                            ctx.rlc_stream, 0, accepted, true))
+    return r;
+  HIP_TRY(hipMemcpyAsync(ok, a.ok, n, hipMemcpyDeviceToHost, ctx.rlc_stream));
+  HIP_TRY(hipStreamSynchronize(ctx.rlc_stream));
+  return DSV_OK;
+}
+}  // namespace
+}  // extern "C++"
+int dsv_verify_single_mont_cols_rlc(const dsv_column* cols, size_t n, uint8_t* ok, int* accepted) { return verify_mont_cols_rlc(0, cols, n, ok, accepted); }
+int dsv_verify_double_mont_cols_rlc(const dsv_column* cols, size_t n, uint8_t* ok, int* accepted) { return verify_mont_cols_rlc(1, cols, n, ok, accepted); }
+int dsv_verify_vargen_mont_cols_rlc(const dsv_column* cols, size_t n, uint8_t* ok, int* accepted) { return verify_mont_cols_rlc(2, cols, n, ok, accepted); }
 
 size_t dsv_mont_workspace_bytes(size_t n) { return mont_workspace_bytes(n); }
 

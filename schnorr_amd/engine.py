@@ -222,6 +222,26 @@ def verify_mont_cols(scheme, cols):
     return ok
 
 
+def verify_mont_cols_rlc(scheme, cols):
+    """dsv_verify_*_mont_cols_rlc: the same columns through the batch fast accept -> (verdicts, accepted)"""
+    name, widths = _MONT_COLS[scheme]
+    if len(cols) != len(widths):
+        raise ValueError("%s takes %d columns" % (name, len(widths)))
+    n = cols[0].shape[0]
+    arr = (_lib.Column * len(cols))()
+    for k, (c, w) in enumerate(zip(cols, widths)):
+        if c.dtype != np.uint8 or c.ndim != 2 or c.shape != (n, w) or (w > 1 and c.strides[1] != 1) \
+                or c.strides[0] < w:
+            raise ValueError("column %d: expected uint8 [n, %d] rows with contiguous bytes, got %r / strides %r"
+                             % (k, w, c.shape, c.strides))
+        arr[k].base = c.ctypes.data
+        arr[k].stride = c.strides[0]
+    ok = np.zeros(n, dtype=np.uint8)
+    accepted = ctypes.c_int(0)
+    _lib.check(getattr(_lib.load(), name + "_rlc")(arr, ctypes.c_size_t(n), _p(ok), ctypes.byref(accepted)))
+    return ok, bool(accepted.value)
+
+
 class MontColsJob:
     """A batch in flight (dsv_verify_*_mont_cols_submit): `wait()` blocks until the verdicts are
     there and returns them.  Keeps the column arrays alive until then."""

@@ -250,3 +250,35 @@ def test_full_size_batches(engine):
     ok.zero_()
     assert not engine.verify_single_rlc_dev(b["u"], b["R"], b["PK"], b["m"], ok, ws)
     assert torch.equal(ok, b["expected"])
+
+
+@pytest.mark.parametrize("scheme", ["single", "double", "vargen"])
+def test_host_fast_accept_over_typed_objects(engine, scheme):
+    """dsv_verify_*_mont_cols_rlc: records laid out like the Rust structs (Montgomery limbs, projective
+    points with a random z; tests/mont_cases.py) in host memory.  The oracle's verdicts on a tampered
+    batch (per-signature kernels on the resident arena), on its valid items alone (accepted) and on valid
+    + malformed items — z = 0, limbs >= the modulus: verdict 0 by the encoding, out of the sum — (accepted);
+    a one-chunk call and one of several chunks with a ragged tail."""
+    import mont_cases as C
+    cols, want = C.mont_case(scheme, 400, 980 + len(scheme), period=5)
+    assert 0 < want.sum() < len(want)
+    for n in (313, (1 << 16) + (1 << 15) + 77):
+        reps = -(-n // 400)
+        tcols = [np.ascontiguousarray(np.tile(c, (reps, 1))[:n]) for c in cols]
+        got, accepted = engine.verify_mont_cols_rlc(scheme, C.as_records(scheme, tcols)[3])
+        assert not accepted and np.array_equal(got, np.tile(want, reps)[:n]), n
+        keep = np.flatnonzero(want)
+        reps = -(-n // len(keep))
+        vcols = [np.ascontiguousarray(np.tile(c[keep], (reps, 1))[:n]) for c in cols]
+        got, accepted = engine.verify_mont_cols_rlc(scheme, C.as_records(scheme, vcols)[3])
+        assert accepted and got.all(), n
+    # only item 0 tampered (dropped); the planted encodings the Rust types cannot hold stay in
+    cols, want = C.mont_case(scheme, 300, 990 + len(scheme), period=10 ** 9)
+    assert not want[0] and want[1:].sum() == 299 - 2 * (len(cols) - 2) - 2
+    n = (1 << 16) + 5
+    reps = -(-n // 299)
+    mcols = [np.ascontiguousarray(np.tile(c[1:], (reps, 1))[:n]) for c in cols]
+    got, accepted = engine.verify_mont_cols_rlc(scheme, C.as_records(scheme, mcols)[3])
+    assert accepted and np.array_equal(got, np.tile(want[1:], reps)[:n])
+    # the same objects through the ordinary column path: identical verdicts
+    assert np.array_equal(engine.verify_mont_cols(scheme, C.as_records(scheme, mcols)[3]), got)
