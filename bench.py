@@ -276,6 +276,27 @@ def _verify_batch_e2e(E, hu, hR, hPK, hm, expected, cores):
         res["one_shot"] = {"best_ms": res["threads_default"]["best_ms"], "median_ms": res["threads_default"]["median_ms"],
                            "value": res["threads_default"]["value"]}
         res["streamed"] = _e2e_streamed(L, 0, ok, expected, n)
+        # verify_batch_fast (SURVEY §8(f)-4 at the named entry point): the batch's VALID objects alone — the
+        # aggregate decides — and the whole 1/16-tampered batch (aggregate, then the per-signature kernels)
+        if hasattr(L, "vb_e2e_run_fast"):
+            cnt, acc = ctypes.c_size_t(0), ctypes.c_int(0)
+            fast = {}
+            for label, mask in (("all_valid", np.ascontiguousarray(expected)), ("graded_workload", None)):
+                times = []
+                for rep in range(5):
+                    if L.vb_e2e_run_fast(p(mask) if mask is not None else None, p(ok), ctypes.byref(cnt),
+                                         ctypes.byref(acc), ctypes.byref(ms)) != 0:
+                        raise SystemExit("verify_batch_fast: engine error")
+                    want = np.ones(cnt.value, np.uint8) if mask is not None else expected
+                    if (ok[:cnt.value] != want).any() or bool(acc.value) != (mask is not None):
+                        raise SystemExit("verify_batch_fast (%s): verdicts / acceptance differ" % label)
+                    if rep:
+                        times.append(ms.value)
+                times.sort()
+                fast[label] = {"items": int(cnt.value), "best_ms": times[0], "median_ms": times[len(times) // 2],
+                               "value": cnt.value / (times[0] * 1e-3), "accepted_by_aggregate": bool(acc.value)}
+            fast["all_valid"]["vs_verify_batch_one_shot"] = fast["all_valid"]["value"] / res["one_shot"]["value"]
+            res["fast_accept"] = fast
         sub = min(n, 1 << 17)
         conv, tot = ctypes.c_double(0), ctypes.c_double(0)
         if L.vb_e2e_to_bytes_path(ctypes.c_size_t(sub), p(ok), ctypes.byref(conv), ctypes.byref(tot)) != 0:
