@@ -68,6 +68,10 @@ extern "C" {
     fn dsv_verify_double_mont_cols_submit(cols: *const Column, n: usize, ok: *mut u8, job: *mut *mut c_void) -> c_int;
     fn dsv_verify_vargen_mont_cols_submit(cols: *const Column, n: usize, ok: *mut u8, job: *mut *mut c_void) -> c_int;
     fn dsv_job_wait(job: *mut c_void) -> c_int;
+    // batch fast accept (include/dsv.h): same verdicts, one aggregate decides "all true"
+    fn dsv_verify_single_mont_cols_rlc(cols: *const Column, n: usize, ok: *mut u8, accepted: *mut c_int) -> c_int;
+    fn dsv_verify_double_mont_cols_rlc(cols: *const Column, n: usize, ok: *mut u8, accepted: *mut c_int) -> c_int;
+    fn dsv_verify_vargen_mont_cols_rlc(cols: *const Column, n: usize, ok: *mut u8, accepted: *mut c_int) -> c_int;
 }
 
 /// Engine failure (no GPU, HIP error).  Never a verdict.
@@ -215,6 +219,81 @@ pub fn try_verify_batch_var_gen(sigs: &[SignatureVarGen], pks: &[PublicKeyVarGen
         check(unsafe { dsv_verify_vargen_mont_cols(soa.cols().as_ptr(), n, ok.as_mut_ptr()) })?;
     }
     Ok(verdicts(ok))
+}
+
+/// For batches expected to be ENTIRELY valid (a block's signatures): the same verdicts as
+/// [`verify_batch`], through one random-linear-combination aggregate over the whole batch (<= 2^22
+/// items) when every item is valid — about twice as fast — and through the per-signature kernels
+/// otherwise (a batch that fails has paid for both).  The second value says whether the aggregate
+/// decided.  The aggregate also proves every key and nonce point to be of prime order, so it is exact
+/// on the reference's cofactorless equation; its error probability (accepting a batch that holds a
+/// wrong signature) is <= 2^-112, the weights come from `getrandom` per call.
+pub fn verify_batch_fast(sigs: &[Signature], pks: &[PublicKey], msgs: &[BlsScalar]) -> (Vec<bool>, bool) {
+    try_verify_batch_fast(sigs, pks, msgs).expect("dusk-schnorr-gpu: engine failure")
+}
+pub fn try_verify_batch_fast(sigs: &[Signature], pks: &[PublicKey], msgs: &[BlsScalar])
+    -> Result<(Vec<bool>, bool), EngineError> {
+    assert!(sigs.len() == pks.len() && sigs.len() == msgs.len());
+    let n = sigs.len();
+    if n == 0 {
+        return Ok((Vec::new(), false));
+    }
+    init_all()?;
+    let mut ok = vec![0u8; n];
+    let mut accepted: c_int = 0;
+    if layout_ok() {
+        let cols = [col(sigs[0].u(), sigs), col(sigs[0].R(), sigs), col(pks[0].as_ref(), pks),
+                    col(&msgs[0], msgs)];
+        check(unsafe { dsv_verify_single_mont_cols_rlc(cols.as_ptr(), n, ok.as_mut_ptr(), &mut accepted) })?;
+    } else {
+        let soa = fallback::Soa::gather(n, |i| sigs[i].u(), |i| [sigs[i].R(), pks[i].as_ref()], |i| &msgs[i]);
+        check(unsafe { dsv_verify_single_mont_cols_rlc(soa.cols().as_ptr(), n, ok.as_mut_ptr(), &mut accepted) })?;
+    }
+    Ok((verdicts(ok), accepted == 1))
+}
+/// ... `PublicKeyDouble::verify`
+pub fn try_verify_batch_double_fast(sigs: &[SignatureDouble], pks: &[PublicKeyDouble], msgs: &[BlsScalar])
+    -> Result<(Vec<bool>, bool), EngineError> {
+    assert!(sigs.len() == pks.len() && sigs.len() == msgs.len());
+    let n = sigs.len();
+    if n == 0 {
+        return Ok((Vec::new(), false));
+    }
+    init_all()?;
+    let mut ok = vec![0u8; n];
+    let mut accepted: c_int = 0;
+    if layout_ok() {
+        let cols = [col(sigs[0].u(), sigs), col(sigs[0].R(), sigs), col(sigs[0].R_prime(), sigs),
+                    col(pks[0].pk(), pks), col(pks[0].pk_prime(), pks), col(&msgs[0], msgs)];
+        check(unsafe { dsv_verify_double_mont_cols_rlc(cols.as_ptr(), n, ok.as_mut_ptr(), &mut accepted) })?;
+    } else {
+        let soa = fallback::Soa::gather(n, |i| sigs[i].u(),
+            |i| [sigs[i].R(), sigs[i].R_prime(), pks[i].pk(), pks[i].pk_prime()], |i| &msgs[i]);
+        check(unsafe { dsv_verify_double_mont_cols_rlc(soa.cols().as_ptr(), n, ok.as_mut_ptr(), &mut accepted) })?;
+    }
+    Ok((verdicts(ok), accepted == 1))
+}
+/// ... `PublicKeyVarGen::verify`
+pub fn try_verify_batch_var_gen_fast(sigs: &[SignatureVarGen], pks: &[PublicKeyVarGen], msgs: &[BlsScalar])
+    -> Result<(Vec<bool>, bool), EngineError> {
+    assert!(sigs.len() == pks.len() && sigs.len() == msgs.len());
+    let n = sigs.len();
+    if n == 0 {
+        return Ok((Vec::new(), false));
+    }
+    init_all()?;
+    let mut ok = vec![0u8; n];
+    let mut accepted: c_int = 0;
+    if layout_ok() {
+        let cols = [col(sigs[0].u(), sigs), col(sigs[0].R(), sigs), col(pks[0].public_key(), pks),
+                    col(pks[0].generator(), pks), col(&msgs[0], msgs)];
+        check(unsafe { dsv_verify_vargen_mont_cols_rlc(cols.as_ptr(), n, ok.as_mut_ptr(), &mut accepted) })?;
+    } else {
+        let soa = fallback::Soa::gather(n, |i| sigs[i].u(),
+            |i| [sigs[i].R(), pks[i].public_key(), pks[i].generator()], |i| &msgs[i]);
+        check(unsafe { dsv_verify_vargen_mont_cols_rlc(soa.cols().as_ptr(), n, ok.as_mut_ptr(), &mut accepted) })?;
+    }
+    Ok((verdicts(ok), accepted == 1))
 }
 
 /// A batch in flight.  Borrows the slices it was started from (the engine reads the objects in place
@@ -410,6 +489,14 @@ mod tests {
             assert_eq!(gpu[i], pks[i].verify(&sigs[i], msgs[i]), "item {i}");
         }
         assert!(!gpu[3] && !gpu[4] && gpu[5]);
+        // the fast accept: same verdicts, decided item by item (two wrong keys) ...
+        let (fast, accepted) = verify_batch_fast(&sigs, &pks, &msgs);
+        assert!(fast == gpu && !accepted);
+        // ... and by the aggregate once the keys are back in place
+        pks.swap(3, 4);
+        let (fast, accepted) = verify_batch_fast(&sigs, &pks, &msgs);
+        assert!(accepted && fast.iter().all(|&b| b));
+        pks.swap(3, 4);
         // the layout-agnostic path gives the same verdicts
         let soa = fallback::Soa::gather(sigs.len(), |i| sigs[i].u(),
                                         |i| [sigs[i].R(), pks[i].as_ref()], |i| &msgs[i]);
