@@ -938,8 +938,7 @@ int verify_rlc_on(Context& ctx, int scheme, const void* u, const void* R_uv, con
     in.pk[0] = pPK + 64 * off, in.r[0] = pR + 64 * off;
     if (scheme == 1) in.pk[1] = pPKp + 64 * off, in.r[1] = pRp + 64 * off;
     if (scheme == 2) in.gen = pG + 64 * off;
-    launch_rlc(scheme, plan, cv.b, in, key, ctx.table[0], ctx.table[1], pok + off, s);
-    HIP_TRY(hipGetLastError());
+    HIP_TRY(launch_rlc(scheme, plan, cv.b, in, key, ctx.table[0], ctx.table[1], pok + off, s));
     u32 flags[4] = {~0u, 0, 0, 0};
     HIP_TRY(hipMemcpyAsync(flags, cv.b.flags, sizeof flags, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));

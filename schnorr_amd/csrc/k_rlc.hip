@@ -369,6 +369,10 @@ k_rlc_accumulate(const u32* __restrict__ order, const u32* __restrict__ start, c
   if (b >= p.buckets) return;  // (cannot happen: the sort moves what k_rlc_counts wrote)
   u32 lo = 0, hi = 0;
   if (b & ((1u << p.c) - 1u)) lo = start[b], hi = start[b + 1];
+  // (a sort that failed leaves anything in `start`: never read outside the pair arrays; the aggregate
+  //  then simply does not come out as the identity)
+  if (hi > p.entries) hi = (u32)p.entries;
+  if (lo > hi) lo = hi;
   const u32 last_pt = (u32)(p.lpts + p.spts) * p.n - 1u;
   Ext acc = ext_identity();
   if (lo < hi) {
@@ -602,9 +606,10 @@ size_t rlc_sort_temp_bytes(const RlcPlan& p) {
   return bytes > bytes2 ? bytes : bytes2;
 }
 
-void launch_rlc(int scheme, const RlcPlan& p, const RlcBuffers& b, const RlcInputs& in, ChaChaKey key,
-                const uint32_t* tableG, const uint32_t* tableG2, uint8_t* ok, hipStream_t s) {
-  (void)hipMemsetAsync(b.flags, 0, 16, s);
+hipError_t launch_rlc(int scheme, const RlcPlan& p, const RlcBuffers& b, const RlcInputs& in, ChaChaKey key,
+                      const uint32_t* tableG, const uint32_t* tableG2, uint8_t* ok, hipStream_t s) {
+  hipError_t err = hipMemsetAsync(b.flags, 0, 16, s);
+  if (err != hipSuccess) return err;
   const dim3 grid(grid_for(p.n)), block(256);
   if (scheme == 0)
     hipLaunchKernelGGL(k_rlc_prep<0>, grid, block, 0, s, in, key, p, ok, b.pts, b.fsc, b.keys[0], b.vals[0], b.flags);
@@ -617,13 +622,15 @@ void launch_rlc(int scheme, const RlcPlan& p, const RlcBuffers& b, const RlcInpu
     hipLaunchKernelGGL(k_rlc_fsum, dim3(1), dim3(256), 0, s, b.fpart, (size_t)kRlcFsumBlocks, b.fsum + 8 * k);
   }
   size_t temp = b.sort_temp_bytes;
-  (void)hipcub::DeviceRadixSort::SortPairs(b.sort_temp, temp, b.keys[0], b.keys[1], b.vals[0], b.vals[1], p.entries, 0,
+  err = hipcub::DeviceRadixSort::SortPairs(b.sort_temp, temp, b.keys[0], b.keys[1], b.vals[0], b.vals[1], p.entries, 0,
                                            p.key_bits, s);
+  if (err != hipSuccess) return err;
   hipLaunchKernelGGL(k_rlc_starts, dim3(grid_for(p.entries + 1)), dim3(256), 0, s, b.keys[1], p, b.start);
   hipLaunchKernelGGL(k_rlc_counts, dim3(grid_for(p.buckets)), dim3(256), 0, s, b.start, p, b.cnt[0], b.order[0]);
   temp = b.sort_temp_bytes;
-  (void)hipcub::DeviceRadixSort::SortPairsDescending(b.sort_temp, temp, b.cnt[0], b.cnt[1], b.order[0], b.order[1],
+  err = hipcub::DeviceRadixSort::SortPairsDescending(b.sort_temp, temp, b.cnt[0], b.cnt[1], b.order[0], b.order[1],
                                                      p.buckets, 0, 8, s);
+  if (err != hipSuccess) return err;
   hipLaunchKernelGGL(k_rlc_accumulate, dim3(grid_for(p.buckets, 64)), dim3(64), 0, s, b.order[1], b.start, b.vals[1],
                      b.pts, p, b.buckets);
   const unsigned side = 1u << p.half;
@@ -634,6 +641,7 @@ void launch_rlc(int scheme, const RlcPlan& p, const RlcBuffers& b, const RlcInpu
   const unsigned lanes = (unsigned)p.windows * p.c, g = (lanes + 63) / 64;
   hipLaunchKernelGGL(k_rlc_scale, dim3(2 * g + 1), dim3(256), 0, s, b.tmp[1], b.fsum, tableG, tableG2, p, b.tmp[0], b.flags);
   hipLaunchKernelGGL(k_rlc_final, dim3(1), dim3(64), 0, s, b.tmp[0], p, b.flags);
+  return hipGetLastError();
 }
 
 }  // namespace dsv

@@ -83,8 +83,9 @@ inline size_t rlc_tmp_points(const RlcPlan& p, int k) {
   return a > b ? a : b;
 }
 size_t rlc_sort_temp_bytes(const RlcPlan& p);
-// hash output c / valid of the group in, ok[i] = "item i is well-formed" and flags out; never synchronises
-void launch_rlc(int scheme, const RlcPlan& p, const RlcBuffers& b, const RlcInputs& in, ChaChaKey key,
+// hash output c / valid of the group in, ok[i] = "item i is well-formed" and flags out; never synchronises;
+// returns the first error of a launch or of the sorts
+hipError_t launch_rlc(int scheme, const RlcPlan& p, const RlcBuffers& b, const RlcInputs& in, ChaChaKey key,
                 const uint32_t* tableG, const uint32_t* tableG2, uint8_t* ok, hipStream_t s);
 
 }  // namespace dsv

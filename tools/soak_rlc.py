@@ -11,6 +11,9 @@ the group logic see ragged sizes), explicit or automatic window bits, and one of
   torsion    an order-8 / order-4 / order-2 component added to one random point (the signature may
              stay valid under the reference's cofactorless equation or not) -> must NOT be accepted
   malformed  non-canonical encodings only            -> accepted, those items 0
+Every fourth round runs the TYPED-OBJECT form instead (dsv_verify_*_mont_cols_rlc over records laid out like the
+Rust structs, Montgomery limbs, random z, planted encodings the types cannot hold: tests/mont_cases.py):
+tampered -> not accepted; its valid + malformed items alone -> accepted.
 Verdicts always equal the oracle's (the oracle is test infrastructure; nothing here is timed)."""
 import os
 import sys
@@ -24,6 +27,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 import torch  # noqa: E402
 
 import harness as H  # noqa: E402
+import mont_cases as C  # noqa: E402
 import oracle_lib as O  # noqa: E402
 import pymodel as M  # noqa: E402
 import test_halfgcd as TH  # noqa: E402
@@ -41,6 +45,36 @@ t0 = time.time()
 for rd in range(rounds):
     scheme = ("single", "double", "vargen")[int(rng.integers(0, 3))]
     n = int(SIZES[int(rng.integers(0, len(SIZES)))])
+    if rd % 4 == 3:
+        cols, want = C.mont_case(scheme, 300, int(rng.integers(1, 1 << 30)), period=int(rng.integers(4, 40)))
+        tamper_free = bool(rng.integers(0, 2))
+        if tamper_free:   # keep the valid items and the planted malformed ones (verdict 0 by the encoding)
+            bad_enc = np.zeros(300, bool)   # items whose verdict is 0 by their encoding alone
+            for k, c in enumerate(cols):
+                width = c.shape[1]
+                for j in range(0, width, 32):
+                    mod = C.R_ORDER if k == 0 else C.Q
+                    vals = [int.from_bytes(bytes(row[j:j + 32]), "little") for row in c]
+                    bad_enc |= np.array([v >= mod for v in vals])
+                if 0 < k < len(cols) - 1:
+                    bad_enc |= np.array([not any(row[64:96]) for row in c])
+            keep = (want == 1) | bad_enc
+            cols = [c[keep] for c in cols]
+            want = want[keep]
+        base = len(want)
+        reps = -(-n // base)
+        tcols = [np.ascontiguousarray(np.tile(c, (reps, 1))[:n]) for c in cols]
+        twant = np.tile(want, reps)[:n]
+        got, accepted = E.verify_mont_cols_rlc(scheme, C.as_records(scheme, tcols)[3])
+        diff = int((got != twant).sum())
+        wrong_accept = accepted != tamper_free
+        total += n
+        bad += diff + (1 if wrong_accept else 0)
+        print("round %d: %s n=%d typed objects %-9s accepted=%d valid=%d/%d%s  (%.0f s)" % (
+            rd, scheme, n, "clean+enc" if tamper_free else "tampered", accepted, int(twant.sum()), n,
+            "  DIFFERENT: %d verdicts%s" % (diff, ", acceptance" if wrong_accept else "") if diff or wrong_accept else "",
+            time.time() - t0), flush=True)
+        continue
     bits = int((0, 0, 0, 4, 6, 8, 12, 14, 16)[int(rng.integers(0, 9))])
     if bits and bits < 8 and n > 5000:
         bits = 8
@@ -83,8 +117,6 @@ for rd in range(rounds):
     accepted = getattr(E, "verify_%s_rlc_dev" % scheme)(*t, ok, ws, window_bits=bits)
     got = ok.cpu().numpy()
     expect_accept = kind in ("clean", "malformed")
-    if kind == "torsion" and False:
-        pass
     diff = int((got != twant).sum())
     wrong_accept = accepted != expect_accept
     total += n
