@@ -196,9 +196,11 @@ int dsv_verify_vargen_mont_cols(const dsv_column *cols /*[5]*/, size_t n, uint8_
 /* ... with the batch fast accept (dsv_verify_*_rlc_dev below: same verdicts; ONE aggregate test decides
  * "all true", anything else is decided by the per-signature kernels): the pipeline only fills a
  * per-device arena — gather, transfer, normalisation and the challenge hash chunk by chunk while the
- * transfers run — then the aggregate runs over the resident group.  One group (n <= 2^22) on the
- * calling thread's device, one such call at a time per device; larger batches take the ordinary
- * column path.  *accepted (may be NULL): 1 = the aggregate decided. */
+ * transfers run — then the aggregate runs over the resident group.  With several devices initialised
+ * and >= 2^17 items per device the batch is sharded like the *_multi forms, one group (one aggregate)
+ * per device; else one group (n <= 2^22) on the calling thread's device; larger batches take the
+ * ordinary column path.  One such call at a time per device.  *accepted (may be NULL): 1 = every
+ * group's aggregate decided. */
 int dsv_verify_single_mont_cols_rlc(const dsv_column *cols /*[4]*/, size_t n, uint8_t *ok, int *accepted);
 int dsv_verify_double_mont_cols_rlc(const dsv_column *cols /*[6]*/, size_t n, uint8_t *ok, int *accepted);
 int dsv_verify_vargen_mont_cols_rlc(const dsv_column *cols /*[5]*/, size_t n, uint8_t *ok, int *accepted);

@@ -2091,16 +2091,13 @@ int fill_arena(Context& ctx, int kind, const HostIn (&ins)[NIN], size_t n, uint8
         return (int)DSV_OK;
       });
 }
-int verify_mont_cols_rlc(int kind, const dsv_column* cols, size_t n, uint8_t* ok, int* accepted) {
-  if (accepted) *accepted = 0;
-  if (int r = check_cols(kind, cols, n, ok)) return r;
-  if (n == 0) return DSV_OK;
-  if (n > kRlcMaxGroup) return verify_mont_cols(kind, cols, n, ok, true);
-  Context* ctxp = nullptr;
-  if (int r = host_context(ctxp)) return r;
-  Context& ctx = *ctxp;
+// one shard [off, off + cnt) on one device: ONE group, cnt <= kRlcMaxGroup
+int verify_mont_cols_rlc_shard(Context& ctx, int kind, const dsv_column* cols, size_t off, size_t n, uint8_t* ok,
+                               int* accepted) {
   DSV_ON_DEVICE(ctx);
   std::lock_guard<std::mutex> one(ctx.rlc_mu);
+  if (!ctx.ready.load(std::memory_order_acquire))
+    return fail(DSV_ERR_NOT_INITIALIZED, "device %d was shut down", ctx.device);
   const size_t need = carve_arena(reinterpret_cast<uint8_t*>((uintptr_t)4096), kind, n).bytes + 256;
   if (ctx.rlc_arena_bytes < need) {
     if (ctx.rlc_arena) HIP_TRY(hipFree(ctx.rlc_arena));
@@ -2113,18 +2110,18 @@ int verify_mont_cols_rlc(int kind, const dsv_column* cols, size_t n, uint8_t* ok
   const RlcArena a = carve_arena(ctx.rlc_arena, kind, n);
   const Workspace w = carve(a.ws, n);  // where the aggregate (and the per-signature kernels) expect c / valid
   auto in = [&](int k, size_t width) {
-    return HostIn{static_cast<const uint8_t*>(cols[k].base), width, cols[k].stride};
+    return HostIn{static_cast<const uint8_t*>(cols[k].base) + off * cols[k].stride, width, cols[k].stride};
   };
   int rc;
   if (kind == 0) {
     const HostIn ins[4] = {in(0, 32), in(1, 96), in(2, 96), in(3, 32)};
-    rc = fill_arena(ctx, 0, ins, n, ok, a, w);
+    rc = fill_arena(ctx, 0, ins, n, ok + off, a, w);
   } else if (kind == 1) {
     const HostIn ins[6] = {in(0, 32), in(1, 96), in(2, 96), in(3, 96), in(4, 96), in(5, 32)};
-    rc = fill_arena(ctx, 1, ins, n, ok, a, w);
+    rc = fill_arena(ctx, 1, ins, n, ok + off, a, w);
   } else {
     const HostIn ins[5] = {in(0, 32), in(1, 96), in(2, 96), in(3, 96), in(4, 32)};
-    rc = fill_arena(ctx, 2, ins, n, ok, a, w);
+    rc = fill_arena(ctx, 2, ins, n, ok + off, a, w);
   }
   if (rc) return rc;
   // (run_pipelined returned: every chunk's kernels are done.)  Columns: single u R PK m, double u R R' PK
@@ -2134,9 +2131,35 @@ int verify_mont_cols_rlc(int kind, const dsv_column* cols, size_t n, uint8_t* ok
   if (int r = verify_rlc_on(ctx, kind, a.u, R, Rp, PK, PKp, Gen, /*m: hashed already*/ a.u, n, a.ok, a.ws,
                             ctx.rlc_stream, 0, accepted, true))
     return r;
-  HIP_TRY(hipMemcpyAsync(ok, a.ok, n, hipMemcpyDeviceToHost, ctx.rlc_stream));
+  HIP_TRY(hipMemcpyAsync(ok + off, a.ok, n, hipMemcpyDeviceToHost, ctx.rlc_stream));
   HIP_TRY(hipStreamSynchronize(ctx.rlc_stream));
   return DSV_OK;
+}
+// Shards like the *_multi forms: one group per initialised device (each with its own aggregate; all of
+// them must accept), as long as every shard is one group of a useful size; else one group on the calling
+// thread's device, or — beyond 2^22 items — the ordinary column path.
+int verify_mont_cols_rlc(int kind, const dsv_column* cols, size_t n, uint8_t* ok, int* accepted) {
+  if (accepted) *accepted = 0;
+  if (int r = check_cols(kind, cols, n, ok)) return r;
+  if (n == 0) return DSV_OK;
+  int nd = 0;
+  for (int d = 0; d < kMaxDevices; d++) nd += g_ctx[d].ready.load(std::memory_order_acquire) ? 1 : 0;
+  if (const char* e = getenv("DSV_MULTI_SHARDS")) nd = atoi(e) > nd ? atoi(e) : nd;  // (run_multi's rehearsal knob)
+  if (nd > 1 && n >= (size_t)nd << 17 && (n + nd - 1) / nd <= kRlcMaxGroup) {
+    std::atomic<int> rejected{0};
+    const int rc = run_multi(n, [&, kind, cols, ok](Context& ctx, size_t off, size_t cnt) {
+      int acc = 0;
+      const int r = verify_mont_cols_rlc_shard(ctx, kind, cols, off, cnt, ok, &acc);
+      if (!acc) rejected.fetch_add(1);
+      return r;
+    });
+    if (rc == DSV_OK && accepted) *accepted = rejected.load() == 0 ? 1 : 0;
+    return rc;
+  }
+  if (n > kRlcMaxGroup) return verify_mont_cols(kind, cols, n, ok, true);
+  Context* ctxp = nullptr;
+  if (int r = host_context(ctxp)) return r;
+  return verify_mont_cols_rlc_shard(*ctxp, kind, cols, 0, n, ok, accepted);
 }
 }  // namespace
 }  // extern "C++"

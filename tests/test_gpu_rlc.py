@@ -282,3 +282,25 @@ def test_host_fast_accept_over_typed_objects(engine, scheme):
     assert accepted and np.array_equal(got, np.tile(want[1:], reps)[:n])
     # the same objects through the ordinary column path: identical verdicts
     assert np.array_equal(engine.verify_mont_cols(scheme, C.as_records(scheme, mcols)[3]), got)
+
+
+def test_host_fast_accept_shards_like_the_multi_forms(engine, monkeypatch):
+    """DSV_MULTI_SHARDS=3 on one GPU: three shards, each ONE group with its own aggregate (they take the
+    device's arena in turn); accepted only if every shard's aggregate accepted."""
+    import mont_cases as C
+    cols, want = C.mont_case("single", 300, 1001, period=10 ** 9)   # item 0 tampered, planted encodings
+    n = 3 * (1 << 17) + 11
+    reps = -(-n // 299)
+    good = [np.ascontiguousarray(np.tile(c[1:], (reps, 1))[:n]) for c in cols]
+    gwant = np.tile(want[1:], reps)[:n]
+    monkeypatch.setenv("DSV_MULTI_SHARDS", "3")
+    got, accepted = engine.verify_mont_cols_rlc("single", C.as_records("single", good)[3])
+    assert accepted and np.array_equal(got, gwant)
+    bad = [c.copy() for c in good]
+    victim = n - 5                                   # in the last shard only
+    assert gwant[victim]
+    bad[0][victim] = good[0][victim - 1]             # another item's u
+    bwant = gwant.copy()
+    bwant[victim] = 0
+    got, accepted = engine.verify_mont_cols_rlc("single", C.as_records("single", bad)[3])
+    assert not accepted and np.array_equal(got, bwant)
