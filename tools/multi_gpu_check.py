@@ -140,6 +140,17 @@ def main():
     dt = time.perf_counter() - t0
     step("5. two batches in flight over %d device(s)" % ngpu, all(np.array_equal(o, want) for o in outs),
          "%.2f ms for both = %.1f M/s" % (dt * 1e3, 2 * n / dt / 1e6))
+
+    # ---- 5b. the batch fast accept, one aggregate per device (the batch holds tampered items: every shard
+    # falls back to its per-signature kernels; then the valid items alone: every shard's aggregate accepts)
+    got, accepted = E.verify_mont_cols_rlc("single", mont)
+    step("5b. dsv_verify_single_mont_cols_rlc over %d device(s), tampered batch" % ngpu,
+         np.array_equal(got, want) and not accepted, "accepted=%d" % accepted)
+    keep = np.flatnonzero(want)
+    valid_cols = [np.ascontiguousarray(c[keep]) for c in mont]
+    t, (got, accepted) = best(lambda: E.verify_mont_cols_rlc("single", valid_cols))
+    step("5b. ... valid items alone", bool(got.all()) and accepted,
+         "%d items, %.2f ms = %.1f M/s, accepted=%d" % (len(keep), t * 1e3, len(keep) / t / 1e6, accepted))
     del b
 
     # ---- 6. one process per GPU over RCCL
