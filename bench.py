@@ -769,6 +769,19 @@ def main():
                 raise SystemExit("rlc (%s): verdicts / acceptance differ from the expected pattern" % label)
             rlc[label] = {"value": n * reps / t_, "ms_per_call": t_ / reps * 1e3, "accepted_by_aggregate": label == "all_valid",
                           "vs_per_signature": (n * reps / t_) / value}
+        # the other two schemes at their configuration sizes, all-valid batches
+        for label, gen_, cols_, fn_, n_, ref_ in (
+                ("double_all_valid", W.gen_double, ("u", "R", "Rp", "PK", "PKp", "m"), E.verify_double_rlc_dev, n, out["double"]["value"]),
+                ("vargen_all_valid", W.gen_vargen, ("u", "R", "PK", "Gen", "m"), E.verify_vargen_rlc_dev, nv, out["vargen"]["value"])):
+            b_ = gen_(n_, seed=99, device=dev, tamper=False)
+            acc = []
+            f_ = lambda: acc.append(fn_(*[b_[k] for k in cols_], okr[:n_], wsr))
+            t_ = timed(f_, reps, 1)
+            if not bool(okr[:n_].all()) or not all(acc):
+                raise SystemExit("rlc (%s): not accepted" % label)
+            rlc[label] = {"items": n_, "value": n_ * reps / t_, "ms_per_call": t_ / reps * 1e3,
+                          "vs_per_signature": (n_ * reps / t_) / ref_}
+            del b_
         out["rlc"] = rlc
         del wsr, okr
 

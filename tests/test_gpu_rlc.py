@@ -304,3 +304,22 @@ def test_host_fast_accept_shards_like_the_multi_forms(engine, monkeypatch):
     bwant[victim] = 0
     got, accepted = engine.verify_mont_cols_rlc("single", C.as_records("single", bad)[3])
     assert not accepted and np.array_equal(got, bwant)
+
+
+def test_more_than_one_group(engine):
+    """2^22 + 777 signatures: two groups (the second one tiny), each with its own aggregate and weights.
+    All valid -> accepted; one wrong signature in the second group -> only that group falls back, the
+    verdicts are the construction-time pattern either way."""
+    from schnorr_amd import workload as W
+    n = (1 << 22) + 777
+    b = W.gen_single(n, seed=5, tamper=False)
+    ws = torch.empty(engine.rlc_workspace_bytes(n), dtype=torch.uint8, device=DEV)
+    ok = torch.zeros(n, dtype=torch.uint8, device=DEV)
+    assert engine.verify_single_rlc_dev(b["u"], b["R"], b["PK"], b["m"], ok, ws)
+    assert bool(ok.all())
+    b["u"][n - 3] = b["u"][n - 4]
+    ok.zero_()
+    assert not engine.verify_single_rlc_dev(b["u"], b["R"], b["PK"], b["m"], ok, ws)
+    want = torch.ones(n, dtype=torch.uint8, device=DEV)
+    want[n - 3] = 0
+    assert torch.equal(ok, want)
