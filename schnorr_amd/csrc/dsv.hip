@@ -170,11 +170,15 @@ struct Context {
   int pipe_slots = 0;                     // DSV_PIPE_SLOTS: chunks in flight per call (<= kPipeSlots); 0 = three
   int norm_per_lane = 0, norm_block = 0;  // DSV_NORM_PER_LANE / DSV_NORM_BLOCK: shape of the pipeline's normalisation kernels
   // batch fast accept from host memory (dsv_verify_*_mont_cols_rlc): the whole group's normalised inputs,
-  // its verdict bytes and the aggregate's workspace stay resident; one such call at a time per device
-  std::mutex rlc_mu;
-  uint8_t* rlc_arena = nullptr;
-  size_t rlc_arena_bytes = 0;
-  hipStream_t rlc_stream = nullptr;
+  // its verdict bytes and the aggregate's workspace stay resident in an arena for the duration of a
+  // call.  Two arenas per device: while one call's aggregate runs (a latency-bound tail on a stream of
+  // its own), the next call's pipeline already fills the other
+  struct RlcHostArena {
+    std::mutex mu;
+    uint8_t* dev = nullptr;
+    size_t bytes = 0;
+    hipStream_t stream = nullptr;
+  } rlc_arenas[2];
 };
 Context g_ctx[kMaxDevices];
 std::mutex g_init_mu;               // dsv_init / dsv_shutdown
@@ -540,11 +544,13 @@ void release_context(Context& ctx) {
   }
   destroy_pipe_streams(ctx);
   ctx.pipe_failed = false;
-  if (ctx.rlc_arena) (void)hipFree(ctx.rlc_arena);
-  ctx.rlc_arena = nullptr;
-  ctx.rlc_arena_bytes = 0;
-  if (ctx.rlc_stream) (void)hipStreamDestroy(ctx.rlc_stream);
-  ctx.rlc_stream = nullptr;
+  for (auto& ar : ctx.rlc_arenas) {
+    if (ar.dev) (void)hipFree(ar.dev);
+    ar.dev = nullptr;
+    ar.bytes = 0;
+    if (ar.stream) (void)hipStreamDestroy(ar.stream);
+    ar.stream = nullptr;
+  }
 }
 
 }  // namespace
@@ -687,7 +693,8 @@ int dsv_shutdown_device(int device) {
     std::unique_lock<std::mutex> pl(ctx.pipe_sync.mu);
     ctx.pipe_sync.cv.wait(pl, [&] { return ctx.pipe_sync.idle(); });
     pl.unlock();
-    std::lock_guard<std::mutex> rlc(ctx.rlc_mu);  // a fast-accept host call past its pipeline phase finishes first
+    // fast-accept host calls past their pipeline phase finish first
+    std::lock_guard<std::mutex> rlc0(ctx.rlc_arenas[0].mu), rlc1(ctx.rlc_arenas[1].mu);
     std::lock_guard<std::mutex> hold(ctx.mu);
     std::lock_guard<std::mutex> enq(ctx.enq_mu);
     release_context(ctx);
@@ -2095,19 +2102,30 @@ int fill_arena(Context& ctx, int kind, const HostIn (&ins)[NIN], size_t n, uint8
 int verify_mont_cols_rlc_shard(Context& ctx, int kind, const dsv_column* cols, size_t off, size_t n, uint8_t* ok,
                                int* accepted) {
   DSV_ON_DEVICE(ctx);
-  std::lock_guard<std::mutex> one(ctx.rlc_mu);
+  // whichever arena is free; both busy: wait for the first
+  std::unique_lock<std::mutex> own(ctx.rlc_arenas[0].mu, std::try_to_lock);
+  int which = 0;
+  if (!own.owns_lock()) {
+    own = std::unique_lock<std::mutex>(ctx.rlc_arenas[1].mu, std::try_to_lock);
+    which = 1;
+    if (!own.owns_lock()) {
+      own = std::unique_lock<std::mutex>(ctx.rlc_arenas[0].mu);
+      which = 0;
+    }
+  }
+  Context::RlcHostArena& ar = ctx.rlc_arenas[which];
   if (!ctx.ready.load(std::memory_order_acquire))
     return fail(DSV_ERR_NOT_INITIALIZED, "device %d was shut down", ctx.device);
   const size_t need = carve_arena(reinterpret_cast<uint8_t*>((uintptr_t)4096), kind, n).bytes + 256;
-  if (ctx.rlc_arena_bytes < need) {
-    if (ctx.rlc_arena) HIP_TRY(hipFree(ctx.rlc_arena));
-    ctx.rlc_arena = nullptr;
-    ctx.rlc_arena_bytes = 0;
-    HIP_TRY(hipMalloc(&ctx.rlc_arena, need + need / 8));
-    ctx.rlc_arena_bytes = need + need / 8;
+  if (ar.bytes < need) {
+    if (ar.dev) HIP_TRY(hipFree(ar.dev));
+    ar.dev = nullptr;
+    ar.bytes = 0;
+    HIP_TRY(hipMalloc(&ar.dev, need + need / 8));
+    ar.bytes = need + need / 8;
   }
-  if (!ctx.rlc_stream) HIP_TRY(hipStreamCreateWithFlags(&ctx.rlc_stream, hipStreamNonBlocking));
-  const RlcArena a = carve_arena(ctx.rlc_arena, kind, n);
+  if (!ar.stream) HIP_TRY(hipStreamCreateWithFlags(&ar.stream, hipStreamNonBlocking));
+  const RlcArena a = carve_arena(ar.dev, kind, n);
   const Workspace w = carve(a.ws, n);  // where the aggregate (and the per-signature kernels) expect c / valid
   auto in = [&](int k, size_t width) {
     return HostIn{static_cast<const uint8_t*>(cols[k].base) + off * cols[k].stride, width, cols[k].stride};
@@ -2129,10 +2147,10 @@ int verify_mont_cols_rlc_shard(Context& ctx, int kind, const dsv_column* cols, s
   const uint8_t *R = a.pts[0], *Rp = kind == 1 ? a.pts[1] : nullptr, *PK = a.pts[kind == 1 ? 2 : 1],
                 *PKp = kind == 1 ? a.pts[3] : nullptr, *Gen = kind == 2 ? a.pts[2] : nullptr;
   if (int r = verify_rlc_on(ctx, kind, a.u, R, Rp, PK, PKp, Gen, /*m: hashed already*/ a.u, n, a.ok, a.ws,
-                            ctx.rlc_stream, 0, accepted, true))
+                            ar.stream, 0, accepted, true))
     return r;
-  HIP_TRY(hipMemcpyAsync(ok + off, a.ok, n, hipMemcpyDeviceToHost, ctx.rlc_stream));
-  HIP_TRY(hipStreamSynchronize(ctx.rlc_stream));
+  HIP_TRY(hipMemcpyAsync(ok + off, a.ok, n, hipMemcpyDeviceToHost, ar.stream));
+  HIP_TRY(hipStreamSynchronize(ar.stream));
   return DSV_OK;
 }
 // Shards like the *_multi forms: one group per initialised device (each with its own aggregate; all of
