@@ -323,3 +323,49 @@ def test_more_than_one_group(engine):
     want = torch.ones(n, dtype=torch.uint8, device=DEV)
     want[n - 3] = 0
     assert torch.equal(ok, want)
+
+
+def test_host_fast_accept_from_several_threads(engine):
+    """Three threads on the blocking typed-object entry points at once, a different scheme each (two
+    arenas per device: two calls overlap, the third waits), valid and tampered batches alternating; beside
+    them a thread on the ordinary column path.  Every call's verdicts are the oracle's."""
+    import threading
+    import mont_cases as C
+    n = (1 << 16) + (1 << 14) + 9
+    work = []
+    for scheme in ("single", "double", "vargen"):
+        cols, want = C.mont_case(scheme, 300, 1010 + len(scheme), period=6)
+        reps = -(-n // 300)
+        bad = C.as_records(scheme, [np.ascontiguousarray(np.tile(c, (reps, 1))[:n]) for c in cols])[3]
+        keep = np.flatnonzero(want)
+        reps = -(-n // len(keep))
+        good = C.as_records(scheme, [np.ascontiguousarray(np.tile(c[keep], (reps, 1))[:n]) for c in cols])[3]
+        work.append((scheme, bad, np.tile(want, -(-n // 300))[:n], good))
+    errors = []
+
+    def fast(scheme, bad, bwant, good):
+        try:
+            for rep in range(3):
+                got, acc = engine.verify_mont_cols_rlc(scheme, good)
+                if not acc or not got.all():
+                    errors.append("%s valid batch, call %d: accepted=%d" % (scheme, rep, acc))
+                got, acc = engine.verify_mont_cols_rlc(scheme, bad)
+                if acc or not np.array_equal(got, bwant):
+                    errors.append("%s tampered batch, call %d" % (scheme, rep))
+        except Exception as e:  # noqa: BLE001
+            errors.append("%s: %r" % (scheme, e))
+
+    def plain():
+        try:
+            for _ in range(4):
+                if not np.array_equal(engine.verify_mont_cols(work[0][0], work[0][1]), work[0][2]):
+                    errors.append("ordinary column path beside the fast accept: verdicts differ")
+        except Exception as e:  # noqa: BLE001
+            errors.append("plain: %r" % (e,))
+
+    th = [threading.Thread(target=fast, args=w) for w in work] + [threading.Thread(target=plain)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert not errors, errors
