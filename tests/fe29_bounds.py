@@ -453,3 +453,65 @@ def prove_normalize_and_limb_conversion():
     q = mul(plain, zinv)                             # plain coordinate x Montgomery 1/z
     canon_ok(q)
     return {"quotient": q, "inverse": inv}
+
+
+# ---- k_rlc.hip: batch fast accept, r05 --------------------------------------------
+def prove_fast_accept():
+    """the field code k_rlc.hip adds to the group law: the curve test and the affine-niels form of a decoded
+    point (k_rlc_prep), and the four-waves-per-point operations of k_rlc_scale, which carry tt = t1 * t2
+    in the running point — checked as a fixpoint of their own against the niels forms the group-law
+    proof admits (every running sum of k_rlc.hip starts from the identity and adds ext_to_niels /
+    affine_niels forms: the compositions prove_group_law covers)."""
+    inv = prove_group_law()
+    d2 = canonical()
+    one = const(_load("DSV_ONE"))
+    u = v = mul(canonical(), const(_load("DSV_R2")))          # load_fq: fe_to_mont of a decoded coordinate
+    # on_curve: 2 v^2 == 2 u^2 + 2 + (2d) u^2 v^2
+    uu, vv = sqr(u), sqr(v)
+    rhs = mul(mul(uu, vv), d2)
+    a = carry(dbl(vv))
+    b = carry(add(carry(add(dbl(uu), dbl(one))), rhs))
+    equal_ok(a, b)
+    # affine_niels(u, v, negate): the forms ext_add_aniels reads must lie inside the group-law invariant
+    t = mul(mul(u, v), d2)
+    an = {"vpu": join(carry(add(v, u)), sub(v, u, 2)), "t2d": join(t, sub(B([0] * NL), t, 2))}
+    an["vmu"] = an["vpu"]
+    for k in ("vpu", "vmu", "t2d"):
+        _check(leq(an[k], inv["niels"][k]), "affine_niels %s exceeds the niels invariant" % k)
+    # xp_double / xp_add: (u, v, z, tt) with tt = t1 * t2 from the idle wave of the second round
+    niels = inv["niels"]
+    ident = {"u": B([0] * NL), "v": one, "z": one, "tt": B([0] * NL)}
+
+    def xp_double(p):
+        uu, vv, zz, s = sqr(p["u"]), sqr(p["v"]), sqr(p["z"]), sqr(add(p["u"], p["v"]))
+        zz2, vpu = dbl(zz), add(vv, uu)
+        cu = sub(s, vpu, "4w")
+        vmu = sub_raw(vv, uu, 2)
+        ct = sub(zz2, vmu, "4w")
+        return {"u": mul(cu, ct), "v": mul(vpu, vmu), "z": mul(vmu, ct), "tt": mul(cu, vpu)}
+
+    def xp_add(p, n):
+        a = mul(sub_raw(p["v"], p["u"], 2), n["vmu"])
+        b = mul(add(p["v"], p["u"]), n["vpu"])
+        c = mul(p["tt"], n["t2d"])
+        d = dbl(mul(p["z"], n["z"]))
+        cu, cv, cz, ct = sub_raw(b, a, 2), add(b, a), add(d, c), sub(d, c, 2)
+        return {"u": mul(cu, ct), "v": mul(cv, cz), "z": mul(cz, ct), "tt": mul(cu, cv)}
+
+    acc = ident
+    for rnd in range(40):
+        nxt = join_pt(acc, xp_double(acc))
+        nxt = join_pt(nxt, xp_add(acc, niels))
+        if rnd >= 2:
+            nxt = {k: widen(x) for k, x in nxt.items()}
+        if leq_pt(nxt, acc):
+            # what leaves the kernel: the identity test and the niels form of a weighted sum
+            equal_ok(acc["u"], B([0] * NL))
+            equal_ok(acc["v"], acc["z"])
+            out = {"vpu": carry(add(acc["v"], acc["u"])), "vmu": sub(acc["v"], acc["u"], 2), "z": acc["z"],
+                   "t2d": mul(acc["tt"], d2)}
+            for k in out:
+                _check(leq(out[k], niels[k]), "weighted sum's %s exceeds the niels invariant" % k)
+            return {"acc": acc, "rounds": rnd}
+        acc = nxt
+    raise OverflowError_("xp bounds keep growing")

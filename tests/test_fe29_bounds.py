@@ -46,3 +46,10 @@ def test_normalisation_and_limb_conversion_field_code_cannot_overflow():
     """r04: k_scalars_from_mont and k_normalize_uvz with the Euclidean inversion (inv29.h)"""
     out = FB.prove_normalize_and_limb_conversion()
     assert out["quotient"].v < 3 * FB.Q
+
+
+def test_batch_fast_accept_field_code_cannot_overflow():
+    """r05, k_rlc.hip: the curve test, the affine-niels form of decoded points and the four-waves-per-point
+    operations (running point with tt = t1 * t2) stay inside the group law's proven invariants"""
+    out = FB.prove_fast_accept()
+    assert out["rounds"] < 12 and out["acc"]["u"].v < 2 * FB.Q
