@@ -198,8 +198,8 @@ int dsv_verify_vargen_mont_cols(const dsv_column *cols /*[5]*/, size_t n, uint8_
  * per-device arena — gather, transfer, normalisation and the challenge hash chunk by chunk while the
  * transfers run — then the aggregate runs over the resident group.  With several devices initialised
  * and >= 2^17 items per device the batch is sharded like the *_multi forms, one group (one aggregate)
- * per device; else one group (n <= 2^22) on the calling thread's device; larger batches take the
- * ordinary column path.  One such call at a time per device.  *accepted (may be NULL): 1 = every
+ * per device; else one group (2^17 <= n <= 2^22) on the calling thread's device; larger and smaller
+ * batches take the ordinary column path.  One such call at a time per device.  *accepted (may be NULL): 1 = every
  * group's aggregate decided. */
 int dsv_verify_single_mont_cols_rlc(const dsv_column *cols /*[4]*/, size_t n, uint8_t *ok, int *accepted);
 int dsv_verify_double_mont_cols_rlc(const dsv_column *cols /*[6]*/, size_t n, uint8_t *ok, int *accepted);
@@ -280,7 +280,8 @@ int dsv_verify_vargen_dev(const void *u, const void *R_uv, const void *PK_uv, co
  * or a point off the curve), the group is verified by dsv_verify_single_dev's kernels and gets their
  * verdicts: nothing is ever decided by the aggregate except "all true".  Worth it where batches are
  * expected to be entirely valid (~2.7x less arithmetic then; a batch that fails pays both paths).
- * window_bits: 0 = chosen from n, else one of 4, 6, 8, 12, 14, 16 (bucket windows; tests).
+ * window_bits: 0 = chosen from n — and groups below 2^17 items, where an aggregate does not pay, go
+ * straight to the per-signature kernels —, else one of 4, 6, 8, 12, 14, 16 (bucket windows; tests).
  * *accepted (may be NULL): 1 if every group took the fast path.
  * Unlike the other *_dev calls this one BLOCKS on `stream` (the decision is taken on the host).
  * workspace: dsv_rlc_workspace_bytes(n, window_bits) device bytes, 256-byte aligned. */

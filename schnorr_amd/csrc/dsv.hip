@@ -905,7 +905,13 @@ RlcCarve carve_rlc(void* ws, size_t n, const RlcPlan& p) {
   r.bytes = align_up(dsv_workspace_bytes(n), 256) + st.off;
   return r;
 }
-size_t rlc_group_items(size_t n) { return n < kRlcMaxGroup ? n : kRlcMaxGroup; }
+// groups of equal size (a batch just above 2^22 items is two halves, not one full group and a tail too
+// small for an aggregate)
+size_t rlc_group_items(size_t n) {
+  if (n <= kRlcMaxGroup) return n;
+  const size_t groups = (n + kRlcMaxGroup - 1) / kRlcMaxGroup;
+  return (n + groups - 1) / groups;
+}
 int rlc_random_key(ChaChaKey& key) {
   uint8_t* p = reinterpret_cast<uint8_t*>(key.w);
   size_t have = 0;
@@ -933,6 +939,21 @@ int verify_rlc_on(Context& ctx, int scheme, const void* u, const void* R_uv, con
     const size_t cnt = n - off < group ? n - off : group;
     const RlcPlan plan = rlc_plan(scheme, cnt, window_bits ? window_bits : rlc_default_bits(cnt));
     const RlcCarve cv = carve_rlc(workspace, cnt, plan);
+    if (!window_bits && cnt < kRlcMinAuto && !have_challenges) {
+      // too small for an aggregate to pay: the per-signature entry point as it is
+      all = false;
+      int r;
+      if (scheme == 0)
+        r = verify_single_on(ctx, pu + 32 * off, pR + 64 * off, pPK + 64 * off, pm + 32 * off, cnt, pok + off, workspace, s);
+      else if (scheme == 1)
+        r = verify_double_on(ctx, pu + 32 * off, pR + 64 * off, pRp + 64 * off, pPK + 64 * off, pPKp + 64 * off,
+                             pm + 32 * off, cnt, pok + off, workspace, s);
+      else
+        r = verify_vargen_on(ctx, pu + 32 * off, pR + 64 * off, pPK + 64 * off, pG + 64 * off, pm + 32 * off, cnt,
+                             pok + off, workspace, s);
+      if (r) return r;
+      continue;
+    }
     ChaChaKey key;
     if (int r = rlc_random_key(key)) return r;
     // (have_challenges: one group whose c / valid are in the workspace already — the host form hashes
@@ -2174,7 +2195,7 @@ int verify_mont_cols_rlc(int kind, const dsv_column* cols, size_t n, uint8_t* ok
     if (rc == DSV_OK && accepted) *accepted = rejected.load() == 0 ? 1 : 0;
     return rc;
   }
-  if (n > kRlcMaxGroup) return verify_mont_cols(kind, cols, n, ok, true);
+  if (n > kRlcMaxGroup || n < kRlcMinAuto) return verify_mont_cols(kind, cols, n, ok, true);
   Context* ctxp = nullptr;
   if (int r = host_context(ctxp)) return r;
   return verify_mont_cols_rlc_shard(*ctxp, kind, cols, 0, n, ok, accepted);

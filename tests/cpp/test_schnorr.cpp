@@ -173,15 +173,22 @@ static void batch_double_vargen_and_chunks() {
   const std::vector<uint8_t> okb = verify_batch_bytes(big_s.data(), big_p.data(), big_m.data(), big_s.size());
   CHECK(okb.size() == n * reps);
   for (size_t i = 0; i < okb.size(); i++) CHECK(okb[i] == (i % n == 3 ? 0 : 1));
-  // the fast accept over the same objects: the same verdicts, decided by the per-signature kernels
-  // (item 3 of every 60 is wrong); with the wrong items repaired, by the aggregate
+  // the fast accept over the same objects (verify_batch_fast*): the same verdicts.  70 020 items are too
+  // few for an aggregate (< 2^17: the ordinary path); doubled, the wrong items send it to the
+  // per-signature kernels, and with those repaired the aggregate decides
   bool accepted = true;
   CHECK(verify_batch_fast_bytes(big_s.data(), big_p.data(), big_m.data(), big_s.size(), &accepted) == okb && !accepted);
-  for (size_t r = 0; r < reps; r++) big_s[r * n + 3] = big_s[r * n + 4], big_p[r * n + 3] = big_p[r * n + 4], big_m[r * n + 3] = big_m[r * n + 4];
+  auto twice = [](auto& v) { v.insert(v.end(), v.begin(), v.begin() + (long)v.size()); };
+  twice(big_s), twice(big_p), twice(big_m);
+  CHECK(big_s.size() >= ((size_t)1 << 17));
+  std::vector<uint8_t> okb2 = okb;
+  twice(okb2);
+  CHECK(verify_batch_fast_bytes(big_s.data(), big_p.data(), big_m.data(), big_s.size(), &accepted) == okb2 && !accepted);
+  for (size_t r = 0; r < 2 * reps; r++) big_s[r * n + 3] = big_s[r * n + 4], big_p[r * n + 3] = big_p[r * n + 4], big_m[r * n + 3] = big_m[r * n + 4];
   const std::vector<bool> fast = verify_batch_fast(big_s, big_p, big_m, &accepted);
-  CHECK(accepted && fast.size() == n * reps);
+  CHECK(accepted && fast.size() == 2 * n * reps);
   for (size_t i = 0; i < fast.size(); i++) CHECK(fast[i]);
-  // double and var-generator: tampered -> item by item, the valid ones alone -> aggregate
+  // double and var-generator: tampered -> item by item; the valid ones alone, repeated past 2^17 -> aggregate
   CHECK(verify_batch_double_fast(dsigs, dpks, msgs, &accepted) == okd && !accepted);
   CHECK(verify_batch_var_gen_fast(vsigs, vpks, msgs, &accepted) == okv && !accepted);
   std::vector<SignatureDouble> gd;
@@ -189,15 +196,16 @@ static void batch_double_vargen_and_chunks() {
   std::vector<SignatureVarGen> gv;
   std::vector<PublicKeyVarGen> gvp;
   std::vector<BlsScalar> gdm, gvm;
-  for (size_t i = 0; i < n; i++) {
-    if (okd[i]) gd.push_back(dsigs[i]), gdp.push_back(dpks[i]), gdm.push_back(msgs[i]);
-    if (okv[i]) gv.push_back(vsigs[i]), gvp.push_back(vpks[i]), gvm.push_back(msgs[i]);
-  }
+  for (size_t r = 0; r < 2300; r++)
+    for (size_t i = 0; i < n; i++) {
+      if (okd[i]) gd.push_back(dsigs[i]), gdp.push_back(dpks[i]), gdm.push_back(msgs[i]);
+      if (okv[i]) gv.push_back(vsigs[i]), gvp.push_back(vpks[i]), gvm.push_back(msgs[i]);
+    }
   const std::vector<bool> fd = verify_batch_double_fast(gd, gdp, gdm, &accepted);
-  CHECK(accepted && fd.size() == n - 2);
+  CHECK(accepted && fd.size() == 2300 * (n - 2) && fd.size() >= ((size_t)1 << 17));
   for (bool b : fd) CHECK(b);
   const std::vector<bool> fv = verify_batch_var_gen_fast(gv, gvp, gvm, &accepted);
-  CHECK(accepted && fv.size() == n - 2);
+  CHECK(accepted && fv.size() == 2300 * (n - 2));
   for (bool b : fv) CHECK(b);
   CHECK(verify_batch_fast({}, {}, {}, &accepted).empty() && !accepted);
 }

@@ -57,7 +57,7 @@ def test_double_and_var_generator_schemes(engine, scheme):
     d = _signed(n, 970 + len(scheme), scheme)
     for bits in (8, 12, 0):
         accepted, ok = _run(engine, d, bits)
-        assert accepted and ok.all(), bits
+        assert accepted == (bits != 0) and ok.all(), bits      # (automatic bits: too small for an aggregate)
     points = [k for k in COLS[scheme] if k not in ("u", "m")]
     for j, field in enumerate(COLS[scheme]):
         a = {k: v.copy() for k, v in d.items()}
@@ -90,8 +90,14 @@ def test_double_and_var_generator_schemes(engine, scheme):
 
 @pytest.mark.parametrize("bits", [4, 6, 8, 12, 14, 16, 0])
 def test_all_valid_batch_is_accepted_by_the_aggregate(engine, bits):
-    n = 1500 if bits else 4500
-    d = _signed(n, 900 + bits)
+    d = _signed(1500, 900 + bits)
+    if bits == 0:
+        # automatic window bits: groups below 2^17 items skip the aggregate (it would be slower) ...
+        accepted, ok = _run(engine, d)
+        assert not accepted and ok.all()
+        # ... from there on it decides
+        reps = -(-((1 << 17) + 5) // 1500)
+        d = {k: np.tile(v, (reps, 1))[:(1 << 17) + 5] for k, v in d.items()}
     accepted, ok = _run(engine, d, bits)
     assert accepted and ok.all()
 
@@ -228,7 +234,9 @@ def test_argument_checks(engine):
                                      ctypes.c_size_t(16), ctypes.c_void_p(ok.data_ptr()), ctypes.c_void_p(ws.data_ptr()),
                                      None, ctypes.c_int(18), None)
     assert rc == -2
-    accepted, got = _run(engine, d)  # tiny batch, default bits
+    accepted, got = _run(engine, d)  # tiny batch, default bits: the per-signature kernels
+    assert not accepted and got.all()
+    accepted, got = _run(engine, d, 4)
     assert accepted and got.all()
     acc0 = ctypes.c_int(5)
     rc = L.dsv_verify_single_rlc_dev(None, None, None, None, ctypes.c_size_t(0), None, None, None, ctypes.c_int(0),
@@ -258,11 +266,11 @@ def test_host_fast_accept_over_typed_objects(engine, scheme):
     points with a random z; tests/mont_cases.py) in host memory.  The oracle's verdicts on a tampered
     batch (per-signature kernels on the resident arena), on its valid items alone (accepted) and on valid
     + malformed items — z = 0, limbs >= the modulus: verdict 0 by the encoding, out of the sum — (accepted);
-    a one-chunk call and one of several chunks with a ragged tail."""
+    a one-chunk call (too small for an aggregate: the ordinary path) and one of several chunks with a ragged tail."""
     import mont_cases as C
     cols, want = C.mont_case(scheme, 400, 980 + len(scheme), period=5)
     assert 0 < want.sum() < len(want)
-    for n in (313, (1 << 16) + (1 << 15) + 77):
+    for n in (313, (1 << 17) + (1 << 15) + 77):      # (below 2^17 items: the ordinary column path)
         reps = -(-n // 400)
         tcols = [np.ascontiguousarray(np.tile(c, (reps, 1))[:n]) for c in cols]
         got, accepted = engine.verify_mont_cols_rlc(scheme, C.as_records(scheme, tcols)[3])
@@ -271,11 +279,11 @@ def test_host_fast_accept_over_typed_objects(engine, scheme):
         reps = -(-n // len(keep))
         vcols = [np.ascontiguousarray(np.tile(c[keep], (reps, 1))[:n]) for c in cols]
         got, accepted = engine.verify_mont_cols_rlc(scheme, C.as_records(scheme, vcols)[3])
-        assert accepted and got.all(), n
+        assert accepted == (n >= 1 << 17) and got.all(), n
     # only item 0 tampered (dropped); the planted encodings the Rust types cannot hold stay in
     cols, want = C.mont_case(scheme, 300, 990 + len(scheme), period=10 ** 9)
     assert not want[0] and want[1:].sum() == 299 - 2 * (len(cols) - 2) - 2
-    n = (1 << 16) + 5
+    n = (1 << 17) + 5
     reps = -(-n // 299)
     mcols = [np.ascontiguousarray(np.tile(c[1:], (reps, 1))[:n]) for c in cols]
     got, accepted = engine.verify_mont_cols_rlc(scheme, C.as_records(scheme, mcols)[3])
@@ -307,7 +315,7 @@ def test_host_fast_accept_shards_like_the_multi_forms(engine, monkeypatch):
 
 
 def test_more_than_one_group(engine):
-    """2^22 + 777 signatures: two groups (the second one tiny), each with its own aggregate and weights.
+    """2^22 + 777 signatures: two groups of half the batch each, each with its own aggregate and weights.
     All valid -> accepted; one wrong signature in the second group -> only that group falls back, the
     verdicts are the construction-time pattern either way."""
     from schnorr_amd import workload as W
@@ -331,7 +339,7 @@ def test_host_fast_accept_from_several_threads(engine):
     them a thread on the ordinary column path.  Every call's verdicts are the oracle's."""
     import threading
     import mont_cases as C
-    n = (1 << 16) + (1 << 14) + 9
+    n = (1 << 17) + (1 << 14) + 9
     work = []
     for scheme in ("single", "double", "vargen"):
         cols, want = C.mont_case(scheme, 300, 1010 + len(scheme), period=6)
