@@ -305,6 +305,19 @@ int dsv_verify_vargen_rlc_dev(const void *u, const void *R_uv, const void *PK_uv
                               const void *m, size_t n, void *ok, void *workspace, void *stream,
                               int window_bits, int *accepted);
 
+/* ... and in front of dsv_verify_*_wire_dev (serialized records resident in HBM; layouts below): decode,
+ * then the aggregate.  A record that does not decode has verdict 0 and stays out of the sum; decoded
+ * points lie on the curve but not necessarily in the prime-order subgroup (`from_bytes`,
+ * src/keys/public.rs:94-100), which is what the aggregate's subgroup test is for.
+ * workspace: dsv_wire_rlc_workspace_bytes(n, window_bits). */
+size_t dsv_wire_rlc_workspace_bytes(size_t n, int window_bits);
+int dsv_verify_single_wire_rlc_dev(const void *sig64, const void *pk32, const void *m, size_t n, void *ok,
+                                   void *workspace, void *stream, int window_bits, int *accepted);
+int dsv_verify_double_wire_rlc_dev(const void *sig96, const void *pk64, const void *m, size_t n, void *ok,
+                                   void *workspace, void *stream, int window_bits, int *accepted);
+int dsv_verify_vargen_wire_rlc_dev(const void *sig64, const void *pk64, const void *m, size_t n, void *ok,
+                                   void *workspace, void *stream, int window_bits, int *accepted);
+
 /* second stage alone: ok[i] = (accumulate ? ok[i] : valid[i]) & [u*Gen + c*PK == R], Gen = G
  * (which = 0) or G' (which = 1); c and valid as produced by dsv_challenge_*_dev */
 int dsv_verify_core_dev(const void *u, const void *c, const void *valid, const void *PK_uv,

@@ -48,10 +48,12 @@ SYMBOLS = [
     "dsv_rlc_workspace_bytes", "dsv_verify_single_rlc_dev", "dsv_verify_double_rlc_dev",
     "dsv_verify_vargen_rlc_dev", "dsv_rlc_plan_info",
     "dsv_verify_single_mont_cols_rlc", "dsv_verify_double_mont_cols_rlc", "dsv_verify_vargen_mont_cols_rlc",
+    "dsv_wire_rlc_workspace_bytes", "dsv_verify_single_wire_rlc_dev", "dsv_verify_double_wire_rlc_dev",
+    "dsv_verify_vargen_wire_rlc_dev",
 ]
 _SIZE_T_FUNCS = ("dsv_workspace_bytes", "dsv_mixed_workspace_bytes", "dsv_split_scratch_bytes",
                  "dsv_ext_workspace_bytes", "dsv_wire_workspace_bytes", "dsv_mont_workspace_bytes",
-                 "dsv_rlc_workspace_bytes")
+                 "dsv_rlc_workspace_bytes", "dsv_wire_rlc_workspace_bytes")
 
 
 class Column(ctypes.Structure):
@@ -93,7 +95,7 @@ def load():
     L.dsv_last_error.restype = ctypes.c_char_p
     for name in _SIZE_T_FUNCS:
         getattr(L, name).restype = ctypes.c_size_t
-        getattr(L, name).argtypes = [ctypes.c_size_t] + ([ctypes.c_int] if name == "dsv_rlc_workspace_bytes" else [])
+        getattr(L, name).argtypes = [ctypes.c_size_t] + ([ctypes.c_int] if name in ("dsv_rlc_workspace_bytes", "dsv_wire_rlc_workspace_bytes") else [])
     for name in SYMBOLS:
         fn = getattr(L, name)  # AttributeError if a declared symbol is not exported
         if name not in ("dsv_version", "dsv_last_error") + _SIZE_T_FUNCS:

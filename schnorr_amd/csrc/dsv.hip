@@ -557,7 +557,7 @@ void release_context(Context& ctx) {
 
 extern "C" {
 
-const char* dsv_version(void) { return "dsv 0.5.0 (gfx950, fe29)"; }
+const char* dsv_version(void) { return "dsv 0.5.1 (gfx950, fe29)"; }
 const char* dsv_last_error(void) { return g_err.c_str(); }
 
 int dsv_device_count(void) {
@@ -928,7 +928,8 @@ int rlc_random_key(ChaChaKey& key) {
 // scheme 0 single (R, PK), 1 double (R, R', PK, PK'), 2 var-generator (R, PK, Gen): unused pointers null
 int verify_rlc_on(Context& ctx, int scheme, const void* u, const void* R_uv, const void* Rp_uv, const void* PK_uv,
                   const void* PKp_uv, const void* Gen_uv, const void* m, size_t n, void* ok, void* workspace,
-                  hipStream_t s, int window_bits, int* accepted, bool have_challenges = false) {
+                  hipStream_t s, int window_bits, int* accepted, bool have_challenges = false,
+                  const uint8_t* valid_in = nullptr) {
   const uint8_t *pu = (const uint8_t*)u, *pR = (const uint8_t*)R_uv, *pRp = (const uint8_t*)Rp_uv,
                 *pPK = (const uint8_t*)PK_uv, *pPKp = (const uint8_t*)PKp_uv, *pG = (const uint8_t*)Gen_uv,
                 *pm = (const uint8_t*)m;
@@ -943,14 +944,15 @@ int verify_rlc_on(Context& ctx, int scheme, const void* u, const void* R_uv, con
       // too small for an aggregate to pay: the per-signature entry point as it is
       all = false;
       int r;
+      const uint8_t* vin = valid_in ? valid_in + off : nullptr;
       if (scheme == 0)
-        r = verify_single_on(ctx, pu + 32 * off, pR + 64 * off, pPK + 64 * off, pm + 32 * off, cnt, pok + off, workspace, s);
+        r = verify_single_on(ctx, pu + 32 * off, pR + 64 * off, pPK + 64 * off, pm + 32 * off, cnt, pok + off, workspace, s, vin);
       else if (scheme == 1)
         r = verify_double_on(ctx, pu + 32 * off, pR + 64 * off, pRp + 64 * off, pPK + 64 * off, pPKp + 64 * off,
-                             pm + 32 * off, cnt, pok + off, workspace, s);
+                             pm + 32 * off, cnt, pok + off, workspace, s, vin);
       else
         r = verify_vargen_on(ctx, pu + 32 * off, pR + 64 * off, pPK + 64 * off, pG + 64 * off, pm + 32 * off, cnt,
-                             pok + off, workspace, s);
+                             pok + off, workspace, s, vin);
       if (r) return r;
       continue;
     }
@@ -960,7 +962,7 @@ int verify_rlc_on(Context& ctx, int scheme, const void* u, const void* R_uv, con
     //  chunk by chunk while the transfers run)
     if (!have_challenges)
       launch_challenge(scheme == 1, pR + 64 * off, scheme == 1 ? pRp + 64 * off : (const uint8_t*)nullptr,
-                       pm + 32 * off, cnt, cv.w.c, cv.w.valid, s);
+                       pm + 32 * off, cnt, cv.w.c, cv.w.valid, s, valid_in ? valid_in + off : nullptr);
     RlcInputs in = {};
     in.u = pu + 32 * off, in.c = cv.w.c, in.valid = cv.w.valid;
     in.pk[0] = pPK + 64 * off, in.r[0] = pR + 64 * off;
@@ -970,6 +972,11 @@ int verify_rlc_on(Context& ctx, int scheme, const void* u, const void* R_uv, con
     u32 flags[4] = {~0u, 0, 0, 0};
     HIP_TRY(hipMemcpyAsync(flags, cv.b.flags, sizeof flags, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
+    static const bool trace = getenv("DSV_RLC_TRACE") != nullptr;  // why a group was (not) accepted
+    if (trace)
+      std::fprintf(stderr, "[dsv rlc] scheme %d items %zu..%zu c=%d: %s%s%s%s\n", scheme, off, off + cnt, plan.c,
+                   flags[1] == 1 ? "" : "chain incomplete ", flags[0] & kRlcOffCurve ? "off-curve " : "",
+                   flags[0] & kRlcTorsion ? "subgroup-test " : "", flags[0] & kRlcSum ? "sum " : (flags[0] ? "" : "accepted"));
     if (flags[0] == 0 && flags[1] == 1) continue;  // ok[] = "well-formed" is the verdict vector
     all = false;
     // the per-signature kernels, from the challenges already in the workspace (run_split carves it the same way)
@@ -2680,6 +2687,61 @@ int verify_wire_dev(int kind, const void* sig, const void* pk, const void* m, si
                         (hipStream_t)stream);
 }
 }  // namespace
+
+// serialized records through the batch fast accept: decode (what `from_bytes` does: curve points, not
+// necessarily of prime order), then the aggregate; a record that does not decode has verdict 0 and stays
+// out of the sum
+extern "C++" {
+namespace {
+size_t wire_arrays_bytes(size_t n) { return align_up(n * 32, 256) + 4 * align_up(n * 64, 256) + align_up(n, 256); }
+int verify_wire_rlc_dev(int kind, const void* sig, const void* pk, const void* m, size_t n, void* ok,
+                        void* workspace, void* stream, int window_bits, int* accepted) {
+  if (accepted) *accepted = 0;
+  if (n && (!sig || !pk || !m || !ok || !workspace)) return fail(DSV_ERR_INVALID_ARGUMENT, "null pointer");
+  if (((uintptr_t)sig | (uintptr_t)pk) & 15) return fail(DSV_ERR_INVALID_ARGUMENT, "records must be 16-byte aligned");
+  if (window_bits && !rlc_bits_ok(window_bits))
+    return fail(DSV_ERR_INVALID_ARGUMENT, "window_bits must be 0 (automatic) or one of 4, 6, 8, 12, 14, 16");
+  DSV_DEV_PROLOGUE(n, ok);
+  const hipStream_t st = (hipStream_t)stream;
+  Stager x(static_cast<uint8_t*>(workspace));
+  WireWs w;
+  w.u = x.take(n * 32);
+  w.R = x.take(n * 64);
+  w.Rp = x.take(n * 64);
+  w.P0 = x.take(n * 64);
+  w.P1 = x.take(n * 64);
+  w.valid = x.take(n);
+  void* rws = x.take(0);
+  const uint8_t *dsig = (const uint8_t*)sig, *dpk = (const uint8_t*)pk;
+  const size_t sig_bytes = kind == 1 ? 96 : 64, pk_bytes = kind == 0 ? 32 : 64;
+  launch_gather32(dsig, sig_bytes, n, w.u, st);
+  if (int r = decompress_on(ctx, dsig + 32, sig_bytes, n, w.R, w.valid, 0, st)) return r;
+  if (kind == 1)
+    if (int r = decompress_on(ctx, dsig + 64, sig_bytes, n, w.Rp, w.valid, 1, st)) return r;
+  if (int r = decompress_on(ctx, dpk, pk_bytes, n, w.P0, w.valid, 1, st)) return r;
+  if (kind != 0)
+    if (int r = decompress_on(ctx, dpk + 32, pk_bytes, n, w.P1, w.valid, 1, st)) return r;
+  return verify_rlc_on(ctx, kind, w.u, w.R, kind == 1 ? w.Rp : nullptr, w.P0, kind == 1 ? w.P1 : nullptr,
+                       kind == 2 ? w.P1 : nullptr, m, n, ok, rws, st, window_bits, accepted, false, w.valid);
+}
+}  // namespace
+}  // extern "C++"
+size_t dsv_wire_rlc_workspace_bytes(size_t n, int window_bits) {
+  const size_t r = dsv_rlc_workspace_bytes(n, window_bits);
+  return r ? wire_arrays_bytes(n) + r + 256 : 0;
+}
+int dsv_verify_single_wire_rlc_dev(const void* sig64, const void* pk32, const void* m, size_t n, void* ok,
+                                   void* workspace, void* stream, int window_bits, int* accepted) {
+  return verify_wire_rlc_dev(0, sig64, pk32, m, n, ok, workspace, stream, window_bits, accepted);
+}
+int dsv_verify_double_wire_rlc_dev(const void* sig96, const void* pk64, const void* m, size_t n, void* ok,
+                                   void* workspace, void* stream, int window_bits, int* accepted) {
+  return verify_wire_rlc_dev(1, sig96, pk64, m, n, ok, workspace, stream, window_bits, accepted);
+}
+int dsv_verify_vargen_wire_rlc_dev(const void* sig64, const void* pk64, const void* m, size_t n, void* ok,
+                                   void* workspace, void* stream, int window_bits, int* accepted) {
+  return verify_wire_rlc_dev(2, sig64, pk64, m, n, ok, workspace, stream, window_bits, accepted);
+}
 
 size_t dsv_wire_workspace_bytes(size_t n) {
   return align_up(n * 32, 256) + 4 * align_up(n * 64, 256) + align_up(n, 256) +

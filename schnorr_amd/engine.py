@@ -674,6 +674,29 @@ def verify_vargen_wire_dev(sig64, pk64, m, ok, workspace, stream=None):
     _wire_dev("dsv_verify_vargen_wire_dev", sig64, 64, pk64, 64, m, ok, workspace, stream)
 
 
+def wire_rlc_workspace_bytes(n, window_bits=0):
+    b = int(_lib.load().dsv_wire_rlc_workspace_bytes(ctypes.c_size_t(n), ctypes.c_int(window_bits)))
+    if b == 0:
+        raise ValueError("window_bits must be 0 or one of 4, 6, 8, 12, 14, 16")
+    return b
+
+
+_WIRE_WIDTHS = {"single": (64, 32), "double": (96, 64), "vargen": (64, 64)}
+
+
+def verify_wire_rlc_dev(scheme, sig, pk, m, ok, workspace, stream=None, window_bits=0):
+    """dsv_verify_*_wire_rlc_dev: serialized records resident in HBM through the batch fast accept.
+    Blocks on `stream`; returns True if the aggregate decided every group."""
+    sw, pw = _WIRE_WIDTHS[scheme]
+    n, dev = _rows((sig, sw, "sig"), (pk, pw, "pk"), (m, 32, "m"))
+    accepted = ctypes.c_int(0)
+    _lib.check(getattr(_lib.load(), "dsv_verify_%s_wire_rlc_dev" % scheme)(
+        _tp(sig, sw), _tp(pk, pw), _tp(m, 32), ctypes.c_size_t(n), _bytes_out(ok, n, dev, "ok"),
+        _bytes_out(workspace, wire_rlc_workspace_bytes(n, window_bits), dev, "workspace"),
+        _stream_ptr(stream, dev), ctypes.c_int(window_bits), ctypes.byref(accepted)))
+    return bool(accepted.value)
+
+
 def verify_core_dev(u, c, valid, PK, R, ok, workspace, which=0, accumulate=False, stream=None):
     n, dev = _rows((u, 32, "u"), (c, 32, "c"), (PK, 64, "PK"), (R, 64, "R"))
     _lib.check(_lib.load().dsv_verify_core_dev(

@@ -377,3 +377,59 @@ def test_host_fast_accept_from_several_threads(engine):
     for t in th:
         t.join()
     assert not errors, errors
+
+
+@pytest.mark.parametrize("scheme", ["single", "double", "vargen"])
+def test_wire_records_through_the_fast_accept(engine, scheme):
+    """dsv_verify_*_wire_rlc_dev against the oracle's from_bytes + verify: a tampered batch with undecodable
+    records (per-signature kernels decide), and valid + undecodable records alone (the aggregate decides:
+    what does not decode has verdict 0 and stays out of the sum)."""
+    n = 700
+    d = _signed(n, 1020 + len(scheme), scheme)
+    cp = engine.compress_points
+    if scheme == "single":
+        sig, pk = np.concatenate([d["u"], cp(d["R"])], axis=1), cp(d["PK"])
+    elif scheme == "double":
+        sig = np.concatenate([d["u"], cp(d["R"]), cp(d["Rp"])], axis=1)
+        pk = np.concatenate([cp(d["PK"]), cp(d["PKp"])], axis=1)
+    else:
+        sig, pk = np.concatenate([d["u"], cp(d["R"])], axis=1), np.concatenate([cp(d["PK"]), cp(d["Gen"])], axis=1)
+    sig, pk, m = np.ascontiguousarray(sig), np.ascontiguousarray(pk), d["m"].copy()
+    for bit in range(64):    # a compressed R that decodes to NO curve point (about half of all v do not)
+        cand = sig[5:6, 32:64].copy()
+        cand[0, bit >> 3] ^= 1 << (bit & 7)
+        if not O.decompress(cand)[1][0]:
+            sig[5, 32:64] = cand[0]
+            break
+    else:
+        raise AssertionError("no undecodable neighbour found")
+    pk[7, -1] |= 0x7f        # v >= q
+    wire = getattr(O, "verify_%s_wire" % scheme)
+
+    def run(sig, pk, m, bits):
+        t = [torch.from_numpy(np.ascontiguousarray(x)).to(DEV) for x in (sig, pk, m)]
+        ok = torch.full((len(m),), 5, dtype=torch.uint8, device=DEV)
+        ws = torch.empty(engine.wire_rlc_workspace_bytes(len(m), bits), dtype=torch.uint8, device=DEV)
+        acc = engine.verify_wire_rlc_dev(scheme, *t, ok, ws, window_bits=bits)
+        torch.cuda.synchronize()
+        return acc, ok.cpu().numpy()
+
+    want = wire(sig, pk, m)
+    assert want.sum() == n - 2 and not want[5] and not want[7]
+    for bits in (8, 12):
+        acc, ok = run(sig, pk, m, bits)
+        assert acc and np.array_equal(ok, want), bits
+    m2 = m.copy()
+    m2[300, 1] ^= 2
+    want2 = wire(sig, pk, m2)
+    assert want2.sum() == n - 3
+    acc, ok = run(sig, pk, m2, 8)
+    assert not acc and np.array_equal(ok, want2)
+    # automatic bits past 2^17 records
+    big = (1 << 17) + 3
+    reps = -(-big // n)
+    tile = lambda a: np.tile(a, (reps, 1))[:big]
+    acc, ok = run(tile(sig), tile(pk), tile(m), 0)
+    assert acc and np.array_equal(ok, np.tile(want, reps)[:big])
+    acc, ok = run(tile(sig), tile(pk), tile(m2), 0)
+    assert not acc and np.array_equal(ok, np.tile(want2, reps)[:big])
