@@ -376,12 +376,14 @@ k_rlc_accumulate(const u32* __restrict__ order, const u32* __restrict__ start, c
   const u32 last_pt = (u32)(p.lpts + p.spts) * p.n - 1u;
   Ext acc = ext_identity();
   if (lo < hi) {
+    // the index of entry j + 2 and the point of entry j + 1 are on their way while entry j is added
     u32 id = vals[lo];
     ANiels cur = load_pt(pts + (size_t)(id < last_pt ? id : last_pt) * kPtWords);
+    id = vals[lo + 1 < hi ? lo + 1 : lo];
 #pragma unroll 1
     for (u32 j = lo; j < hi; j++) {
-      id = vals[j + 1 < hi ? j + 1 : j];
       const ANiels nxt = load_pt(pts + (size_t)(id < last_pt ? id : last_pt) * kPtWords);
+      id = vals[j + 2 < hi ? j + 2 : hi - 1];
       acc = ext_add_aniels(acc, cur);
       cur = nxt;
     }
