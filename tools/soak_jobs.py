@@ -7,7 +7,8 @@ Every round builds a few signed + tampered batches (three schemes, projective po
 Montgomery limbs, the planted encodings the Rust types cannot hold: tests/mont_cases.py) tiled to random
 sizes from one small chunk to several pipeline chunks with ragged tails, then runs them ALL AT ONCE:
 some as jobs (dsv_verify_*_mont_cols_submit, more than dsv_max_in_flight() of them), some as blocking
-calls from threads of their own (affine bytes, limbs, wire records), with 1 to 4 copy threads.  Whatever
+calls from threads of their own (affine bytes, limbs, wire records, the typed-object fast accept
+dsv_verify_*_mont_cols_rlc), with 1 to 4 copy threads.  Whatever
 shares the compute lanes, every call's verdicts must be the oracle's.  One line per round, a total, exit
 code 1 on any difference.  The oracle (test infrastructure) only checks; nothing here is timed.
 """
@@ -47,8 +48,11 @@ for rd in range(rounds):
         reps = -(-n // base)
         tcols = [np.ascontiguousarray(np.tile(c, (reps, 1))[:n]) for c in cols]
         twant = np.tile(want, reps)[:n]
-        form = int(rng.integers(0, 3))
-        if form == 0:
+        form = int(rng.integers(0, 4))
+        if form == 3:   # the typed-object fast accept (its verdicts must be the oracle's whether or not it accepts)
+            views = C.as_records(scheme, tcols)[3]
+            calls.append(("%s fast accept n=%d" % (scheme, n), ("call", lambda v=views, s=scheme: E.verify_mont_cols_rlc(s, v)[0], None), twant))
+        elif form == 0:
             views = C.as_records(scheme, tcols)[3]
             calls.append(("%s job n=%d" % (scheme, n), ("job", scheme, views), twant))
         elif form == 1:
@@ -101,8 +105,8 @@ for rd in range(rounds):
             nb = len(want) if got is None else int((got != want).sum())
             bad += nb
             diffs.append("%s: %d different" % (label, nb))
-    print("round %d: %d calls at once (%d jobs), %d verdicts%s  (%.0f s)" % (
-        rd, len(calls), len(jobs), sum(len(c[2]) for c in calls),
+    print("round %d: %d calls at once (%d jobs, %d fast accepts), %d verdicts%s  (%.0f s)" % (
+        rd, len(calls), len(jobs), sum("fast accept" in c[0] for c in calls), sum(len(c[2]) for c in calls),
         ("  DIFFERENT: " + "; ".join(diffs + errors)) if diffs or errors else "", time.time() - t0), flush=True)
     if errors:
         bad += 1
