@@ -1052,6 +1052,17 @@ def main():
             out["wire"]["host"] = {"value": n / tw, "unit": "verifies/s",
                                    "note": "dsv_verify_single_wire on %d host-resident records (128 B "
                                            "per item) incl. PCIe staging" % n}
+            # the valid records alone through the fast accept, from host memory (what a node does with a block)
+            keep_h = np.flatnonzero(batch["expected"].cpu().numpy())
+            vs, vp, vm_ = (np.ascontiguousarray(a[keep_h]) for a in (hsig, hpk, hm))
+            got, acc_ = E.verify_wire_rlc("single", vs, vp, vm_)
+            if not got.all() or acc_ != (len(keep_h) >= RLC_MIN):
+                raise SystemExit("host wire fast accept: not accepted")
+            tf, _ = host_best(lambda: E.verify_wire_rlc("single", vs, vp, vm_)[0])
+            out["wire"]["host"]["fast_accept_all_valid"] = {"items": int(len(keep_h)), "value": len(keep_h) / tf,
+                                                            "ms_per_call": tf * 1e3,
+                                                            "vs_wire_host_per_signature": (len(keep_h) / tf) / (n / tw)}
+            del vs, vp, vm_
         # ---- verify_batch END TO END from typed objects (what north_star names): the C++ mirror of the
         # reference's types holds Montgomery limbs and 160-byte projective points; conversion, PCIe,
         # engine and Vec<bool> packing are all inside the timed call (tools/verify_batch_e2e.cpp)

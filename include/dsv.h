@@ -318,6 +318,17 @@ int dsv_verify_double_wire_rlc_dev(const void *sig96, const void *pk64, const vo
 int dsv_verify_vargen_wire_rlc_dev(const void *sig64, const void *pk64, const void *m, size_t n, void *ok,
                                    void *workspace, void *stream, int window_bits, int *accepted);
 
+/* ... and from serialized records in HOST memory (the layouts of dsv_verify_*_wire): the pipeline decodes
+ * chunk by chunk into a per-device arena while the transfers run (128 B per single signature on the bus,
+ * half of the typed-object form), one aggregate follows.  One group, 2^17 <= n <= 2^22, on the calling
+ * thread's device; other sizes take dsv_verify_*_wire. */
+int dsv_verify_single_wire_rlc(const uint8_t *sig64, const uint8_t *pk32, const uint8_t *m, size_t n, uint8_t *ok,
+                               int *accepted);
+int dsv_verify_double_wire_rlc(const uint8_t *sig96, const uint8_t *pk64, const uint8_t *m, size_t n, uint8_t *ok,
+                               int *accepted);
+int dsv_verify_vargen_wire_rlc(const uint8_t *sig64, const uint8_t *pk64, const uint8_t *m, size_t n, uint8_t *ok,
+                               int *accepted);
+
 /* second stage alone: ok[i] = (accumulate ? ok[i] : valid[i]) & [u*Gen + c*PK == R], Gen = G
  * (which = 0) or G' (which = 1); c and valid as produced by dsv_challenge_*_dev */
 int dsv_verify_core_dev(const void *u, const void *c, const void *valid, const void *PK_uv,

@@ -2126,9 +2126,10 @@ int fill_arena(Context& ctx, int kind, const HostIn (&ins)[NIN], size_t n, uint8
         return (int)DSV_OK;
       });
 }
-// one shard [off, off + cnt) on one device: ONE group, cnt <= kRlcMaxGroup
-int verify_mont_cols_rlc_shard(Context& ctx, int kind, const dsv_column* cols, size_t off, size_t n, uint8_t* ok,
-                               int* accepted) {
+// one shard of n <= kRlcMaxGroup items on one device, ONE group: take an arena, let `fill(arena, workspace
+// carve)` run the pipeline that leaves u, the affine points and c / valid resident, then the aggregate
+template <class Fill>
+int rlc_host_shard(Context& ctx, int kind, size_t n, uint8_t* ok, int* accepted, Fill fill) {
   DSV_ON_DEVICE(ctx);
   // whichever arena is free; both busy: wait for the first
   std::unique_lock<std::mutex> own(ctx.rlc_arenas[0].mu, std::try_to_lock);
@@ -2155,31 +2156,36 @@ int verify_mont_cols_rlc_shard(Context& ctx, int kind, const dsv_column* cols, s
   if (!ar.stream) HIP_TRY(hipStreamCreateWithFlags(&ar.stream, hipStreamNonBlocking));
   const RlcArena a = carve_arena(ar.dev, kind, n);
   const Workspace w = carve(a.ws, n);  // where the aggregate (and the per-signature kernels) expect c / valid
-  auto in = [&](int k, size_t width) {
-    return HostIn{static_cast<const uint8_t*>(cols[k].base) + off * cols[k].stride, width, cols[k].stride};
-  };
-  int rc;
-  if (kind == 0) {
-    const HostIn ins[4] = {in(0, 32), in(1, 96), in(2, 96), in(3, 32)};
-    rc = fill_arena(ctx, 0, ins, n, ok + off, a, w);
-  } else if (kind == 1) {
-    const HostIn ins[6] = {in(0, 32), in(1, 96), in(2, 96), in(3, 96), in(4, 96), in(5, 32)};
-    rc = fill_arena(ctx, 1, ins, n, ok + off, a, w);
-  } else {
-    const HostIn ins[5] = {in(0, 32), in(1, 96), in(2, 96), in(3, 96), in(4, 32)};
-    rc = fill_arena(ctx, 2, ins, n, ok + off, a, w);
-  }
-  if (rc) return rc;
-  // (run_pipelined returned: every chunk's kernels are done.)  Columns: single u R PK m, double u R R' PK
-  // PK' m, var-generator u R PK Gen m
+  if (int rc = fill(a, w)) return rc;
+  // (run_pipelined returned: every chunk's kernels are done.)  Points in the arena: single R PK, double R R'
+  // PK PK', var-generator R PK Gen
   const uint8_t *R = a.pts[0], *Rp = kind == 1 ? a.pts[1] : nullptr, *PK = a.pts[kind == 1 ? 2 : 1],
                 *PKp = kind == 1 ? a.pts[3] : nullptr, *Gen = kind == 2 ? a.pts[2] : nullptr;
   if (int r = verify_rlc_on(ctx, kind, a.u, R, Rp, PK, PKp, Gen, /*m: hashed already*/ a.u, n, a.ok, a.ws,
                             ar.stream, 0, accepted, true))
     return r;
-  HIP_TRY(hipMemcpyAsync(ok + off, a.ok, n, hipMemcpyDeviceToHost, ar.stream));
+  HIP_TRY(hipMemcpyAsync(ok, a.ok, n, hipMemcpyDeviceToHost, ar.stream));
   HIP_TRY(hipStreamSynchronize(ar.stream));
   return DSV_OK;
+}
+int verify_mont_cols_rlc_shard(Context& ctx, int kind, const dsv_column* cols, size_t off, size_t n, uint8_t* ok,
+                               int* accepted) {
+  Context* cp = &ctx;
+  return rlc_host_shard(ctx, kind, n, ok + off, accepted, [=](const RlcArena& a, const Workspace& w) {
+    auto in = [&](int k, size_t width) {
+      return HostIn{static_cast<const uint8_t*>(cols[k].base) + off * cols[k].stride, width, cols[k].stride};
+    };
+    if (kind == 0) {
+      const HostIn ins[4] = {in(0, 32), in(1, 96), in(2, 96), in(3, 32)};
+      return fill_arena(*cp, 0, ins, n, ok + off, a, w);
+    }
+    if (kind == 1) {
+      const HostIn ins[6] = {in(0, 32), in(1, 96), in(2, 96), in(3, 96), in(4, 96), in(5, 32)};
+      return fill_arena(*cp, 1, ins, n, ok + off, a, w);
+    }
+    const HostIn ins[5] = {in(0, 32), in(1, 96), in(2, 96), in(3, 96), in(4, 32)};
+    return fill_arena(*cp, 2, ins, n, ok + off, a, w);
+  });
 }
 // Shards like the *_multi forms: one group per initialised device (each with its own aggregate; all of
 // them must accept), as long as every shard is one group of a useful size; else one group on the calling
@@ -2758,6 +2764,61 @@ int dsv_verify_double_wire_dev(const void* sig96, const void* pk64, const void* 
 int dsv_verify_vargen_wire_dev(const void* sig64, const void* pk64, const void* m, size_t n, void* ok,
                                void* workspace, void* stream) {
   return verify_wire_dev(2, sig64, pk64, m, n, ok, workspace, stream);
+}
+
+// serialized records in HOST memory through the batch fast accept: the pipeline decodes chunk by chunk
+// into an arena (and hashes in the shadow of the transfers), one aggregate follows — half the bus
+// traffic of the typed-object form (128 B per single signature)
+extern "C++" {
+namespace {
+int verify_wire_rlc_host(int kind, const uint8_t* sig, const uint8_t* pk, const uint8_t* m, size_t n, uint8_t* ok,
+                         int* accepted) {
+  if (accepted) *accepted = 0;
+  if (n && (!sig || !pk || !m || !ok)) return fail(DSV_ERR_INVALID_ARGUMENT, "null pointer");
+  if (int r = check_n(n)) return r;
+  if (n == 0) return DSV_OK;
+  Context* ctxp = nullptr;
+  if (int r = host_context(ctxp)) return r;
+  Context& ctx = *ctxp;
+  if (n > kRlcMaxGroup || n < kRlcMinAuto) return verify_wire(ctx, kind, sig, pk, m, n, ok);
+  const size_t sig_bytes = kind == 1 ? 96 : 64, pk_bytes = kind == 0 ? 32 : 64;
+  Context* cp = &ctx;
+  return rlc_host_shard(ctx, kind, n, ok, accepted, [=](const RlcArena& a, const Workspace& w) {
+    const HostIn ins[3] = {{sig, sig_bytes}, {pk, pk_bytes}, {m, 32}};
+    return run_pipelined(*cp, ins, ok, n, 0, /*per item: the decoder's verdict byte*/ 1, NoPrep{},
+                         [=](const Staged& g, size_t off, size_t cnt, void*, void*, Stager& x, hipStream_t st) {
+      const size_t at = t_chunk_first + off;
+      const uint8_t *dsig = g.p[0] + off * sig_bytes, *dpk = g.p[1] + off * pk_bytes;
+      uint8_t* valid = x.take(cnt);
+      launch_gather32(dsig, sig_bytes, cnt, a.u + 32 * at, st);
+      // arena order: single R PK, double R R' PK PK', var-generator R PK Gen
+      int slot = 0;
+      if (int r = decompress_on(*cp, dsig + 32, sig_bytes, cnt, a.pts[slot++] + 64 * at, valid, 0, st)) return r;
+      if (kind == 1)
+        if (int r = decompress_on(*cp, dsig + 64, sig_bytes, cnt, a.pts[slot++] + 64 * at, valid, 1, st)) return r;
+      if (int r = decompress_on(*cp, dpk, pk_bytes, cnt, a.pts[slot++] + 64 * at, valid, 1, st)) return r;
+      if (kind != 0)
+        if (int r = decompress_on(*cp, dpk + 32, pk_bytes, cnt, a.pts[slot++] + 64 * at, valid, 1, st)) return r;
+      launch_challenge(kind == 1, a.pts[0] + 64 * at, kind == 1 ? a.pts[1] + 64 * at : (const uint8_t*)nullptr,
+                       g.p[2] + 32 * off, cnt, w.c + 32 * at, w.valid + at, st, valid);
+      HIP_TRY(hipGetLastError());
+      return (int)DSV_OK;
+    });
+  });
+}
+}  // namespace
+}  // extern "C++"
+int dsv_verify_single_wire_rlc(const uint8_t* sig64, const uint8_t* pk32, const uint8_t* m, size_t n, uint8_t* ok,
+                               int* accepted) {
+  return verify_wire_rlc_host(0, sig64, pk32, m, n, ok, accepted);
+}
+int dsv_verify_double_wire_rlc(const uint8_t* sig96, const uint8_t* pk64, const uint8_t* m, size_t n, uint8_t* ok,
+                               int* accepted) {
+  return verify_wire_rlc_host(1, sig96, pk64, m, n, ok, accepted);
+}
+int dsv_verify_vargen_wire_rlc(const uint8_t* sig64, const uint8_t* pk64, const uint8_t* m, size_t n, uint8_t* ok,
+                               int* accepted) {
+  return verify_wire_rlc_host(2, sig64, pk64, m, n, ok, accepted);
 }
 
 int dsv_verify_single_wire(const uint8_t* sig64, const uint8_t* pk32, const uint8_t* m, size_t n,

@@ -379,6 +379,19 @@ def verify_single_wire(sig64, pk32, m):
     return ok
 
 
+def verify_wire_rlc(scheme, sig, pk, m):
+    """dsv_verify_*_wire_rlc: serialized records in host memory through the batch fast accept ->
+    (verdicts, accepted)"""
+    sw, pw = {"single": (64, 32), "double": (96, 64), "vargen": (64, 64)}[scheme]
+    sig, pk, m = _arr(sig, sw), _arr(pk, pw), _arr(m, 32)
+    n = _same_n(sig, pk, m)
+    ok = np.zeros(n, dtype=np.uint8)
+    accepted = ctypes.c_int(0)
+    _lib.check(getattr(_lib.load(), "dsv_verify_%s_wire_rlc" % scheme)(
+        _p(sig), _p(pk), _p(m), ctypes.c_size_t(n), _p(ok), ctypes.byref(accepted)))
+    return ok, bool(accepted.value)
+
+
 def verify_double_wire(sig96, pk64, m):
     sig, pk, m = _arr(sig96, 96), _arr(pk64, 64), _arr(m, 32)
     n = _same_n(sig, pk, m)

@@ -433,3 +433,10 @@ def test_wire_records_through_the_fast_accept(engine, scheme):
     assert acc and np.array_equal(ok, np.tile(want, reps)[:big])
     acc, ok = run(tile(sig), tile(pk), tile(m2), 0)
     assert not acc and np.array_equal(ok, np.tile(want2, reps)[:big])
+    # the same records from HOST memory (dsv_verify_*_wire_rlc): decoded chunk by chunk into the arena
+    ok, acc = engine.verify_wire_rlc(scheme, tile(sig), tile(pk), tile(m))
+    assert acc and np.array_equal(ok, np.tile(want, reps)[:big])
+    ok, acc = engine.verify_wire_rlc(scheme, tile(sig), tile(pk), tile(m2))
+    assert not acc and np.array_equal(ok, np.tile(want2, reps)[:big])
+    ok, acc = engine.verify_wire_rlc(scheme, sig, pk, m)          # too small for an aggregate: the ordinary path
+    assert not acc and np.array_equal(ok, want)
