@@ -13,7 +13,8 @@ the group logic see ragged sizes), explicit or automatic window bits, and one of
   malformed  non-canonical encodings only            -> accepted, those items 0
 Every fourth round runs the TYPED-OBJECT form instead (dsv_verify_*_mont_cols_rlc over records laid out like the
 Rust structs, Montgomery limbs, random z, planted encodings the types cannot hold: tests/mont_cases.py):
-tampered -> not accepted; its valid + malformed items alone -> accepted.
+tampered -> not accepted; its valid + malformed items alone -> accepted.  Every eighth round: the batch as
+serialized records in host memory (dsv_verify_*_wire_rlc) against the oracle's from_bytes + verify.
 Verdicts always equal the oracle's (the oracle is test infrastructure; nothing here is timed)."""
 import os
 import sys
@@ -107,6 +108,31 @@ for rd in range(rounds):
             else:
                 d[f][i, 32 * int(rng.integers(0, 2)):][:32] = top
     want = getattr(O, "verify_" + scheme)(*[d[k] for k in COLS[scheme]], nthreads=8)
+    if rd % 8 == 5 and kind != "malformed":
+        # the same batch as serialized records in host memory (dsv_verify_*_wire_rlc); a point with a small-order
+        # component survives compression, so every defect kind carries over
+        cp = E.compress_points
+        if scheme == "single":
+            sig, pk = np.concatenate([d["u"], cp(d["R"])], axis=1), cp(d["PK"])
+        elif scheme == "double":
+            sig = np.concatenate([d["u"], cp(d["R"]), cp(d["Rp"])], axis=1)
+            pk = np.concatenate([cp(d["PK"]), cp(d["PKp"])], axis=1)
+        else:
+            sig, pk = np.concatenate([d["u"], cp(d["R"])], axis=1), np.concatenate([cp(d["PK"]), cp(d["Gen"])], axis=1)
+        wwant = getattr(O, "verify_%s_wire" % scheme)(np.ascontiguousarray(sig), np.ascontiguousarray(pk), d["m"])
+        reps = -(-n // base)
+        tile = lambda a: np.ascontiguousarray(np.tile(a, (reps, 1))[:n])
+        got, accepted = E.verify_wire_rlc(scheme, tile(sig), tile(pk), tile(d["m"]))
+        twant = np.tile(wwant, reps)[:n]
+        diff = int((got != twant).sum())
+        wrong_accept = accepted != (bool(wwant.all()) and n >= 1 << 17)
+        total += n
+        bad += diff + (1 if wrong_accept else 0)
+        print("round %d: %s n=%d wire records %-9s accepted=%d valid=%d/%d%s  (%.0f s)" % (
+            rd, scheme, n, kind, accepted, int(twant.sum()), n,
+            "  DIFFERENT: %d verdicts%s" % (diff, ", acceptance" if wrong_accept else "") if diff or wrong_accept else "",
+            time.time() - t0), flush=True)
+        continue
     # tile to n: items repeat, their weights do not (one z per item and call)
     reps = -(-n // base)
     a = [np.ascontiguousarray(np.tile(d[k], (reps, 1))[:n]) for k in COLS[scheme]]
