@@ -14,3 +14,21 @@ for path in sys.argv[1:]:
         print("  small batch %.3f ms" % d["small_batch"]["ms_per_call"])
     for k, v in d.get("roofline", {}).get("kernels", {}).items():
         print("  %-62s %8.3f ms  mad_frac %.3f" % (k[:62], v["ms_per_launch"], v["mad_frac"]))
+    e = d.get("verify_batch_e2e")
+    if e:
+        s = e.get("streamed", {})
+        print("  verify_batch (typed objects): one shot %.2f ms = %.1f M/s, two in flight %.2f ms = %.1f M/s" % (
+            e["one_shot"]["best_ms"], e["one_shot"]["value"] / 1e6,
+            s.get("two_in_flight", {}).get("ms_per_call", 0), s.get("two_in_flight", {}).get("value", 0) / 1e6))
+    r = d.get("rlc")
+    if r:
+        f = (e or {}).get("fast_accept", {})
+        w = d.get("wire", {})
+        print("  fast accept, all-valid batch: single %.1f M/s (x%.2f)  double %.1f  vargen %.1f | graded workload %.1f M/s (x%.2f)" % (
+            r["all_valid"]["value"] / 1e6, r["all_valid"]["vs_per_signature"],
+            r.get("double_all_valid", {}).get("value", 0) / 1e6, r.get("vargen_all_valid", {}).get("value", 0) / 1e6,
+            r["graded_workload"]["value"] / 1e6, r["graded_workload"]["vs_per_signature"]))
+        print("    typed objects %.1f M/s (two in flight %.1f)  wire records %.1f M/s in HBM, %.1f M/s from host memory" % (
+            f.get("all_valid", {}).get("value", 0) / 1e6, f.get("all_valid_two_in_flight", {}).get("value", 0) / 1e6,
+            w.get("fast_accept_all_valid", {}).get("value", 0) / 1e6,
+            w.get("host", {}).get("fast_accept_all_valid", {}).get("value", 0) / 1e6))
