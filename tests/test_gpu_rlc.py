@@ -440,3 +440,46 @@ def test_wire_records_through_the_fast_accept(engine, scheme):
     assert not acc and np.array_equal(ok, np.tile(want2, reps)[:big])
     ok, acc = engine.verify_wire_rlc(scheme, sig, pk, m)          # too small for an aggregate: the ordinary path
     assert not acc and np.array_equal(ok, want)
+
+
+def test_sample_check_follows_the_recent_groups():
+    """The adaptive sample check (dsv.hip: Context::rlc_suspicion), seen through DSV_RLC_TRACE in a process of its
+    own: valid batches switch it off; the next tampered batch then pays its aggregate ("sum"), which switches
+    it on; the one after that is caught by the sample ("no aggregate").  Verdicts are the pattern every time."""
+    import os
+    import subprocess
+    import sys
+    code = r"""
+import numpy as np, torch
+from schnorr_amd import engine as E, workload as W
+E.init(0)
+n = (1 << 17) + 64
+ws = torch.empty(E.rlc_workspace_bytes(n), dtype=torch.uint8, device="cuda:0")
+ok = torch.zeros(n, dtype=torch.uint8, device="cuda:0")
+good = W.gen_single(n, seed=3, tamper=False)
+bad = W.gen_single(n, seed=3, tamper=True)          # every 16th item wrong: some among the first 1024
+run = lambda b: E.verify_single_rlc_dev(b["u"], b["R"], b["PK"], b["m"], ok, ws)
+for label, b, want_acc in (("valid-1", good, True), ("valid-2", good, True), ("tampered-1", bad, False),
+                           ("tampered-2", bad, False), ("valid-3", good, True)):
+    print("CALL", label, flush=True)
+    import sys; sys.stderr.write("CALL %s\n" % label); sys.stderr.flush()
+    acc = run(b)
+    assert acc == want_acc and torch.equal(ok, b["expected"]), label
+print("done")
+"""
+    env = dict(os.environ, DSV_RLC_TRACE="1")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, (r.stdout[-800:], r.stderr[-2000:])
+    calls = {}
+    cur = None
+    for line in r.stderr.splitlines():
+        if line.startswith("CALL "):
+            cur = line[5:]
+            calls[cur] = []
+        elif "[dsv rlc]" in line and cur:
+            calls[cur].append(line)
+    assert any("accepted" in x for x in calls["valid-1"]) and any("accepted" in x for x in calls["valid-2"])
+    assert any(" sum" in x for x in calls["tampered-1"]) and not any("no aggregate" in x for x in calls["tampered-1"])
+    assert any("no aggregate" in x for x in calls["tampered-2"])
+    assert any("accepted" in x for x in calls["valid-3"])          # the sample passes, the aggregate decides
