@@ -996,23 +996,29 @@ int verify_rlc_on(Context& ctx, int scheme, const void* u, const void* R_uv, con
         launch_verify_fixed_double(ctx, pu + 32 * off, cv.w.c, pPK + 64 * off, pR + 64 * off, pPKp + 64 * off,
                                    pRp + 64 * off, cv.w.valid, sn, cv.sample_ok, tables, s);
       // a WRONG item counts, a malformed one does not (it stays out of the aggregate: verdict 0 either way)
-      static thread_local uint8_t verdicts[kRlcSample], wellformed[kRlcSample], us[32 * kRlcSample];
+      // (`valid` covers what the hash reads — R, R', m; u and the keys are range-checked by the verify kernel)
+      static thread_local uint8_t verdicts[kRlcSample], wellformed[kRlcSample], us[32 * kRlcSample],
+          keys[2][64 * kRlcSample];
       HIP_TRY(hipMemcpyAsync(verdicts, cv.sample_ok, sn, hipMemcpyDeviceToHost, s));
       HIP_TRY(hipMemcpyAsync(wellformed, cv.w.valid, sn, hipMemcpyDeviceToHost, s));
       HIP_TRY(hipMemcpyAsync(us, pu + 32 * off, 32 * sn, hipMemcpyDeviceToHost, s));
+      HIP_TRY(hipMemcpyAsync(keys[0], pPK + 64 * off, 64 * sn, hipMemcpyDeviceToHost, s));
+      if (scheme == 1) HIP_TRY(hipMemcpyAsync(keys[1], pPKp + 64 * off, 64 * sn, hipMemcpyDeviceToHost, s));
       HIP_TRY(hipStreamSynchronize(s));
-      static const uint32_t r_words[8] = DSV_R32;
+      static const uint32_t r_words[8] = DSV_R32, q_words[8] = DSV_Q32;
+      auto below = [](const uint8_t* le32, const uint32_t (&mod)[8]) {  // most significant word first
+        uint32_t w[8];
+        memcpy(w, le32, 32);
+        for (int j = 7; j >= 0; j--)
+          if (w[j] != mod[j]) return w[j] < mod[j];
+        return false;
+      };
       for (size_t k = 0; k < sn; k++) {
         if (verdicts[k] == 1 || !wellformed[k]) continue;
-        uint32_t w[8];
-        memcpy(w, us + 32 * k, 32);
-        bool below = false;  // u < r, most significant word first
-        for (int j = 7; j >= 0; j--)
-          if (w[j] != r_words[j]) {
-            below = w[j] < r_words[j];
-            break;
-          }
-        sample_bad |= below;
+        bool canonical = below(us + 32 * k, r_words);
+        for (int h = 0; h < (scheme == 1 ? 2 : 1); h++)
+          canonical = canonical && below(keys[h] + 64 * k, q_words) && below(keys[h] + 64 * k + 32, q_words);
+        sample_bad |= canonical;  // well-formed and still verdict 0: a wrong signature
       }
     }
     if (trace && sample_bad)

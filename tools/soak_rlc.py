@@ -125,7 +125,8 @@ for rd in range(rounds):
         got, accepted = E.verify_wire_rlc(scheme, tile(sig), tile(pk), tile(d["m"]))
         twant = np.tile(wwant, reps)[:n]
         diff = int((got != twant).sum())
-        wrong_accept = accepted != (bool(wwant.all()) and n >= 1 << 17)
+        # (a point with a small-order component may leave its item valid: never accepted all the same)
+        wrong_accept = accepted != (kind == "clean" and n >= 1 << 17)
         total += n
         bad += diff + (1 if wrong_accept else 0)
         print("round %d: %s n=%d wire records %-9s accepted=%d valid=%d/%d%s  (%.0f s)" % (
