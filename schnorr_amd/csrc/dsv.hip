@@ -898,7 +898,7 @@ struct RlcCarve {
 // tampered with throughout — the graded workload: every 16th item — then skips the aggregate and
 // pays the per-signature path alone.  Only while the device's recent groups give reason to
 // (Context::rlc_suspicion); automatic window bits only (explicit ones are for tests, which want the
-// aggregate itself to say no); not for the var-generator scheme (no eight-lane kernel).
+// aggregate itself to say no).  The var-generator scheme has no eight-lane kernel: its sample takes ~1 ms.
 constexpr size_t kRlcSample = 1024;
 RlcCarve carve_rlc(void* ws, size_t n, const RlcPlan& p) {
   RlcCarve r;
@@ -977,7 +977,7 @@ int verify_rlc_on(Context& ctx, int scheme, const void* u, const void* R_uv, con
     if (int r = rlc_random_key(key)) return r;
     static const bool trace = getenv("DSV_RLC_TRACE") != nullptr;  // why a group was (not) accepted
     static const bool sample_on = !(getenv("DSV_RLC_SAMPLE") && atoi(getenv("DSV_RLC_SAMPLE")) == 0);
-    const bool do_sample = !window_bits && scheme != 2 && sample_on && ctx.quad && ctx.rlc_suspicion.load() > 0;
+    const bool do_sample = !window_bits && sample_on && (ctx.quad || scheme == 2) && ctx.rlc_suspicion.load() > 0;
     const size_t sn = cnt < kRlcSample ? cnt : kRlcSample;
     // (have_challenges: one group whose c / valid are in the workspace already — the host form hashes
     //  chunk by chunk while the transfers run)
@@ -992,9 +992,12 @@ int verify_rlc_on(Context& ctx, int scheme, const void* u, const void* R_uv, con
       if (scheme == 0)
         launch_verify_fixed(ctx, false, pu + 32 * off, cv.w.c, pPK + 64 * off, pR + 64 * off, 0, cv.w.valid, sn,
                             cv.sample_ok, tables, s);
-      else
+      else if (scheme == 1)
         launch_verify_fixed_double(ctx, pu + 32 * off, cv.w.c, pPK + 64 * off, pR + 64 * off, pPKp + 64 * off,
                                    pRp + 64 * off, cv.w.valid, sn, cv.sample_ok, tables, s);
+      else  // (one lane per signature: ~1 ms for the sample — worth it only because it is rarely taken)
+        launch_verify_var(pu + 32 * off, cv.w.c, pPK + 64 * off, pG + 64 * off, pR + 64 * off, cv.w.valid, sn,
+                          cv.sample_ok, tables, s);
       // a WRONG item counts, a malformed one does not (it stays out of the aggregate: verdict 0 either way)
       // (`valid` covers what the hash reads — R, R', m; u and the keys are range-checked by the verify kernel)
       static thread_local uint8_t verdicts[kRlcSample], wellformed[kRlcSample], us[32 * kRlcSample],
@@ -1003,7 +1006,8 @@ int verify_rlc_on(Context& ctx, int scheme, const void* u, const void* R_uv, con
       HIP_TRY(hipMemcpyAsync(wellformed, cv.w.valid, sn, hipMemcpyDeviceToHost, s));
       HIP_TRY(hipMemcpyAsync(us, pu + 32 * off, 32 * sn, hipMemcpyDeviceToHost, s));
       HIP_TRY(hipMemcpyAsync(keys[0], pPK + 64 * off, 64 * sn, hipMemcpyDeviceToHost, s));
-      if (scheme == 1) HIP_TRY(hipMemcpyAsync(keys[1], pPKp + 64 * off, 64 * sn, hipMemcpyDeviceToHost, s));
+      if (scheme != 0)
+        HIP_TRY(hipMemcpyAsync(keys[1], (scheme == 1 ? pPKp : pG) + 64 * off, 64 * sn, hipMemcpyDeviceToHost, s));
       HIP_TRY(hipStreamSynchronize(s));
       static const uint32_t r_words[8] = DSV_R32, q_words[8] = DSV_Q32;
       auto below = [](const uint8_t* le32, const uint32_t (&mod)[8]) {  // most significant word first
@@ -1016,7 +1020,7 @@ int verify_rlc_on(Context& ctx, int scheme, const void* u, const void* R_uv, con
       for (size_t k = 0; k < sn; k++) {
         if (verdicts[k] == 1 || !wellformed[k]) continue;
         bool canonical = below(us + 32 * k, r_words);
-        for (int h = 0; h < (scheme == 1 ? 2 : 1); h++)
+        for (int h = 0; h < (scheme == 0 ? 1 : 2); h++)
           canonical = canonical && below(keys[h] + 64 * k, q_words) && below(keys[h] + 64 * k + 32, q_words);
         sample_bad |= canonical;  // well-formed and still verdict 0: a wrong signature
       }
