@@ -184,6 +184,8 @@ struct Context {
   // caller whose batches are valid pays for it on the first call only, one whose batches are tampered
   // with pays an aggregate once and 0.26 ms per group from then on
   std::atomic<int> rlc_suspicion{1};
+  std::mutex rlc_sample_mu;
+  uint8_t* rlc_sample_host = nullptr;  // pinned: the sample's verdicts and what tells a wrong item from a malformed one
 };
 Context g_ctx[kMaxDevices];
 std::mutex g_init_mu;               // dsv_init / dsv_shutdown
@@ -550,6 +552,8 @@ void release_context(Context& ctx) {
   destroy_pipe_streams(ctx);
   ctx.pipe_failed = false;
   ctx.rlc_suspicion.store(1);
+  if (ctx.rlc_sample_host) (void)hipHostFree(ctx.rlc_sample_host);
+  ctx.rlc_sample_host = nullptr;
   for (auto& ar : ctx.rlc_arenas) {
     if (ar.dev) (void)hipFree(ar.dev);
     ar.dev = nullptr;
@@ -1000,8 +1004,11 @@ int verify_rlc_on(Context& ctx, int scheme, const void* u, const void* R_uv, con
                           cv.sample_ok, tables, s);
       // a WRONG item counts, a malformed one does not (it stays out of the aggregate: verdict 0 either way)
       // (`valid` covers what the hash reads — R, R', m; u and the keys are range-checked by the verify kernel)
-      static thread_local uint8_t verdicts[kRlcSample], wellformed[kRlcSample], us[32 * kRlcSample],
-          keys[2][64 * kRlcSample];
+      // into pinned memory the device owns for this purpose (one sampler at a time: the phase is short)
+      std::lock_guard<std::mutex> sampler(ctx.rlc_sample_mu);
+      if (!ctx.rlc_sample_host) HIP_TRY(hipHostMalloc((void**)&ctx.rlc_sample_host, (1 + 1 + 32 + 2 * 64) * kRlcSample));
+      uint8_t *verdicts = ctx.rlc_sample_host, *wellformed = verdicts + kRlcSample, *us = wellformed + kRlcSample,
+              *keys[2] = {us + 32 * kRlcSample, us + (32 + 64) * kRlcSample};
       HIP_TRY(hipMemcpyAsync(verdicts, cv.sample_ok, sn, hipMemcpyDeviceToHost, s));
       HIP_TRY(hipMemcpyAsync(wellformed, cv.w.valid, sn, hipMemcpyDeviceToHost, s));
       HIP_TRY(hipMemcpyAsync(us, pu + 32 * off, 32 * sn, hipMemcpyDeviceToHost, s));
