@@ -178,6 +178,7 @@ struct Context {
     uint8_t* dev = nullptr;
     size_t bytes = 0;
     hipStream_t stream = nullptr;
+    hipEvent_t ev[2] = {nullptr, nullptr};  // "the compute lanes have reached the staged range's end"
   } rlc_arenas[2];
   // the fast accept's sample check (kRlcSample items through the per-signature kernel before an aggregate
   // is paid for) runs while this is > 0: a rejected group sets it to 8, an accepted one takes 1 off — a
@@ -560,6 +561,10 @@ void release_context(Context& ctx) {
     ar.bytes = 0;
     if (ar.stream) (void)hipStreamDestroy(ar.stream);
     ar.stream = nullptr;
+    for (auto& e : ar.ev) {
+      if (e) (void)hipEventDestroy(e);
+      e = nullptr;
+    }
   }
 }
 
@@ -890,6 +895,10 @@ int dsv_verify_single_dev(const void* u, const void* R_uv, const void* PK_uv, co
 // THEIR verdicts.  The call blocks on `stream` once per group (the decision is taken on the host).
 extern "C++" {
 namespace {
+struct RlcStaged {  // a host call whose bucket pass over items [0, boundary) was enqueued while the rest was still on the bus
+  ChaChaKey key;
+  size_t boundary;
+};
 struct RlcCarve {
   Workspace w;  // the per-signature path's own workspace comes first: the fallback uses it as it is
   RlcBuffers b;
@@ -917,6 +926,7 @@ RlcCarve carve_rlc(void* ws, size_t n, const RlcPlan& p) {
   r.b.start = words(p.buckets + 1);
   for (int k = 0; k < 2; k++) r.b.cnt[k] = words(p.buckets), r.b.order[k] = words(p.buckets);
   r.b.buckets = words(p.buckets * 36);
+  r.b.buckets2 = words(p.buckets * 36);
   for (int k = 0; k < 2; k++) r.b.tmp[k] = words(rlc_tmp_points(p, k) * 36);
   r.b.flags = words(4);
   r.b.sort_temp_bytes = rlc_sort_temp_bytes(p);
@@ -950,7 +960,7 @@ int rlc_random_key(ChaChaKey& key) {
 int verify_rlc_on(Context& ctx, int scheme, const void* u, const void* R_uv, const void* Rp_uv, const void* PK_uv,
                   const void* PKp_uv, const void* Gen_uv, const void* m, size_t n, void* ok, void* workspace,
                   hipStream_t s, int window_bits, int* accepted, bool have_challenges = false,
-                  const uint8_t* valid_in = nullptr) {
+                  const uint8_t* valid_in = nullptr, const RlcStaged* staged = nullptr) {
   const uint8_t *pu = (const uint8_t*)u, *pR = (const uint8_t*)R_uv, *pRp = (const uint8_t*)Rp_uv,
                 *pPK = (const uint8_t*)PK_uv, *pPKp = (const uint8_t*)PKp_uv, *pG = (const uint8_t*)Gen_uv,
                 *pm = (const uint8_t*)m;
@@ -978,7 +988,8 @@ int verify_rlc_on(Context& ctx, int scheme, const void* u, const void* R_uv, con
       continue;
     }
     ChaChaKey key;
-    if (int r = rlc_random_key(key)) return r;
+    if (staged) key = staged->key;  // (one group: the bucket pass of its first items is on the stream already)
+    else if (int r = rlc_random_key(key)) return r;
     static const bool trace = getenv("DSV_RLC_TRACE") != nullptr;  // why a group was (not) accepted
     static const bool sample_on = !(getenv("DSV_RLC_SAMPLE") && atoi(getenv("DSV_RLC_SAMPLE")) == 0);
     const bool do_sample = !window_bits && sample_on && (ctx.quad || scheme == 2) && ctx.rlc_suspicion.load() > 0;
@@ -1042,7 +1053,13 @@ int verify_rlc_on(Context& ctx, int scheme, const void* u, const void* R_uv, con
     if (scheme == 2) in.gen = pG + 64 * off;
     u32 flags[4] = {~0u, 0, 0, 0};
     if (!sample_bad) {
-      HIP_TRY(launch_rlc(scheme, plan, cv.b, in, key, ctx.table[0], ctx.table[1], pok + off, s));
+      if (staged) {
+        HIP_TRY(launch_rlc_buckets(scheme, rlc_range(plan, staged->boundary, cnt - staged->boundary), cv.b, in, key,
+                                   pok + off, true, s));
+        HIP_TRY(launch_rlc_finish(plan, cv.b, ctx.table[0], ctx.table[1], true, s));
+      } else {
+        HIP_TRY(launch_rlc(scheme, plan, cv.b, in, key, ctx.table[0], ctx.table[1], pok + off, s));
+      }
       HIP_TRY(hipMemcpyAsync(flags, cv.b.flags, sizeof flags, hipMemcpyDeviceToHost, s));
       HIP_TRY(hipStreamSynchronize(s));
     }
@@ -2166,9 +2183,46 @@ RlcArena carve_arena(uint8_t* base, int kind, size_t n) {
   a.bytes = st.off;
   return a;
 }
+// The bucket pass in two ranges: when the pipeline is about to enqueue the first sub-batch at or beyond the
+// middle of the group, everything before it is resident (or will be, in the lanes' order): the aggregate's
+// prep / sort / accumulate over THAT range goes onto the arena's stream at once and runs while the second
+// half is still being gathered and transferred — the GPU has little else to do during a fill (normalisation
+// and hash: ~2.7 ms of work in ~6 ms).  What remains after the fill is the second range, a merge of the two
+// bucket arrays and the tail.  Speculative: if the sample check then says no, the work is dropped.
+struct RlcHook {
+  Context* ctx = nullptr;
+  int kind = 0;
+  size_t n = 0;
+  RlcPlan plan;
+  RlcCarve cv;
+  RlcInputs in;
+  ChaChaKey key;
+  uint8_t* ok = nullptr;
+  hipStream_t stream = nullptr;
+  hipEvent_t ev[2] = {nullptr, nullptr};
+  bool on = false, fired = false;
+  size_t boundary = 0;
+  int rc = DSV_OK;
+  size_t last_at = 0;
+  int at_part(size_t at) {  // (called under the pipeline's enqueue lock, before sub-batch `at` is enqueued)
+    // what the staging rests on: the pipeline enqueues a call's sub-batches in item order
+    if (at < last_at) return fail(DSV_ERR_HIP, "host pipeline enqueued item %zu after item %zu", at, last_at);
+    last_at = at;
+    if (!on || fired || at < n / 2 || at == 0) return DSV_OK;
+    fired = true;
+    boundary = at;
+    for (int k = 0; k < 2; k++) {
+      HIP_TRY(hipEventRecord(ev[k], ctx->pipe_lane[k]));
+      HIP_TRY(hipStreamWaitEvent(stream, ev[k], 0));
+    }
+    HIP_TRY(launch_rlc_begin(cv.b, stream));
+    HIP_TRY(launch_rlc_buckets(kind, rlc_range(plan, 0, boundary), cv.b, in, key, ok, false, stream));
+    return DSV_OK;
+  }
+};
 template <size_t NIN>
 int fill_arena(Context& ctx, int kind, const HostIn (&ins)[NIN], size_t n, uint8_t* ok, const RlcArena& a,
-               const Workspace& w) {
+               const Workspace& w, RlcHook* hook) {
   Context* cp = &ctx;
   const int np = kind == 0 ? 2 : (kind == 1 ? 4 : 3);
   return run_pipelined(
@@ -2199,6 +2253,7 @@ int fill_arena(Context& ctx, int kind, const HostIn (&ins)[NIN], size_t n, uint8
       },
       [=](const Staged& g, size_t off, size_t cnt, void*, void*, Stager&, hipStream_t st) {
         const size_t at = t_chunk_first + off;
+        if (int r = hook->at_part(at)) return r;
         launch_challenge(kind == 1, g.p[1] + 64 * off, kind == 1 ? g.p[2] + 64 * off : (const uint8_t*)nullptr,
                          g.p[1 + np] + 32 * off, cnt, w.c + 32 * at, w.valid + at, st, g.valid + off);
         HIP_TRY(hipGetLastError());
@@ -2235,13 +2290,36 @@ int rlc_host_shard(Context& ctx, int kind, size_t n, uint8_t* ok, int* accepted,
   if (!ar.stream) HIP_TRY(hipStreamCreateWithFlags(&ar.stream, hipStreamNonBlocking));
   const RlcArena a = carve_arena(ar.dev, kind, n);
   const Workspace w = carve(a.ws, n);  // where the aggregate (and the per-signature kernels) expect c / valid
-  if (int rc = fill(a, w)) return rc;
-  // (run_pipelined returned: every chunk's kernels are done.)  Points in the arena: single R PK, double R R'
-  // PK PK', var-generator R PK Gen
+  // Points in the arena: single R PK, double R R' PK PK', var-generator R PK Gen
   const uint8_t *R = a.pts[0], *Rp = kind == 1 ? a.pts[1] : nullptr, *PK = a.pts[kind == 1 ? 2 : 1],
                 *PKp = kind == 1 ? a.pts[3] : nullptr, *Gen = kind == 2 ? a.pts[2] : nullptr;
+  static const bool staged_on = !(getenv("DSV_RLC_STAGED") && atoi(getenv("DSV_RLC_STAGED")) == 0);
+  RlcHook hook;
+  hook.on = staged_on && n >= ((size_t)1 << 18);
+  if (hook.on) {
+    for (auto& e : ar.ev)
+      if (!e) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    hook.ctx = &ctx, hook.kind = kind, hook.n = n, hook.ok = a.ok, hook.stream = ar.stream;
+    hook.ev[0] = ar.ev[0], hook.ev[1] = ar.ev[1];
+    hook.plan = rlc_plan(kind, n, rlc_default_bits(n));  // (what verify_rlc_on plans for this group)
+    hook.cv = carve_rlc(a.ws, n, hook.plan);
+    hook.in = RlcInputs{};
+    hook.in.u = a.u, hook.in.c = hook.cv.w.c, hook.in.valid = hook.cv.w.valid;
+    hook.in.pk[0] = PK, hook.in.r[0] = R;
+    if (kind == 1) hook.in.pk[1] = PKp, hook.in.r[1] = Rp;
+    if (kind == 2) hook.in.gen = Gen;
+    if (int r = rlc_random_key(hook.key)) return r;
+  }
+  if (int rc = fill(a, w, &hook)) {
+    if (hook.fired) (void)hipStreamSynchronize(ar.stream);  // nothing of this call may still run on the arena
+    return rc;
+  }
+  // (run_pipelined returned: every chunk's kernels are done.)
+  RlcStaged staged;
+  staged.key = hook.key;
+  staged.boundary = hook.boundary;
   if (int r = verify_rlc_on(ctx, kind, a.u, R, Rp, PK, PKp, Gen, /*m: hashed already*/ a.u, n, a.ok, a.ws,
-                            ar.stream, 0, accepted, true))
+                            ar.stream, 0, accepted, true, nullptr, hook.fired ? &staged : nullptr))
     return r;
   HIP_TRY(hipMemcpyAsync(ok, a.ok, n, hipMemcpyDeviceToHost, ar.stream));
   HIP_TRY(hipStreamSynchronize(ar.stream));
@@ -2250,20 +2328,20 @@ int rlc_host_shard(Context& ctx, int kind, size_t n, uint8_t* ok, int* accepted,
 int verify_mont_cols_rlc_shard(Context& ctx, int kind, const dsv_column* cols, size_t off, size_t n, uint8_t* ok,
                                int* accepted) {
   Context* cp = &ctx;
-  return rlc_host_shard(ctx, kind, n, ok + off, accepted, [=](const RlcArena& a, const Workspace& w) {
+  return rlc_host_shard(ctx, kind, n, ok + off, accepted, [=](const RlcArena& a, const Workspace& w, RlcHook* hook) {
     auto in = [&](int k, size_t width) {
       return HostIn{static_cast<const uint8_t*>(cols[k].base) + off * cols[k].stride, width, cols[k].stride};
     };
     if (kind == 0) {
       const HostIn ins[4] = {in(0, 32), in(1, 96), in(2, 96), in(3, 32)};
-      return fill_arena(*cp, 0, ins, n, ok + off, a, w);
+      return fill_arena(*cp, 0, ins, n, ok + off, a, w, hook);
     }
     if (kind == 1) {
       const HostIn ins[6] = {in(0, 32), in(1, 96), in(2, 96), in(3, 96), in(4, 96), in(5, 32)};
-      return fill_arena(*cp, 1, ins, n, ok + off, a, w);
+      return fill_arena(*cp, 1, ins, n, ok + off, a, w, hook);
     }
     const HostIn ins[5] = {in(0, 32), in(1, 96), in(2, 96), in(3, 96), in(4, 32)};
-    return fill_arena(*cp, 2, ins, n, ok + off, a, w);
+    return fill_arena(*cp, 2, ins, n, ok + off, a, w, hook);
   });
 }
 // Shards like the *_multi forms: one group per initialised device (each with its own aggregate; all of
@@ -2862,11 +2940,12 @@ int verify_wire_rlc_host(int kind, const uint8_t* sig, const uint8_t* pk, const 
   if (n > kRlcMaxGroup || n < kRlcMinAuto) return verify_wire(ctx, kind, sig, pk, m, n, ok);
   const size_t sig_bytes = kind == 1 ? 96 : 64, pk_bytes = kind == 0 ? 32 : 64;
   Context* cp = &ctx;
-  return rlc_host_shard(ctx, kind, n, ok, accepted, [=](const RlcArena& a, const Workspace& w) {
+  return rlc_host_shard(ctx, kind, n, ok, accepted, [=](const RlcArena& a, const Workspace& w, RlcHook* hook) {
     const HostIn ins[3] = {{sig, sig_bytes}, {pk, pk_bytes}, {m, 32}};
     return run_pipelined(*cp, ins, ok, n, 0, /*per item: the decoder's verdict byte*/ 1, NoPrep{},
                          [=](const Staged& g, size_t off, size_t cnt, void*, void*, Stager& x, hipStream_t st) {
       const size_t at = t_chunk_first + off;
+      if (int r = hook->at_part(at)) return r;
       const uint8_t *dsig = g.p[0] + off * sig_bytes, *dpk = g.p[1] + off * pk_bytes;
       uint8_t* valid = x.take(cnt);
       launch_gather32(dsig, sig_bytes, cnt, a.u + 32 * at, st);

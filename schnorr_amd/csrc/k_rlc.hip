@@ -191,7 +191,8 @@ DSV_DEV ANiels affine_niels(const Fe& u, const Fe& v, bool negate) {
 // (/root/reference/src/keys/public.rs:121-130, :222-244, :401-415), z and z' independent.
 namespace {
 struct PrepOut {
-  size_t i;
+  size_t i;   // the item's place in its group (inputs, points, weights)
+  size_t il;  // ... and in the range this pass covers (the pair arrays)
   const RlcPlan& p;
   u32* pts;
   u32* keys;
@@ -202,7 +203,7 @@ DSV_DEV bool prep_point(const PrepOut& o, const uint8_t* __restrict__ uv, int sl
   Fe pu, pv;
   good &= load_fq(pu, uv, 2 * o.i);
   good &= load_fq(pv, uv, 2 * o.i + 1);
-  store_pt(o.pts + ((size_t)slot * o.p.n + o.i) * kPtWords, affine_niels(pu, pv, negate));
+  store_pt(o.pts + ((size_t)slot * o.p.total + o.i) * kPtWords, affine_niels(pu, pv, negate));
   return on_curve(pu, pv);
 }
 // e' = e + k r, k uniform below floor(2^(wpk c) / r): the same multiple of a point of the prime-order
@@ -226,9 +227,9 @@ DSV_DEV void emit_long(const PrepOut& o, u32 (&e)[8], u32 kr, int slot) {
 #pragma unroll
     for (int k = 0; k < 7; k++) e[k] = __funnelshift_r(e[k], e[k + 1], p.c);
     e[7] >>= p.c;
-    const size_t at = ((size_t)w * p.lpts + slot) * p.n + o.i;
+    const size_t at = ((size_t)w * p.lpts + slot) * p.n + o.il;
     o.keys[at] = d ? (((u32)w << p.c) | d) : none;
-    o.vals[at] = (u32)((size_t)slot * p.n + o.i);
+    o.vals[at] = (u32)((size_t)slot * p.total + o.i);
   }
 }
 DSV_DEV void emit_short(const PrepOut& o, const u32 (&zz)[8], int slot) {
@@ -242,9 +243,9 @@ DSV_DEV void emit_short(const PrepOut& o, const u32 (&zz)[8], int slot) {
 #pragma unroll
     for (int k = 0; k < 4; k++) z[k] = __funnelshift_r(z[k], z[k + 1], p.c);
     z[4] >>= p.c;
-    const size_t at = first + ((size_t)w * p.spts + slot) * p.n + o.i;
+    const size_t at = first + ((size_t)w * p.spts + slot) * p.n + o.il;
     o.keys[at] = d ? (((u32)(p.wpk + w) << p.c) | d) : none;
-    o.vals[at] = (u32)((size_t)(p.lpts + slot) * p.n + o.i);
+    o.vals[at] = (u32)((size_t)(p.lpts + slot) * p.total + o.i);
   }
 }
 // wr * c >= 128 random bits from five keystream words: every window of z is uniform
@@ -262,9 +263,10 @@ template <int SCHEME>
 __global__ void __launch_bounds__(256)
 k_rlc_prep(RlcInputs in, ChaChaKey key, RlcPlan p, uint8_t* __restrict__ ok, u32* __restrict__ pts,
            u32* __restrict__ fsc, u32* __restrict__ keys, u32* __restrict__ vals, u32* __restrict__ flags) {
-  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-  if (i >= p.n) return;
-  const PrepOut o{i, p, pts, keys, vals};
+  const size_t il = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (il >= p.n) return;
+  const size_t i = p.first + il;
+  const PrepOut o{i, il, p, pts, keys, vals};
   bool good = in.valid[i] != 0;
   u32 us[8], cs[8];
   load_words8(us, in.u, i);
@@ -294,7 +296,7 @@ k_rlc_prep(RlcInputs in, ChaChaKey key, RlcPlan p, uint8_t* __restrict__ ok, u32
     emit_long(o, e, good ? blk[8 * eq + 5] % p.kmul : 0u, eq);
     fr_mul(e, z, us);
     if (SCHEME == 2) emit_long(o, e, good ? blk[6] % p.kmul : 0u, 1);
-    else store_words8(reinterpret_cast<uint8_t*>(fsc), (size_t)eq * p.n + i, e);
+    else store_words8(reinterpret_cast<uint8_t*>(fsc), (size_t)eq * p.total + i, e);
     emit_short(o, z, eq);
   }
 }
@@ -373,7 +375,7 @@ k_rlc_accumulate(const u32* __restrict__ order, const u32* __restrict__ start, c
   //  then simply does not come out as the identity)
   if (hi > p.entries) hi = (u32)p.entries;
   if (lo > hi) lo = hi;
-  const u32 last_pt = (u32)(p.lpts + p.spts) * p.n - 1u;
+  const u32 last_pt = (u32)(p.lpts + p.spts) * p.total - 1u;
   Ext acc = ext_identity();
   if (lo < hi) {
     // the index of entry j + 2 and the point of entry j + 1 are on their way while entry j is added
@@ -389,6 +391,16 @@ k_rlc_accumulate(const u32* __restrict__ order, const u32* __restrict__ start, c
     }
   }
   store_niels(buckets + (size_t)b * kNielsWords, ext_to_niels(acc));
+}
+
+// buckets[b] += buckets2[b]: the two ranges of a staged bucket pass
+__global__ void __launch_bounds__(64)
+k_rlc_merge(u32* __restrict__ buckets, const u32* __restrict__ buckets2, RlcPlan p) {
+  const size_t b = (size_t)blockIdx.x * 64 + threadIdx.x;
+  if (b >= p.buckets) return;
+  Ext acc = ext_add_niels(ext_identity(), load_niels(buckets + b * kNielsWords));
+  acc = ext_add_niels(acc, load_niels(buckets2 + b * kNielsWords));
+  store_niels(buckets + b * kNielsWords, ext_to_niels(acc));
 }
 
 // ---- short sums of stored points: out[o] = sum_k in[addr(o, k)] ------------------------------------
@@ -608,10 +620,10 @@ size_t rlc_sort_temp_bytes(const RlcPlan& p) {
   return bytes > bytes2 ? bytes : bytes2;
 }
 
-hipError_t launch_rlc(int scheme, const RlcPlan& p, const RlcBuffers& b, const RlcInputs& in, ChaChaKey key,
-                      const uint32_t* tableG, const uint32_t* tableG2, uint8_t* ok, hipStream_t s) {
-  hipError_t err = hipMemsetAsync(b.flags, 0, 16, s);
-  if (err != hipSuccess) return err;
+hipError_t launch_rlc_begin(const RlcBuffers& b, hipStream_t s) { return hipMemsetAsync(b.flags, 0, 16, s); }
+
+hipError_t launch_rlc_buckets(int scheme, const RlcPlan& p, const RlcBuffers& b, const RlcInputs& in, ChaChaKey key,
+                              uint8_t* ok, bool second, hipStream_t s) {
   const dim3 grid(grid_for(p.n)), block(256);
   if (scheme == 0)
     hipLaunchKernelGGL(k_rlc_prep<0>, grid, block, 0, s, in, key, p, ok, b.pts, b.fsc, b.keys[0], b.vals[0], b.flags);
@@ -619,13 +631,9 @@ hipError_t launch_rlc(int scheme, const RlcPlan& p, const RlcBuffers& b, const R
     hipLaunchKernelGGL(k_rlc_prep<1>, grid, block, 0, s, in, key, p, ok, b.pts, b.fsc, b.keys[0], b.vals[0], b.flags);
   else
     hipLaunchKernelGGL(k_rlc_prep<2>, grid, block, 0, s, in, key, p, ok, b.pts, b.fsc, b.keys[0], b.vals[0], b.flags);
-  for (int k = 0; k < p.fixed; k++) {
-    hipLaunchKernelGGL(k_rlc_fsum, dim3(kRlcFsumBlocks), dim3(256), 0, s, b.fsc + (size_t)k * p.n * 8, (size_t)p.n, b.fpart);
-    hipLaunchKernelGGL(k_rlc_fsum, dim3(1), dim3(256), 0, s, b.fpart, (size_t)kRlcFsumBlocks, b.fsum + 8 * k);
-  }
   size_t temp = b.sort_temp_bytes;
-  err = hipcub::DeviceRadixSort::SortPairs(b.sort_temp, temp, b.keys[0], b.keys[1], b.vals[0], b.vals[1], p.entries, 0,
-                                           p.key_bits, s);
+  hipError_t err = hipcub::DeviceRadixSort::SortPairs(b.sort_temp, temp, b.keys[0], b.keys[1], b.vals[0], b.vals[1],
+                                                      p.entries, 0, p.key_bits, s);
   if (err != hipSuccess) return err;
   hipLaunchKernelGGL(k_rlc_starts, dim3(grid_for(p.entries + 1)), dim3(256), 0, s, b.keys[1], p, b.start);
   hipLaunchKernelGGL(k_rlc_counts, dim3(grid_for(p.buckets)), dim3(256), 0, s, b.start, p, b.cnt[0], b.order[0]);
@@ -634,7 +642,17 @@ hipError_t launch_rlc(int scheme, const RlcPlan& p, const RlcBuffers& b, const R
                                                      p.buckets, 0, 8, s);
   if (err != hipSuccess) return err;
   hipLaunchKernelGGL(k_rlc_accumulate, dim3(grid_for(p.buckets, 64)), dim3(64), 0, s, b.order[1], b.start, b.vals[1],
-                     b.pts, p, b.buckets);
+                     b.pts, p, second ? b.buckets2 : b.buckets);
+  return hipGetLastError();
+}
+
+hipError_t launch_rlc_finish(const RlcPlan& p, const RlcBuffers& b, const uint32_t* tableG, const uint32_t* tableG2,
+                             bool merged, hipStream_t s) {
+  if (merged) hipLaunchKernelGGL(k_rlc_merge, dim3(grid_for(p.buckets, 64)), dim3(64), 0, s, b.buckets, b.buckets2, p);
+  for (int k = 0; k < p.fixed; k++) {
+    hipLaunchKernelGGL(k_rlc_fsum, dim3(kRlcFsumBlocks), dim3(256), 0, s, b.fsc + (size_t)k * p.total * 8, (size_t)p.total, b.fpart);
+    hipLaunchKernelGGL(k_rlc_fsum, dim3(1), dim3(256), 0, s, b.fpart, (size_t)kRlcFsumBlocks, b.fsum + 8 * k);
+  }
   const unsigned side = 1u << p.half;
   hipLaunchKernelGGL(k_rlc_sum<0>, dim3(grid_for((size_t)p.windows * 2 * side * p.nseg, 64)), dim3(64), 0, s, b.buckets, p, b.tmp[0]);
   hipLaunchKernelGGL(k_rlc_sum<1>, dim3(grid_for((size_t)p.windows * 2 * side, 64)), dim3(64), 0, s, b.tmp[0], p, b.tmp[1]);
@@ -644,6 +662,15 @@ hipError_t launch_rlc(int scheme, const RlcPlan& p, const RlcBuffers& b, const R
   hipLaunchKernelGGL(k_rlc_scale, dim3(2 * g + 1), dim3(256), 0, s, b.tmp[1], b.fsum, tableG, tableG2, p, b.tmp[0], b.flags);
   hipLaunchKernelGGL(k_rlc_final, dim3(1), dim3(64), 0, s, b.tmp[0], p, b.flags);
   return hipGetLastError();
+}
+
+hipError_t launch_rlc(int scheme, const RlcPlan& p, const RlcBuffers& b, const RlcInputs& in, ChaChaKey key,
+                      const uint32_t* tableG, const uint32_t* tableG2, uint8_t* ok, hipStream_t s) {
+  hipError_t err = launch_rlc_begin(b, s);
+  if (err != hipSuccess) return err;
+  err = launch_rlc_buckets(scheme, p, b, in, key, ok, false, s);
+  if (err != hipSuccess) return err;
+  return launch_rlc_finish(p, b, tableG, tableG2, false, s);
 }
 
 }  // namespace dsv

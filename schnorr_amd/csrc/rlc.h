@@ -12,7 +12,9 @@ namespace dsv {
 // A window's 2^c buckets are a 2^half x 2^half matrix; row / column sums run in nseg segments, the
 // per-bit subset sums over them in nseg2 segments, so that no serial chain exceeds ~32 additions.
 struct RlcPlan {
-  uint32_t n;
+  uint32_t n;             // items of this bucket pass ...
+  uint32_t first, total;  // ... which are items first .. first + n of a group of `total` (a host call may run its
+                          // bucket pass in two ranges: the first while the second is still on the bus)
   int lpts, spts, fixed;  // per item: points with 252-bit scalars, points with the z themselves, fixed-base terms
   int c, half, wpk, wr, windows, nseg, nseg2, key_bits;
   uint32_t kmul;   // floor(2^(wpk c) / r): the keys' scalars get a random multiple of r below it added
@@ -29,11 +31,21 @@ inline int rlc_default_bits(size_t n) {
   return n >= ((size_t)1 << 19) ? 16 : n >= ((size_t)1 << 17) ? 14 : n >= ((size_t)1 << 14) ? 12 : 8;
 }
 // even, and the keys' windows cover 252 or 256 bits exactly (10 would need 260: a ninth scalar word)
+// the plan of a range [first, first + cnt) of a group planned as `whole`: same bucket geometry, fewer pairs
+inline RlcPlan rlc_range(const RlcPlan& whole, size_t first, size_t cnt) {
+  RlcPlan p = whole;
+  p.n = (uint32_t)cnt;
+  p.first = (uint32_t)first;
+  p.entries = cnt * ((size_t)p.wpk * p.lpts + (size_t)p.wr * p.spts);
+  return p;
+}
 inline bool rlc_bits_ok(int c) { return c == 4 || c == 6 || c == 8 || c == 12 || c == 14 || c == 16; }
 // scheme: 0 single, 1 double, 2 var-generator (k_rlc.hip: k_rlc_prep says which point gets which scalar)
 inline RlcPlan rlc_plan(int scheme, size_t n, int c) {
   RlcPlan p;
   p.n = (uint32_t)n;
+  p.first = 0;
+  p.total = (uint32_t)n;
   p.lpts = scheme == 0 ? 1 : 2;
   p.spts = scheme == 1 ? 2 : 1;
   p.fixed = scheme == 0 ? 1 : (scheme == 1 ? 2 : 0);
@@ -71,6 +83,7 @@ struct RlcBuffers {
   uint32_t* cnt[2];   // buckets each: run lengths (unsorted / sorted, longest first)
   uint32_t* order[2]; // buckets each: bucket numbers (identity / in the order of the sorted lengths)
   uint32_t* buckets;  // buckets x 36 words (extended niels)
+  uint32_t* buckets2; // the same for a second range (null: device-pointer calls run one range)
   uint32_t* tmp[2];   // rlc_tmp_points(p, k) x 36 words
   uint32_t* flags;    // 4 words
   void* sort_temp;
@@ -90,5 +103,12 @@ size_t rlc_sort_temp_bytes(const RlcPlan& p);
 // returns the first error of a launch or of the sorts
 hipError_t launch_rlc(int scheme, const RlcPlan& p, const RlcBuffers& b, const RlcInputs& in, ChaChaKey key,
                 const uint32_t* tableG, const uint32_t* tableG2, uint8_t* ok, hipStream_t s);
+// the same in pieces: begin (flags), the bucket pass of one range into b.buckets (second = false) or
+// b.buckets2, and the rest over the whole group (`merged`: the two bucket arrays are added first)
+hipError_t launch_rlc_begin(const RlcBuffers& b, hipStream_t s);
+hipError_t launch_rlc_buckets(int scheme, const RlcPlan& range, const RlcBuffers& b, const RlcInputs& in,
+                              ChaChaKey key, uint8_t* ok, bool second, hipStream_t s);
+hipError_t launch_rlc_finish(const RlcPlan& whole, const RlcBuffers& b, const uint32_t* tableG,
+                             const uint32_t* tableG2, bool merged, hipStream_t s);
 
 }  // namespace dsv

@@ -483,3 +483,50 @@ print("done")
     assert any(" sum" in x for x in calls["tampered-1"]) and not any("no aggregate" in x for x in calls["tampered-1"])
     assert any("no aggregate" in x for x in calls["tampered-2"])
     assert any("accepted" in x for x in calls["valid-3"])          # the sample passes, the aggregate decides
+
+
+@pytest.mark.parametrize("scheme", ["single", "double", "vargen"])
+def test_host_fast_accept_with_the_bucket_pass_in_two_ranges(engine, scheme):
+    """From 2^18 items on the host forms run their bucket pass in two ranges (dsv.hip: RlcHook): the first
+    while the second is still on the bus, then the second, a merge of the two bucket arrays and the tail.
+    Valid + malformed items -> accepted; ONE wrong signature in the first range, in the second, in the item at
+    the range boundary's neighbourhood -> the per-signature kernels' (the oracle's) verdicts, not accepted.
+    Typed objects and serialized records."""
+    import mont_cases as C
+    n = (1 << 18) + (1 << 16) + 5
+    cols, want = C.mont_case(scheme, 300, 1030 + len(scheme), period=10 ** 9)   # item 0 tampered (dropped), planted encodings kept
+    reps = -(-n // 299)
+    good = [np.ascontiguousarray(np.tile(c[1:], (reps, 1))[:n]) for c in cols]
+    gwant = np.tile(want[1:], reps)[:n]
+    got, accepted = engine.verify_mont_cols_rlc(scheme, C.as_records(scheme, good)[3])
+    assert accepted and np.array_equal(got, gwant)
+    for victim in (7, n // 2 - 3, n // 2 + (1 << 15), n - 2):
+        while not gwant[victim]:
+            victim += 1
+        bad = [c.copy() for c in good]
+        src = victim - 1 if gwant[victim - 1] else victim + 1
+        bad[0][victim] = good[0][src]                        # another item's u
+        bwant = gwant.copy()
+        bwant[victim] = 0
+        got, accepted = engine.verify_mont_cols_rlc(scheme, C.as_records(scheme, bad)[3])
+        assert not accepted and np.array_equal(got, bwant), victim
+    # serialized records
+    d = _signed(500, 1040 + len(scheme), scheme)
+    cp = engine.compress_points
+    if scheme == "single":
+        sig, pk = np.concatenate([d["u"], cp(d["R"])], axis=1), cp(d["PK"])
+    elif scheme == "double":
+        sig = np.concatenate([d["u"], cp(d["R"]), cp(d["Rp"])], axis=1)
+        pk = np.concatenate([cp(d["PK"]), cp(d["PKp"])], axis=1)
+    else:
+        sig, pk = np.concatenate([d["u"], cp(d["R"])], axis=1), np.concatenate([cp(d["PK"]), cp(d["Gen"])], axis=1)
+    reps = -(-n // 500)
+    tile = lambda a: np.ascontiguousarray(np.tile(a, (reps, 1))[:n])
+    tsig, tpk, tm = tile(sig), tile(pk), tile(d["m"])
+    got, accepted = engine.verify_wire_rlc(scheme, tsig, tpk, tm)
+    assert accepted and got.all()
+    for victim in (3, n - 9):
+        m2 = tm.copy()
+        m2[victim, 0] ^= 1
+        got, accepted = engine.verify_wire_rlc(scheme, tsig, tpk, m2)
+        assert not accepted and got.sum() == n - 1 and not got[victim]

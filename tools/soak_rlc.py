@@ -40,7 +40,7 @@ rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 60
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 E.init(0)
 t8 = TH.order8_point()
-SIZES = [40, 700, 4097, (1 << 14) + 3, (1 << 15) - 1, 40000, (1 << 16) + 77, (1 << 17) + 1, (1 << 17) + (1 << 16) + 13, (1 << 18) + 5]
+SIZES = [40, 700, 4097, (1 << 14) + 3, (1 << 15) - 1, 40000, (1 << 16) + 77, (1 << 17) + 1, (1 << 17) + (1 << 16) + 13, (1 << 18) + 5, (1 << 18) + (1 << 17) + 7]
 total = bad = 0
 t0 = time.time()
 for rd in range(rounds):
