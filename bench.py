@@ -165,6 +165,28 @@ def _e2e_streamed(L, scheme_idx, ok, expected, n, calls=8, reps=3):
     return res
 
 
+def _e2e_fast_scheme(L, scheme_idx, ok, expected):
+    """verify_batch_{double,var_gen}_fast over the VALID objects of the prepared batch (the aggregate decides)"""
+    import ctypes
+    if not hasattr(L, "vb_e2e_run_fast_scheme"):
+        return None
+    p = lambda a: ctypes.c_void_p(a.ctypes.data)
+    cnt, acc, ms = ctypes.c_size_t(0), ctypes.c_int(0), ctypes.c_double(0)
+    mask = np.ascontiguousarray(expected)
+    times = []
+    for rep in range(4):
+        if L.vb_e2e_run_fast_scheme(ctypes.c_int(scheme_idx), p(mask), p(ok), ctypes.byref(cnt), ctypes.byref(acc),
+                                    ctypes.byref(ms)) != 0:
+            raise SystemExit("verify_batch_fast (scheme %d): engine error" % scheme_idx)
+        if not ok[:cnt.value].all() or bool(acc.value) != (cnt.value >= RLC_MIN):
+            raise SystemExit("verify_batch_fast (scheme %d): verdicts / acceptance differ" % scheme_idx)
+        if rep:
+            times.append(ms.value)
+    times.sort()
+    return {"items": int(cnt.value), "best_ms": times[0], "value": cnt.value / (times[0] * 1e-3),
+            "accepted_by_aggregate": bool(acc.value)}
+
+
 def _verify_batch_e2e_double(E, bd, cores):
     """`verify_batch_double` of the C++ mirror over the double batch as typed objects (SignatureDouble
     352 B, PublicKeyDouble 320 B): six strided columns, 448 B gathered per item."""
@@ -192,12 +214,13 @@ def _verify_batch_e2e_double(E, bd, cores):
         if (ok != expected).any():
             raise SystemExit("verify_batch_e2e (double): verdicts differ from the expected pattern")
         streamed = _e2e_streamed(L, 1, ok, expected, n)
+        fast = _e2e_fast_scheme(L, 1, ok, expected)
     finally:
         L.vb_e2e_release()
     times.sort()
     return {"value": n / (times[0] * 1e-3), "unit": "verifies/s", "items": n, "best_ms": times[0],
             "median_ms": times[len(times) // 2], "objects_not_representable": int(bad),
-            "streamed": streamed,
+            "streamed": streamed, "fast_accept_all_valid": fast,
             "copy_threads": E.set_host_threads(0),
             "workload": "verify_batch_double over %d typed objects (SignatureDouble 352 B, PublicKeyDouble "
                         "320 B, BlsScalar 32 B) -> vector<bool>; dsv_verify_double_mont_cols" % n}
@@ -230,12 +253,13 @@ def _verify_batch_e2e_vargen(E, bv, cores):
         if (ok != expected).any():
             raise SystemExit("verify_batch_e2e (var-generator): verdicts differ from the expected pattern")
         streamed = _e2e_streamed(L, 2, ok, expected, n)
+        fast = _e2e_fast_scheme(L, 2, ok, expected)
     finally:
         L.vb_e2e_release()
     times.sort()
     return {"value": n / (times[0] * 1e-3), "unit": "verifies/s", "items": n, "best_ms": times[0],
             "median_ms": times[len(times) // 2], "objects_not_representable": int(bad),
-            "streamed": streamed,
+            "streamed": streamed, "fast_accept_all_valid": fast,
             "workload": "verify_batch_var_gen over %d typed objects (SignatureVarGen 192 B, PublicKeyVarGen "
                         "320 B, BlsScalar 32 B) -> vector<bool>; dsv_verify_vargen_mont_cols" % n}
 

@@ -241,6 +241,37 @@ int vb_e2e_run_double(uint8_t* ok, double* ms) {
   }
 }
 
+// verify_batch_double_fast / verify_batch_var_gen_fast over the objects a mask selects (scheme 1 / 2): as
+// vb_e2e_run_fast
+extern "C++" {
+template <class S, class P, class F>
+static int run_fast_masked(const std::vector<S>& all_s, const std::vector<P>& all_p, const std::vector<BlsScalar>& all_m,
+                           const uint8_t* mask, uint8_t* ok, size_t* count, int* accepted, double* ms, F verify) {
+  try {
+    std::vector<S> sigs;
+    std::vector<P> pks;
+    std::vector<BlsScalar> msgs;
+    for (size_t i = 0; i < all_s.size(); i++)
+      if (!mask || mask[i]) {
+        sigs.push_back(all_s[i]);
+        pks.push_back(all_p[i]);
+        msgs.push_back(all_m[i]);
+      }
+    bool acc = false;
+    const double t0 = now_ms();
+    const std::vector<bool> out = verify(sigs, pks, msgs, &acc);
+    *ms = now_ms() - t0;
+    for (size_t i = 0; i < out.size(); i++) ok[i] = out[i] ? 1 : 0;
+    *count = out.size();
+    *accepted = acc ? 1 : 0;
+    return 0;
+  } catch (const std::exception& e) {
+    std::fprintf(stderr, "vb_e2e_run_fast_scheme: %s\n", e.what());
+    return -1;
+  }
+}
+}  // extern "C++"
+
 // ---- the var-generator scheme: verify_batch_var_gen over SignatureVarGen (192 B) / PublicKeyVarGen (320 B) ----
 static std::vector<SignatureVarGen> g_vsigs;
 static std::vector<PublicKeyVarGen> g_vpks;
@@ -299,6 +330,16 @@ int vb_e2e_run_vargen(uint8_t* ok, double* ms) {
 // sequence incl. every Vec<bool>; ok = the LAST batch's verdicts; every batch's result is compared
 // with the first one's (returns 1 on a mismatch, -1 on an engine error).  scheme: 0 single, 1 double,
 // 2 var-generator.
+int vb_e2e_run_fast_scheme(int scheme, const uint8_t* mask, uint8_t* ok, size_t* count, int* accepted, double* ms) {
+  if (scheme == 1)
+    return run_fast_masked(g_dsigs, g_dpks, g_dmsgs, mask, ok, count, accepted, ms,
+                           [](auto& s, auto& p, auto& m, bool* a) { return verify_batch_double_fast(s, p, m, a); });
+  if (scheme == 2)
+    return run_fast_masked(g_vsigs, g_vpks, g_vmsgs, mask, ok, count, accepted, ms,
+                           [](auto& s, auto& p, auto& m, bool* a) { return verify_batch_var_gen_fast(s, p, m, a); });
+  return -1;
+}
+
 int vb_e2e_run_streamed(int scheme, int calls, int in_flight, uint8_t* ok, double* ms) {
   try {
     if (calls < 1 || in_flight < 1) return -1;
