@@ -820,6 +820,19 @@ def main():
             rlc[label] = {"items": n_, "value": n_ * reps / t_, "ms_per_call": t_ / reps * 1e3,
                           "vs_per_signature": (n_ * reps / t_) / ref_}
             del b_
+        # the mixed batch (configs[4]'s shape on one GPU: n/2 singles and n/2 doubles interleaved), all valid
+        bm_ = W.gen_mixed(n, seed=31, device=dev, tamper=False)
+        wsm_ = torch.empty(E.mixed_rlc_workspace_bytes(n), dtype=torch.uint8, device=dev)
+        wsp_ = torch.empty(E.mixed_workspace_bytes(n), dtype=torch.uint8, device=dev)
+        margs = (bm_["kinds"], bm_["u"], bm_["R"], bm_["Rp"], bm_["PK"], bm_["PKp"], bm_["m"], bm_["n_double"])
+        acc = []
+        t_ = timed(lambda: acc.append(E.verify_mixed_rlc_dev(*margs, okr, wsm_)), reps, 1)
+        if not bool(okr.all()) or any(a != (n // 2 >= RLC_MIN) for a in acc):
+            raise SystemExit("rlc (mixed): not accepted")
+        tp_ = timed(lambda: E.verify_mixed_dev(*margs, okr, wsp_), reps, 1)
+        rlc["mixed_all_valid"] = {"items": n, "value": n * reps / t_, "ms_per_call": t_ / reps * 1e3,
+                                  "vs_per_signature": tp_ / t_}
+        del bm_, wsm_, wsp_
         out["rlc"] = rlc
         del wsr, okr
 

@@ -358,6 +358,13 @@ size_t dsv_mixed_workspace_bytes(size_t n);
 int dsv_verify_mixed_dev(const void *kinds, const void *u, const void *R_uv, const void *Rp_uv,
                          const void *PK_uv, const void *PKp_uv, const void *m, size_t n,
                          size_t n_double, void *ok, void *workspace, void *stream);
+/* ... with each kind's items through the batch fast accept (dsv_verify_*_rlc_dev above: same verdicts;
+ * blocks on `stream`; *accepted = every group of both kinds was decided by its aggregate).
+ * workspace: dsv_mixed_rlc_workspace_bytes(n). */
+size_t dsv_mixed_rlc_workspace_bytes(size_t n);
+int dsv_verify_mixed_rlc_dev(const void *kinds, const void *u, const void *R_uv, const void *Rp_uv,
+                             const void *PK_uv, const void *PKp_uv, const void *m, size_t n,
+                             size_t n_double, void *ok, void *workspace, void *stream, int *accepted);
 /* the pieces, for callers that shard each kind separately (schnorr_amd/distributed.py):
  *   split : idx_single[j] / idx_double[j] = batch position (uint32) of the j-th item of that kind,
  *           at most cap_* entries written; scratch: dsv_split_scratch_bytes(n) device bytes whose

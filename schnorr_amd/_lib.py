@@ -51,10 +51,11 @@ SYMBOLS = [
     "dsv_wire_rlc_workspace_bytes", "dsv_verify_single_wire_rlc_dev", "dsv_verify_double_wire_rlc_dev",
     "dsv_verify_vargen_wire_rlc_dev",
     "dsv_verify_single_wire_rlc", "dsv_verify_double_wire_rlc", "dsv_verify_vargen_wire_rlc",
+    "dsv_mixed_rlc_workspace_bytes", "dsv_verify_mixed_rlc_dev",
 ]
 _SIZE_T_FUNCS = ("dsv_workspace_bytes", "dsv_mixed_workspace_bytes", "dsv_split_scratch_bytes",
                  "dsv_ext_workspace_bytes", "dsv_wire_workspace_bytes", "dsv_mont_workspace_bytes",
-                 "dsv_rlc_workspace_bytes", "dsv_wire_rlc_workspace_bytes")
+                 "dsv_rlc_workspace_bytes", "dsv_wire_rlc_workspace_bytes", "dsv_mixed_rlc_workspace_bytes")
 
 
 class Column(ctypes.Structure):

@@ -1264,9 +1264,14 @@ size_t dsv_mixed_workspace_bytes(size_t n) {
 // One batch holding single (kind 0) and double (kind 1) signatures in any interleaving, as a
 // structure of arrays over ALL n items (Rp_uv / PKp_uv rows of single items are ignored).
 // n_double = number of kind-1 items (the caller knows its batch); every other item must be kind 0.
-int dsv_verify_mixed_dev(const void* kinds, const void* u, const void* R_uv, const void* Rp_uv,
-                         const void* PK_uv, const void* PKp_uv, const void* m, size_t n,
-                         size_t n_double, void* ok, void* workspace, void* stream) {
+extern "C++" {
+namespace {
+// fast: both kinds' groups through the batch fast accept (verify_rlc_on; blocks on the stream); *accepted =
+// every group of both kinds was decided by its aggregate
+int verify_mixed_dev(const void* kinds, const void* u, const void* R_uv, const void* Rp_uv, const void* PK_uv,
+                     const void* PKp_uv, const void* m, size_t n, size_t n_double, void* ok, void* workspace,
+                     void* stream, bool fast, int* accepted) {
+  if (accepted) *accepted = 0;
   if (n && (!kinds || !u || !R_uv || !Rp_uv || !PK_uv || !PKp_uv || !m || !ok || !workspace))
     return fail(DSV_ERR_INVALID_ARGUMENT, "null pointer");
   if (n_double > n) return fail(DSV_ERR_INVALID_ARGUMENT, "n_double exceeds n");
@@ -1281,7 +1286,7 @@ int dsv_verify_mixed_dev(const void* kinds, const void* u, const void* R_uv, con
   uint8_t *cR = st.take(n * 64), *cPK = st.take(n * 64);
   uint8_t *cRp = st.take(n * 64), *cPKp = st.take(n * 64);  // doubles only
   uint8_t *oks = st.take(n), *okd = st.take(n);
-  void* vws = st.take(dsv_workspace_bytes(n));
+  void* vws = st.take(fast ? dsv_rlc_workspace_bytes(n, 0) : dsv_workspace_bytes(n));
   HIP_TRY(hipMemsetAsync(ok, 0, n, s));  // items of an invalid kind keep verdict 0
   if (int r = split_on(kinds, n, idx_s, ns, idx_d, nd, scratch, s)) return r;
   // Only index entries the split really wrote are dereferenced: every gather / scatter is bounded
@@ -1299,19 +1304,41 @@ int dsv_verify_mixed_dev(const void* kinds, const void* u, const void* R_uv, con
                               {Rp_uv, 64, cRp},           {PKp_uv, 64, cPKp}};
   for (const Col& c : double_cols)
     if (int r = gather_on(c.src, n, c.bytes, idx_d, nd, totals + 1, c.dst, s)) return r;
+  int acc_s = 1, acc_d = 1;
   if (ns) {
-    if (int r = verify_single_on(ctx, cu, cR, cPK, cm, ns, oks, vws, s)) return r;
+    if (int r = fast ? verify_rlc_on(ctx, 0, cu, cR, nullptr, cPK, nullptr, nullptr, cm, ns, oks, vws, s, 0, &acc_s)
+                     : verify_single_on(ctx, cu, cR, cPK, cm, ns, oks, vws, s))
+      return r;
     launch_scatter_bytes(oks, idx_s, ns, totals, (uint8_t*)ok, n, s);
   }
   if (nd) {
-    if (int r = verify_double_on(ctx, cu + ns * 32, cR + ns * 64, cRp, cPK + ns * 64, cPKp,
-                                 cm + ns * 32, nd, okd, vws, s))
+    if (int r = fast ? verify_rlc_on(ctx, 1, cu + ns * 32, cR + ns * 64, cRp, cPK + ns * 64, cPKp, nullptr,
+                                     cm + ns * 32, nd, okd, vws, s, 0, &acc_d)
+                     : verify_double_on(ctx, cu + ns * 32, cR + ns * 64, cRp, cPK + ns * 64, cPKp, cm + ns * 32, nd,
+                                        okd, vws, s))
       return r;
     launch_scatter_bytes(okd, idx_d, nd, totals + 1, (uint8_t*)ok, n, s);
   }
   launch_mixed_check(totals, (u32)ns, (u32)nd, (uint8_t*)ok, n, s);
   HIP_TRY(hipGetLastError());
+  if (fast && accepted) *accepted = (acc_s && acc_d) ? 1 : 0;
   return DSV_OK;
+}
+}  // namespace
+}  // extern "C++"
+int dsv_verify_mixed_dev(const void* kinds, const void* u, const void* R_uv, const void* Rp_uv,
+                         const void* PK_uv, const void* PKp_uv, const void* m, size_t n,
+                         size_t n_double, void* ok, void* workspace, void* stream) {
+  return verify_mixed_dev(kinds, u, R_uv, Rp_uv, PK_uv, PKp_uv, m, n, n_double, ok, workspace, stream, false, nullptr);
+}
+// the same with each kind's items through the batch fast accept (a wrong n_double: every verdict 0, as above)
+size_t dsv_mixed_rlc_workspace_bytes(size_t n) {
+  return dsv_mixed_workspace_bytes(n) - align_up(dsv_workspace_bytes(n), 256) + align_up(dsv_rlc_workspace_bytes(n, 0), 256);
+}
+int dsv_verify_mixed_rlc_dev(const void* kinds, const void* u, const void* R_uv, const void* Rp_uv,
+                             const void* PK_uv, const void* PKp_uv, const void* m, size_t n, size_t n_double,
+                             void* ok, void* workspace, void* stream, int* accepted) {
+  return verify_mixed_dev(kinds, u, R_uv, Rp_uv, PK_uv, PKp_uv, m, n, n_double, ok, workspace, stream, true, accepted);
 }
 
 // ---- host-pointer entry points ----------------------------------------------------------

@@ -739,6 +739,24 @@ def verify_mixed_dev(kinds, u, R, Rp, PK, PKp, m, n_double, ok, workspace, strea
         _stream_ptr(stream, dev)))
 
 
+def mixed_rlc_workspace_bytes(n):
+    return int(_lib.load().dsv_mixed_rlc_workspace_bytes(ctypes.c_size_t(n)))
+
+
+def verify_mixed_rlc_dev(kinds, u, R, Rp, PK, PKp, m, n_double, ok, workspace, stream=None):
+    """dsv_verify_mixed_rlc_dev: the mixed batch with each kind through the batch fast accept; blocks on
+    `stream`; returns True if every group of both kinds was decided by its aggregate."""
+    n, dev = _rows((u, 32, "u"), (R, 64, "R"), (Rp, 64, "Rp"), (PK, 64, "PK"), (PKp, 64, "PKp"),
+                   (m, 32, "m"))
+    accepted = ctypes.c_int(0)
+    _lib.check(_lib.load().dsv_verify_mixed_rlc_dev(
+        _bytes_out(kinds, n, dev, "kinds"), _tp(u, 32), _tp(R, 64), _tp(Rp, 64), _tp(PK, 64),
+        _tp(PKp, 64), _tp(m, 32), ctypes.c_size_t(n), ctypes.c_size_t(int(n_double)),
+        _bytes_out(ok, n, dev, "ok"), _bytes_out(workspace, mixed_rlc_workspace_bytes(n), dev, "workspace"),
+        _stream_ptr(stream, dev), ctypes.byref(accepted)))
+    return bool(accepted.value)
+
+
 def _idx(t, need, dev, name):
     import torch
 

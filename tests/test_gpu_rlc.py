@@ -530,3 +530,34 @@ def test_host_fast_accept_with_the_bucket_pass_in_two_ranges(engine, scheme):
         m2[victim, 0] ^= 1
         got, accepted = engine.verify_wire_rlc(scheme, tsig, tpk, m2)
         assert not accepted and got.sum() == n - 1 and not got[victim]
+
+
+def test_mixed_batch_through_the_fast_accept(engine):
+    """dsv_verify_mixed_rlc_dev (BASELINE configs[4]'s shape: singles and doubles interleaved): each kind's items
+    are one group.  All valid -> accepted; one wrong double signature -> only that kind's group falls back,
+    not accepted; a wrong n_double -> every verdict 0, as dsv_verify_mixed_dev."""
+    from schnorr_amd import workload as W
+    n = 1 << 19                                        # 2^18 singles + 2^18 doubles
+    b = W.gen_mixed(n, seed=77, tamper=False)
+    ws = torch.empty(engine.mixed_rlc_workspace_bytes(n), dtype=torch.uint8, device=DEV)
+    ok = torch.zeros(n, dtype=torch.uint8, device=DEV)
+    args = lambda bb: (bb["kinds"], bb["u"], bb["R"], bb["Rp"], bb["PK"], bb["PKp"], bb["m"])
+    assert engine.verify_mixed_rlc_dev(*args(b), b["n_double"], ok, ws)
+    torch.cuda.synchronize()
+    assert bool(ok.all())
+    b["u"][n - 1] = b["u"][n - 3]                      # the last double item
+    ok.zero_()
+    assert not engine.verify_mixed_rlc_dev(*args(b), b["n_double"], ok, ws)
+    torch.cuda.synchronize()
+    want = torch.ones(n, dtype=torch.uint8, device=DEV)
+    want[n - 1] = 0
+    assert torch.equal(ok, want)
+    t = W.gen_mixed(n, seed=78)                        # the graded pattern in both kinds: the plain entry point's verdicts
+    ok.zero_()
+    assert not engine.verify_mixed_rlc_dev(*args(t), t["n_double"], ok, ws)
+    torch.cuda.synchronize()
+    assert torch.equal(ok, t["expected"])
+    ok.fill_(3)
+    engine.verify_mixed_rlc_dev(*args(t), t["n_double"] - 1, ok, ws)   # a wrong count
+    torch.cuda.synchronize()
+    assert not bool(ok.any())
