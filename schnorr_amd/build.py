@@ -2,7 +2,7 @@
 
     python -m schnorr_amd.build [--force] [-DNAME=VALUE ...]
 
-One hipcc job per translation unit (the host side dsv.hip and the kernel units k_*.hip; no
+One hipcc job per translation unit (the host units dsv_*.hip and the kernel units k_*.hip; no
 relocatable device code), run in parallel, objects under build/obj/; only units whose sources
 changed are recompiled.  No GPU is needed to build (hipcc cross-compiles); the resulting
 schnorr_amd/libdsv.so is git-ignored but travels to the GPU box with the working tree.
@@ -18,7 +18,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libdsv.so")
-UNITS = ["dsv.hip", "k_hash.hip", "k_verify.hip", "k_quad.hip", "k_vargen.hip", "k_misc.hip", "k_rlc.hip"]
+UNITS = ["dsv_context.hip", "dsv_device.hip", "dsv_host.hip", "dsv_wire.hip", "dsv_rlc.hip", "dsv_inputs.hip", "k_hash.hip", "k_verify.hip", "k_quad.hip", "k_vargen.hip", "k_misc.hip", "k_rlc.hip"]
 ARCH = "gfx950"
 FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wextra"]
 

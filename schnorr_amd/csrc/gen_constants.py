@@ -384,7 +384,7 @@ def main():
             table[i] = d
         w("#define DSV_TS_HASH_K1 0x%08xu\n#define DSV_TS_HASH_K2 0x%08xu\n#define DSV_TS_HASH_BITS %d\n"
           % (k1, k2, HASH_BITS))
-        w("// host-side tables: only for the translation units that upload them (dsv.hip, k_hash.hip)\n")
+        w("// host-side tables: only for the translation units that upload them (dsv_context.hip, k_hash.hip)\n")
         w("#ifdef DSV_HOST_TABLES\n")
         w("static const uint8_t DSV_TS_HASH_HOST[%d] = {\n" % (1 << HASH_BITS))
         for i in range(0, 1 << HASH_BITS, 32):

@@ -1,4 +1,4 @@
-// host_sync.h — the HIP-free part of the host pipeline (dsv.hip: run_pipelined): the copy-thread pool,
+// host_sync.h — the HIP-free part of the host pipeline (dsv_pipeline.h: run_pipelined): the copy-thread pool,
 // the order in which calls in flight get a pipe and their turn on the compute lanes, and the chunk /
 // sub-batch plan of a call.  Plain C++17 so that it can be exercised WITHOUT a GPU under
 // ThreadSanitizer (tests/cpp/test_host_sync.cpp, run by tests/test_host_sync.py): GPU sanitizers are

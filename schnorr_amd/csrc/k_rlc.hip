@@ -9,7 +9,7 @@
 //   (1) every PK_i and R_i that enters the sum lies in the prime-order subgroup, and
 //   (2) (sum z_i u_i) G + sum (z_i c_i) PK_i - sum z_i R_i == O     with secret random 128-bit z_i,
 // under which every per-signature verdict is `true` (error <= 2^-112: see below).  If either fails
-// the caller (dsv.hip) runs the per-signature kernels and returns THEIR verdicts, so the bool vector
+// the caller (dsv_rlc.hip) runs the per-signature kernels and returns THEIR verdicts, so the bool vector
 // is the reference's in every case; only the time differs.
 //
 // Both come out of ONE bucket pass.  With c-bit unsigned windows, (2) is Pippenger: bucket (w, d)

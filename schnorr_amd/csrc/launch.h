@@ -1,4 +1,4 @@
-// launch.h — what the host side (dsv.hip) knows about the kernel translation units: table / grid
+// launch.h — what the host units (dsv_*.hip) know about the kernel translation units: table / grid
 // geometry and one launcher per kernel.  The kernels themselves are compiled separately
 // (k_hash.hip, k_verify.hip, k_quad.hip, k_vargen.hip, k_misc.hip; one hipcc job each, no
 // relocatable device code: nothing on the device crosses a translation unit).

@@ -1,5 +1,5 @@
 // rlc.h — geometry and launcher of k_rlc.hip (random-linear-combination fast accept, SURVEY.md
-// §8(f)-4), shared with the host side (dsv.hip).  Kept out of launch.h: that header is part of the
+// §8(f)-4), shared with the host side (dsv_rlc.hip).  Kept out of launch.h: that header is part of the
 // dominant kernel's translation unit, whose sources are what the recorded roofline evidence is
 // valid for (schnorr_amd/build.py: unit_sources_sha256).
 #pragma once

@@ -2,7 +2,7 @@
 //
 // The reference's tests and benches draw every input from rand 0.8 `StdRng::seed_from_u64(seed)`
 // (tests/schnorr.rs:16, benches/signature.rs:81): StdRng = ChaCha12, key = eight PCG32 outputs
-// (expanded on the host, dsv.hip), 64-bit block counter from 0, stream id 0.  Per item the harness
+// (expanded on the host, dsv_inputs.hip), 64-bit block counter from 0, stream id 0.  Per item the harness
 // draws, in order, sk = Fr::random, message = BlsScalar::random and (inside sign) the nonce
 // r = Fr::random — each `from_bytes_wide` of 64 keystream bytes.  Item i therefore owns keystream
 // blocks 3i, 3i+1, 3i+2 and every lane can generate its own item independently.

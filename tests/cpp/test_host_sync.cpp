@@ -59,7 +59,7 @@ static void leases_and_turns() {
   PipeSync sync;
   Log log;
   std::atomic<int> in_flight{0}, max_in_flight{0}, calls{0};
-  std::mutex enq_mu;  // dsv.hip: one chunk's enqueue is atomic
+  std::mutex enq_mu;  // dsv_pipeline.h: one chunk's enqueue is atomic
   auto caller = [&](unsigned seed) {
     std::mt19937 rng(seed);
     for (int call = 0; call < 40; call++) {

@@ -240,7 +240,7 @@ def ext_to_niels(p, d2):
 
 def table_entry(p, d2):
     """What load_var_entry can hand to ext_add_niels for an entry built from p: a negated entry
-    swaps vpu/vmu and reads fe_neg2(t2d) (store_var_entry / load_var_entry in dsv.hip), so every
+    swaps vpu/vmu and reads fe_neg2(t2d) (store_var_entry / load_var_entry in common.h), so every
     role must tolerate either bound."""
     n = ext_to_niels(p, d2)
     both = join(n["vpu"], n["vmu"])
@@ -398,7 +398,7 @@ def prove_hades():
     return {"hash3": out3[1], "hash5": out5[1]}
 
 
-# ---- decode29.h / k_decompress (dsv.hip) ------------------------------------------------------
+# ---- decode29.h / k_decompress (k_misc.hip) ------------------------------------------------------
 def canon_ok(a):
     for x in a.l:
         _check(x < (1 << 31), "fe_ripple input limb exceeds 2^31")

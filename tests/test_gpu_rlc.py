@@ -443,7 +443,7 @@ def test_wire_records_through_the_fast_accept(engine, scheme):
 
 
 def test_sample_check_follows_the_recent_groups():
-    """The adaptive sample check (dsv.hip: Context::rlc_suspicion), seen through DSV_RLC_TRACE in a process of its
+    """The adaptive sample check (dsv_host.h: Context::rlc_suspicion), seen through DSV_RLC_TRACE in a process of its
     own: valid batches switch it off; the next tampered batch then pays its aggregate ("sum"), which switches
     it on; the one after that is caught by the sample ("no aggregate").  Verdicts are the pattern every time."""
     import os
@@ -487,7 +487,7 @@ print("done")
 
 @pytest.mark.parametrize("scheme", ["single", "double", "vargen"])
 def test_host_fast_accept_with_the_bucket_pass_in_two_ranges(engine, scheme):
-    """From 2^18 items on the host forms run their bucket pass in two ranges (dsv.hip: RlcHook): the first
+    """From 2^18 items on the host forms run their bucket pass in two ranges (dsv_rlc.hip: RlcHook): the first
     while the second is still on the bus, then the second, a merge of the two bucket arrays and the tail.
     Valid + malformed items -> accepted; ONE wrong signature in the first range, in the second, in the item at
     the range boundary's neighbourhood -> the per-signature kernels' (the oracle's) verdicts, not accepted.
