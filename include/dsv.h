@@ -279,22 +279,40 @@ int dsv_verify_vargen_dev(const void *u, const void *R_uv, const void *PK_uv, co
  * small-order component — the reference's types can hold those and its equation is cofactorless —
  * or a point off the curve), the group is verified by dsv_verify_single_dev's kernels and gets their
  * verdicts: nothing is ever decided by the aggregate except "all true".  Worth it where batches are
- * expected to be entirely valid (~2.7x less arithmetic then).  A batch that fails pays both paths —
- * unless the library's sample check catches it first: while recent groups on the device were rejected,
- * the first 1024 items of a group go through the per-signature kernel before the aggregate (0.26 ms)
- * and a wrong one among them skips it (0.95x the per-signature time on a batch tampered with
- * throughout; DSV_RLC_SAMPLE=0 in the environment switches the check off).
+ * expected to be entirely valid (~2.7x less arithmetic then).
+ * ENQUEUE-ONLY like every other *_dev call: the per-signature kernels are launched unconditionally
+ * behind the aggregate and return in their first instructions where it accepted (they read its flag
+ * words from device memory); no decision is taken on the host.
+ * Failure localisation.  A rejected group costs both paths, so the library adapts per device: a counter
+ * kept by the device itself (8 after a call that held a rejected aggregate, one less after a call whose
+ * aggregates all accepted, 1 after dsv_init; the host reads it without waiting, possibly one call late)
+ * decides how the NEXT calls run.  While it is > 0 a group is cut into sub-groups of ~2^18 items that
+ * share the hash and one set of launches, each with its own aggregate — one wrong signature in 2^20 then
+ * sends 2^18 items to the per-signature kernels, not 2^20 —, and 1024 consecutive items at a position
+ * drawn from the call's secret key are verified first: a wrong one among them skips the aggregates
+ * altogether (a batch tampered with throughout pays hash + sample + per-signature path; a heuristic,
+ * DSV_RLC_SAMPLE=0 switches it off, DSV_RLC_SUB_LOG2 / DSV_RLC_SUBGROUPS tune / force the sub-groups).
+ * A caller whose batches are valid runs one aggregate per group and nothing else.
  * window_bits: 0 = chosen from n — and groups below 2^17 items, where an aggregate does not pay, go
  * straight to the per-signature kernels —, else one of 4, 6, 8, 12, 14, 16 (bucket windows; tests).
- * *accepted (may be NULL): 1 if every group took the fast path.
- * Unlike the other *_dev calls this one BLOCKS on `stream` (the decision is taken on the host).
- * workspace: dsv_rlc_workspace_bytes(n, window_bits) device bytes, 256-byte aligned. */
+ * accepted (may be NULL): receives 1 if every group was decided by its aggregates, else 0.  If it points
+ * to memory the device can write — device memory, or host memory from hipHostMalloc / hipHostRegister —
+ * it is written by a kernel when `stream` gets there and the call does not block; if it is ordinary
+ * host memory the call waits for `stream` at its end and stores the value itself.
+ * workspace: dsv_rlc_workspace_bytes(n, window_bits) device bytes, 256-byte aligned (never less for a
+ * larger n: a workspace sized for n serves any smaller batch). */
 size_t dsv_rlc_workspace_bytes(size_t n, int window_bits);
 /* geometry of one group's aggregate (tests, sizing; works without a GPU): scheme 0 single / 1 double /
- * 2 var-generator; out[16] = window bits c, c/2, key windows, nonce windows, windows, row/column
- * segments, bit-sum segments, sort key bits, multiples of r added to a key scalar, long / short
- * points and fixed-base terms per item, (bucket, point) pairs, buckets, points of the two scratch areas */
-int dsv_rlc_plan_info(int scheme, size_t n, int window_bits, uint64_t *out /*[16]*/);
+ * 2 var-generator, `groups` sub-groups (0 or 1: one); out[24] = window bits c, c/2, key windows, nonce
+ * windows, windows, row/column segments, bit-sum segments, low digit bits sorted through LDS, multiples
+ * of r added to a key scalar, long / short points and fixed-base terms per item, (digit, point) pairs
+ * per sub-group, buckets per sub-group, points of the two scratch areas, high digit bits (bins per
+ * window = 2^that), digit rows, digits per row, bins, slots per bin, sub-groups, items per sub-group,
+ * workspace bytes of this plan */
+int dsv_rlc_plan_info(int scheme, size_t n, int window_bits, int groups, uint64_t *out /*[24]*/);
+/* the device's history counter (see above; tests and tools): returns it, or a negative dsv_status;
+ * set >= 0 overrides it */
+int dsv_debug_rlc_history(int device, int set);
 int dsv_verify_single_rlc_dev(const void *u, const void *R_uv, const void *PK_uv, const void *m,
                               size_t n, void *ok, void *workspace, void *stream, int window_bits,
                               int *accepted);
@@ -359,7 +377,7 @@ int dsv_verify_mixed_dev(const void *kinds, const void *u, const void *R_uv, con
                          const void *PK_uv, const void *PKp_uv, const void *m, size_t n,
                          size_t n_double, void *ok, void *workspace, void *stream);
 /* ... with each kind's items through the batch fast accept (dsv_verify_*_rlc_dev above: same verdicts;
- * blocks on `stream`; *accepted = every group of both kinds was decided by its aggregate).
+ * `accepted` as there: 1 = every group of both kinds was decided by its aggregates).
  * workspace: dsv_mixed_rlc_workspace_bytes(n). */
 size_t dsv_mixed_rlc_workspace_bytes(size_t n);
 int dsv_verify_mixed_rlc_dev(const void *kinds, const void *u, const void *R_uv, const void *Rp_uv,

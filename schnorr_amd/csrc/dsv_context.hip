@@ -206,34 +206,34 @@ int device_context(const void* ptr, Context*& out) {
 // the dominant kernel: one lane per signature, or eight (small batches); same verdicts
 void launch_verify_fixed(const Context& ctx, bool accumulate, const void* u, const void* c,
                          const void* PK_uv, const void* R_uv, int which, const void* valid,
-                         size_t n, void* ok, u32* tables, hipStream_t s, bool tables_ready) {
+                         size_t n, void* ok, u32* tables, hipStream_t s, bool tables_ready, const u32* gate) {
   const ChainOperands op{(const uint8_t*)PK_uv, (const uint8_t*)R_uv, ctx.table[which]};
   if (ctx.quad && n <= kQuadMaxItems)
     launch_verify_half_quad(1, accumulate, tables_ready, (const uint8_t*)u, (const uint8_t*)c, op, op,
-                            (const uint8_t*)valid, n, (uint8_t*)ok, tables, s);
+                            (const uint8_t*)valid, n, (uint8_t*)ok, tables, s, gate);
   else
     launch_verify_half(1, accumulate, (const uint8_t*)u, (const uint8_t*)c, op, op,
-                       (const uint8_t*)valid, n, (uint8_t*)ok, tables, s);
+                       (const uint8_t*)valid, n, (uint8_t*)ok, tables, s, gate);
 }
 // both equations of a double signature: one fused launch, or two single-equation ones
 // (DSV_DOUBLE_FUSED=0: the second pass ANDs into ok[])
 void launch_verify_fixed_double(const Context& ctx, const void* u, const void* c, const void* PK_uv,
                                 const void* R_uv, const void* PKp_uv, const void* Rp_uv,
                                 const void* valid, size_t n, void* ok, u32* tables, hipStream_t s,
-                                bool tables_ready) {
+                                bool tables_ready, const u32* gate) {
   if (ctx.fuse_double) {
     const ChainOperands op0{(const uint8_t*)PK_uv, (const uint8_t*)R_uv, ctx.table[0]};
     const ChainOperands op1{(const uint8_t*)PKp_uv, (const uint8_t*)Rp_uv, ctx.table[1]};
     if (ctx.quad && n <= kQuadMaxItems)
       launch_verify_half_quad(2, false, tables_ready, (const uint8_t*)u, (const uint8_t*)c, op0, op1,
-                              (const uint8_t*)valid, n, (uint8_t*)ok, tables, s);
+                              (const uint8_t*)valid, n, (uint8_t*)ok, tables, s, gate);
     else
       launch_verify_half(2, false, (const uint8_t*)u, (const uint8_t*)c, op0, op1,
-                         (const uint8_t*)valid, n, (uint8_t*)ok, tables, s);
+                         (const uint8_t*)valid, n, (uint8_t*)ok, tables, s, gate);
     return;
   }
-  launch_verify_fixed(ctx, false, u, c, PK_uv, R_uv, 0, valid, n, ok, tables, s, tables_ready);
-  launch_verify_fixed(ctx, true, u, c, PKp_uv, Rp_uv, 1, valid, n, ok, tables, s);
+  launch_verify_fixed(ctx, false, u, c, PK_uv, R_uv, 0, valid, n, ok, tables, s, tables_ready, gate);
+  launch_verify_fixed(ctx, true, u, c, PKp_uv, Rp_uv, 1, valid, n, ok, tables, s, false, gate);
 }
 
 int acquire_lane(Context& ctx, hipStream_t user, SplitLane*& out) {
@@ -314,9 +314,8 @@ void release_context(Context& ctx) {
   }
   destroy_pipe_streams(ctx);
   ctx.pipe_failed = false;
-  ctx.rlc_suspicion.store(1);
-  if (ctx.rlc_sample_host) (void)hipHostFree(ctx.rlc_sample_host);
-  ctx.rlc_sample_host = nullptr;
+  if (ctx.rlc_pinned) (void)hipHostFree(ctx.rlc_pinned);
+  ctx.rlc_pinned = nullptr;
   for (auto& ar : ctx.rlc_arenas) {
     if (ar.dev) (void)hipFree(ar.dev);
     ar.dev = nullptr;

@@ -247,16 +247,21 @@ size_t dsv_mixed_workspace_bytes(size_t n) {
 // n_double = number of kind-1 items (the caller knows its batch); every other item must be kind 0.
 extern "C++" {
 namespace {
-// fast: both kinds' groups through the batch fast accept (verify_rlc_on; blocks on the stream); *accepted =
-// every group of both kinds was decided by its aggregate
+// fast: both kinds' groups through the batch fast accept (verify_rlc_on: enqueue-only); *accepted =
+// every group of both kinds was decided by its aggregates
 int verify_mixed_dev(const void* kinds, const void* u, const void* R_uv, const void* Rp_uv, const void* PK_uv,
                      const void* PKp_uv, const void* m, size_t n, size_t n_double, void* ok, void* workspace,
                      void* stream, bool fast, int* accepted) {
-  if (accepted) *accepted = 0;
+  if (n == 0 || !fast) {
+    if (int r = rlc_clear_accepted(accepted)) return r;
+  }
   if (n && (!kinds || !u || !R_uv || !Rp_uv || !PK_uv || !PKp_uv || !m || !ok || !workspace))
     return fail(DSV_ERR_INVALID_ARGUMENT, "null pointer");
   if (n_double > n) return fail(DSV_ERR_INVALID_ARGUMENT, "n_double exceeds n");
   DSV_DEV_PROLOGUE(n, ok);
+  RlcVerdictTarget vt;
+  if (fast)
+    if (int r = rlc_verdict_target(ctx, accepted, vt)) return r;
   hipStream_t s = (hipStream_t)stream;
   const size_t ns = n - n_double, nd = n_double;
   Stager st(static_cast<uint8_t*>(workspace));
@@ -285,16 +290,15 @@ int verify_mixed_dev(const void* kinds, const void* u, const void* R_uv, const v
                               {Rp_uv, 64, cRp},           {PKp_uv, 64, cPKp}};
   for (const Col& c : double_cols)
     if (int r = gather_on(c.src, n, c.bytes, idx_d, nd, totals + 1, c.dst, s)) return r;
-  int acc_s = 1, acc_d = 1;
   if (ns) {
-    if (int r = fast ? verify_rlc_on(ctx, 0, cu, cR, nullptr, cPK, nullptr, nullptr, cm, ns, oks, vws, s, 0, &acc_s)
+    if (int r = fast ? verify_rlc_on(ctx, 0, cu, cR, nullptr, cPK, nullptr, nullptr, cm, ns, oks, vws, s, 0, vt.dev)
                      : verify_single_on(ctx, cu, cR, cPK, cm, ns, oks, vws, s))
       return r;
     launch_scatter_bytes(oks, idx_s, ns, totals, (uint8_t*)ok, n, s);
   }
   if (nd) {
     if (int r = fast ? verify_rlc_on(ctx, 1, cu + ns * 32, cR + ns * 64, cRp, cPK + ns * 64, cPKp, nullptr,
-                                     cm + ns * 32, nd, okd, vws, s, 0, &acc_d)
+                                     cm + ns * 32, nd, okd, vws, s, 0, vt.dev, /*and_into*/ ns != 0)
                      : verify_double_on(ctx, cu + ns * 32, cR + ns * 64, cRp, cPK + ns * 64, cPKp, cm + ns * 32, nd,
                                         okd, vws, s))
       return r;
@@ -302,8 +306,7 @@ int verify_mixed_dev(const void* kinds, const void* u, const void* R_uv, const v
   }
   launch_mixed_check(totals, (u32)ns, (u32)nd, (uint8_t*)ok, n, s);
   HIP_TRY(hipGetLastError());
-  if (fast && accepted) *accepted = (acc_s && acc_d) ? 1 : 0;
-  return DSV_OK;
+  return fast ? rlc_verdict_wait(vt, s) : (int)DSV_OK;
 }
 }  // namespace
 }  // extern "C++"

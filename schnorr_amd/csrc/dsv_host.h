@@ -147,13 +147,13 @@ struct Context {
     hipStream_t stream = nullptr;
     hipEvent_t ev[2] = {nullptr, nullptr};  // "the compute lanes have reached the staged range's end"
   } rlc_arenas[2];
-  // the fast accept's sample check (kRlcSample items through the per-signature kernel before an aggregate
-  // is paid for) runs while this is > 0: a rejected group sets it to 8, an accepted one takes 1 off — a
-  // caller whose batches are valid pays for it on the first call only, one whose batches are tampered
-  // with pays an aggregate once and 0.26 ms per group from then on
-  std::atomic<int> rlc_suspicion{1};
-  std::mutex rlc_sample_mu;
-  uint8_t* rlc_sample_host = nullptr;  // pinned: the sample's verdicts and what tells a wrong item from a malformed one
+  // the fast accept's words in pinned host memory, written by its verdict kernels (dsv_rlc.hip): [0] the
+  // history counter — a call with a rejected sub-group sets it to 8, one whose aggregates all accepted takes 1
+  // off; while it is > 0 calls check a sample first and run in sub-groups —, [1] calls completed, then a ring
+  // of verdict slots for callers whose `accepted` is pageable memory
+  std::mutex rlc_pinned_mu;
+  u32* rlc_pinned = nullptr;
+  std::atomic<u32> rlc_slot{0};
 };
 extern Context g_ctx[kMaxDevices];
 extern std::mutex g_init_mu;               // dsv_init / dsv_shutdown
@@ -233,13 +233,14 @@ struct Stager {
 // the dominant kernel: one lane per signature, or eight (small batches); same verdicts
 void launch_verify_fixed(const Context& ctx, bool accumulate, const void* u, const void* c,
                          const void* PK_uv, const void* R_uv, int which, const void* valid,
-                         size_t n, void* ok, u32* tables, hipStream_t s, bool tables_ready = false);
+                         size_t n, void* ok, u32* tables, hipStream_t s, bool tables_ready = false,
+                         const u32* gate = nullptr);
 // both equations of a double signature: one fused launch, or two single-equation ones
 // (DSV_DOUBLE_FUSED=0: the second pass ANDs into ok[])
 void launch_verify_fixed_double(const Context& ctx, const void* u, const void* c, const void* PK_uv,
                                 const void* R_uv, const void* PKp_uv, const void* Rp_uv,
                                 const void* valid, size_t n, void* ok, u32* tables, hipStream_t s,
-                                bool tables_ready = false);
+                                bool tables_ready = false, const u32* gate = nullptr);
 
 // Sub-batch scheduling of the device-pointer verify entry points.
 // One launch over 2^20 signatures pays a fill and a drain phase per kernel (~0.5 ms + ~0.8 ms of
@@ -322,10 +323,22 @@ struct RlcStaged {  // a host call whose bucket pass over items [0, boundary) wa
   size_t boundary;
 };
 // scheme 0 single (R, PK), 1 double (R, R', PK, PK'), 2 var-generator (R, PK, Gen): unused pointers null
+// Enqueue-only; *accepted_dev (device-accessible memory, may be null) is written by a kernel at the end.
 int verify_rlc_on(Context& ctx, int scheme, const void* u, const void* R_uv, const void* Rp_uv, const void* PK_uv,
                   const void* PKp_uv, const void* Gen_uv, const void* m, size_t n, void* ok, void* workspace,
-                  hipStream_t s, int window_bits, int* accepted, bool have_challenges = false,
+                  hipStream_t s, int window_bits, u32* accepted_dev, bool and_into = false, bool have_challenges = false,
                   const uint8_t* valid_in = nullptr, const RlcStaged* staged = nullptr);
+// where a call's verdict goes: `dev` is what the verdict kernel writes; a caller's pageable `int* accepted`
+// gets a pinned slot of the context and the call waits for the stream at its end (rlc_verdict_wait)
+struct RlcVerdictTarget {
+  u32* dev = nullptr;
+  u32* slot = nullptr;
+  int* out = nullptr;
+};
+int rlc_verdict_target(Context& ctx, int* accepted, RlcVerdictTarget& t);
+int rlc_verdict_wait(const RlcVerdictTarget& t, hipStream_t s);
+int rlc_clear_accepted(int* accepted);
+int rlc_history(Context& ctx);  // the device's history counter (-1: no pinned memory to be had)
 
 #define H2D(dst, src, bytes) HIP_TRY(hipMemcpyAsync((dst), (src), (bytes), hipMemcpyHostToDevice, 0))
 #define D2H(dst, src, bytes) HIP_TRY(hipMemcpyAsync((dst), (src), (bytes), hipMemcpyDeviceToHost, 0))

@@ -9,49 +9,83 @@ using namespace dsvh;
 extern "C" {
 
 // ---- random-linear-combination fast accept in front of the per-signature path ----
-// Per group of at most kRlcMaxGroup items: hash, then one aggregate test (k_rlc.hip: every key and
-// nonce point in the prime-order subgroup AND the z-weighted sum of the equations is the identity,
-// z_i secret, fresh per call).  Accepted: every well-formed item's verdict is `true`, as the
-// reference's (error <= 2^-112).  Rejected — one wrong signature, one point with a small-order
-// component or off the curve — the group goes through dsv_verify_single_dev's kernels and gets
-// THEIR verdicts.  The call blocks on `stream` once per group (the decision is taken on the host).
+// Per group of at most kRlcMaxGroup items: hash, then one aggregate test per SUB-GROUP (k_rlc.hip: every
+// key and nonce point in the prime-order subgroup AND the z-weighted sum of the equations is the identity,
+// z_i secret, fresh per call).  Accepted: every well-formed item's verdict is `true`, as the reference's
+// (error <= 2^-112).  Rejected — one wrong signature, one point with a small-order component or off the
+// curve — the sub-group goes through dsv_verify_single_dev's kernels and gets THEIR verdicts.
+//
+// ENQUEUE-ONLY (r06; r05 took the decision on the host, one stream synchronisation per group): the
+// per-signature kernels are launched unconditionally behind the aggregate with a pointer to their
+// sub-group's flag words as `gate` (launch.h) and return in their first instructions when the aggregate
+// accepted; the call's verdict is written by a one-thread kernel into memory the device can reach.
+//
+// Failure localisation (SURVEY's "bisect on failure", done the way this chip allows): not sequential
+// halving — every level would pay the aggregate's latency-bound tail again — but sub-groups UP FRONT while
+// the device's recent calls give reason to: a group is cut into 2^k sub-groups of ~2^18 items that share
+// the hash pass and ONE set of launches (blockIdx.y = sub-group), so the tail is paid once; only a
+// failing sub-group's per-signature kernels do any work.  "Reason to" is a counter in pinned host memory
+// that the verdict kernel itself maintains (8 after a call with a rejected sub-group, one less after an
+// accepted call; 1 after dsv_init): the host reads it, possibly one call late, and never waits for it.
+// While it is > 0 a SAMPLE is verified first as well (below).
 extern "C++" {
 namespace {
+// Before an aggregate is paid for, the per-signature kernel (eight lanes per signature: 0.26 ms)
+// verifies kRlcSample consecutive items — at a position drawn from the call's secret key — from the
+// challenges just computed, and a one-wave kernel sets the group's "skip" word if a WRONG item is among
+// them (malformed ones do not count: they stay out of the sum): every kernel of the aggregate then
+// returns at once and the per-signature kernels decide.  A batch that is tampered with throughout pays
+// hash + sample + per-signature path instead of all three stages.  A heuristic, and only that: it runs
+// only while the history counter is > 0, never with explicit window bits (tests want the aggregate itself
+// to say no), DSV_RLC_SAMPLE=0 switches it off.  The var-generator scheme has no eight-lane kernel: its
+// sample takes ~1 ms.
+constexpr size_t kRlcSample = 1024;
 struct RlcCarve {
   Workspace w;  // the per-signature path's own workspace comes first: the fallback uses it as it is
   RlcBuffers b;
+  u32* flags_area;     // kRlcMaxGroupsPerCall flag blocks (b.flags = this group's)
   uint8_t* sample_ok;  // kRlcSample verdicts of the pre-check
   void* sample_ws;     // ... and its per-signature workspace
   size_t bytes;
 };
-// Before an aggregate is paid for, the per-signature kernel (eight lanes per signature: 0.26 ms)
-// verifies the group's first kRlcSample items from the challenges just computed: a batch that is
-// tampered with throughout — the graded workload: every 16th item — then skips the aggregate and
-// pays the per-signature path alone.  Only while the device's recent groups give reason to
-// (Context::rlc_suspicion); automatic window bits only (explicit ones are for tests, which want the
-// aggregate itself to say no).  The var-generator scheme has no eight-lane kernel: its sample takes ~1 ms.
-constexpr size_t kRlcSample = 1024;
-RlcCarve carve_rlc(void* ws, size_t n, const RlcPlan& p) {
+// nmax: items of the largest group of the call (the per-signature workspace in front is sized for it);
+// cnt: items of this group (its c / valid lie where run_split's carve of the fallback expects them)
+RlcCarve carve_rlc(void* ws, size_t nmax, size_t cnt, const RlcPlan& p) {
   RlcCarve r;
-  r.w = carve(ws, n);
-  Stager st(static_cast<uint8_t*>(ws) + align_up(dsv_workspace_bytes(n), 256));
+  r.w = carve(ws, cnt);
+  Stager st(static_cast<uint8_t*>(ws) + align_up(dsv_workspace_bytes(nmax), 256));
   auto words = [&](size_t count) { return reinterpret_cast<u32*>(st.take(count * 4)); };
-  r.b.pts = words((size_t)(p.lpts + p.spts) * n * 32);
-  r.b.fsc = words((size_t)(p.fixed ? p.fixed : 1) * n * 8);
-  r.b.fpart = words((size_t)kRlcFsumBlocks * 8);
-  r.b.fsum = words(16);
-  for (int k = 0; k < 2; k++) r.b.keys[k] = words(p.entries), r.b.vals[k] = words(p.entries);
-  r.b.start = words(p.buckets + 1);
-  for (int k = 0; k < 2; k++) r.b.cnt[k] = words(p.buckets), r.b.order[k] = words(p.buckets);
-  r.b.buckets = words(p.buckets * 36);
-  r.b.buckets2 = words(p.buckets * 36);
-  for (int k = 0; k < 2; k++) r.b.tmp[k] = words(rlc_tmp_points(p, k) * 36);
-  r.b.flags = words(4);
-  r.b.sort_temp_bytes = rlc_sort_temp_bytes(p);
-  r.b.sort_temp = st.take(r.b.sort_temp_bytes);
+  const size_t G = p.groups, sub = p.sub;
+  // fixed places first: the same whatever the plan
+  r.flags_area = words(kRlcMaxGroupsPerCall * kRlcGroupFlagWords);
+  r.b.flags = r.flags_area;
   r.sample_ok = st.take(kRlcSample);
   r.sample_ws = st.take(dsv_workspace_bytes(kRlcSample));
-  r.bytes = align_up(dsv_workspace_bytes(n), 256) + st.off;
+  RlcBuffers& b = r.b;
+  b.pts_stride = (size_t)(p.lpts + p.spts) * sub * 32;
+  b.pts = words(G * b.pts_stride);
+  b.fsc_stride = (size_t)(p.fixed ? p.fixed : 1) * sub * 8;
+  b.fsc = words(G * b.fsc_stride);
+  b.fpart = words(G * 2 * kRlcFsumBlocks * 8);
+  b.fsum = words(G * 16);
+  b.digits_stride = align_up((size_t)p.rows * p.row_stride, 128);
+  b.digits = reinterpret_cast<uint16_t*>(st.take(G * b.digits_stride * 2));
+  b.counters_stride = (size_t)p.bins + 512;
+  b.counters = words(G * b.counters_stride);
+  b.bin_stride = (size_t)p.bins * p.bin_cap;
+  b.binned = words(G * b.bin_stride);
+  b.sorted = words(G * b.bin_stride);
+  b.bucket_stride = p.buckets;
+  b.start = words(G * p.buckets);
+  b.cnt = words(G * p.buckets);
+  b.order = words(G * p.buckets);
+  b.buckets = words(G * p.buckets * 36);
+  b.buckets2 = G == 1 ? words(p.buckets * 36) : nullptr;
+  for (int k = 0; k < 2; k++) {
+    b.tmp_stride[k] = rlc_tmp_points(p, k);
+    b.tmp[k] = words(G * b.tmp_stride[k] * 36);
+  }
+  r.bytes = align_up(dsv_workspace_bytes(nmax), 256) + st.off;
   return r;
 }
 // groups of equal size (a batch just above 2^22 items is two halves, not one full group and a tail too
@@ -60,6 +94,27 @@ size_t rlc_group_items(size_t n) {
   if (n <= kRlcMaxGroup) return n;
   const size_t groups = (n + kRlcMaxGroup - 1) / kRlcMaxGroup;
   return (n + groups - 1) / groups;
+}
+// sub-groups a group of cnt items is cut into while the history says "batches fail": sub-groups of
+// 2^kSubLog2 items (DSV_RLC_SUB_LOG2), at least two from 2^18 items on, at most kRlcMaxSub
+int rlc_split_groups(size_t cnt, int window_bits) {
+  static const int sub_log2 = [] {
+    const char* e = getenv("DSV_RLC_SUB_LOG2");
+    const int v = e ? atoi(e) : 18;
+    return v < 10 ? 10 : (v > 22 ? 22 : v);
+  }();
+  size_t g = cnt >> sub_log2;
+  if (g < 2 && (window_bits ? cnt >= 2 : cnt >= 2 * kRlcMinAuto)) g = 2;
+  if (g > (size_t)kRlcMaxSub) g = kRlcMaxSub;
+  return g < 1 ? 1 : (int)g;
+}
+// the plan of one group: window bits from the SUB-group's size; sub-groups are whole sub-batches of the
+// per-signature path (kSplitItems), so that no launch of the fallback straddles two of them
+RlcPlan rlc_group_plan(int scheme, size_t cnt, int window_bits, int groups) {
+  if (groups <= 1) return rlc_plan(scheme, cnt, window_bits ? window_bits : rlc_default_bits(cnt));
+  const size_t align = cnt >= 2 * kSplitItems ? kSplitItems : 64;
+  RlcPlan probe = rlc_plan(scheme, cnt, window_bits ? window_bits : 8, groups, align);
+  return rlc_plan(scheme, cnt, window_bits ? window_bits : rlc_default_bits(probe.sub), groups, align);
 }
 int rlc_random_key(ChaChaKey& key) {
   uint8_t* p = reinterpret_cast<uint8_t*>(key.w);
@@ -74,26 +129,97 @@ int rlc_random_key(ChaChaKey& key) {
   }
   return DSV_OK;
 }
+// pinned host words the device writes: [0] the history counter, [1] calls completed, [2 ..] a ring of
+// verdict slots for callers whose `accepted` is pageable memory
+constexpr u32 kRlcSlots = 62;
+int ensure_rlc_pinned(Context& ctx) {
+  std::lock_guard<std::mutex> lk(ctx.rlc_pinned_mu);
+  if (ctx.rlc_pinned) return DSV_OK;
+  u32* p = nullptr;
+  HIP_TRY(hipHostMalloc((void**)&p, (2 + kRlcSlots) * sizeof(u32), hipHostMallocDefault));
+  for (u32 k = 0; k < 2 + kRlcSlots; k++) p[k] = 0;
+  p[0] = 1;  // the first call of a device checks a sample and runs in sub-groups
+  ctx.rlc_pinned = p;
+  return DSV_OK;
+}
 }  // namespace
 namespace dsvh {
-// scheme 0 single (R, PK), 1 double (R, R', PK, PK'), 2 var-generator (R, PK, Gen): unused pointers null
+int rlc_history(Context& ctx) {
+  if (ensure_rlc_pinned(ctx) != DSV_OK) return -1;
+  return (int)*reinterpret_cast<volatile u32*>(ctx.rlc_pinned);
+}
+// where the verdict kernel writes `accepted`: the caller's own word if the device can reach it (device or
+// pinned / registered host memory), else a pinned slot of the context — the call then blocks at its end
+int rlc_verdict_target(Context& ctx, int* accepted, RlcVerdictTarget& t) {
+  t = RlcVerdictTarget{};
+  if (!accepted) return DSV_OK;
+  hipPointerAttribute_t attr;
+  if (hipPointerGetAttributes(&attr, accepted) == hipSuccess &&
+      (attr.type == hipMemoryTypeDevice || attr.type == hipMemoryTypeManaged || attr.type == hipMemoryTypeHost) &&
+      attr.devicePointer) {
+    t.dev = static_cast<u32*>(attr.devicePointer);
+    return DSV_OK;
+  }
+  (void)hipGetLastError();  // a failed query leaves a sticky "invalid value"
+  if (int r = ensure_rlc_pinned(ctx)) return r;
+  const u32 k = ctx.rlc_slot.fetch_add(1) % kRlcSlots;
+  t.slot = ctx.rlc_pinned + 2 + k;
+  t.dev = t.slot;
+  t.out = accepted;
+  return DSV_OK;
+}
+// *accepted = 0 wherever it lives (calls that enqueue nothing)
+int rlc_clear_accepted(int* accepted) {
+  if (!accepted) return DSV_OK;
+  hipPointerAttribute_t attr;
+  if (hipPointerGetAttributes(&attr, accepted) == hipSuccess &&
+      (attr.type == hipMemoryTypeDevice || attr.type == hipMemoryTypeManaged)) {
+    HIP_TRY(hipMemset(accepted, 0, sizeof(int)));
+    return DSV_OK;
+  }
+  (void)hipGetLastError();
+  *accepted = 0;
+  return DSV_OK;
+}
+int rlc_verdict_wait(const RlcVerdictTarget& t, hipStream_t s) {
+  if (!t.out) return DSV_OK;
+  HIP_TRY(hipStreamSynchronize(s));
+  *t.out = (int)*reinterpret_cast<volatile u32*>(t.slot);
+  return DSV_OK;
+}
+// scheme 0 single (R, PK), 1 double (R, R', PK, PK'), 2 var-generator (R, PK, Gen): unused pointers null.
+// Enqueues everything on `s` and returns; *accepted_dev (device-accessible, may be null) = every group was
+// decided by its aggregates (and_into: ... AND what the word held: the second kind of a mixed batch).
 int verify_rlc_on(Context& ctx, int scheme, const void* u, const void* R_uv, const void* Rp_uv, const void* PK_uv,
                   const void* PKp_uv, const void* Gen_uv, const void* m, size_t n, void* ok, void* workspace,
-                  hipStream_t s, int window_bits, int* accepted, bool have_challenges,
+                  hipStream_t s, int window_bits, u32* accepted_dev, bool and_into, bool have_challenges,
                   const uint8_t* valid_in, const RlcStaged* staged) {
   const uint8_t *pu = (const uint8_t*)u, *pR = (const uint8_t*)R_uv, *pRp = (const uint8_t*)Rp_uv,
                 *pPK = (const uint8_t*)PK_uv, *pPKp = (const uint8_t*)PKp_uv, *pG = (const uint8_t*)Gen_uv,
                 *pm = (const uint8_t*)m;
   uint8_t* pok = (uint8_t*)ok;
+  if (int r = ensure_rlc_pinned(ctx)) return r;
   const size_t group = rlc_group_items(n);
-  bool all = true;
-  for (size_t off = 0; off < n; off += group) {
+  static const bool trace = getenv("DSV_RLC_TRACE") != nullptr;  // why a group was (not) accepted: makes the call synchronous
+  static const bool sample_on = !(getenv("DSV_RLC_SAMPLE") && atoi(getenv("DSV_RLC_SAMPLE")) == 0);
+  static const int force_groups = getenv("DSV_RLC_SUBGROUPS") ? atoi(getenv("DSV_RLC_SUBGROUPS")) : 0;
+  // what the device's recent calls say (written by the verdict kernels; read without waiting for anything)
+  const u32 history = *reinterpret_cast<volatile u32*>(ctx.rlc_pinned);
+  RlcVerdictArgs va = {};
+  u32* flags_area = nullptr;
+  struct Traced {
+    size_t off, cnt;
+    RlcPlan plan;
+    bool sampled;
+  } traced[kRlcMaxGroupsPerCall];
+  for (size_t off = 0, k = 0; off < n; off += group, k++) {
     const size_t cnt = n - off < group ? n - off : group;
-    const RlcPlan plan = rlc_plan(scheme, cnt, window_bits ? window_bits : rlc_default_bits(cnt));
-    const RlcCarve cv = carve_rlc(workspace, cnt, plan);
+    if (k >= kRlcMaxGroupsPerCall) return fail(DSV_ERR_TOO_LARGE, "more than %zu groups", kRlcMaxGroupsPerCall);
+    va.ngroups = (u32)k + 1;
     if (!window_bits && cnt < kRlcMinAuto && !have_challenges) {
       // too small for an aggregate to pay: the per-signature entry point as it is
-      all = false;
+      va.subs[k] = 0;
+      traced[k] = Traced{off, cnt, RlcPlan{}, false};
       int r;
       const uint8_t* vin = valid_in ? valid_in + off : nullptr;
       if (scheme == 0)
@@ -107,165 +233,205 @@ int verify_rlc_on(Context& ctx, int scheme, const void* u, const void* R_uv, con
       if (r) return r;
       continue;
     }
+    int G = 1;
+    if (staged) G = 1;  // (its first range is on the stream already, planned as one sub-group)
+    else if (force_groups > 0) G = force_groups;
+    else if (history > 0) G = rlc_split_groups(cnt, window_bits);
+    const RlcPlan plan = rlc_group_plan(scheme, cnt, window_bits, G);
+    RlcCarve cv = carve_rlc(workspace, group, cnt, plan);
+    flags_area = cv.flags_area;
+    cv.b.flags = cv.flags_area + k * kRlcGroupFlagWords;
+    va.subs[k] = (uint8_t)plan.groups;
     ChaChaKey key;
     if (staged) key = staged->key;  // (one group: the bucket pass of its first items is on the stream already)
     else if (int r = rlc_random_key(key)) return r;
-    static const bool trace = getenv("DSV_RLC_TRACE") != nullptr;  // why a group was (not) accepted
-    static const bool sample_on = !(getenv("DSV_RLC_SAMPLE") && atoi(getenv("DSV_RLC_SAMPLE")) == 0);
-    const bool do_sample = !window_bits && sample_on && (ctx.quad || scheme == 2) && ctx.rlc_suspicion.load() > 0;
-    const size_t sn = cnt < kRlcSample ? cnt : kRlcSample;
+    const bool do_sample = !window_bits && sample_on && (ctx.quad || scheme == 2) && history > 0;
+    traced[k] = Traced{off, cnt, plan, do_sample};
+    if (!staged) HIP_TRY(launch_rlc_begin(cv.b, s));  // (staged: the hook did, before the first range)
     // (have_challenges: one group whose c / valid are in the workspace already — the host form hashes
     //  chunk by chunk while the transfers run)
     if (!have_challenges)
       launch_challenge(scheme == 1, pR + 64 * off, scheme == 1 ? pRp + 64 * off : (const uint8_t*)nullptr,
                        pm + 32 * off, cnt, cv.w.c, cv.w.valid, s, valid_in ? valid_in + off : nullptr);
-    bool sample_bad = false;
     if (do_sample) {
       // (beside the hash on a stream of its own it costs MORE — 0.4 ms: a small kernel next to one that fills
-      //  the chip, §3 "Host pipeline" — than in line behind it: 0.26 ms)
+      //  the chip — than in line behind it: 0.26 ms)
+      const size_t sn = cnt < kRlcSample ? cnt : kRlcSample;
+      const size_t at = off + (size_t)(key.w[7] % (u32)((cnt - sn) / 64 + 1)) * 64;  // (the key's last word: no weight uses it)
+      const size_t rel = at - off;
       u32* tables = carve(cv.sample_ws, sn).tables;
       if (scheme == 0)
-        launch_verify_fixed(ctx, false, pu + 32 * off, cv.w.c, pPK + 64 * off, pR + 64 * off, 0, cv.w.valid, sn,
+        launch_verify_fixed(ctx, false, pu + 32 * at, cv.w.c + 32 * rel, pPK + 64 * at, pR + 64 * at, 0, cv.w.valid + rel, sn,
                             cv.sample_ok, tables, s);
       else if (scheme == 1)
-        launch_verify_fixed_double(ctx, pu + 32 * off, cv.w.c, pPK + 64 * off, pR + 64 * off, pPKp + 64 * off,
-                                   pRp + 64 * off, cv.w.valid, sn, cv.sample_ok, tables, s);
+        launch_verify_fixed_double(ctx, pu + 32 * at, cv.w.c + 32 * rel, pPK + 64 * at, pR + 64 * at, pPKp + 64 * at,
+                                   pRp + 64 * at, cv.w.valid + rel, sn, cv.sample_ok, tables, s);
       else  // (one lane per signature: ~1 ms for the sample — worth it only because it is rarely taken)
-        launch_verify_var(pu + 32 * off, cv.w.c, pPK + 64 * off, pG + 64 * off, pR + 64 * off, cv.w.valid, sn,
+        launch_verify_var(pu + 32 * at, cv.w.c + 32 * rel, pPK + 64 * at, pG + 64 * at, pR + 64 * at, cv.w.valid + rel, sn,
                           cv.sample_ok, tables, s);
-      // a WRONG item counts, a malformed one does not (it stays out of the aggregate: verdict 0 either way)
-      // (`valid` covers what the hash reads — R, R', m; u and the keys are range-checked by the verify kernel)
-      // into pinned memory the device owns for this purpose (one sampler at a time: the phase is short)
-      std::lock_guard<std::mutex> sampler(ctx.rlc_sample_mu);
-      if (!ctx.rlc_sample_host) HIP_TRY(hipHostMalloc((void**)&ctx.rlc_sample_host, (1 + 1 + 32 + 2 * 64) * kRlcSample));
-      uint8_t *verdicts = ctx.rlc_sample_host, *wellformed = verdicts + kRlcSample, *us = wellformed + kRlcSample,
-              *keys[2] = {us + 32 * kRlcSample, us + (32 + 64) * kRlcSample};
-      HIP_TRY(hipMemcpyAsync(verdicts, cv.sample_ok, sn, hipMemcpyDeviceToHost, s));
-      HIP_TRY(hipMemcpyAsync(wellformed, cv.w.valid, sn, hipMemcpyDeviceToHost, s));
-      HIP_TRY(hipMemcpyAsync(us, pu + 32 * off, 32 * sn, hipMemcpyDeviceToHost, s));
-      HIP_TRY(hipMemcpyAsync(keys[0], pPK + 64 * off, 64 * sn, hipMemcpyDeviceToHost, s));
-      if (scheme != 0)
-        HIP_TRY(hipMemcpyAsync(keys[1], (scheme == 1 ? pPKp : pG) + 64 * off, 64 * sn, hipMemcpyDeviceToHost, s));
-      HIP_TRY(hipStreamSynchronize(s));
-      static const uint32_t r_words[8] = DSV_R32, q_words[8] = DSV_Q32;
-      auto below = [](const uint8_t* le32, const uint32_t (&mod)[8]) {  // most significant word first
-        uint32_t w[8];
-        memcpy(w, le32, 32);
-        for (int j = 7; j >= 0; j--)
-          if (w[j] != mod[j]) return w[j] < mod[j];
-        return false;
-      };
-      for (size_t k = 0; k < sn; k++) {
-        if (verdicts[k] == 1 || !wellformed[k]) continue;
-        bool canonical = below(us + 32 * k, r_words);
-        for (int h = 0; h < (scheme == 0 ? 1 : 2); h++)
-          canonical = canonical && below(keys[h] + 64 * k, q_words) && below(keys[h] + 64 * k + 32, q_words);
-        sample_bad |= canonical;  // well-formed and still verdict 0: a wrong signature
-      }
+      // a WRONG item counts, a malformed one does not (`valid` covers what the hash reads — R, R', m; u and
+      // the keys are range-checked here as the verify kernel does)
+      launch_rlc_sample_decide(cv.sample_ok, cv.w.valid + rel, pu + 32 * at, pPK + 64 * at,
+                               scheme == 0 ? (const uint8_t*)nullptr : (scheme == 1 ? pPKp : pG) + 64 * at, 0, sn, cv.b.flags, s);
     }
-    if (trace && sample_bad)
-      std::fprintf(stderr, "[dsv rlc] scheme %d items %zu..%zu: a wrong item among the first %zu, no aggregate\n",
-                   scheme, off, off + cnt, sn);
     RlcInputs in = {};
     in.u = pu + 32 * off, in.c = cv.w.c, in.valid = cv.w.valid;
     in.pk[0] = pPK + 64 * off, in.r[0] = pR + 64 * off;
     if (scheme == 1) in.pk[1] = pPKp + 64 * off, in.r[1] = pRp + 64 * off;
     if (scheme == 2) in.gen = pG + 64 * off;
-    u32 flags[4] = {~0u, 0, 0, 0};
-    if (!sample_bad) {
-      if (staged) {
-        HIP_TRY(launch_rlc_buckets(scheme, rlc_range(plan, staged->boundary, cnt - staged->boundary), cv.b, in, key,
-                                   pok + off, true, s));
-        HIP_TRY(launch_rlc_finish(plan, cv.b, ctx.table[0], ctx.table[1], true, s));
-      } else {
-        HIP_TRY(launch_rlc(scheme, plan, cv.b, in, key, ctx.table[0], ctx.table[1], pok + off, s));
-      }
-      HIP_TRY(hipMemcpyAsync(flags, cv.b.flags, sizeof flags, hipMemcpyDeviceToHost, s));
-      HIP_TRY(hipStreamSynchronize(s));
+    if (staged) {
+      HIP_TRY(launch_rlc_buckets(scheme, rlc_range(plan, staged->boundary, cnt - staged->boundary), cv.b, in, key,
+                                 pok + off, true, s));
+      HIP_TRY(launch_rlc_finish(plan, cv.b, ctx.table[0], ctx.table[1], true, s));
+    } else {
+      HIP_TRY(launch_rlc_buckets(scheme, plan, cv.b, in, key, pok + off, false, s));
+      HIP_TRY(launch_rlc_finish(plan, cv.b, ctx.table[0], ctx.table[1], false, s));
     }
-    if (trace && !sample_bad)
-      std::fprintf(stderr, "[dsv rlc] scheme %d items %zu..%zu c=%d: %s%s%s%s\n", scheme, off, off + cnt, plan.c,
-                   flags[1] == 1 ? "" : "chain incomplete ", flags[0] & kRlcOffCurve ? "off-curve " : "",
-                   flags[0] & kRlcTorsion ? "subgroup-test " : "", flags[0] & kRlcSum ? "sum " : (flags[0] ? "" : "accepted"));
-    if (flags[0] == 0 && flags[1] == 1) {  // ok[] = "well-formed" is the verdict vector
-      int susp = ctx.rlc_suspicion.load();
-      while (susp > 0 && !ctx.rlc_suspicion.compare_exchange_weak(susp, susp - 1)) {
-      }
-      continue;
-    }
-    ctx.rlc_suspicion.store(8);
-    all = false;
-    // the per-signature kernels, from the challenges already in the workspace (run_split carves it the same way)
+    // the per-signature kernels, from the challenges already in the workspace (run_split carves it the same
+    // way), each launch gated by its sub-group's flag words: no work where the aggregate accepted
     Context* cp = &ctx;
+    const u32* gflags = cv.b.flags;
+    const size_t sub = plan.sub;
     const int r = run_split(ctx, cnt, workspace, s, [=](size_t o, size_t part, const Workspace& w, hipStream_t ps) {
-      const size_t at = off + o;
-      if (scheme == 0)
-        launch_verify_fixed(*cp, false, pu + 32 * at, w.c, pPK + 64 * at, pR + 64 * at, 0, w.valid, part, pok + at,
-                            w.tables, ps);
-      else if (scheme == 1)
-        launch_verify_fixed_double(*cp, pu + 32 * at, w.c, pPK + 64 * at, pR + 64 * at, pPKp + 64 * at,
-                                   pRp + 64 * at, w.valid, part, pok + at, w.tables, ps);
-      else
-        launch_verify_var(pu + 32 * at, (const uint8_t*)w.c, pPK + 64 * at, pG + 64 * at, pR + 64 * at,
-                          (const uint8_t*)w.valid, part, pok + at, w.tables, ps);
+      // (sub-groups are whole sub-batches; an unsplit launch covers one sub-group or is cut here)
+      for (size_t done = 0; done < part;) {
+        const size_t at = off + o + done, g = (o + done) / sub;
+        size_t take = (g + 1) * sub - (o + done);
+        if (take > part - done) take = part - done;
+        const u32* gate = gflags + 4 + 4 * g;
+        if (scheme == 0)
+          launch_verify_fixed(*cp, false, pu + 32 * at, w.c + 32 * done, pPK + 64 * at, pR + 64 * at, 0, w.valid + done, take,
+                              pok + at, w.tables, ps, false, gate);
+        else if (scheme == 1)
+          launch_verify_fixed_double(*cp, pu + 32 * at, w.c + 32 * done, pPK + 64 * at, pR + 64 * at, pPKp + 64 * at,
+                                     pRp + 64 * at, w.valid + done, take, pok + at, w.tables, ps, false, gate);
+        else
+          launch_verify_var(pu + 32 * at, (const uint8_t*)w.c + 32 * done, pPK + 64 * at, pG + 64 * at, pR + 64 * at,
+                            (const uint8_t*)w.valid + done, take, pok + at, w.tables, ps, gate);
+        done += take;
+      }
     });
     if (r) return r;
   }
-  if (accepted) *accepted = all ? 1 : 0;
+  if (!flags_area)
+    flags_area = carve_rlc(workspace, group, group, rlc_group_plan(scheme, group, window_bits ? window_bits : 8, 1)).flags_area;
+  va.and_into = and_into ? 1u : 0u;
+  launch_rlc_verdict(flags_area, va, accepted_dev, ctx.rlc_pinned, s);
+  HIP_TRY(hipGetLastError());
+  if (trace) {
+    HIP_TRY(hipStreamSynchronize(s));
+    std::vector<u32> f(kRlcMaxGroupsPerCall * kRlcGroupFlagWords);
+    HIP_TRY(hipMemcpy(f.data(), flags_area, f.size() * sizeof(u32), hipMemcpyDeviceToHost));
+    for (u32 k = 0; k < va.ngroups; k++) {
+      const Traced& t = traced[k];
+      if (!va.subs[k]) {
+        std::fprintf(stderr, "[dsv rlc] scheme %d items %zu..%zu: too small for an aggregate, per-signature path\n", scheme,
+                     t.off, t.off + t.cnt);
+        continue;
+      }
+      const u32* gf = f.data() + (size_t)k * kRlcGroupFlagWords;
+      if (gf[0])
+        std::fprintf(stderr, "[dsv rlc] scheme %d items %zu..%zu: a wrong item in the sample, no aggregate\n", scheme, t.off,
+                     t.off + t.cnt);
+      for (u32 g = 0; g < va.subs[k] && !gf[0]; g++) {
+        const u32* fl = gf + 4 + 4 * g;
+        const size_t lo = t.off + (size_t)g * t.plan.sub, hi = lo + t.plan.sub < t.off + t.cnt ? lo + t.plan.sub : t.off + t.cnt;
+        std::fprintf(stderr, "[dsv rlc] scheme %d items %zu..%zu c=%d sub-group %u/%u%s (history %u): %s%s%s%s%s\n", scheme, lo, hi,
+                     t.plan.c, g + 1, (u32)va.subs[k], t.sampled ? " sampled" : "", history,
+                     fl[1] == 1 ? "" : "chain incomplete ", fl[0] & kRlcOffCurve ? "off-curve " : "",
+                     fl[0] & kRlcTorsion ? "subgroup-test " : "", fl[0] & kRlcOverflow ? "bin-overflow " : "",
+                     fl[0] & kRlcSum ? "sum " : (fl[0] == 0 && fl[1] == 1 ? "accepted" : ""));
+      }
+    }
+  }
   return DSV_OK;
 }
 }  // namespace dsvh
 namespace {
+// the largest workspace any plan of a call of n items takes (one group: every sub-group count)
+size_t rlc_workspace_for(size_t n, int window_bits) {
+  // the size for min(n, 2^22) items, not for the call's own group size: it must not DROP where the group
+  // count steps up (a mixed batch sizes ONE workspace for both kinds' item counts, n / 2 each
+  // just above 2^22 items where the whole batch runs in groups of n / 2 as well)
+  const size_t g = n < kRlcMaxGroup ? n : kRlcMaxGroup;
+  size_t most = 0;
+  for (int G = 1; G <= kRlcMaxSub; G++) {
+    // the double scheme's needs: four points per item, two fixed-base terms (the others fit inside)
+    const RlcPlan p = rlc_group_plan(1, g, window_bits, G);
+    const size_t b = carve_rlc(reinterpret_cast<void*>((uintptr_t)4096), g, g, p).bytes;
+    most = b > most ? b : most;
+  }
+  return most;
+}
 }  // namespace
 }  // extern "C++"
 size_t dsv_rlc_workspace_bytes(size_t n, int window_bits) {
-  const size_t g = rlc_group_items(n);
-  if (g == 0) return 256;
-  const int c = window_bits ? window_bits : rlc_default_bits(g);
-  if (!rlc_bits_ok(c)) return 0;
-  // the double scheme's needs: four points per item, two fixed-base terms (the others fit inside)
-  return carve_rlc(reinterpret_cast<void*>((uintptr_t)4096), g, rlc_plan(1, g, c)).bytes + 256;
+  if (n == 0) return 256;
+  if (window_bits && !rlc_bits_ok(window_bits)) return 0;
+  return rlc_workspace_for(n, window_bits) + 256;
 }
-// the geometry of one group's aggregate, for tests and sizing (no GPU needed): out[0..15] =
-// c, half, wpk, wr, windows, nseg, nseg2, key_bits, kmul, lpts, spts, fixed, entries, buckets,
-// points of tmp[0], points of tmp[1]
-int dsv_rlc_plan_info(int scheme, size_t n, int window_bits, uint64_t* out) {
-  if (!out || scheme < 0 || scheme > 2 || n == 0 || n > kRlcMaxGroup)
+// the geometry of one group's aggregate, for tests and sizing (no GPU needed): `groups` sub-groups
+// (0 or 1: one); out[0..23] = c, half, wpk, wr, windows, nseg, nseg2, fine_bits, kmul, lpts, spts, fixed,
+// entries, buckets, points of tmp[0], points of tmp[1], coarse_bits, rows, row_stride, bins, bin_cap,
+// sub-groups, items per sub-group, workspace bytes of this plan
+int dsv_rlc_plan_info(int scheme, size_t n, int window_bits, int groups, uint64_t* out) {
+  if (!out || scheme < 0 || scheme > 2 || n == 0 || n > kRlcMaxGroup || groups < 0 || groups > kRlcMaxSub)
     return fail(DSV_ERR_INVALID_ARGUMENT, "bad argument");
-  const int c = window_bits ? window_bits : rlc_default_bits(n);
-  if (!rlc_bits_ok(c)) return fail(DSV_ERR_INVALID_ARGUMENT, "window_bits must be 0 (automatic) or one of 4, 6, 8, 12, 14, 16");
-  const RlcPlan p = rlc_plan(scheme, n, c);
-  const uint64_t v[16] = {(uint64_t)p.c, (uint64_t)p.half, (uint64_t)p.wpk, (uint64_t)p.wr, (uint64_t)p.windows,
-                          (uint64_t)p.nseg, (uint64_t)p.nseg2, (uint64_t)p.key_bits, p.kmul, (uint64_t)p.lpts,
+  if (window_bits && !rlc_bits_ok(window_bits))
+    return fail(DSV_ERR_INVALID_ARGUMENT, "window_bits must be 0 (automatic) or one of 4, 6, 8, 12, 14, 16");
+  const RlcPlan p = rlc_group_plan(scheme, n, window_bits, groups);
+  const uint64_t v[24] = {(uint64_t)p.c, (uint64_t)p.half, (uint64_t)p.wpk, (uint64_t)p.wr, (uint64_t)p.windows,
+                          (uint64_t)p.nseg, (uint64_t)p.nseg2, (uint64_t)p.fine_bits, p.kmul, (uint64_t)p.lpts,
                           (uint64_t)p.spts, (uint64_t)p.fixed, p.entries, p.buckets, rlc_tmp_points(p, 0),
-                          rlc_tmp_points(p, 1)};
-  for (int k = 0; k < 16; k++) out[k] = v[k];
+                          rlc_tmp_points(p, 1), (uint64_t)p.coarse_bits, p.rows, p.row_stride, p.bins, p.bin_cap,
+                          p.groups, p.sub, carve_rlc(reinterpret_cast<void*>((uintptr_t)4096), n, n, p).bytes};
+  for (int k = 0; k < 24; k++) out[k] = v[k];
   return DSV_OK;
 }
+// the history counter of a device (tests, tools): > 0 = the next call checks a sample and runs in
+// sub-groups; set >= 0 overrides it
+int dsv_debug_rlc_history(int device, int set) {
+  if (device < 0 || device >= kMaxDevices || !g_ctx[device].ready.load(std::memory_order_acquire))
+    return fail(DSV_ERR_NOT_INITIALIZED, "device %d is not initialised", device);
+  Context& ctx = g_ctx[device];
+  DSV_ON_DEVICE(ctx);
+  const int h = rlc_history(ctx);
+  if (h < 0) return DSV_ERR_HIP;
+  if (set >= 0) *reinterpret_cast<volatile u32*>(ctx.rlc_pinned) = (u32)set;
+  return h;
+}
 #define DSV_RLC_PROLOGUE(nullcheck)                                                              \
-  if (accepted) *accepted = 0;                                                                   \
-  if (n && (nullcheck)) return fail(DSV_ERR_INVALID_ARGUMENT, "null pointer");                   \
+  if (n == 0) return rlc_clear_accepted(accepted);                                               \
+  if (nullcheck) return fail(DSV_ERR_INVALID_ARGUMENT, "null pointer");                          \
   if (window_bits && !rlc_bits_ok(window_bits))                                                  \
     return fail(DSV_ERR_INVALID_ARGUMENT, "window_bits must be 0 (automatic) or one of 4, 6, 8, 12, 14, 16"); \
-  DSV_DEV_PROLOGUE(n, ok)
+  DSV_DEV_PROLOGUE(n, ok);                                                                       \
+  RlcVerdictTarget vt;                                                                           \
+  if (int r_ = rlc_verdict_target(ctx, accepted, vt)) return r_
 int dsv_verify_single_rlc_dev(const void* u, const void* R_uv, const void* PK_uv, const void* m, size_t n,
                               void* ok, void* workspace, void* stream, int window_bits, int* accepted) {
   DSV_RLC_PROLOGUE(!u || !R_uv || !PK_uv || !m || !ok || !workspace);
-  return verify_rlc_on(ctx, 0, u, R_uv, nullptr, PK_uv, nullptr, nullptr, m, n, ok, workspace, (hipStream_t)stream,
-                       window_bits, accepted);
+  if (int r = verify_rlc_on(ctx, 0, u, R_uv, nullptr, PK_uv, nullptr, nullptr, m, n, ok, workspace, (hipStream_t)stream,
+                            window_bits, vt.dev))
+    return r;
+  return rlc_verdict_wait(vt, (hipStream_t)stream);
 }
 int dsv_verify_double_rlc_dev(const void* u, const void* R_uv, const void* Rp_uv, const void* PK_uv,
                               const void* PKp_uv, const void* m, size_t n, void* ok, void* workspace, void* stream,
                               int window_bits, int* accepted) {
   DSV_RLC_PROLOGUE(!u || !R_uv || !Rp_uv || !PK_uv || !PKp_uv || !m || !ok || !workspace);
-  return verify_rlc_on(ctx, 1, u, R_uv, Rp_uv, PK_uv, PKp_uv, nullptr, m, n, ok, workspace, (hipStream_t)stream,
-                       window_bits, accepted);
+  if (int r = verify_rlc_on(ctx, 1, u, R_uv, Rp_uv, PK_uv, PKp_uv, nullptr, m, n, ok, workspace, (hipStream_t)stream,
+                            window_bits, vt.dev))
+    return r;
+  return rlc_verdict_wait(vt, (hipStream_t)stream);
 }
 int dsv_verify_vargen_rlc_dev(const void* u, const void* R_uv, const void* PK_uv, const void* Gen_uv, const void* m,
                               size_t n, void* ok, void* workspace, void* stream, int window_bits, int* accepted) {
   DSV_RLC_PROLOGUE(!u || !R_uv || !PK_uv || !Gen_uv || !m || !ok || !workspace);
-  return verify_rlc_on(ctx, 2, u, R_uv, nullptr, PK_uv, nullptr, Gen_uv, m, n, ok, workspace, (hipStream_t)stream,
-                       window_bits, accepted);
+  if (int r = verify_rlc_on(ctx, 2, u, R_uv, nullptr, PK_uv, nullptr, Gen_uv, m, n, ok, workspace, (hipStream_t)stream,
+                            window_bits, vt.dev))
+    return r;
+  return rlc_verdict_wait(vt, (hipStream_t)stream);
 }
 
 // ---- batch fast accept over typed objects in host memory (SURVEY §8(f)-4 at the named entry point) ----
@@ -405,15 +571,18 @@ int rlc_host_shard(Context& ctx, int kind, size_t n, uint8_t* ok, int* accepted,
   const uint8_t *R = a.pts[0], *Rp = kind == 1 ? a.pts[1] : nullptr, *PK = a.pts[kind == 1 ? 2 : 1],
                 *PKp = kind == 1 ? a.pts[3] : nullptr, *Gen = kind == 2 ? a.pts[2] : nullptr;
   static const bool staged_on = !(getenv("DSV_RLC_STAGED") && atoi(getenv("DSV_RLC_STAGED")) == 0);
+  // (two ranges only in the steady state: while the history says "batches fail" the group runs in sub-groups,
+  //  all of them after the fill)
+  static const int force_groups = getenv("DSV_RLC_SUBGROUPS") ? atoi(getenv("DSV_RLC_SUBGROUPS")) : 0;
   RlcHook hook;
-  hook.on = staged_on && n >= ((size_t)1 << 18);
+  hook.on = staged_on && n >= ((size_t)1 << 18) && rlc_history(ctx) == 0 && force_groups <= 1;
   if (hook.on) {
     for (auto& e : ar.ev)
       if (!e) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     hook.ctx = &ctx, hook.kind = kind, hook.n = n, hook.ok = a.ok, hook.stream = ar.stream;
     hook.ev[0] = ar.ev[0], hook.ev[1] = ar.ev[1];
-    hook.plan = rlc_plan(kind, n, rlc_default_bits(n));  // (what verify_rlc_on plans for this group)
-    hook.cv = carve_rlc(a.ws, n, hook.plan);
+    hook.plan = rlc_group_plan(kind, n, 0, 1);  // (what verify_rlc_on plans for a staged group)
+    hook.cv = carve_rlc(a.ws, n, n, hook.plan);
     hook.in = RlcInputs{};
     hook.in.u = a.u, hook.in.c = hook.cv.w.c, hook.in.valid = hook.cv.w.valid;
     hook.in.pk[0] = PK, hook.in.r[0] = R;
@@ -429,11 +598,14 @@ int rlc_host_shard(Context& ctx, int kind, size_t n, uint8_t* ok, int* accepted,
   RlcStaged staged;
   staged.key = hook.key;
   staged.boundary = hook.boundary;
+  RlcVerdictTarget vt;
+  if (int r = rlc_verdict_target(ctx, accepted, vt)) return r;
   if (int r = verify_rlc_on(ctx, kind, a.u, R, Rp, PK, PKp, Gen, /*m: hashed already*/ a.u, n, a.ok, a.ws,
-                            ar.stream, 0, accepted, true, nullptr, hook.fired ? &staged : nullptr))
+                            ar.stream, 0, vt.dev, false, true, nullptr, hook.fired ? &staged : nullptr))
     return r;
   HIP_TRY(hipMemcpyAsync(ok, a.ok, n, hipMemcpyDeviceToHost, ar.stream));
   HIP_TRY(hipStreamSynchronize(ar.stream));
+  if (accepted) *accepted = vt.out ? (int)*reinterpret_cast<volatile u32*>(vt.slot) : *accepted;
   return DSV_OK;
 }
 int verify_mont_cols_rlc_shard(Context& ctx, int kind, const dsv_column* cols, size_t off, size_t n, uint8_t* ok,
@@ -496,8 +668,8 @@ namespace {
 size_t wire_arrays_bytes(size_t n) { return align_up(n * 32, 256) + 4 * align_up(n * 64, 256) + align_up(n, 256); }
 int verify_wire_rlc_dev(int kind, const void* sig, const void* pk, const void* m, size_t n, void* ok,
                         void* workspace, void* stream, int window_bits, int* accepted) {
-  if (accepted) *accepted = 0;
-  if (n && (!sig || !pk || !m || !ok || !workspace)) return fail(DSV_ERR_INVALID_ARGUMENT, "null pointer");
+  if (n == 0) return rlc_clear_accepted(accepted);
+  if (!sig || !pk || !m || !ok || !workspace) return fail(DSV_ERR_INVALID_ARGUMENT, "null pointer");
   if (((uintptr_t)sig | (uintptr_t)pk) & 15) return fail(DSV_ERR_INVALID_ARGUMENT, "records must be 16-byte aligned");
   if (window_bits && !rlc_bits_ok(window_bits))
     return fail(DSV_ERR_INVALID_ARGUMENT, "window_bits must be 0 (automatic) or one of 4, 6, 8, 12, 14, 16");
@@ -521,8 +693,12 @@ int verify_wire_rlc_dev(int kind, const void* sig, const void* pk, const void* m
   if (int r = decompress_on(ctx, dpk, pk_bytes, n, w.P0, w.valid, 1, st)) return r;
   if (kind != 0)
     if (int r = decompress_on(ctx, dpk + 32, pk_bytes, n, w.P1, w.valid, 1, st)) return r;
-  return verify_rlc_on(ctx, kind, w.u, w.R, kind == 1 ? w.Rp : nullptr, w.P0, kind == 1 ? w.P1 : nullptr,
-                       kind == 2 ? w.P1 : nullptr, m, n, ok, rws, st, window_bits, accepted, false, w.valid);
+  RlcVerdictTarget vt;
+  if (int r = rlc_verdict_target(ctx, accepted, vt)) return r;
+  if (int r = verify_rlc_on(ctx, kind, w.u, w.R, kind == 1 ? w.Rp : nullptr, w.P0, kind == 1 ? w.P1 : nullptr,
+                            kind == 2 ? w.P1 : nullptr, m, n, ok, rws, st, window_bits, vt.dev, false, false, w.valid))
+    return r;
+  return rlc_verdict_wait(vt, st);
 }
 }  // namespace
 }  // extern "C++"

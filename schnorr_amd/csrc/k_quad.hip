@@ -40,7 +40,8 @@ __global__ void __launch_bounds__(kQuadBlock)
 k_verify_fixed_half_oct(const uint8_t* __restrict__ u, const uint8_t* __restrict__ c,
                         ChainOperands op0, ChainOperands op1, const uint8_t* __restrict__ valid,
                         bool accumulate, bool tables_ready, size_t n, uint8_t* __restrict__ ok,
-                        u32* __restrict__ var_tables) {
+                        u32* __restrict__ var_tables, const u32* __restrict__ gate) {
+  if (gate_says_done(gate)) return;  // (uniform: before any barrier)
   const size_t i = ((size_t)blockIdx.x * kQuadBlock + threadIdx.x) >> 3;
   const int q = threadIdx.x & 3;
   const bool upper = (threadIdx.x & 4) != 0;  // quad 1 of the octet: the -b*R half
@@ -157,14 +158,14 @@ void launch_prep_var_tables(const uint8_t* PK_uv, const uint8_t* R_uv, size_t n,
 void launch_verify_half_quad(int nchain, bool accumulate, bool tables_ready, const uint8_t* u,
                              const uint8_t* c, ChainOperands op0, ChainOperands op1,
                              const uint8_t* valid, size_t n, uint8_t* ok, uint32_t* var_tables,
-                             hipStream_t s) {
+                             hipStream_t s, const uint32_t* gate) {
   const dim3 grid((unsigned)((8 * n + kQuadBlock - 1) / kQuadBlock)), block(kQuadBlock);
   if (nchain == 2)
     hipLaunchKernelGGL(k_verify_fixed_half_oct<2>, grid, block, 0, s, u, c, op0, op1, valid,
-                       accumulate, tables_ready, n, ok, var_tables);
+                       accumulate, tables_ready, n, ok, var_tables, gate);
   else
     hipLaunchKernelGGL(k_verify_fixed_half_oct<1>, grid, block, 0, s, u, c, op0, op1, valid,
-                       accumulate, tables_ready, n, ok, var_tables);
+                       accumulate, tables_ready, n, ok, var_tables, gate);
 }
 
 }  // namespace dsv

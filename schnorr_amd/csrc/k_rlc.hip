@@ -24,19 +24,22 @@
 // Cost per signature at c = 16: 16 + 8 mixed additions (7 multiplications each) against ~1900
 // multiplications of the half-gcd chain, plus a sort of 24 (key, index) pairs.
 //
-// Kernels (launch order; every stage reads what the previous one wrote, same stream):
+// Kernels (launch order; every stage reads what the previous one wrote, same stream; blockIdx.y = the
+// sub-group of the group, rlc.h):
 //   k_rlc_prep        per item: z_i = ChaCha12(key, i), e_i = z_i c_i, f_i = z_i u_i (mod r), range and
-//                     curve checks, the points as affine niels (PK_i, -R_i), (bucket, index) pairs
-//   k_rlc_fsum[2]     sum f_i mod r
-//   (hipcub radix sort of the pairs by bucket)
-//   k_rlc_starts      where each bucket's run of the sorted pairs begins
-//   k_rlc_counts      run lengths; (hipcub sort of the bucket numbers by run length)
+//                     curve checks, the points as affine niels (PK_i, -R_i), one 16-bit digit per window
+//   k_rlc_part1       a row of digits -> bins by the digit's high bits (workgroup-aggregated reservations)
+//   k_rlc_part2       one bin -> its buckets' runs of point indices (counting sort through LDS), run starts
+//                     and lengths in the same pass
+//   k_rlc_lenhist / k_rlc_order   bucket numbers by run length, longest first (counting sort)
 //   k_rlc_accumulate  one lane per bucket: mixed additions over its run
+//   k_rlc_fsum[2]     sum f_i mod r
 //   k_rlc_sum<0..3>   row / column sums, then the per-bit subset sums S_p        (short chains)
 //   k_rlc_scale       lanes A: r * S_p == O ?    lanes B: 2^p * S_p    one more lane: (sum f_i) * G
 //   k_rlc_final       sum of all of lanes B's and that lane's results, identity test -> flags
-#include <hipcub/hipcub.hpp>
-
+//   k_rlc_sample_decide / k_rlc_verdict   the sample's and the call's verdicts (dsv_rlc.hip: no host round trip)
+// Every kernel of the chain returns at once when word 0 of the group's flag block is set (the sample
+// found a wrong signature: the per-signature kernels decide).
 #include "common.h"
 #include "rlc.h"
 #include "stdrng.h"
@@ -190,27 +193,49 @@ DSV_DEV ANiels affine_niels(const Fe& u, const Fe& v, bool negate) {
 //   vargen  u Gen + c PK - R            : long { PK: z c, Gen: z u },  short { -R: z },          fixed { }
 // (/root/reference/src/keys/public.rs:121-130, :222-244, :401-415), z and z' independent.
 namespace {
+// which items a workgroup's sub-group covers (rlc.h: RlcPlan)
+struct SubView {
+  u32 g;      // the sub-group (blockIdx.y)
+  u32 base;   // its first item in the group's arrays
+  u32 first;  // first item of this pass inside the sub-group
+  u32 n;      // items of this pass
+  u32 total;  // items of the sub-group
+};
+DSV_DEV SubView sub_view(const RlcPlan& p) {
+  SubView v;
+  v.g = blockIdx.y;
+  if (p.groups == 1) {
+    v.base = 0, v.first = p.first, v.n = p.n, v.total = p.total;
+  } else {
+    v.base = v.g * p.sub;
+    const u32 left = p.items - v.base;
+    v.total = left < p.sub ? left : p.sub;
+    v.first = 0, v.n = v.total;
+  }
+  return v;
+}
 struct PrepOut {
-  size_t i;   // the item's place in its group (inputs, points, weights)
-  size_t il;  // ... and in the range this pass covers (the pair arrays)
+  size_t gi;  // the item's place in the group's arrays (inputs, ok)
+  u32 i;      // ... in its sub-group (points, weights)
+  u32 il;     // ... and in the range this pass covers (the digit rows)
+  u32 total;  // items of the sub-group
   const RlcPlan& p;
   u32* pts;
-  u32* keys;
-  u32* vals;
+  uint16_t* digits;
 };
 // loads one point, folds its range check into `good`, returns "is on the curve", stores it as affine niels
 DSV_DEV bool prep_point(const PrepOut& o, const uint8_t* __restrict__ uv, int slot, bool negate, bool& good) {
   Fe pu, pv;
-  good &= load_fq(pu, uv, 2 * o.i);
-  good &= load_fq(pv, uv, 2 * o.i + 1);
-  store_pt(o.pts + ((size_t)slot * o.p.total + o.i) * kPtWords, affine_niels(pu, pv, negate));
+  good &= load_fq(pu, uv, 2 * o.gi);
+  good &= load_fq(pv, uv, 2 * o.gi + 1);
+  store_pt(o.pts + ((size_t)slot * o.total + o.i) * kPtWords, affine_niels(pu, pv, negate));
   return on_curve(pu, pv);
 }
 // e' = e + k r, k uniform below floor(2^(wpk c) / r): the same multiple of a point of the prime-order
 // subgroup (any other point fails the subgroup test anyway), but uniform over ALL wpk * c bits —
 // without it the top window of a 252-bit scalar has a few thousand (c = 16: 2^12) digits only, and
 // its buckets get runs 16 times as long as the others: a lane per bucket would wait for those.
-// Then one (bucket, point) pair per window.
+// Then one digit per window into the point's row of that window (digit 0: the entry enters no bucket).
 DSV_DEV void emit_long(const PrepOut& o, u32 (&e)[8], u32 kr, int slot) {
   const RlcPlan& p = o.p;
   u64 carry = 0;
@@ -220,32 +245,28 @@ DSV_DEV void emit_long(const PrepOut& o, u32 (&e)[8], u32 kr, int slot) {
     e[k] = (u32)t;
     carry = t >> 32;
   }
-  const u32 mask = (1u << p.c) - 1u, none = (u32)p.windows << p.c;
+  const u32 mask = (1u << p.c) - 1u;
 #pragma unroll 1
   for (int w = 0; w < p.wpk; w++) {
     const u32 d = e[0] & mask;
 #pragma unroll
     for (int k = 0; k < 7; k++) e[k] = __funnelshift_r(e[k], e[k + 1], p.c);
     e[7] >>= p.c;
-    const size_t at = ((size_t)w * p.lpts + slot) * p.n + o.il;
-    o.keys[at] = d ? (((u32)w << p.c) | d) : none;
-    o.vals[at] = (u32)((size_t)slot * p.total + o.i);
+    o.digits[(size_t)(w * p.lpts + slot) * p.row_stride + o.il] = (uint16_t)d;
   }
 }
 DSV_DEV void emit_short(const PrepOut& o, const u32 (&zz)[8], int slot) {
   const RlcPlan& p = o.p;
   u32 z[5] = {zz[0], zz[1], zz[2], zz[3], zz[4]};
-  const u32 mask = (1u << p.c) - 1u, none = (u32)p.windows << p.c;
-  const size_t first = (size_t)p.wpk * p.lpts * p.n;
+  const u32 mask = (1u << p.c) - 1u;
+  const size_t first = (size_t)p.wpk * p.lpts;
 #pragma unroll 1
   for (int w = 0; w < p.wr; w++) {
     const u32 d = z[0] & mask;
 #pragma unroll
     for (int k = 0; k < 4; k++) z[k] = __funnelshift_r(z[k], z[k + 1], p.c);
     z[4] >>= p.c;
-    const size_t at = first + ((size_t)w * p.spts + slot) * p.n + o.il;
-    o.keys[at] = d ? (((u32)(p.wpk + w) << p.c) | d) : none;
-    o.vals[at] = (u32)((size_t)(p.lpts + slot) * p.total + o.i);
+    o.digits[(first + (size_t)(w * p.spts + slot)) * p.row_stride + o.il] = (uint16_t)d;
   }
 }
 // wr * c >= 128 random bits from five keystream words: every window of z is uniform
@@ -261,16 +282,19 @@ DSV_DEV void draw_z(u32 (&z)[8], const u32* blk, int zbits, bool good) {
 
 template <int SCHEME>
 __global__ void __launch_bounds__(256)
-k_rlc_prep(RlcInputs in, ChaChaKey key, RlcPlan p, uint8_t* __restrict__ ok, u32* __restrict__ pts,
-           u32* __restrict__ fsc, u32* __restrict__ keys, u32* __restrict__ vals, u32* __restrict__ flags) {
-  const size_t il = (size_t)blockIdx.x * 256 + threadIdx.x;
-  if (il >= p.n) return;
-  const size_t i = p.first + il;
-  const PrepOut o{i, il, p, pts, keys, vals};
-  bool good = in.valid[i] != 0;
+k_rlc_prep(RlcInputs in, ChaChaKey key, RlcPlan p, RlcBuffers b, uint8_t* __restrict__ ok) {
+  if (b.flags[0]) return;
+  const SubView v = sub_view(p);
+  const u32 il = blockIdx.x * 256 + threadIdx.x;
+  if (il >= v.n) return;
+  const u32 i = v.first + il;
+  const size_t gi = (size_t)v.base + i;
+  const PrepOut o{gi, i, il, v.total, p, b.pts + (size_t)v.g * b.pts_stride, b.digits + (size_t)v.g * b.digits_stride};
+  u32* fsc = b.fsc + (size_t)v.g * b.fsc_stride;
+  bool good = in.valid[gi] != 0;
   u32 us[8], cs[8];
-  load_words8(us, in.u, i);
-  load_words8(cs, in.c, i);
+  load_words8(us, in.u, gi);
+  load_words8(cs, in.c, gi);
   good &= words_lt(us, kR32);
   // slots: long points first (PK, then PK' / Gen), then the short ones (-R, -R')
   bool curve = prep_point(o, in.pk[0], 0, false, good);
@@ -278,11 +302,11 @@ k_rlc_prep(RlcInputs in, ChaChaKey key, RlcPlan p, uint8_t* __restrict__ ok, u32
   if (SCHEME == 2) curve &= prep_point(o, in.gen, 1, false, good);
   curve &= prep_point(o, in.r[0], p.lpts, true, good);
   if (SCHEME == 1) curve &= prep_point(o, in.r[1], p.lpts + 1, true, good);
-  // a point off the curve has no place in a group sum: the per-signature kernels decide the batch
-  if (good && !curve) atomicOr(&flags[0], kRlcOffCurve);
-  ok[i] = good ? 1 : 0;
+  // a point off the curve has no place in a group sum: the per-signature kernels decide the sub-group
+  if (good && !curve) atomicOr(&b.flags[4 + 4 * v.g], kRlcOffCurve);
+  ok[gi] = good ? 1 : 0;
   u32 blk[16];
-  chacha12_block(blk, key.w, (u64)i);
+  chacha12_block(blk, key.w, (u64)gi);
   if (!good) {
     us[7] &= 0x0fffffffu;  // keep fr_mul's inputs in range; the products are 0 anyway
     cs[7] &= 0x0fffffffu;
@@ -296,86 +320,246 @@ k_rlc_prep(RlcInputs in, ChaChaKey key, RlcPlan p, uint8_t* __restrict__ ok, u32
     emit_long(o, e, good ? blk[8 * eq + 5] % p.kmul : 0u, eq);
     fr_mul(e, z, us);
     if (SCHEME == 2) emit_long(o, e, good ? blk[6] % p.kmul : 0u, 1);
-    else store_words8(reinterpret_cast<uint8_t*>(fsc), (size_t)eq * p.total + i, e);
+    else store_words8(reinterpret_cast<uint8_t*>(fsc), (size_t)eq * v.total + i, e);
     emit_short(o, z, eq);
   }
 }
 
-// sum of n scalars mod r: stage 0 -> kRlcFsumBlocks partial sums, stage 1 (one workgroup) -> out
-__global__ void __launch_bounds__(256) k_rlc_fsum(const u32* __restrict__ in, size_t n, u32* __restrict__ out) {
+// sum of n scalars mod r: stage 0 -> kRlcFsumBlocks partial sums (of fixed-base term blockIdx.y of
+// sub-group blockIdx.z), stage 1 (one workgroup each) -> fsum
+__global__ void __launch_bounds__(256) k_rlc_fsum(RlcPlan p, RlcBuffers b, int stage) {
+  if (b.flags[0]) return;
   __shared__ u32 sh[256][8];
+  const u32 g = blockIdx.z, k = blockIdx.y;
+  u32 total = p.total;
+  if (p.groups > 1) {
+    const u32 left = p.items - g * p.sub;
+    total = left < p.sub ? left : p.sub;
+  }
+  u32* fpart = b.fpart + ((size_t)g * 2 + k) * kRlcFsumBlocks * 8;
+  const u32* in = stage == 0 ? b.fsc + (size_t)g * b.fsc_stride + (size_t)k * total * 8 : fpart;
+  const size_t n = stage == 0 ? total : kRlcFsumBlocks;
+  u32* out = stage == 0 ? fpart : b.fsum + ((size_t)g * 2 + k) * 8;
   u32 acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
     u32 x[8], t[8];
     load_words8(x, reinterpret_cast<const uint8_t*>(in), i);
     fr_add(t, acc, x);
 #pragma unroll
-    for (int k = 0; k < 8; k++) acc[k] = t[k];
+    for (int j = 0; j < 8; j++) acc[j] = t[j];
   }
 #pragma unroll
-  for (int k = 0; k < 8; k++) sh[threadIdx.x][k] = acc[k];
+  for (int j = 0; j < 8; j++) sh[threadIdx.x][j] = acc[j];
   __syncthreads();
   for (int step = 128; step > 0; step >>= 1) {
     if ((int)threadIdx.x < step) {
-      u32 a[8], b[8], t[8];
+      u32 x[8], y[8], t[8];
 #pragma unroll
-      for (int k = 0; k < 8; k++) a[k] = sh[threadIdx.x][k], b[k] = sh[threadIdx.x + step][k];
-      fr_add(t, a, b);
+      for (int j = 0; j < 8; j++) x[j] = sh[threadIdx.x][j], y[j] = sh[threadIdx.x + step][j];
+      fr_add(t, x, y);
 #pragma unroll
-      for (int k = 0; k < 8; k++) sh[threadIdx.x][k] = t[k];
+      for (int j = 0; j < 8; j++) sh[threadIdx.x][j] = t[j];
     }
     __syncthreads();
   }
   if (threadIdx.x == 0) {
     u32 t[8];
 #pragma unroll
-    for (int k = 0; k < 8; k++) t[k] = sh[0][k];
+    for (int j = 0; j < 8; j++) t[j] = sh[0][j];
     store_words8(reinterpret_cast<uint8_t*>(out), blockIdx.x, t);
   }
 }
 
 // ---- buckets ----------------------------------------------------------------------------------
-// start[b] = first sorted entry with key >= b, for b = 0 .. buckets (entries with digit 0 carry the key
-// `buckets` and sort behind everything): every entry fills in the keys between its predecessor's and
-// its own, so empty buckets get their (empty) range too
+// Pass 1.  One workgroup takes kRlcTile digits of ONE row (window w, point slot): a histogram of their
+// bins in LDS, ONE reservation per bin and workgroup in the bin's fill counter, then every entry goes to
+// its place as (low digit bits << 24 | point index).  The digits are all a row holds: the window is the
+// row's, the point index follows from the position.
 __global__ void __launch_bounds__(256)
-k_rlc_starts(const u32* __restrict__ keys, RlcPlan p, u32* __restrict__ start) {
-  const size_t j = (size_t)blockIdx.x * 256 + threadIdx.x;
-  if (j > p.entries) return;
-  const u32 last = (u32)p.buckets;
-  u32 lo = j ? keys[j - 1] + 1u : 0u, hi = j < p.entries ? keys[j] : last;
-  if (hi > last) hi = last;  // (cannot happen)
-  for (u32 k = lo; k <= hi && j < p.entries; k++) start[k] = (u32)j;
-  if (j == p.entries)
-    for (u32 k = lo; k <= last; k++) start[k] = (u32)j;
+k_rlc_part1(RlcPlan p, RlcBuffers b) {
+  if (b.flags[0]) return;
+  __shared__ u32 hist[256], base[256];
+  const SubView v = sub_view(p);
+  const u32 tiles = (p.row_stride + kRlcTile - 1) / kRlcTile;
+  const u32 row = blockIdx.x / tiles, tile = blockIdx.x % tiles;
+  const u32 long_rows = (u32)(p.wpk * p.lpts);
+  u32 w, slot;
+  if (row < long_rows) w = row / p.lpts, slot = row % p.lpts;
+  else w = p.wpk + (row - long_rows) / p.spts, slot = p.lpts + (row - long_rows) % p.spts;
+  const uint16_t* digits = b.digits + (size_t)v.g * b.digits_stride + (size_t)row * p.row_stride;
+  u32* fill = b.counters + (size_t)v.g * b.counters_stride + ((size_t)w << p.coarse_bits);
+  u32* bins = b.binned + (size_t)v.g * b.bin_stride + ((size_t)w << p.coarse_bits) * p.bin_cap;
+  const u32 val0 = slot * v.total + v.first;
+  const u32 fine_mask = (1u << p.fine_bits) - 1u;
+  hist[threadIdx.x] = 0;
+  __syncthreads();
+  constexpr int kPer = kRlcTile / (256 * 8);  // 16-byte loads per thread
+  u32 d[kPer][8];
+#pragma unroll
+  for (int k = 0; k < kPer; k++) {
+    const u32 il = tile * kRlcTile + (u32)k * 2048u + threadIdx.x * 8u;
+    uint4 x = make_uint4(0, 0, 0, 0);
+    if (il < p.row_stride) x = *reinterpret_cast<const uint4*>(digits + il);
+    const u32 words[4] = {x.x, x.y, x.z, x.w};
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+      const u32 dj = (words[j >> 1] >> (16 * (j & 1))) & 0xffffu;
+      d[k][j] = il + j < v.n ? dj : 0u;  // (beyond the pass's items a row holds nothing)
+      if (d[k][j]) atomicAdd(&hist[d[k][j] >> p.fine_bits], 1u);
+    }
+  }
+  __syncthreads();
+  {
+    const u32 h = hist[threadIdx.x];
+    base[threadIdx.x] = h ? atomicAdd(&fill[threadIdx.x], h) : 0u;  // (bins beyond 1 << coarse_bits: h == 0)
+    hist[threadIdx.x] = 0;
+  }
+  __syncthreads();
+  bool overflow = false;
+#pragma unroll
+  for (int k = 0; k < kPer; k++) {
+    const u32 il = tile * kRlcTile + (u32)k * 2048u + threadIdx.x * 8u;
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+      const u32 dj = d[k][j];
+      if (!dj) continue;
+      const u32 bin = dj >> p.fine_bits;
+      const u32 pos = base[bin] + atomicAdd(&hist[bin], 1u);
+      if (pos < p.bin_cap) bins[(size_t)bin * p.bin_cap + pos] = ((dj & fine_mask) << 24) | (val0 + il + j);
+      else overflow = true;
+    }
+  }
+  if (overflow) atomicOr(&b.flags[4 + 4 * v.g], kRlcOverflow);
 }
-// run lengths (clipped to 8 bits) and the identity permutation: sorted by length, longest first, they
-// give every wave of the accumulation 64 runs of (nearly) the same length — with buckets in their
-// natural order a wave waits for its longest run (Poisson, mean 16: the maximum of 64 is ~26)
+// Pass 2.  One workgroup per bin: a counting sort of its entries by the low digit bits through LDS; the
+// buckets' runs (start in `sorted`, length) come out of the same pass.
 __global__ void __launch_bounds__(256)
-k_rlc_counts(const u32* __restrict__ start, RlcPlan p, u32* __restrict__ cnt, u32* __restrict__ ids) {
-  const size_t b = (size_t)blockIdx.x * 256 + threadIdx.x;
-  if (b >= p.buckets) return;
-  u32 len = (b & ((1u << p.c) - 1u)) ? start[b + 1] - start[b] : 0u;  // digit 0 enters no sum
-  cnt[b] = len < 255u ? len : 255u;
-  ids[b] = (u32)b;
+k_rlc_part2(RlcPlan p, RlcBuffers b) {
+  if (b.flags[0]) return;
+  __shared__ u32 hist[256], offs[256];
+  const u32 g = blockIdx.y, bin = blockIdx.x;
+  const u32 w = bin >> p.coarse_bits, coarse = bin & ((1u << p.coarse_bits) - 1u);
+  const u32 nfine = 1u << p.fine_bits;
+  u32 have = b.counters[(size_t)g * b.counters_stride + bin];
+  if (have > p.bin_cap) have = p.bin_cap;
+  const u32* in = b.binned + (size_t)g * b.bin_stride + (size_t)bin * p.bin_cap;
+  u32* out = b.sorted + (size_t)g * b.bin_stride + (size_t)bin * p.bin_cap;
+  hist[threadIdx.x] = 0;
+  __syncthreads();
+  for (u32 i = threadIdx.x; i < have; i += 256) atomicAdd(&hist[in[i] >> 24], 1u);
+  __syncthreads();
+  // exclusive prefix sums of the 256 counts (Hillis - Steele through LDS)
+  const u32 mine = hist[threadIdx.x];
+  offs[threadIdx.x] = mine;
+  __syncthreads();
+  for (u32 step = 1; step < 256; step <<= 1) {
+    const u32 add = threadIdx.x >= step ? offs[threadIdx.x - step] : 0u;
+    __syncthreads();
+    offs[threadIdx.x] += add;
+    __syncthreads();
+  }
+  const u32 first = offs[threadIdx.x] - mine;
+  __syncthreads();
+  offs[threadIdx.x] = first;  // from here on: the bucket's cursor
+  if (threadIdx.x < nfine) {
+    const size_t bucket = (size_t)g * b.bucket_stride + (((size_t)w << p.c) | ((size_t)coarse << p.fine_bits) | threadIdx.x);
+    b.start[bucket] = bin * p.bin_cap + first;
+    b.cnt[bucket] = mine;
+  }
+  __syncthreads();
+  for (u32 i = threadIdx.x; i < have; i += 256) {
+    const u32 e = in[i];
+    out[atomicAdd(&offs[e >> 24], 1u)] = e & 0x00ffffffu;
+  }
 }
-// one lane per bucket (in the order of `order`): its run of the sorted pairs, one mixed addition per
-// entry; the next entry's point is loaded while the current one is added
+// Bucket numbers sorted by run length, longest first: every wave of the accumulation gets 64 runs of
+// (nearly) the same length — with buckets in their natural order a wave waits for its longest run
+// (Poisson, mean 16: the maximum of 64 is ~26).  A counting sort over the lengths (clipped to 255):
+// histogram (workgroup-aggregated), then placement.
+constexpr int kLenPerThread = 32;
+__global__ void __launch_bounds__(256)
+k_rlc_lenhist(RlcPlan p, RlcBuffers b) {
+  if (b.flags[0]) return;
+  __shared__ u32 hist[256];
+  const u32 g = blockIdx.y;
+  const u32* cnt = b.cnt + (size_t)g * b.bucket_stride;
+  hist[threadIdx.x] = 0;
+  __syncthreads();
+  const size_t first = (size_t)blockIdx.x * 256 * kLenPerThread;
+  for (int k = 0; k < kLenPerThread; k++) {
+    const size_t bk = first + (size_t)k * 256 + threadIdx.x;
+    if (bk < p.buckets) {
+      const u32 len = cnt[bk];
+      atomicAdd(&hist[len < 255u ? len : 255u], 1u);
+    }
+  }
+  __syncthreads();
+  if (hist[threadIdx.x]) atomicAdd(&b.counters[(size_t)g * b.counters_stride + p.bins + threadIdx.x], hist[threadIdx.x]);
+}
+__global__ void __launch_bounds__(256)
+k_rlc_order(RlcPlan p, RlcBuffers b) {
+  if (b.flags[0]) return;
+  __shared__ u32 hist[256], base[256], scan[256];
+  const u32 g = blockIdx.y;
+  const u32* cnt = b.cnt + (size_t)g * b.bucket_stride;
+  u32* order = b.order + (size_t)g * b.bucket_stride;
+  u32* counters = b.counters + (size_t)g * b.counters_stride + p.bins;
+  hist[threadIdx.x] = 0;
+  // buckets with a LONGER run than t: suffix sums of the global histogram
+  const u32 mine = counters[threadIdx.x];
+  scan[threadIdx.x] = mine;
+  __syncthreads();
+  for (u32 step = 1; step < 256; step <<= 1) {
+    const u32 add = threadIdx.x + step < 256 ? scan[threadIdx.x + step] : 0u;
+    __syncthreads();
+    scan[threadIdx.x] += add;
+    __syncthreads();
+  }
+  const u32 longer = scan[threadIdx.x] - mine;
+  const size_t first = (size_t)blockIdx.x * 256 * kLenPerThread;
+  u32 len[kLenPerThread];
+  for (int k = 0; k < kLenPerThread; k++) {
+    const size_t bk = first + (size_t)k * 256 + threadIdx.x;
+    len[k] = 256;
+    if (bk < p.buckets) {
+      const u32 l = cnt[bk];
+      len[k] = l < 255u ? l : 255u;
+      atomicAdd(&hist[len[k]], 1u);
+    }
+  }
+  __syncthreads();
+  {
+    const u32 h = hist[threadIdx.x];
+    base[threadIdx.x] = longer + (h ? atomicAdd(&counters[256 + threadIdx.x], h) : 0u);
+    hist[threadIdx.x] = 0;
+  }
+  __syncthreads();
+  for (int k = 0; k < kLenPerThread; k++) {
+    if (len[k] > 255u) continue;
+    const size_t bk = first + (size_t)k * 256 + threadIdx.x;
+    const u32 pos = base[len[k]] + atomicAdd(&hist[len[k]], 1u);
+    if (pos < p.buckets) order[pos] = (u32)bk;
+  }
+}
+// one lane per bucket (in the order of `order`): its run of the sorted point indices, one mixed addition
+// per entry; the next entry's point is loaded while the current one is added
 __global__ void __launch_bounds__(64)
-k_rlc_accumulate(const u32* __restrict__ order, const u32* __restrict__ start, const u32* __restrict__ vals,
-                 const u32* __restrict__ pts, RlcPlan p, u32* __restrict__ buckets) {
+k_rlc_accumulate(RlcPlan p, RlcBuffers b, bool second) {
+  if (b.flags[0]) return;
+  const SubView v = sub_view(p);
   const size_t t = (size_t)blockIdx.x * 64 + threadIdx.x;
   if (t >= p.buckets) return;
-  const u32 b = order[t];
-  if (b >= p.buckets) return;  // (cannot happen: the sort moves what k_rlc_counts wrote)
-  u32 lo = 0, hi = 0;
-  if (b & ((1u << p.c) - 1u)) lo = start[b], hi = start[b + 1];
-  // (a sort that failed leaves anything in `start`: never read outside the pair arrays; the aggregate
-  //  then simply does not come out as the identity)
-  if (hi > p.entries) hi = (u32)p.entries;
-  if (lo > hi) lo = hi;
-  const u32 last_pt = (u32)(p.lpts + p.spts) * p.total - 1u;
+  const u32 bk = b.order[(size_t)v.g * b.bucket_stride + t];
+  if (bk >= p.buckets) return;  // (cannot happen: k_rlc_order writes a permutation)
+  const u32* vals = b.sorted + (size_t)v.g * b.bin_stride;
+  const u32* pts = b.pts + (size_t)v.g * b.pts_stride;
+  u32 lo = b.start[(size_t)v.g * b.bucket_stride + bk], len = b.cnt[(size_t)v.g * b.bucket_stride + bk];
+  // (never read outside the arrays, whatever the counters hold)
+  const u32 slots = p.bins * p.bin_cap;
+  if (lo > slots) lo = slots;
+  if (len > slots - lo) len = slots - lo;
+  const u32 hi = lo + len;
+  const u32 last_pt = (u32)(p.lpts + p.spts) * v.total - 1u;
   Ext acc = ext_identity();
   if (lo < hi) {
     // the index of entry j + 2 and the point of entry j + 1 are on their way while entry j is added
@@ -390,14 +574,18 @@ k_rlc_accumulate(const u32* __restrict__ order, const u32* __restrict__ start, c
       cur = nxt;
     }
   }
-  store_niels(buckets + (size_t)b * kNielsWords, ext_to_niels(acc));
+  u32* out = (second ? b.buckets2 : b.buckets) + (size_t)v.g * b.bucket_stride * kNielsWords;
+  store_niels(out + (size_t)bk * kNielsWords, ext_to_niels(acc));
 }
 
 // buckets[b] += buckets2[b]: the two ranges of a staged bucket pass
 __global__ void __launch_bounds__(64)
-k_rlc_merge(u32* __restrict__ buckets, const u32* __restrict__ buckets2, RlcPlan p) {
+k_rlc_merge(RlcPlan p, RlcBuffers bf) {
+  if (bf.flags[0]) return;
   const size_t b = (size_t)blockIdx.x * 64 + threadIdx.x;
   if (b >= p.buckets) return;
+  u32* buckets = bf.buckets + (size_t)blockIdx.y * bf.bucket_stride * kNielsWords;
+  const u32* buckets2 = bf.buckets2 + (size_t)blockIdx.y * bf.bucket_stride * kNielsWords;
   Ext acc = ext_add_niels(ext_identity(), load_niels(buckets + b * kNielsWords));
   acc = ext_add_niels(acc, load_niels(buckets2 + b * kNielsWords));
   store_niels(buckets + b * kNielsWords, ext_to_niels(acc));
@@ -410,7 +598,11 @@ k_rlc_merge(u32* __restrict__ buckets, const u32* __restrict__ buckets2, RlcPlan
 //   MODE 3  segments -> S[w * c + kind * half + j], the subset sum of bit (kind * half + j) of window w
 template <int MODE>
 __global__ void __launch_bounds__(64)
-k_rlc_sum(const u32* __restrict__ in, RlcPlan p, u32* __restrict__ out) {
+k_rlc_sum(const u32* __restrict__ in, size_t in_stride, RlcPlan p, u32* __restrict__ out, size_t out_stride,
+          const u32* __restrict__ gate) {
+  if (gate[0]) return;
+  in += (size_t)blockIdx.y * in_stride * kNielsWords;    // (strides in points)
+  out += (size_t)blockIdx.y * out_stride * kNielsWords;
   const u32 o = blockIdx.x * 64 + threadIdx.x;
   const u32 side = 1u << p.half;
   u32 total, count;
@@ -524,10 +716,15 @@ DSV_DEV Xp xp_identity() {
 // (every lane runs the workgroup's longest chain and keeps its own result once it is there).
 // Workgroup 2g: W_lanes = (sum f_i) * G (+ (sum f'_i) * G') from the fixed-base tables, one lane.
 __global__ void __launch_bounds__(256)
-k_rlc_scale(const u32* __restrict__ S, const u32* __restrict__ fsum, const u32* __restrict__ tableG,
-            const u32* __restrict__ tableG2, RlcPlan p, u32* __restrict__ W, u32* __restrict__ flags) {
+k_rlc_scale(const u32* __restrict__ S, size_t S_stride, const u32* __restrict__ fsum, const u32* __restrict__ tableG,
+            const u32* __restrict__ tableG2, RlcPlan p, u32* __restrict__ W, size_t W_stride, u32* __restrict__ gflags) {
+  if (gflags[0]) return;  // (uniform: no barrier is left waiting)
   __shared__ u32 sh[2 * 4 * NL * 64];
   __shared__ u32 sh_max;
+  S += (size_t)blockIdx.y * S_stride * kNielsWords;
+  W += (size_t)blockIdx.y * W_stride * kNielsWords;
+  fsum += (size_t)blockIdx.y * 16;
+  u32* flags = gflags + 4 + 4 * blockIdx.y;
   const u32 lanes = (u32)p.windows * p.c, g = (lanes + 63) / 64;
   if (blockIdx.x == 2 * g) {  // (no barrier on this path)
     if (threadIdx.x) return;
@@ -590,8 +787,11 @@ k_rlc_scale(const u32* __restrict__ S, const u32* __restrict__ fsum, const u32* 
 // sum of the windows * c weighted subset sums and of (sum f_i) * G == O ?  One wave: a strided pass,
 // then a tree through LDS.
 __global__ void __launch_bounds__(64)
-k_rlc_final(const u32* __restrict__ W, RlcPlan p, u32* __restrict__ flags) {
+k_rlc_final(const u32* __restrict__ W, size_t W_stride, RlcPlan p, u32* __restrict__ gflags) {
+  if (gflags[0]) return;
   __shared__ __attribute__((aligned(16))) u32 sh[64 * kNielsWords];
+  W += (size_t)blockIdx.y * W_stride * kNielsWords;
+  u32* flags = gflags + 4 + 4 * blockIdx.y;
   const u32 count = (u32)p.windows * p.c + 1u, t = threadIdx.x;
   Ext acc = ext_identity();
 #pragma unroll 1
@@ -609,58 +809,108 @@ k_rlc_final(const u32* __restrict__ W, RlcPlan p, u32* __restrict__ flags) {
   }
 }
 
-// ---- host side ----------------------------------------------------------------------------------------
-size_t rlc_sort_temp_bytes(const RlcPlan& p) {
-  size_t bytes = 0;
-  const u32* k = nullptr;
-  u32* ko = nullptr;
-  (void)hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, k, ko, k, ko, p.entries, 0, p.key_bits, (hipStream_t) nullptr);
-  size_t bytes2 = 0;
-  (void)hipcub::DeviceRadixSort::SortPairsDescending(nullptr, bytes2, k, ko, k, ko, p.buckets, 0, 8, (hipStream_t) nullptr);
-  return bytes > bytes2 ? bytes : bytes2;
+// ---- the sample's and the call's verdicts ----------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+k_rlc_sample_decide(const uint8_t* __restrict__ sample_ok, const uint8_t* __restrict__ valid, const uint8_t* __restrict__ u,
+                    const uint8_t* __restrict__ pk0, const uint8_t* __restrict__ pk1, size_t first, size_t count,
+                    u32* __restrict__ flags) {
+  const size_t k = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (k >= count) return;
+  if (sample_ok[k] != 0) return;
+  const size_t i = first + k;
+  bool wellformed = valid[i] != 0;
+  u32 w[8];
+  load_words8(w, u, i);
+  wellformed &= words_lt(w, kR32);
+  for (int h = 0; h < 2; h++) {
+    const uint8_t* pk = h ? pk1 : pk0;
+    if (!pk) continue;
+    load_words8(w, pk, 2 * i);
+    wellformed &= words_lt(w, kQ32);
+    load_words8(w, pk, 2 * i + 1);
+    wellformed &= words_lt(w, kQ32);
+  }
+  if (wellformed) flags[0] = 1;  // well-formed and still verdict 0: a wrong signature
+}
+__global__ void k_rlc_verdict(const u32* __restrict__ flags, RlcVerdictArgs a, u32* __restrict__ accepted,
+                              u32* __restrict__ history) {
+  if (threadIdx.x || blockIdx.x) return;
+  bool all = true, rejected = false, any = false;
+  for (u32 k = 0; k < a.ngroups; k++) {
+    const u32* f = flags + (size_t)k * kRlcGroupFlagWords;
+    for (u32 g = 0; g < a.subs[k]; g++) {
+      const bool acc = f[4 + 4 * g] == 0u && f[4 + 4 * g + 1] == 1u;
+      rejected |= !acc;
+      any = true;
+    }
+    if (a.subs[k] == 0) all = false;  // a group that took the per-signature path as it is
+  }
+  all &= !rejected;
+  if (accepted) *accepted = (all && (!a.and_into || *accepted != 0u)) ? 1u : 0u;
+  if (history) {
+    const u32 h = history[0];
+    if (rejected) history[0] = 8u;
+    else if (any && h > 0) history[0] = h - 1;
+    history[1] += 1u;
+  }
 }
 
-hipError_t launch_rlc_begin(const RlcBuffers& b, hipStream_t s) { return hipMemsetAsync(b.flags, 0, 16, s); }
+// ---- host side ----------------------------------------------------------------------------------------
+void launch_rlc_sample_decide(const uint8_t* sample_ok, const uint8_t* valid, const uint8_t* u, const uint8_t* pk0,
+                              const uint8_t* pk1, size_t first, size_t count, uint32_t* flags, hipStream_t s) {
+  if (!count) return;
+  hipLaunchKernelGGL(k_rlc_sample_decide, dim3(grid_for(count)), dim3(256), 0, s, sample_ok, valid, u, pk0, pk1, first,
+                     count, flags);
+}
+void launch_rlc_verdict(const uint32_t* flags, RlcVerdictArgs a, uint32_t* accepted, uint32_t* history, hipStream_t s) {
+  hipLaunchKernelGGL(k_rlc_verdict, dim3(1), dim3(64), 0, s, flags, a, accepted, history);
+}
+
+hipError_t launch_rlc_begin(const RlcBuffers& b, hipStream_t s) {
+  return hipMemsetAsync(b.flags, 0, kRlcGroupFlagWords * sizeof(uint32_t), s);
+}
 
 hipError_t launch_rlc_buckets(int scheme, const RlcPlan& p, const RlcBuffers& b, const RlcInputs& in, ChaChaKey key,
                               uint8_t* ok, bool second, hipStream_t s) {
-  const dim3 grid(grid_for(p.n)), block(256);
-  if (scheme == 0)
-    hipLaunchKernelGGL(k_rlc_prep<0>, grid, block, 0, s, in, key, p, ok, b.pts, b.fsc, b.keys[0], b.vals[0], b.flags);
-  else if (scheme == 1)
-    hipLaunchKernelGGL(k_rlc_prep<1>, grid, block, 0, s, in, key, p, ok, b.pts, b.fsc, b.keys[0], b.vals[0], b.flags);
-  else
-    hipLaunchKernelGGL(k_rlc_prep<2>, grid, block, 0, s, in, key, p, ok, b.pts, b.fsc, b.keys[0], b.vals[0], b.flags);
-  size_t temp = b.sort_temp_bytes;
-  hipError_t err = hipcub::DeviceRadixSort::SortPairs(b.sort_temp, temp, b.keys[0], b.keys[1], b.vals[0], b.vals[1],
-                                                      p.entries, 0, p.key_bits, s);
+  const unsigned G = p.groups;
+  // the sort's counters: bin fills, run-length histogram, placement cursors
+  hipError_t err = hipMemsetAsync(b.counters, 0, (size_t)G * b.counters_stride * sizeof(uint32_t), s);
   if (err != hipSuccess) return err;
-  hipLaunchKernelGGL(k_rlc_starts, dim3(grid_for(p.entries + 1)), dim3(256), 0, s, b.keys[1], p, b.start);
-  hipLaunchKernelGGL(k_rlc_counts, dim3(grid_for(p.buckets)), dim3(256), 0, s, b.start, p, b.cnt[0], b.order[0]);
-  temp = b.sort_temp_bytes;
-  err = hipcub::DeviceRadixSort::SortPairsDescending(b.sort_temp, temp, b.cnt[0], b.cnt[1], b.order[0], b.order[1],
-                                                     p.buckets, 0, 8, s);
-  if (err != hipSuccess) return err;
-  hipLaunchKernelGGL(k_rlc_accumulate, dim3(grid_for(p.buckets, 64)), dim3(64), 0, s, b.order[1], b.start, b.vals[1],
-                     b.pts, p, second ? b.buckets2 : b.buckets);
+  const dim3 grid(grid_for(p.n), G), block(256);
+  if (scheme == 0) hipLaunchKernelGGL(k_rlc_prep<0>, grid, block, 0, s, in, key, p, b, ok);
+  else if (scheme == 1) hipLaunchKernelGGL(k_rlc_prep<1>, grid, block, 0, s, in, key, p, b, ok);
+  else hipLaunchKernelGGL(k_rlc_prep<2>, grid, block, 0, s, in, key, p, b, ok);
+  const unsigned tiles = (p.row_stride + kRlcTile - 1) / kRlcTile;
+  hipLaunchKernelGGL(k_rlc_part1, dim3(p.rows * tiles, G), dim3(256), 0, s, p, b);
+  hipLaunchKernelGGL(k_rlc_part2, dim3(p.bins, G), dim3(256), 0, s, p, b);
+  const unsigned lgrid = grid_for(p.buckets, 256 * kLenPerThread);
+  hipLaunchKernelGGL(k_rlc_lenhist, dim3(lgrid, G), dim3(256), 0, s, p, b);
+  hipLaunchKernelGGL(k_rlc_order, dim3(lgrid, G), dim3(256), 0, s, p, b);
+  hipLaunchKernelGGL(k_rlc_accumulate, dim3(grid_for(p.buckets, 64), G), dim3(64), 0, s, p, b, second);
   return hipGetLastError();
 }
 
 hipError_t launch_rlc_finish(const RlcPlan& p, const RlcBuffers& b, const uint32_t* tableG, const uint32_t* tableG2,
                              bool merged, hipStream_t s) {
-  if (merged) hipLaunchKernelGGL(k_rlc_merge, dim3(grid_for(p.buckets, 64)), dim3(64), 0, s, b.buckets, b.buckets2, p);
-  for (int k = 0; k < p.fixed; k++) {
-    hipLaunchKernelGGL(k_rlc_fsum, dim3(kRlcFsumBlocks), dim3(256), 0, s, b.fsc + (size_t)k * p.total * 8, (size_t)p.total, b.fpart);
-    hipLaunchKernelGGL(k_rlc_fsum, dim3(1), dim3(256), 0, s, b.fpart, (size_t)kRlcFsumBlocks, b.fsum + 8 * k);
+  const unsigned G = p.groups;
+  if (merged) hipLaunchKernelGGL(k_rlc_merge, dim3(grid_for(p.buckets, 64), G), dim3(64), 0, s, p, b);
+  if (p.fixed) {
+    hipLaunchKernelGGL(k_rlc_fsum, dim3(kRlcFsumBlocks, p.fixed, G), dim3(256), 0, s, p, b, 0);
+    hipLaunchKernelGGL(k_rlc_fsum, dim3(1, p.fixed, G), dim3(256), 0, s, p, b, 1);
   }
   const unsigned side = 1u << p.half;
-  hipLaunchKernelGGL(k_rlc_sum<0>, dim3(grid_for((size_t)p.windows * 2 * side * p.nseg, 64)), dim3(64), 0, s, b.buckets, p, b.tmp[0]);
-  hipLaunchKernelGGL(k_rlc_sum<1>, dim3(grid_for((size_t)p.windows * 2 * side, 64)), dim3(64), 0, s, b.tmp[0], p, b.tmp[1]);
-  hipLaunchKernelGGL(k_rlc_sum<2>, dim3(grid_for((size_t)p.windows * 2 * p.half * p.nseg2, 64)), dim3(64), 0, s, b.tmp[1], p, b.tmp[0]);
-  hipLaunchKernelGGL(k_rlc_sum<3>, dim3(grid_for((size_t)p.windows * 2 * p.half, 64)), dim3(64), 0, s, b.tmp[0], p, b.tmp[1]);
+  hipLaunchKernelGGL(k_rlc_sum<0>, dim3(grid_for((size_t)p.windows * 2 * side * p.nseg, 64), G), dim3(64), 0, s, b.buckets,
+                     b.bucket_stride, p, b.tmp[0], b.tmp_stride[0], b.flags);
+  hipLaunchKernelGGL(k_rlc_sum<1>, dim3(grid_for((size_t)p.windows * 2 * side, 64), G), dim3(64), 0, s, b.tmp[0],
+                     b.tmp_stride[0], p, b.tmp[1], b.tmp_stride[1], b.flags);
+  hipLaunchKernelGGL(k_rlc_sum<2>, dim3(grid_for((size_t)p.windows * 2 * p.half * p.nseg2, 64), G), dim3(64), 0, s, b.tmp[1],
+                     b.tmp_stride[1], p, b.tmp[0], b.tmp_stride[0], b.flags);
+  hipLaunchKernelGGL(k_rlc_sum<3>, dim3(grid_for((size_t)p.windows * 2 * p.half, 64), G), dim3(64), 0, s, b.tmp[0],
+                     b.tmp_stride[0], p, b.tmp[1], b.tmp_stride[1], b.flags);
   const unsigned lanes = (unsigned)p.windows * p.c, g = (lanes + 63) / 64;
-  hipLaunchKernelGGL(k_rlc_scale, dim3(2 * g + 1), dim3(256), 0, s, b.tmp[1], b.fsum, tableG, tableG2, p, b.tmp[0], b.flags);
-  hipLaunchKernelGGL(k_rlc_final, dim3(1), dim3(64), 0, s, b.tmp[0], p, b.flags);
+  hipLaunchKernelGGL(k_rlc_scale, dim3(2 * g + 1, G), dim3(256), 0, s, b.tmp[1], b.tmp_stride[1], b.fsum, tableG, tableG2, p,
+                     b.tmp[0], b.tmp_stride[0], b.flags);
+  hipLaunchKernelGGL(k_rlc_final, dim3(1, G), dim3(64), 0, s, b.tmp[0], b.tmp_stride[0], p, b.flags);
   return hipGetLastError();
 }
 

@@ -18,7 +18,8 @@ __global__ void __launch_bounds__(kVerifyBlock, kWavesVerify)
 k_verify_var(const uint8_t* __restrict__ u, const uint8_t* __restrict__ c,
              const uint8_t* __restrict__ PK_uv, const uint8_t* __restrict__ Gen_uv,
              const uint8_t* __restrict__ R_uv, const uint8_t* __restrict__ valid, size_t n,
-             uint8_t* __restrict__ ok, u32* __restrict__ var_tables) {
+             uint8_t* __restrict__ ok, u32* __restrict__ var_tables, const u32* __restrict__ gate) {
+  if (gate_says_done(gate)) return;  // the batch fast accept decided these items (launch.h)
   u32* tg = var_tables + ((size_t)blockIdx.x * kVerifyBlock + threadIdx.x) * (3 * kVarLaneWords);
   u32* tp = tg + kVarLaneWords;
   u32* tr = tp + kVarLaneWords;
@@ -168,9 +169,9 @@ void launch_debug_lattice3(const uint8_t* u, const uint8_t* c, size_t n, uint8_t
 
 void launch_verify_var(const uint8_t* u, const uint8_t* c, const uint8_t* PK_uv, const uint8_t* Gen_uv,
                        const uint8_t* R_uv, const uint8_t* valid, size_t n, uint8_t* ok,
-                       uint32_t* var_tables, hipStream_t s) {
+                       uint32_t* var_tables, hipStream_t s, const uint32_t* gate) {
   hipLaunchKernelGGL(k_verify_var, dim3(verify_grid(n)), dim3(kVerifyBlock), 0, s, u, c, PK_uv, Gen_uv,
-                     R_uv, valid, n, ok, var_tables);
+                     R_uv, valid, n, ok, var_tables, gate);
 }
 void launch_var_base_points(const uint8_t* scalar, const uint8_t* P_uv, size_t n, uint8_t* out_uv,
                             uint32_t* var_tables, hipStream_t s) {

@@ -25,7 +25,8 @@ template <int NCHAIN>
 __global__ void __launch_bounds__(kVerifyBlock, kWavesVerify)
 k_verify_fixed_half(const uint8_t* __restrict__ u, const uint8_t* __restrict__ c, ChainOperands op0,
                     ChainOperands op1, const uint8_t* __restrict__ valid, bool accumulate, size_t n,
-                    uint8_t* __restrict__ ok, u32* __restrict__ var_tables) {
+                    uint8_t* __restrict__ ok, u32* __restrict__ var_tables, const u32* __restrict__ gate) {
+  if (gate_says_done(gate)) return;  // the batch fast accept decided these items (launch.h)
   u32* tbl = var_tables + ((size_t)blockIdx.x * kVerifyBlock + threadIdx.x) * kJointLaneWords;
 #pragma unroll 1
   for (size_t base = (size_t)blockIdx.x * kVerifyBlock; base < n;
@@ -93,14 +94,14 @@ k_verify_fixed_half(const uint8_t* __restrict__ u, const uint8_t* __restrict__ c
 
 void launch_verify_half(int nchain, bool accumulate, const uint8_t* u, const uint8_t* c,
                         ChainOperands op0, ChainOperands op1, const uint8_t* valid, size_t n,
-                        uint8_t* ok, uint32_t* var_tables, hipStream_t s) {
+                        uint8_t* ok, uint32_t* var_tables, hipStream_t s, const uint32_t* gate) {
   const dim3 grid(verify_grid(n)), block(kVerifyBlock);
   if (nchain == 2)
     hipLaunchKernelGGL(k_verify_fixed_half<2>, grid, block, 0, s, u, c, op0, op1, valid, accumulate, n,
-                       ok, var_tables);
+                       ok, var_tables, gate);
   else
     hipLaunchKernelGGL(k_verify_fixed_half<1>, grid, block, 0, s, u, c, op0, op1, valid, accumulate, n,
-                       ok, var_tables);
+                       ok, var_tables, gate);
 }
 
 }  // namespace dsv

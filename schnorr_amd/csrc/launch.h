@@ -62,21 +62,26 @@ hipError_t hash_upload_constants();  // the selected device's __constant__ round
 void launch_challenge(bool dbl, const uint8_t* R_uv, const uint8_t* Rp_uv, const uint8_t* m, size_t n,
                       uint8_t* c, uint8_t* valid, hipStream_t s, const uint8_t* valid_in = nullptr);
 // ---- k_verify.hip: ok[i] = (accumulate ? ok[i] : valid[i]) & [every chain's equation holds] ----
+// gate (device memory, may be null; all three verify kernels): two words written earlier on the stream by
+// the batch fast accept (rlc.h).  gate[0] == 0 and gate[1] == 1 — "these items were decided by their
+// aggregate" — makes every workgroup return at once and leaves ok[] as it is: the launch is enqueued
+// unconditionally behind the aggregate and costs a few microseconds when it is not needed.
+inline __device__ bool gate_says_done(const uint32_t* gate) { return gate && gate[0] == 0u && gate[1] == 1u; }
 void launch_verify_half(int nchain, bool accumulate, const uint8_t* u, const uint8_t* c,
                         ChainOperands op0, ChainOperands op1, const uint8_t* valid, size_t n,
-                        uint8_t* ok, uint32_t* var_tables, hipStream_t s);
+                        uint8_t* ok, uint32_t* var_tables, hipStream_t s, const uint32_t* gate = nullptr);
 // ---- k_quad.hip: the same for n <= kQuadMaxItems, eight lanes per signature; tables_ready: the
 // window tables of the FIRST equation's (PK, R) were built by launch_prep_var_tables already ----
 void launch_verify_half_quad(int nchain, bool accumulate, bool tables_ready, const uint8_t* u,
                              const uint8_t* c, ChainOperands op0, ChainOperands op1,
                              const uint8_t* valid, size_t n, uint8_t* ok, uint32_t* var_tables,
-                             hipStream_t s);
+                             hipStream_t s, const uint32_t* gate = nullptr);
 void launch_prep_var_tables(const uint8_t* PK_uv, const uint8_t* R_uv, size_t n, uint32_t* var_tables,
                             hipStream_t s);
 // ---- k_vargen.hip ----------------------------------------------------------------------------
 void launch_verify_var(const uint8_t* u, const uint8_t* c, const uint8_t* PK_uv, const uint8_t* Gen_uv,
                        const uint8_t* R_uv, const uint8_t* valid, size_t n, uint8_t* ok,
-                       uint32_t* var_tables, hipStream_t s);
+                       uint32_t* var_tables, hipStream_t s, const uint32_t* gate = nullptr);
 void launch_debug_lattice3(const uint8_t* u, const uint8_t* c, size_t n, uint8_t* out, hipStream_t s);
 void launch_debug_half_scalars(const uint8_t* c, size_t n, uint8_t* out, hipStream_t s);
 void launch_var_base_points(const uint8_t* scalar, const uint8_t* P_uv, size_t n, uint8_t* out_uv,

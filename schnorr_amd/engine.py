@@ -558,42 +558,69 @@ def rlc_workspace_bytes(n, window_bits=0):
     return b
 
 
-def rlc_plan_info(scheme, n, window_bits=0):
+def rlc_plan_info(scheme, n, window_bits=0, groups=1):
     """dsv_rlc_plan_info as a dict (no GPU needed)"""
-    out = (ctypes.c_uint64 * 16)()
+    out = (ctypes.c_uint64 * 24)()
     _lib.check(_lib.load().dsv_rlc_plan_info(ctypes.c_int({"single": 0, "double": 1, "vargen": 2}[scheme]),
-                                             ctypes.c_size_t(n), ctypes.c_int(window_bits), out))
-    names = ("c", "half", "wpk", "wr", "windows", "nseg", "nseg2", "key_bits", "kmul", "lpts", "spts", "fixed",
-             "entries", "buckets", "tmp0", "tmp1")
+                                             ctypes.c_size_t(n), ctypes.c_int(window_bits), ctypes.c_int(groups), out))
+    names = ("c", "half", "wpk", "wr", "windows", "nseg", "nseg2", "fine_bits", "kmul", "lpts", "spts", "fixed",
+             "entries", "buckets", "tmp0", "tmp1", "coarse_bits", "rows", "row_stride", "bins", "bin_cap", "groups",
+             "sub", "bytes")
     return dict(zip(names, [int(x) for x in out]))
 
 
-def _rlc(name, cols, ok, workspace, stream, window_bits):
+def rlc_history(device=0, set_to=-1):
+    """dsv_debug_rlc_history: the device's fast-accept history counter (> 0: the next call checks a sample
+    and runs in sub-groups); set_to >= 0 overrides it.  Returns the value before the call."""
+    r = _lib.load().dsv_debug_rlc_history(ctypes.c_int(device), ctypes.c_int(set_to))
+    if r < 0:
+        _lib.check(r)
+    return r
+
+
+def _accepted_arg(accepted_out, dev):
+    """the `accepted` argument of the *_rlc_dev calls: None -> a host int (the call waits for the stream and
+    returns a bool); a one-element int32 tensor on `dev` or in pinned host memory -> written by the device
+    when the stream gets there, the call does not block and returns None"""
+    if accepted_out is None:
+        box = ctypes.c_int(0)
+        return ctypes.byref(box), box
+    import torch
+
+    t = accepted_out
+    if t.dtype != torch.int32 or t.numel() < 1 or not (t.is_cuda and t.device == dev or (not t.is_cuda and t.is_pinned())):
+        raise ValueError("accepted_out: need an int32 tensor on the batch's device or in pinned host memory")
+    return ctypes.c_void_p(t.data_ptr()), None
+
+
+def _rlc(name, cols, ok, workspace, stream, window_bits, accepted_out=None):
     n, dev = _rows(*cols)
-    accepted = ctypes.c_int(0)
+    arg, box = _accepted_arg(accepted_out, dev)
     _lib.check(getattr(_lib.load(), name)(
         *[_tp(t, w) for t, w, _ in cols], ctypes.c_size_t(n), _bytes_out(ok, n, dev, "ok"),
         _bytes_out(workspace, rlc_workspace_bytes(n, window_bits), dev, "workspace"),
-        _stream_ptr(stream, dev), ctypes.c_int(window_bits), ctypes.byref(accepted)))
-    return bool(accepted.value)
+        _stream_ptr(stream, dev), ctypes.c_int(window_bits), arg))
+    return bool(box.value) if box is not None else None
 
 
-def verify_single_rlc_dev(u, R, PK, m, ok, workspace, stream=None, window_bits=0):
+def verify_single_rlc_dev(u, R, PK, m, ok, workspace, stream=None, window_bits=0, accepted_out=None):
     """dsv_verify_single_rlc_dev: the verdict vector of verify_single_dev, through one aggregate test
-    per group when the whole group is valid.  Blocks on `stream`.  Returns True if every group was
-    accepted by its aggregate (else the per-signature kernels decided)."""
+    per group (or sub-group) when it is valid.  Enqueue-only when `accepted_out` (an int32 tensor on the
+    device or in pinned host memory) is given: it receives 1 if every group was accepted by its aggregates
+    once the stream gets there.  Without it the call waits for `stream` and returns that as a bool."""
     return _rlc("dsv_verify_single_rlc_dev", ((u, 32, "u"), (R, 64, "R"), (PK, 64, "PK"), (m, 32, "m")),
-                ok, workspace, stream, window_bits)
+                ok, workspace, stream, window_bits, accepted_out)
 
 
-def verify_double_rlc_dev(u, R, Rp, PK, PKp, m, ok, workspace, stream=None, window_bits=0):
+def verify_double_rlc_dev(u, R, Rp, PK, PKp, m, ok, workspace, stream=None, window_bits=0, accepted_out=None):
     return _rlc("dsv_verify_double_rlc_dev", ((u, 32, "u"), (R, 64, "R"), (Rp, 64, "Rp"), (PK, 64, "PK"),
-                                               (PKp, 64, "PKp"), (m, 32, "m")), ok, workspace, stream, window_bits)
+                                               (PKp, 64, "PKp"), (m, 32, "m")), ok, workspace, stream, window_bits,
+                accepted_out)
 
 
-def verify_vargen_rlc_dev(u, R, PK, Gen, m, ok, workspace, stream=None, window_bits=0):
+def verify_vargen_rlc_dev(u, R, PK, Gen, m, ok, workspace, stream=None, window_bits=0, accepted_out=None):
     return _rlc("dsv_verify_vargen_rlc_dev", ((u, 32, "u"), (R, 64, "R"), (PK, 64, "PK"), (Gen, 64, "Gen"),
-                                               (m, 32, "m")), ok, workspace, stream, window_bits)
+                                               (m, 32, "m")), ok, workspace, stream, window_bits, accepted_out)
 
 
 def verify_double_dev(u, R, Rp, PK, PKp, m, ok, workspace, stream=None):
@@ -744,8 +771,9 @@ def mixed_rlc_workspace_bytes(n):
 
 
 def verify_mixed_rlc_dev(kinds, u, R, Rp, PK, PKp, m, n_double, ok, workspace, stream=None):
-    """dsv_verify_mixed_rlc_dev: the mixed batch with each kind through the batch fast accept; blocks on
-    `stream`; returns True if every group of both kinds was decided by its aggregate."""
+    """dsv_verify_mixed_rlc_dev: the mixed batch with each kind through the batch fast accept; waits for
+    `stream` (a host int receives the verdict); returns True if every group of both kinds was decided by its
+    aggregates."""
     n, dev = _rows((u, 32, "u"), (R, 64, "R"), (Rp, 64, "Rp"), (PK, 64, "PK"), (PKp, 64, "PKp"),
                    (m, 32, "m"))
     accepted = ctypes.c_int(0)

@@ -27,11 +27,9 @@ def test_plan_invariants(scheme):
             # e + k r < 2^(wpk c) for every k < kmul, and kmul is the largest such count
             assert p["kmul"] == (1 << (p["wpk"] * c)) // R_ORDER >= 1
             assert (R_ORDER - 1) + (p["kmul"] - 1) * R_ORDER < 1 << (p["wpk"] * c) <= 1 << 256
-            # sort keys: every bucket number and the "digit 0" key (= buckets) fit key_bits
             assert p["buckets"] == p["windows"] << c
-            assert p["buckets"] < 1 << p["key_bits"] <= 1 << 31
-            assert p["entries"] == n * (p["wpk"] * lpts + p["wr"] * spts) < 1 << 32
-            assert (lpts + spts) * n < 1 << 32
+            assert p["groups"] == 1 and p["sub"] == n
+            _check_partition(p, n, lpts, spts)
             # row / column and bit-sum chains: whole segments, none longer than 16 (or the whole side when small)
             side = 1 << p["half"]
             assert side % p["nseg"] == 0 and (side // 2) % p["nseg2"] == 0
@@ -44,6 +42,65 @@ def test_plan_invariants(scheme):
             assert E.rlc_workspace_bytes(n, bits) > 0
 
 
+def _check_partition(p, sub, lpts, spts):
+    """the two-pass partition of the digits (k_rlc_part1 / k_rlc_part2): what the kernels index by"""
+    c = p["c"]
+    # a 16-bit digit per (window, point slot, item); the low bits sorted through LDS in 256 counters
+    assert c <= 16 and p["fine_bits"] == min(c, 8) and p["fine_bits"] + p["coarse_bits"] == c
+    assert p["rows"] == p["wpk"] * lpts + p["wr"] * spts
+    assert p["entries"] == sub * p["rows"] < 1 << 32
+    # rows start 16-byte aligned (uint4 loads of eight digits) and hold every item of the sub-group
+    assert p["row_stride"] % 8 == 0 and sub <= p["row_stride"] < sub + 8
+    # k_rlc_part1 reserves with one LDS counter per bin of a window: at most 256 bins per window
+    assert p["bins"] == p["windows"] << p["coarse_bits"] and (1 << p["coarse_bits"]) <= 256
+    # (low digit bits << 24 | point index): point indices of a sub-group fit 24 bits
+    assert (lpts + spts) * sub <= 1 << 24
+    # a bin takes its mean load + 8 standard deviations, or everything a window can hold.  Mean: uniform digits,
+    # except that the keys' top window is uniform over kmul r / 2^(wpk c) = 0.905 / 0.962 of its digits only
+    most = max(lpts, spts) * sub
+    mean = most / (1 << p["coarse_bits"]) * (1 << (p["wpk"] * c)) / (p["kmul"] * R_ORDER)
+    assert p["bin_cap"] % 64 == 0 and p["bin_cap"] >= min(most, mean + 8 * mean ** 0.5)
+    assert p["bins"] * p["bin_cap"] < 1 << 32
+
+
+@pytest.mark.parametrize("scheme", ["single", "double", "vargen"])
+def test_sub_group_plans(scheme):
+    """a group cut into sub-groups (rlc.h: RlcPlan.groups): whole sub-batches of the per-signature path, the
+    last one ragged, never an empty one; window bits follow the SUB-group's size"""
+    lpts, spts, _ = {"single": (1, 1, 1), "double": (2, 2, 2), "vargen": (2, 1, 0)}[scheme]
+    for n in (2, 1000, (1 << 17) + 5, 1 << 18, (1 << 20) - 3, 1 << 20, (1 << 20) + 12345, 1 << 22):
+        for groups in (2, 3, 4, 8, 16):
+            p = E.rlc_plan_info(scheme, n, 0, groups)
+            G, sub = p["groups"], p["sub"]
+            assert 1 <= G <= groups and (G - 1) * sub < n <= G * sub
+            if n >= 1 << 17:
+                assert sub % (1 << 16) == 0 or G == 1     # no launch of the fallback straddles two sub-groups
+            assert p["c"] == E.rlc_plan_info(scheme, sub)["c"]
+            _check_partition(p, sub, lpts, spts)
+            assert p["bytes"] <= E.rlc_workspace_bytes(n)
+            p8 = E.rlc_plan_info(scheme, n, 8, groups)
+            assert p8["c"] == 8 and p8["bytes"] <= E.rlc_workspace_bytes(n, 8)
+
+
+def test_workspace_size_never_drops_with_the_batch_size():
+    """dsv_verify_mixed_rlc_dev sizes ONE fast-accept workspace for n items and then runs
+    aggregates over ns and nd <= n items of either kind — the size for n must cover every count up to n,
+    also just above 2^22 items, where a call's own groups shrink to n / 2."""
+    sizes = [1, 1000, 1 << 17, (1 << 19) - 1, 1 << 19, 1 << 20, (1 << 22) - 1, 1 << 22, (1 << 22) + 2, 5_000_000,
+             (1 << 23) - 7, 1 << 23, (1 << 23) + 1, 1 << 24]
+    prev = 0
+    for n in sizes:
+        b = E.rlc_workspace_bytes(n)
+        assert b >= prev, (n, b, prev)
+        prev = b
+    # the mixed entry point's share for the aggregates is that size
+    for n in ((1 << 22) + 2, 5_000_000, 1 << 23):
+        whole = E.mixed_rlc_workspace_bytes(n)
+        for k in (n // 2, n - 1, 1 << 22, 4_000_000):
+            if k <= n:
+                assert E.rlc_workspace_bytes(k) <= E.rlc_workspace_bytes(n) <= whole
+
+
 def test_default_window_widths_follow_the_batch_size():
     assert [E.rlc_plan_info("single", n)["c"] for n in (100, (1 << 14) - 1, 1 << 14, 1 << 17, 1 << 19, 1 << 22)] == \
         [8, 8, 12, 14, 16, 16]
@@ -52,10 +109,12 @@ def test_default_window_widths_follow_the_batch_size():
 def test_plan_argument_checks():
     import ctypes
     L = _lib.load()
-    out = (ctypes.c_uint64 * 16)()
-    assert L.dsv_rlc_plan_info(ctypes.c_int(3), ctypes.c_size_t(10), ctypes.c_int(0), out) == -2
-    assert L.dsv_rlc_plan_info(ctypes.c_int(0), ctypes.c_size_t(0), ctypes.c_int(0), out) == -2
-    assert L.dsv_rlc_plan_info(ctypes.c_int(0), ctypes.c_size_t(10), ctypes.c_int(10), out) == -2
-    assert L.dsv_rlc_plan_info(ctypes.c_int(0), ctypes.c_size_t((1 << 22) + 1), ctypes.c_int(0), out) == -2
-    assert L.dsv_rlc_plan_info(ctypes.c_int(0), ctypes.c_size_t(10), ctypes.c_int(0), None) == -2
+    out = (ctypes.c_uint64 * 24)()
+    one = ctypes.c_int(1)
+    assert L.dsv_rlc_plan_info(ctypes.c_int(3), ctypes.c_size_t(10), ctypes.c_int(0), one, out) == -2
+    assert L.dsv_rlc_plan_info(ctypes.c_int(0), ctypes.c_size_t(0), ctypes.c_int(0), one, out) == -2
+    assert L.dsv_rlc_plan_info(ctypes.c_int(0), ctypes.c_size_t(10), ctypes.c_int(10), one, out) == -2
+    assert L.dsv_rlc_plan_info(ctypes.c_int(0), ctypes.c_size_t((1 << 22) + 1), ctypes.c_int(0), one, out) == -2
+    assert L.dsv_rlc_plan_info(ctypes.c_int(0), ctypes.c_size_t(10), ctypes.c_int(0), ctypes.c_int(17), out) == -2
+    assert L.dsv_rlc_plan_info(ctypes.c_int(0), ctypes.c_size_t(10), ctypes.c_int(0), one, None) == -2
     assert int(L.dsv_rlc_workspace_bytes(ctypes.c_size_t(10), ctypes.c_int(10))) == 0

@@ -1,10 +1,16 @@
 #!/usr/bin/env python3
-"""Time dsv_verify_single_rlc_dev beside dsv_verify_single_dev (device-resident inputs):
+"""Time dsv_verify_<scheme>_rlc_dev beside dsv_verify_<scheme>_dev (device-resident inputs):
 
     python tools/rlc_probe.py [log2n=20] [window_bits=0] [reps=10] [scheme=single|double|vargen]
 
-all-valid batch (the aggregate decides) and the graded workload (1/16 tampered: aggregate fails, the
-per-signature kernels decide).  Verdicts checked against the construction-time pattern."""
+Workloads (verdicts checked against the construction-time pattern every time):
+  all valid          steady state of a caller whose batches are valid: one aggregate per group decides
+  all valid, split   the same while the device's history says "batches fail": sub-groups + sample
+  one wrong, first   ONE wrong signature, history 0 (the first such batch): whole-group fallback
+  one wrong, split   ONE wrong signature while the history says so: only its sub-group takes the fallback
+  1/16 tampered      the graded workload (wrong items throughout): the sample skips the aggregates
+The calls are enqueue-only (accepted comes back through a pinned word); the timing loop synchronises
+once per call, like the per-signature baseline."""
 import os
 import sys
 import time
@@ -26,13 +32,18 @@ rlc = getattr(E, "verify_%s_rlc_dev" % scheme)
 plain = getattr(E, "verify_%s_dev" % scheme)
 ws = torch.empty(E.rlc_workspace_bytes(n, bits), dtype=torch.uint8, device="cuda:0")
 ok = torch.zeros(n, dtype=torch.uint8, device="cuda:0")
+acc_word = torch.zeros(1, dtype=torch.int32).pin_memory()
 
 
-def timed(fn):
+def timed(fn, before=None):
+    if before:
+        before()
     fn()
     torch.cuda.synchronize()
     ts = []
     for _ in range(reps):
+        if before:
+            before()
         t0 = time.perf_counter()
         fn()
         torch.cuda.synchronize()
@@ -41,15 +52,44 @@ def timed(fn):
     return ts[0], ts[len(ts) // 2]
 
 
-for label, tamper in (("all valid", False), ("1/16 tampered", True)):
-    b = gen(n, seed=2321, tamper=tamper)
+good = gen(n, seed=2321, tamper=False)
+graded = gen(n, seed=2321, tamper=True)
+one = {k: v.clone() for k, v in good.items()}
+victim = (5 * n) // 8 + 77          # inside the third of four sub-groups, far from the sample's reach on average
+one["u"][victim, 3] ^= 0x10
+one["expected"][victim] = 0
+big = n >= 1 << 17 or bits != 0     # (automatic bits: groups below 2^17 items skip the aggregate)
+
+best0, med0 = timed(lambda: plain(*[good[k] for k in COLS], ok, ws))
+assert torch.equal(ok, good["expected"])
+print("%s n=2^%d bits=%d per-signature path          %.3f ms (median %.3f) = %.1f M/s" % (
+    scheme, n.bit_length() - 1, bits, best0, med0, n / best0 / 1e3), flush=True)
+for label, b, history, expect in (("all valid", good, 0, big), ("all valid, split", good, 8, big),
+                                  ("one wrong, first", one, 0, False), ("one wrong, split", one, 8, False),
+                                  ("1/16 tampered", graded, 8, False)):
     cols = [b[k] for k in COLS]
-    acc = []
-    best, med = timed(lambda: acc.append(rlc(*cols, ok, ws, window_bits=bits)))
-    expect = (not tamper) and (bits != 0 or n >= 1 << 17)   # (automatic bits: groups below 2^17 items skip the aggregate)
-    assert torch.equal(ok, b["expected"]) and all(a == expect for a in acc)
+    accs = []
+
+    def call():
+        rlc(*cols, ok, ws, window_bits=bits, accepted_out=acc_word)
+
+    def check():
+        torch.cuda.synchronize()
+        accs.append(int(acc_word[0]))
+
     ok.zero_()
-    best0, med0 = timed(lambda: plain(*cols, ok, ws))
-    assert torch.equal(ok, b["expected"])
-    print(scheme + " n=2^%d bits=%d %-14s rlc %.3f ms (median %.3f) = %.1f M/s | per-signature %.3f ms (median %.3f) = %.1f M/s | x%.2f" % (
-        n.bit_length() - 1, bits, label, best, med, n / best / 1e3, best0, med0, n / best0 / 1e3, best0 / best), flush=True)
+    ts = []
+    for _ in range(reps + 1):
+        E.rlc_history(0, history)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        call()
+        torch.cuda.synchronize()
+        ts.append((time.perf_counter() - t0) * 1e3)
+        check()
+        assert torch.equal(ok, b["expected"]), label
+    ts = sorted(ts[1:])
+    assert all(a == int(expect) for a in accs), (label, accs)
+    best, med = ts[0], ts[len(ts) // 2]
+    print("%s n=2^%d bits=%d %-18s rlc %.3f ms (median %.3f) = %.1f M/s | x%.2f the per-signature path" % (
+        scheme, n.bit_length() - 1, bits, label, best, med, n / best / 1e3, best0 / best), flush=True)
