@@ -797,25 +797,59 @@ def main():
         # aggregate decides) and on the graded batch (aggregate + per-signature kernels).
         wsr = torch.empty(E.rlc_workspace_bytes(n), dtype=torch.uint8, device=dev)
         okr = torch.zeros(n, dtype=torch.uint8, device=dev)
-        rlc = {"unit": "verifies/s", "entry_point": "dsv_verify_single_rlc_dev (blocks on the stream; weights from getrandom)"}
-        for label, b_ in (("all_valid", W.gen_single(n, seed=2321, device=dev, tamper=False)), ("graded_workload", batch)):
-            acc = []
-            f_ = lambda: acc.append(E.verify_single_rlc_dev(b_["u"], b_["R"], b_["PK"], b_["m"], okr, wsr))
-            t_ = timed(f_, reps, 1)
-            expect_acc = label == "all_valid" and n >= RLC_MIN     # (smaller groups skip the aggregate)
-            if int((okr != b_["expected"]).sum().item()) or any(a != expect_acc for a in acc):
+        acc_word = torch.zeros(1, dtype=torch.int32).pin_memory()   # `accepted`, written by the device: the calls only enqueue
+        rlc = {"unit": "verifies/s",
+               "entry_point": "dsv_verify_single_rlc_dev (enqueue-only: per-signature kernels gated by the aggregate's flag "
+                              "words, verdict through a pinned word; weights from getrandom)",
+               "protocol": "ms_per_call: one call, then a device synchronisation (as the per-signature figures); "
+                           "pipelined: `reps` calls enqueued back to back on one stream, one synchronisation"}
+        valid_b = W.gen_single(n, seed=2321, device=dev, tamper=False)
+        one_b = {k: v.clone() for k, v in valid_b.items()}
+        victim = (5 * n) // 8 + 77
+        one_b["u"][victim, 3] ^= 0x10
+        one_b["expected"][victim] = 0
+        # label, batch, history the device is put into before every call (None: as the calls themselves leave it)
+        cases = (("all_valid", valid_b, None, n >= RLC_MIN),
+                 ("one_bad_first_call", one_b, 0, False),          # the first bad batch of a caller: whole-group fallback
+                 ("one_bad_in_batch", one_b, None, False),         # ... and the following ones: sub-groups localise it
+                 ("graded_workload", batch, None, False))          # wrong items throughout: the sample skips the aggregates
+        for label, b_, hist, expect_acc in cases:
+            accs = []
+
+            def f_():
+                if hist is not None:
+                    torch.cuda.synchronize(dev)
+                    E.rlc_history(dev_index, hist)
+                E.verify_single_rlc_dev(b_["u"], b_["R"], b_["PK"], b_["m"], okr, wsr, accepted_out=acc_word)
+                torch.cuda.synchronize(dev)
+                accs.append(int(acc_word[0]))
+            t_ = timed(f_, reps, 2)
+            if int((okr != b_["expected"]).sum().item()) or any(a != int(expect_acc) for a in accs[-reps:]):
                 raise SystemExit("rlc (%s): verdicts / acceptance differ from the expected pattern" % label)
             rlc[label] = {"value": n * reps / t_, "ms_per_call": t_ / reps * 1e3, "accepted_by_aggregate": expect_acc,
                           "vs_per_signature": (n * reps / t_) / value}
+            if hist is None:
+                tp_ = timed(lambda: E.verify_single_rlc_dev(b_["u"], b_["R"], b_["PK"], b_["m"], okr, wsr, accepted_out=acc_word), reps, 1)
+                if int((okr != b_["expected"]).sum().item()) or int(acc_word[0]) != int(expect_acc):
+                    raise SystemExit("rlc (%s, pipelined): verdicts / acceptance differ from the expected pattern" % label)
+                rlc[label]["pipelined"] = {"value": n * reps / tp_, "ms_per_call": tp_ / reps * 1e3,
+                                           "vs_per_signature": (n * reps / tp_) / value}
+        rlc["one_bad_in_2^20"] = rlc["one_bad_in_batch"] if n == 1 << 20 else None
+        E.rlc_history(dev_index, 0)
+        del valid_b, one_b
         # the other two schemes at their configuration sizes, all-valid batches
         for label, gen_, cols_, fn_, n_, ref_ in (
                 ("double_all_valid", W.gen_double, ("u", "R", "Rp", "PK", "PKp", "m"), E.verify_double_rlc_dev, n, out["double"]["value"]),
                 ("vargen_all_valid", W.gen_vargen, ("u", "R", "PK", "Gen", "m"), E.verify_vargen_rlc_dev, nv, out["vargen"]["value"])):
             b_ = gen_(n_, seed=99, device=dev, tamper=False)
             acc = []
-            f_ = lambda: acc.append(fn_(*[b_[k] for k in cols_], okr[:n_], wsr))
-            t_ = timed(f_, reps, 1)
-            if not bool(okr[:n_].all()) or any(a != (n_ >= RLC_MIN) for a in acc):
+
+            def f_():
+                fn_(*[b_[k] for k in cols_], okr[:n_], wsr, accepted_out=acc_word)
+                torch.cuda.synchronize(dev)
+                acc.append(int(acc_word[0]))
+            t_ = timed(f_, reps, 2)
+            if not bool(okr[:n_].all()) or any(a != int(n_ >= RLC_MIN) for a in acc[-reps:]):
                 raise SystemExit("rlc (%s): not accepted" % label)
             rlc[label] = {"items": n_, "value": n_ * reps / t_, "ms_per_call": t_ / reps * 1e3,
                           "vs_per_signature": (n_ * reps / t_) / ref_}

@@ -313,6 +313,9 @@ int dsv_rlc_plan_info(int scheme, size_t n, int window_bits, int groups, uint64_
 /* the device's history counter (see above; tests and tools): returns it, or a negative dsv_status;
  * set >= 0 overrides it */
 int dsv_debug_rlc_history(int device, int set);
+/* sub-groups per group, process-wide: groups >= 1 forces that many (whatever the history says),
+ * 0 = automatic, < 0 = leave; returns the previous setting ($DSV_RLC_SUBGROUPS initialises it) */
+int dsv_debug_rlc_subgroups(int groups);
 int dsv_verify_single_rlc_dev(const void *u, const void *R_uv, const void *PK_uv, const void *m,
                               size_t n, void *ok, void *workspace, void *stream, int window_bits,
                               int *accepted);

@@ -129,6 +129,8 @@ int rlc_random_key(ChaChaKey& key) {
   }
   return DSV_OK;
 }
+// sub-groups per group, forced (DSV_RLC_SUBGROUPS, dsv_debug_rlc_subgroups; tests and tools); 0: by the history
+std::atomic<int> g_rlc_force_groups{getenv("DSV_RLC_SUBGROUPS") ? atoi(getenv("DSV_RLC_SUBGROUPS")) : 0};
 // pinned host words the device writes: [0] the history counter, [1] calls completed, [2 ..] a ring of
 // verdict slots for callers whose `accepted` is pageable memory
 constexpr u32 kRlcSlots = 62;
@@ -202,7 +204,7 @@ int verify_rlc_on(Context& ctx, int scheme, const void* u, const void* R_uv, con
   const size_t group = rlc_group_items(n);
   static const bool trace = getenv("DSV_RLC_TRACE") != nullptr;  // why a group was (not) accepted: makes the call synchronous
   static const bool sample_on = !(getenv("DSV_RLC_SAMPLE") && atoi(getenv("DSV_RLC_SAMPLE")) == 0);
-  static const int force_groups = getenv("DSV_RLC_SUBGROUPS") ? atoi(getenv("DSV_RLC_SUBGROUPS")) : 0;
+  const int force_groups = g_rlc_force_groups.load(std::memory_order_relaxed);
   // what the device's recent calls say (written by the verdict kernels; read without waiting for anything)
   const u32 history = *reinterpret_cast<volatile u32*>(ctx.rlc_pinned);
   RlcVerdictArgs va = {};
@@ -400,6 +402,11 @@ int dsv_debug_rlc_history(int device, int set) {
   if (set >= 0) *reinterpret_cast<volatile u32*>(ctx.rlc_pinned) = (u32)set;
   return h;
 }
+int dsv_debug_rlc_subgroups(int groups) {
+  const int before = g_rlc_force_groups.load();
+  if (groups >= 0) g_rlc_force_groups.store(groups > kRlcMaxSub ? kRlcMaxSub : groups);
+  return before;
+}
 #define DSV_RLC_PROLOGUE(nullcheck)                                                              \
   if (n == 0) return rlc_clear_accepted(accepted);                                               \
   if (nullcheck) return fail(DSV_ERR_INVALID_ARGUMENT, "null pointer");                          \
@@ -573,7 +580,7 @@ int rlc_host_shard(Context& ctx, int kind, size_t n, uint8_t* ok, int* accepted,
   static const bool staged_on = !(getenv("DSV_RLC_STAGED") && atoi(getenv("DSV_RLC_STAGED")) == 0);
   // (two ranges only in the steady state: while the history says "batches fail" the group runs in sub-groups,
   //  all of them after the fill)
-  static const int force_groups = getenv("DSV_RLC_SUBGROUPS") ? atoi(getenv("DSV_RLC_SUBGROUPS")) : 0;
+  const int force_groups = g_rlc_force_groups.load(std::memory_order_relaxed);
   RlcHook hook;
   hook.on = staged_on && n >= ((size_t)1 << 18) && rlc_history(ctx) == 0 && force_groups <= 1;
   if (hook.on) {

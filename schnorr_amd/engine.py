@@ -578,6 +578,11 @@ def rlc_history(device=0, set_to=-1):
     return r
 
 
+def rlc_subgroups(groups=-1):
+    """dsv_debug_rlc_subgroups: force `groups` sub-groups per group (0: automatic); returns the previous setting"""
+    return int(_lib.load().dsv_debug_rlc_subgroups(ctypes.c_int(groups)))
+
+
 def _accepted_arg(accepted_out, dev):
     """the `accepted` argument of the *_rlc_dev calls: None -> a host int (the call waits for the stream and
     returns a bool); a one-element int32 tensor on `dev` or in pinned host memory -> written by the device

@@ -1,0 +1,204 @@
+"""GPU tests of round 6: failure localisation of the batch fast accept ("bisect on
+failure" done as sub-groups that share one set of launches: schnorr_amd/csrc/rlc.h, dsv_rlc.hip) and its
+enqueue-only control (per-signature kernels gated by the aggregate's flag words, the verdict written by
+a kernel).  The contract is unchanged: the verdict vector of `PublicKey::verify`
+(/root/reference/src/keys/public.rs:121-130; :222-244, :401-415 for the other schemes) item by item —
+the ORACLE's — whatever the sub-group count, history or sample says."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+import harness as H
+import oracle_lib as O
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+COLS = {"single": ("u", "R", "PK", "m"), "double": ("u", "R", "Rp", "PK", "PKp", "m"),
+        "vargen": ("u", "R", "PK", "Gen", "m")}
+
+
+def _signed(n, seed, scheme="single"):
+    d = getattr(O, "keygen_sign_" + scheme)(n, seed, nthreads=8)
+    return {k: d[k] for k in COLS[scheme]}
+
+
+def _oracle(a, scheme):
+    return getattr(O, "verify_" + scheme)(*[a[k] for k in COLS[scheme]], nthreads=8)
+
+
+def _run(engine, a, scheme, window_bits=0, accepted_out=None):
+    n = len(a["u"])
+    t = [torch.from_numpy(np.ascontiguousarray(a[k])).to(DEV) for k in COLS[scheme]]
+    ok = torch.full((n,), 7, dtype=torch.uint8, device=DEV)
+    ws = torch.empty(engine.rlc_workspace_bytes(n, window_bits), dtype=torch.uint8, device=DEV)
+    acc = getattr(engine, "verify_%s_rlc_dev" % scheme)(*t, ok, ws, window_bits=window_bits, accepted_out=accepted_out)
+    torch.cuda.synchronize()
+    return acc, ok.cpu().numpy()
+
+
+@pytest.fixture
+def forced_groups(engine):
+    """sub-groups forced for the test, the automatic choice restored afterwards"""
+    def force(g):
+        engine.rlc_subgroups(g)
+    yield force
+    engine.rlc_subgroups(0)
+
+
+@pytest.mark.parametrize("scheme", ["single", "double", "vargen"])
+@pytest.mark.parametrize("groups", [2, 4, 7])
+def test_sub_groups_give_the_oracles_verdicts(engine, forced_groups, scheme, groups):
+    """a wrong item in each sub-group in turn, two in different sub-groups, none; ragged last sub-group"""
+    n = 3000 + 37
+    forced_groups(groups)
+    d = _signed(n, 600 + groups, scheme)
+    acc, ok = _run(engine, d, scheme, 8)
+    assert acc and ok.all()
+    sub = engine.rlc_plan_info(scheme, n, 8, groups)["sub"]
+    G = engine.rlc_plan_info(scheme, n, 8, groups)["groups"]
+    assert (G - 1) * sub < n <= G * sub and n % sub != 0
+    victims = [g * sub + (17 * g) % min(sub, n - g * sub) for g in range(G)] + [n - 1]
+    for v in victims:
+        a = {k: x.copy() for k, x in d.items()}
+        a["u"][v, 5] ^= 0x02
+        want = _oracle(a, scheme)
+        assert want.sum() == n - 1 and not want[v]
+        acc, ok = _run(engine, a, scheme, 8)
+        assert not acc and np.array_equal(ok, want), v
+    a = {k: x.copy() for k, x in d.items()}
+    a["m"][victims[0], 1] ^= 0x40
+    a["PK"][victims[-1]] = d["PK"][victims[-1] - 1]
+    want = _oracle(a, scheme)
+    assert want.sum() == n - 2
+    acc, ok = _run(engine, a, scheme, 8)
+    assert not acc and np.array_equal(ok, want)
+    # the harness's tamper classes, all over the batch
+    a = {k: x.copy() for k, x in d.items()}
+    H.tamper(a, period=11)
+    want = _oracle(a, scheme)
+    acc, ok = _run(engine, a, scheme, 12)
+    assert not acc and np.array_equal(ok, want)
+
+
+def test_a_small_order_component_fails_only_its_own_sub_group(engine, forced_groups):
+    """a key with an order-8 component whose item is VALID (the torsion parts cancel): its sub-group must not be
+    decided by its aggregate; the verdicts are the oracle's; seen per sub-group through DSV_RLC_TRACE"""
+    code = r"""
+import sys
+sys.path.insert(0, "tests")
+import numpy as np, torch
+import oracle_lib as O, test_halfgcd as TH, test_gpu_rlc as T
+from schnorr_amd import engine as E
+E.init(0)
+n = 4000
+d = O.keygen_sign_single(n, 611, nthreads=8)
+a = {k: d[k].copy() for k in ("u", "R", "PK", "m")}
+rows = T._torsion_rows(TH.order8_point(), TH.rnd, 1, True)
+for k in rows:
+    a[k][2500] = rows[k][0]
+want = O.verify_single(a["u"], a["R"], a["PK"], a["m"], nthreads=8)
+assert want.all()
+E.rlc_subgroups(4)
+t = [torch.from_numpy(np.ascontiguousarray(a[k])).to("cuda:0") for k in ("u", "R", "PK", "m")]
+ok = torch.zeros(n, dtype=torch.uint8, device="cuda:0")
+ws = torch.empty(E.rlc_workspace_bytes(n, 8), dtype=torch.uint8, device="cuda:0")
+acc = E.verify_single_rlc_dev(*t, ok, ws, window_bits=8)
+assert not acc and np.array_equal(ok.cpu().numpy(), want)
+print("done")
+"""
+    env = dict(os.environ, DSV_RLC_TRACE="1")
+    r = subprocess.run([sys.executable, "-c", code], cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, (r.stdout[-800:], r.stderr[-2000:])
+    lines = [x for x in r.stderr.splitlines() if "[dsv rlc]" in x]
+    assert len(lines) == 4, lines
+    assert [("accepted" in x) for x in lines] == [True, True, False, True], lines
+    assert "subgroup-test" in lines[2]
+
+
+def test_history_follows_the_calls(engine):
+    """the device keeps the counter itself: 8 after a call with a rejected aggregate, one less after a call whose
+    aggregates all accepted; groups too small for an aggregate leave it alone; while it is > 0 a group of 2^18
+    items runs in two sub-groups, at 0 in one"""
+    n = 1 << 18
+    d = _signed(4096, 620)
+    big = {k: np.tile(v, (n // 4096, 1)) for k, v in d.items()}
+    bad = {k: v.copy() for k, v in big.items()}
+    bad["u"][n // 2 + 5, 0] ^= 1
+    engine.rlc_history(0, 0)
+    acc, ok = _run(engine, big, "single")
+    assert acc and ok.all() and engine.rlc_history(0) == 0
+    acc, ok = _run(engine, bad, "single")
+    assert not acc and ok.sum() == n - 1 and not ok[n // 2 + 5]
+    assert engine.rlc_history(0) == 8
+    for left in (7, 6):
+        acc, ok = _run(engine, big, "single")
+        assert acc and ok.all() and engine.rlc_history(0) == left
+    acc, ok = _run(engine, d, "single")            # 4096 items: no aggregate, no change
+    assert not acc and ok.all() and engine.rlc_history(0) == 6
+    acc, ok = _run(engine, bad, "single")          # rejected again, in sub-groups this time
+    assert not acc and ok.sum() == n - 1 and engine.rlc_history(0) == 8
+    engine.rlc_history(0, 1)
+
+
+def test_accepted_through_memory_the_device_writes(engine):
+    """`accepted` in pinned host memory or in device memory: written by a kernel, the call returns None at once"""
+    n = 2500
+    d = _signed(n, 630)
+    bad = {k: v.copy() for k, v in d.items()}
+    bad["m"][99, 0] ^= 4
+    for make in (lambda: torch.full((1,), 5, dtype=torch.int32).pin_memory(),
+                 lambda: torch.full((1,), 5, dtype=torch.int32, device=DEV)):
+        word = make()
+        acc, ok = _run(engine, d, "single", 8, accepted_out=word)
+        assert acc is None and int(word.cpu()[0]) == 1 and ok.all()
+        acc, ok = _run(engine, bad, "single", 8, accepted_out=word)
+        assert acc is None and int(word.cpu()[0]) == 0 and ok.sum() == n - 1
+    with pytest.raises(ValueError):
+        _run(engine, d, "single", 8, accepted_out=torch.zeros(1, dtype=torch.int32))   # pageable: not through this argument
+
+
+def test_one_wrong_signature_in_a_full_size_batch(engine):
+    """2^20 signatures with ONE wrong (BASELINE configs[1]'s size): verdicts = the construction pattern, whether
+    the call runs as one group (history 0) or in sub-groups; an oracle sample around the wrong item"""
+    from schnorr_amd import workload as W
+    n = 1 << 20
+    b = W.gen_single(n, seed=77, tamper=False)
+    victim = 700_001
+    b["u"][victim, 2] ^= 0x20
+    b["expected"][victim] = 0
+    ws = torch.empty(engine.rlc_workspace_bytes(n), dtype=torch.uint8, device=DEV)
+    ok = torch.zeros(n, dtype=torch.uint8, device=DEV)
+    for history in (0, 8):
+        engine.rlc_history(0, history)
+        ok.zero_()
+        assert not engine.verify_single_rlc_dev(b["u"], b["R"], b["PK"], b["m"], ok, ws)
+        assert torch.equal(ok, b["expected"])
+    lo = victim - 100
+    cut = {k: b[k][lo:lo + 256].cpu().numpy() for k in COLS["single"]}
+    assert np.array_equal(_oracle(cut, "single"), ok[lo:lo + 256].cpu().numpy())
+    engine.rlc_history(0, 1)
+
+
+def test_mixed_batch_beyond_one_group_per_kind(engine):
+    """a mixed batch just above 2^22 items — its kinds' counts are single groups of ~2^21
+    items while the workspace is sized for n: all valid -> accepted, one wrong double -> the pattern"""
+    from schnorr_amd import workload as W
+    n = (1 << 22) + (1 << 12)
+    b = W.gen_mixed(n, seed=31, tamper=False)
+    ws = torch.empty(engine.mixed_rlc_workspace_bytes(n), dtype=torch.uint8, device=DEV)
+    ok = torch.zeros(n, dtype=torch.uint8, device=DEV)
+    args = [b[k] for k in ("kinds", "u", "R", "Rp", "PK", "PKp", "m")] + [b["n_double"]]
+    engine.rlc_history(0, 0)
+    assert engine.verify_mixed_rlc_dev(*args, ok, ws)
+    assert bool(ok.all())
+    victim = 3_000_001   # odd: a double item
+    b["PKp"][victim] = b["PKp"][victim - 2]
+    ok.zero_()
+    assert not engine.verify_mixed_rlc_dev(*args, ok, ws)
+    assert int(ok.sum()) == n - 1 and int(ok[victim]) == 0
+    engine.rlc_history(0, 1)
