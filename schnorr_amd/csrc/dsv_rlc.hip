@@ -96,11 +96,11 @@ size_t rlc_group_items(size_t n) {
   return (n + groups - 1) / groups;
 }
 // sub-groups a group of cnt items is cut into while the history says "batches fail": sub-groups of
-// 2^kSubLog2 items (DSV_RLC_SUB_LOG2), at least two from 2^18 items on, at most kRlcMaxSub
+// 2^17 items (DSV_RLC_SUB_LOG2; measured: 2^20 items with one wrong signature 7.2 ms in eight sub-groups, 8.1 in four, 10.8 in two), at least two from 2^18 items on, at most kRlcMaxSub
 int rlc_split_groups(size_t cnt, int window_bits) {
   static const int sub_log2 = [] {
     const char* e = getenv("DSV_RLC_SUB_LOG2");
-    const int v = e ? atoi(e) : 18;
+    const int v = e ? atoi(e) : 17;
     return v < 10 ? 10 : (v > 22 ? 22 : v);
   }();
   size_t g = cnt >> sub_log2;
@@ -290,11 +290,14 @@ int verify_rlc_on(Context& ctx, int scheme, const void* u, const void* R_uv, con
       HIP_TRY(launch_rlc_finish(plan, cv.b, ctx.table[0], ctx.table[1], false, s));
     }
     // the per-signature kernels, from the challenges already in the workspace (run_split carves it the same
-    // way), each launch gated by its sub-group's flag words: no work where the aggregate accepted
+    // way), each launch gated by its sub-group's flag words: no work where the aggregate accepted.
+    // ONE sub-group — the steady state, where the aggregate is expected to accept —: one launch over the whole
+    // group (sixteen gated sub-batch launches cost 0.05 ms of an accepted call's 5.3; a rejected group loses
+    // the few percent the sub-batch split returns, once: the next call runs in sub-groups).
     Context* cp = &ctx;
     const u32* gflags = cv.b.flags;
     const size_t sub = plan.sub;
-    const int r = run_split(ctx, cnt, workspace, s, [=](size_t o, size_t part, const Workspace& w, hipStream_t ps) {
+    auto fallback = [=](size_t o, size_t part, const Workspace& w, hipStream_t ps) {
       // (sub-groups are whole sub-batches; an unsplit launch covers one sub-group or is cut here)
       for (size_t done = 0; done < part;) {
         const size_t at = off + o + done, g = (o + done) / sub;
@@ -312,7 +315,14 @@ int verify_rlc_on(Context& ctx, int scheme, const void* u, const void* R_uv, con
                             (const uint8_t*)w.valid + done, take, pok + at, w.tables, ps, gate);
         done += take;
       }
-    });
+    };
+    int r = DSV_OK;
+    if (plan.groups == 1) {
+      fallback((size_t)0, cnt, cv.w, s);
+      HIP_TRY(hipGetLastError());
+    } else {
+      r = run_split(ctx, cnt, workspace, s, fallback);
+    }
     if (r) return r;
   }
   if (!flags_area)

@@ -33,10 +33,10 @@
 //                     and lengths in the same pass
 //   k_rlc_lenhist / k_rlc_order   bucket numbers by run length, longest first (counting sort)
 //   k_rlc_accumulate  one lane per bucket: mixed additions over its run
-//   k_rlc_fsum[2]     sum f_i mod r
-//   k_rlc_sum<0..3>   row / column sums, then the per-bit subset sums S_p        (short chains)
-//   k_rlc_scale       lanes A: r * S_p == O ?    lanes B: 2^p * S_p    one more lane: (sum f_i) * G
-//   k_rlc_final       sum of all of lanes B's and that lane's results, identity test -> flags
+//   k_rlc_sum<0..3>   row / column sums, then the per-bit subset sums S_p (short chains; <1..3>: a butterfly
+//                     over `count` lanes per output); extra workgroups of <0> / <1> sum the f_i mod r
+//   k_rlc_scale       lanes A: r * S_p == O ?    lanes B: 2^p * S_p    one more lane: (sum f_i) * G;  the last
+//                     workgroup of lanes B adds their results up: identity test -> flags
 //   k_rlc_sample_decide / k_rlc_verdict   the sample's and the call's verdicts (dsv_rlc.hip: no host round trip)
 // Every kernel of the chain returns at once when word 0 of the group's flag block is set (the sample
 // found a wrong signature: the per-signature kernels decide).
@@ -159,9 +159,6 @@ DSV_DEV Niels niels_neg(const Niels& n) {
   r.z = n.z;
   r.t2d = fe_neg2(n.t2d);
   return r;
-}
-DSV_DEV bool ext_is_identity(const Ext& p) {  // u == 0 and v == z (z != 0 on the curve: complete formulas)
-  return (bool)((int)fe_equal(p.u, fe_zero()) & (int)fe_equal(p.v, p.z));
 }
 
 // -u^2 + v^2 == 1 + d u^2 v^2, as 2 v^2 == 2 u^2 + 2 + (2d) u^2 v^2 (u, v: fe_mul outputs)
@@ -325,12 +322,11 @@ k_rlc_prep(RlcInputs in, ChaChaKey key, RlcPlan p, RlcBuffers b, uint8_t* __rest
   }
 }
 
-// sum of n scalars mod r: stage 0 -> kRlcFsumBlocks partial sums (of fixed-base term blockIdx.y of
-// sub-group blockIdx.z), stage 1 (one workgroup each) -> fsum
-__global__ void __launch_bounds__(256) k_rlc_fsum(RlcPlan p, RlcBuffers b, int stage) {
-  if (b.flags[0]) return;
-  __shared__ u32 sh[256][8];
-  const u32 g = blockIdx.z, k = blockIdx.y;
+// sum of the sub-group's scalars z_i u_i mod r (fixed-base term k): stage 0 -> kRlcFsumBlocks partial sums
+// (workgroup blk of them), stage 1 (one workgroup) -> fsum.  One 64-thread workgroup; runs as extra
+// workgroups of k_rlc_sum<0> / k_rlc_sum<1> — 0.05 ms of launches of their own otherwise.
+DSV_DEV void fsum_block(const RlcPlan& p, const RlcBuffers& b, int stage, u32 g, u32 k, u32 blk) {
+  __shared__ u32 sh[64][8];
   u32 total = p.total;
   if (p.groups > 1) {
     const u32 left = p.items - g * p.sub;
@@ -339,9 +335,10 @@ __global__ void __launch_bounds__(256) k_rlc_fsum(RlcPlan p, RlcBuffers b, int s
   u32* fpart = b.fpart + ((size_t)g * 2 + k) * kRlcFsumBlocks * 8;
   const u32* in = stage == 0 ? b.fsc + (size_t)g * b.fsc_stride + (size_t)k * total * 8 : fpart;
   const size_t n = stage == 0 ? total : kRlcFsumBlocks;
-  u32* out = stage == 0 ? fpart : b.fsum + ((size_t)g * 2 + k) * 8;
+  u32* out = stage == 0 ? fpart + (size_t)blk * 8 : b.fsum + ((size_t)g * 2 + k) * 8;
+  const size_t nblk = stage == 0 ? kRlcFsumBlocks : 1;
   u32 acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+  for (size_t i = (size_t)blk * 64 + threadIdx.x; i < n; i += nblk * 64) {
     u32 x[8], t[8];
     load_words8(x, reinterpret_cast<const uint8_t*>(in), i);
     fr_add(t, acc, x);
@@ -351,7 +348,7 @@ __global__ void __launch_bounds__(256) k_rlc_fsum(RlcPlan p, RlcBuffers b, int s
 #pragma unroll
   for (int j = 0; j < 8; j++) sh[threadIdx.x][j] = acc[j];
   __syncthreads();
-  for (int step = 128; step > 0; step >>= 1) {
+  for (int step = 32; step > 0; step >>= 1) {
     if ((int)threadIdx.x < step) {
       u32 x[8], y[8], t[8];
 #pragma unroll
@@ -366,7 +363,7 @@ __global__ void __launch_bounds__(256) k_rlc_fsum(RlcPlan p, RlcBuffers b, int s
     u32 t[8];
 #pragma unroll
     for (int j = 0; j < 8; j++) t[j] = sh[0][j];
-    store_words8(reinterpret_cast<uint8_t*>(out), blockIdx.x, t);
+    store_words8(reinterpret_cast<uint8_t*>(out), 0, t);
   }
 }
 
@@ -596,21 +593,36 @@ k_rlc_merge(RlcPlan p, RlcBuffers bf) {
 //   MODE 1  segments -> row / column sums ("lines")
 //   MODE 2  lines -> segments of: sum of the lines whose index has bit j set
 //   MODE 3  segments -> S[w * c + kind * half + j], the subset sum of bit (kind * half + j) of window w
+// MODE 0 (196 k outputs of 16 inputs at c = 16: throughput) runs one lane per output.  MODES 1 - 3 (a few
+// thousand outputs: pure latency, 16 dependent additions of ~4 us each) run `count` lanes per output: every
+// lane takes one input and a butterfly of log2(count) exchanges (36 words through ds_bpermute) and additions
+// leaves the sum in all of them — 3 + 9 log2(count) multiplications deep instead of 8 count.
+// `extra` workgroups behind the outputs' own run fsum_block (MODE 0: stage 0, MODE 1: stage 1).
 template <int MODE>
 __global__ void __launch_bounds__(64)
 k_rlc_sum(const u32* __restrict__ in, size_t in_stride, RlcPlan p, u32* __restrict__ out, size_t out_stride,
-          const u32* __restrict__ gate) {
-  if (gate[0]) return;
+          RlcBuffers bf, u32 main_blocks) {
+  if (bf.flags[0]) return;
+  if (MODE <= 1 && blockIdx.x >= main_blocks) {  // (uniform per workgroup)
+    const u32 e = blockIdx.x - main_blocks;
+    if (MODE == 0) fsum_block(p, bf, 0, blockIdx.y, e / kRlcFsumBlocks, e % kRlcFsumBlocks);
+    else fsum_block(p, bf, 1, blockIdx.y, e, 0);
+    return;
+  }
   in += (size_t)blockIdx.y * in_stride * kNielsWords;    // (strides in points)
   out += (size_t)blockIdx.y * out_stride * kNielsWords;
-  const u32 o = blockIdx.x * 64 + threadIdx.x;
   const u32 side = 1u << p.half;
   u32 total, count;
   if (MODE == 0) total = (u32)p.windows * 2 * side * p.nseg, count = side / p.nseg;
   else if (MODE == 1) total = (u32)p.windows * 2 * side, count = p.nseg;
   else if (MODE == 2) total = (u32)p.windows * 2 * p.half * p.nseg2, count = side / 2 / p.nseg2;
   else total = (u32)p.windows * 2 * p.half, count = p.nseg2;
-  if (o >= total) return;
+  const u32 t = blockIdx.x * 64 + threadIdx.x;
+  const u32 lanes_per = MODE == 0 ? 1u : count;  // a power of two <= 16 (tests/test_rlc_plan.py)
+  const u32 o_raw = t / lanes_per, lane = t % lanes_per;
+  const bool live = o_raw < total;
+  if (MODE == 0 && !live) return;
+  const u32 o = live ? o_raw : total - 1;  // (MODES 1 - 3: idle lanes keep step with the exchanges)
   u32 base = 0, step = 1, j = 0, first = 0;
   if (MODE == 0) {
     const u32 seg = o % p.nseg, line = o / p.nseg, idx = line % side, wk = line / side, kind = wk & 1, w = wk >> 1;
@@ -620,9 +632,9 @@ k_rlc_sum(const u32* __restrict__ in, size_t in_stride, RlcPlan p, u32* __restri
   } else if (MODE == 1 || MODE == 3) {
     base = o * count;
   } else {
-    const u32 s = o % p.nseg2, t = o / p.nseg2;
-    j = t % p.half;
-    base = (t / p.half) * side;  // (w * 2 + kind) * side
+    const u32 s = o % p.nseg2, q = o / p.nseg2;
+    j = q % p.half;
+    base = (q / p.half) * side;  // (w * 2 + kind) * side
     first = s * count;
   }
   auto addr = [&](u32 k) -> size_t {
@@ -632,16 +644,34 @@ k_rlc_sum(const u32* __restrict__ in, size_t in_stride, RlcPlan p, u32* __restri
     }
     return (size_t)(base + k * step) * kNielsWords;
   };
-  Ext acc = ext_identity();
-  Niels cur = load_niels(in + addr(0));
+  if (MODE == 0) {
+    Ext acc = ext_identity();
+    Niels cur = load_niels(in + addr(0));
 #pragma unroll 1
-  for (u32 k = 0; k < count; k++) {
-    const Niels nxt = load_niels(in + addr(k + 1 < count ? k + 1 : k));
-    acc = ext_add_niels(acc, cur);
-    cur = nxt;
+    for (u32 k = 0; k < count; k++) {
+      const Niels nxt = load_niels(in + addr(k + 1 < count ? k + 1 : k));
+      acc = ext_add_niels(acc, cur);
+      cur = nxt;
+    }
+    store_niels(out + (size_t)o * kNielsWords, ext_to_niels(acc));
+    return;
+  }
+  Ext acc = ext_from_niels(load_niels(in + addr(lane)));
+#pragma unroll 1
+  for (u32 m = 1; m < lanes_per; m <<= 1) {
+    const Niels mine = ext_to_niels(acc);
+    Niels other;
+#pragma unroll
+    for (int i = 0; i < NL; i++) {
+      other.vpu.l[i] = (u32)__shfl_xor((int)mine.vpu.l[i], (int)m);
+      other.vmu.l[i] = (u32)__shfl_xor((int)mine.vmu.l[i], (int)m);
+      other.z.l[i] = (u32)__shfl_xor((int)mine.z.l[i], (int)m);
+      other.t2d.l[i] = (u32)__shfl_xor((int)mine.t2d.l[i], (int)m);
+    }
+    acc = ext_add_niels(acc, other);
   }
   // (MODE 3: o = (w * 2 + kind) * half + j is w * c + kind * half + j, the bit's place in window w)
-  store_niels(out + (size_t)o * kNielsWords, ext_to_niels(acc));
+  if (live && lane == 0) store_niels(out + (size_t)o * kNielsWords, ext_to_niels(acc));
 }
 
 // ---- the subset sums: subgroup test and weights -----------------------------------------------------
@@ -715,97 +745,128 @@ DSV_DEV Xp xp_identity() {
 // Workgroups [g, 2g): W_l = 2^pos(l) * S_l, pos = bit position inside the scalar the window belongs to
 // (every lane runs the workgroup's longest chain and keeps its own result once it is there).
 // Workgroup 2g: W_lanes = (sum f_i) * G (+ (sum f'_i) * G') from the fixed-base tables, one lane.
+// The LAST of the g + 1 workgroups that produce a W (a counter in the sub-group's flag words) also adds
+// them all up and tests the sum for the identity — r05 had a kernel of its own for that, 0.07 ms behind
+// this one; here it runs in the shadow of the subgroup test's longer chains (337 point operations against
+// at most 252).  The last of ALL workgroups to finish marks the chain complete.
+namespace {
+// sum of `count` stored points == O ?  All four waves of the workgroup, the cooperative operations above:
+// 64 strided partial sums, then a tree over the 64 lanes through LDS (tree: 64 x kNielsWords words).
+DSV_DEV bool xp_sum_is_identity(const u32* __restrict__ W, u32 count, u32* sh, u32* tree, int wave, int lane) {
+  int buf = 0;
+  Xp acc = xp_identity();
+#pragma unroll 1
+  for (u32 k = 0; k < count; k += 64) {
+    const Niels n = k + lane < count ? load_niels(W + (size_t)(k + lane) * kNielsWords) : niels_identity();
+    acc = xp_add(sh, buf, wave, lane, acc, n);
+  }
+#pragma unroll 1
+  for (u32 step = 32; step > 0; step >>= 1) {
+    // every wave holds the same acc: each computes the niels form, wave 0 hands it to the other lanes
+    Niels mine;
+    mine.vpu = fe_carry(fe_add(acc.v, acc.u));
+    mine.vmu = fe_sub2(acc.v, acc.u);
+    mine.z = acc.z;
+    mine.t2d = fe_mul(acc.tt, fe_const(kD2));
+    __syncthreads();  // (the previous level's reads of `tree` are done)
+    if (wave == 0 && (u32)lane >= step && (u32)lane < 2 * step) store_niels(tree + (size_t)lane * kNielsWords, mine);
+    __syncthreads();
+    const Niels other = (u32)lane < step ? load_niels(tree + (size_t)(lane + step) * kNielsWords) : niels_identity();
+    acc = xp_add(sh, buf, wave, lane, acc, other);
+  }
+  // lane 0 holds the total (in every wave)
+  const bool identity = (bool)((int)fe_equal(acc.u, fe_zero()) & (int)fe_equal(acc.v, acc.z));
+  return __shfl((int)identity, 0) != 0;
+}
+}  // namespace
 __global__ void __launch_bounds__(256)
 k_rlc_scale(const u32* __restrict__ S, size_t S_stride, const u32* __restrict__ fsum, const u32* __restrict__ tableG,
             const u32* __restrict__ tableG2, RlcPlan p, u32* __restrict__ W, size_t W_stride, u32* __restrict__ gflags) {
   if (gflags[0]) return;  // (uniform: no barrier is left waiting)
   __shared__ u32 sh[2 * 4 * NL * 64];
-  __shared__ u32 sh_max;
+  __shared__ __attribute__((aligned(16))) u32 tree[64 * kNielsWords];
+  __shared__ u32 sh_max, sh_last;
   S += (size_t)blockIdx.y * S_stride * kNielsWords;
   W += (size_t)blockIdx.y * W_stride * kNielsWords;
   fsum += (size_t)blockIdx.y * 16;
   u32* flags = gflags + 4 + 4 * blockIdx.y;
   const u32 lanes = (u32)p.windows * p.c, g = (lanes + 63) / 64;
-  if (blockIdx.x == 2 * g) {  // (no barrier on this path)
-    if (threadIdx.x) return;
-    Ext fg = ext_identity();
-#pragma unroll 1
-    for (int k = 0; k < p.fixed; k++) {
-      u32 f[8];
-      load_words8(f, reinterpret_cast<const uint8_t*>(fsum), k);
-      fg = fixed_base_accumulate(fg, f, k ? tableG2 : tableG);
-    }
-    store_niels(W + (size_t)lanes * kNielsWords, ext_to_niels(fg));
-    return;
-  }
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const bool weigh = blockIdx.x >= g;
-  const u32 l = (blockIdx.x - (weigh ? g : 0)) * 64 + lane;
-  const bool live = l < lanes;  // the others keep step with the barriers on the identity
-  const Niels s = live ? load_niels(S + (size_t)l * kNielsWords) : niels_identity();
-  int buf = 0;
-  Xp acc = xp_add(sh, buf, wave, lane, xp_identity(), s);
-  if (weigh) {
-    const u32 w = l / p.c, bit = l % p.c;
-    const u32 pos = live ? (w < (u32)p.wpk ? w : w - p.wpk) * p.c + bit : 0u;
-    if (threadIdx.x == 0) sh_max = 0;
-    __syncthreads();
-    atomicMax(&sh_max, pos);
-    __syncthreads();
-    const u32 longest = sh_max;
+  const bool weigh = blockIdx.x >= g && blockIdx.x < 2 * g, fixed_base = blockIdx.x == 2 * g;
+  if (fixed_base) {
+    if (threadIdx.x == 0) {
+      Ext fg = ext_identity();
 #pragma unroll 1
-    for (u32 k = 0; k < longest; k++) {
-      const Xp d = xp_double(sh, buf, wave, lane, acc);
-      const bool take = k < pos;
-      acc.u = fe_select(take, d.u, acc.u), acc.v = fe_select(take, d.v, acc.v);
-      acc.z = fe_select(take, d.z, acc.z), acc.tt = fe_select(take, d.tt, acc.tt);
+      for (int k = 0; k < p.fixed; k++) {
+        u32 f[8];
+        load_words8(f, reinterpret_cast<const uint8_t*>(fsum), k);
+        fg = fixed_base_accumulate(fg, f, k ? tableG2 : tableG);
+      }
+      store_niels(W + (size_t)lanes * kNielsWords, ext_to_niels(fg));
     }
-    if (wave == 0 && live) {
-      Niels n;
-      n.vpu = fe_carry(fe_add(acc.v, acc.u));
-      n.vmu = fe_sub2(acc.v, acc.u);
-      n.z = acc.z;
-      n.t2d = fe_mul(acc.tt, fe_const(kD2));
-      store_niels(W + (size_t)l * kNielsWords, n);
+  } else {
+    const u32 l = (blockIdx.x - (weigh ? g : 0)) * 64 + lane;
+    const bool live = l < lanes;  // the others keep step with the barriers on the identity
+    const Niels s = live ? load_niels(S + (size_t)l * kNielsWords) : niels_identity();
+    int buf = 0;
+    Xp acc = xp_add(sh, buf, wave, lane, xp_identity(), s);
+    if (weigh) {
+      const u32 w = l / p.c, bit = l % p.c;
+      const u32 pos = live ? (w < (u32)p.wpk ? w : w - p.wpk) * p.c + bit : 0u;
+      if (threadIdx.x == 0) sh_max = 0;
+      __syncthreads();
+      atomicMax(&sh_max, pos);
+      __syncthreads();
+      const u32 longest = sh_max;
+#pragma unroll 1
+      for (u32 k = 0; k < longest; k++) {
+        const Xp d = xp_double(sh, buf, wave, lane, acc);
+        const bool take = k < pos;
+        acc.u = fe_select(take, d.u, acc.u), acc.v = fe_select(take, d.v, acc.v);
+        acc.z = fe_select(take, d.z, acc.z), acc.tt = fe_select(take, d.tt, acc.tt);
+      }
+      if (wave == 0 && live) {
+        Niels n;
+        n.vpu = fe_carry(fe_add(acc.v, acc.u));
+        n.vmu = fe_sub2(acc.v, acc.u);
+        n.z = acc.z;
+        n.t2d = fe_mul(acc.tt, fe_const(kD2));
+        store_niels(W + (size_t)l * kNielsWords, n);
+      }
+    } else {
+      const Niels sn = niels_neg(s);
+#pragma unroll 1
+      for (int k = 251; k >= 0; k--) {  // digit 252 is the +1 acc starts from
+        acc = xp_double(sh, buf, wave, lane, acc);
+        const u32 pb = (kRNafPos[k >> 5] >> (k & 31)) & 1u, nb = (kRNafNeg[k >> 5] >> (k & 31)) & 1u;
+        if (pb) acc = xp_add(sh, buf, wave, lane, acc, s);   // (uniform: the digits are constants)
+        if (nb) acc = xp_add(sh, buf, wave, lane, acc, sn);
+      }
+      if (wave == 0 && live) {
+        const bool identity = (bool)((int)fe_equal(acc.u, fe_zero()) & (int)fe_equal(acc.v, acc.z));
+        if (!identity) atomicOr(&flags[0], kRlcTorsion);
+      }
     }
-    return;
   }
-  const Niels sn = niels_neg(s);
-#pragma unroll 1
-  for (int k = 251; k >= 0; k--) {  // digit 252 is the +1 acc starts from
-    acc = xp_double(sh, buf, wave, lane, acc);
-    const u32 pb = (kRNafPos[k >> 5] >> (k & 31)) & 1u, nb = (kRNafNeg[k >> 5] >> (k & 31)) & 1u;
-    if (pb) acc = xp_add(sh, buf, wave, lane, acc, s);   // (uniform: the digits are constants)
-    if (nb) acc = xp_add(sh, buf, wave, lane, acc, sn);
-  }
-  if (wave == 0 && live) {
-    const bool identity = (bool)((int)fe_equal(acc.u, fe_zero()) & (int)fe_equal(acc.v, acc.z));
-    if (!identity) atomicOr(&flags[0], kRlcTorsion);
-  }
-}
-
-// sum of the windows * c weighted subset sums and of (sum f_i) * G == O ?  One wave: a strided pass,
-// then a tree through LDS.
-__global__ void __launch_bounds__(64)
-k_rlc_final(const u32* __restrict__ W, size_t W_stride, RlcPlan p, u32* __restrict__ gflags) {
-  if (gflags[0]) return;
-  __shared__ __attribute__((aligned(16))) u32 sh[64 * kNielsWords];
-  W += (size_t)blockIdx.y * W_stride * kNielsWords;
-  u32* flags = gflags + 4 + 4 * blockIdx.y;
-  const u32 count = (u32)p.windows * p.c + 1u, t = threadIdx.x;
-  Ext acc = ext_identity();
-#pragma unroll 1
-  for (u32 k = t; k < count; k += 64) acc = ext_add_niels(acc, load_niels(W + (size_t)k * kNielsWords));
-#pragma unroll 1
-  for (u32 step = 32; step > 0; step >>= 1) {
-    if (t >= step && t < 2 * step) store_niels(sh + t * kNielsWords, ext_to_niels(acc));
+  if (weigh || fixed_base) {
+    // this workgroup's W are written: the last producer adds them all up
+    __threadfence();
     __syncthreads();
-    if (t < step) acc = ext_add_niels(acc, load_niels(sh + (t + step) * kNielsWords));
+    if (threadIdx.x == 0) sh_last = atomicAdd(&flags[2], 1u) == g ? 1u : 0u;
     __syncthreads();
+    if (sh_last) {  // (uniform)
+      __threadfence();
+      const bool identity = xp_sum_is_identity(W, lanes + 1u, sh, tree, wave, lane);
+      if (threadIdx.x == 0 && !identity) atomicOr(&flags[0], kRlcSum);
+    }
   }
-  if (t == 0) {
-    if (!ext_is_identity(acc)) atomicOr(&flags[0], kRlcSum);
-    flags[1] = 1;  // the chain of kernels ran to its end
+  // the last workgroup to get here marks the chain of kernels complete (flags[0] is final by then: every
+  // workgroup's atomics on it come before its own count)
+  __threadfence();
+  __syncthreads();
+  if (threadIdx.x == 0 && atomicAdd(&flags[3], 1u) == 2 * g) {
+    __threadfence();
+    flags[1] = 1;
   }
 }
 
@@ -894,23 +955,21 @@ hipError_t launch_rlc_finish(const RlcPlan& p, const RlcBuffers& b, const uint32
                              bool merged, hipStream_t s) {
   const unsigned G = p.groups;
   if (merged) hipLaunchKernelGGL(k_rlc_merge, dim3(grid_for(p.buckets, 64), G), dim3(64), 0, s, p, b);
-  if (p.fixed) {
-    hipLaunchKernelGGL(k_rlc_fsum, dim3(kRlcFsumBlocks, p.fixed, G), dim3(256), 0, s, p, b, 0);
-    hipLaunchKernelGGL(k_rlc_fsum, dim3(1, p.fixed, G), dim3(256), 0, s, p, b, 1);
-  }
   const unsigned side = 1u << p.half;
-  hipLaunchKernelGGL(k_rlc_sum<0>, dim3(grid_for((size_t)p.windows * 2 * side * p.nseg, 64), G), dim3(64), 0, s, b.buckets,
-                     b.bucket_stride, p, b.tmp[0], b.tmp_stride[0], b.flags);
-  hipLaunchKernelGGL(k_rlc_sum<1>, dim3(grid_for((size_t)p.windows * 2 * side, 64), G), dim3(64), 0, s, b.tmp[0],
-                     b.tmp_stride[0], p, b.tmp[1], b.tmp_stride[1], b.flags);
-  hipLaunchKernelGGL(k_rlc_sum<2>, dim3(grid_for((size_t)p.windows * 2 * p.half * p.nseg2, 64), G), dim3(64), 0, s, b.tmp[1],
-                     b.tmp_stride[1], p, b.tmp[0], b.tmp_stride[0], b.flags);
-  hipLaunchKernelGGL(k_rlc_sum<3>, dim3(grid_for((size_t)p.windows * 2 * p.half, 64), G), dim3(64), 0, s, b.tmp[0],
-                     b.tmp_stride[0], p, b.tmp[1], b.tmp_stride[1], b.flags);
+  // outputs x lanes per output (k_rlc_sum), + the workgroups that sum the fixed-base scalars beside them
+  const unsigned g0 = grid_for((size_t)p.windows * 2 * side * p.nseg, 64);
+  const unsigned g1 = grid_for((size_t)p.windows * 2 * side * p.nseg, 64);
+  const unsigned g2 = grid_for((size_t)p.windows * 2 * p.half * p.nseg2 * (side / 2 / p.nseg2), 64);
+  const unsigned g3 = grid_for((size_t)p.windows * 2 * p.half * p.nseg2, 64);
+  hipLaunchKernelGGL(k_rlc_sum<0>, dim3(g0 + kRlcFsumBlocks * p.fixed, G), dim3(64), 0, s, b.buckets, b.bucket_stride, p,
+                     b.tmp[0], b.tmp_stride[0], b, g0);
+  hipLaunchKernelGGL(k_rlc_sum<1>, dim3(g1 + p.fixed, G), dim3(64), 0, s, b.tmp[0], b.tmp_stride[0], p, b.tmp[1],
+                     b.tmp_stride[1], b, g1);
+  hipLaunchKernelGGL(k_rlc_sum<2>, dim3(g2, G), dim3(64), 0, s, b.tmp[1], b.tmp_stride[1], p, b.tmp[0], b.tmp_stride[0], b, g2);
+  hipLaunchKernelGGL(k_rlc_sum<3>, dim3(g3, G), dim3(64), 0, s, b.tmp[0], b.tmp_stride[0], p, b.tmp[1], b.tmp_stride[1], b, g3);
   const unsigned lanes = (unsigned)p.windows * p.c, g = (lanes + 63) / 64;
   hipLaunchKernelGGL(k_rlc_scale, dim3(2 * g + 1, G), dim3(256), 0, s, b.tmp[1], b.tmp_stride[1], b.fsum, tableG, tableG2, p,
                      b.tmp[0], b.tmp_stride[0], b.flags);
-  hipLaunchKernelGGL(k_rlc_final, dim3(1, G), dim3(64), 0, s, b.tmp[0], b.tmp_stride[0], p, b.flags);
   return hipGetLastError();
 }
 
