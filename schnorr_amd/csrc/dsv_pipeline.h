@@ -72,12 +72,14 @@ struct NoPrep {};
 //     chunk's first sub-batch (the other lane waits for its event), results in the slot's own
 //     scratch (prep_item_bytes per item).  Per SUB-BATCH these kernels would be 128 waves each in
 //     front of every hash: 16 low-occupancy phases per 2^20 items instead of 4.
+//   heavy: the scheme does about twice a single signature's device work per item (double, var-generator):
+//     the ramp of a call that finds the GPU idle then uses larger chunks (host_sync.h: plan_chunks)
 //   part(staged, offset, count, dok, ws, extra, stream): one sub-batch; `extra`: scratch of
 //     extra_item_bytes per item behind the lane's verify workspace (the wire path decompresses per
 //     sub-batch: full-occupancy kernels, no reason to serialise a chunk's worth on one lane).
 template <size_t NIN, class Prep, class Part>
 int run_pipelined(Context& ctx, const HostIn (&ins)[NIN], uint8_t* ok, size_t n, size_t prep_item_bytes,
-                  size_t extra_item_bytes, Prep prep, Part part) {
+                  size_t extra_item_bytes, Prep prep, Part part, bool heavy = false) {
   constexpr bool has_prep = !std::is_same<Prep, NoPrep>::value;
   const bool small = n <= kPipeSmallCall;  // transfer, kernels and verdicts on ONE stream, a work area of its own
   TurnTicket turn(ctx.pipe_sync);          // (on an error path its destructor still passes the turn on, in order)
@@ -89,7 +91,7 @@ int run_pipelined(Context& ctx, const HostIn (&ins)[NIN], uint8_t* ok, size_t n,
   // nobody else in flight: the GPU is idle, so start small and grow; behind another call (it holds its
   // pipe until its last verdicts are out): full chunks at once
   const size_t part_cap = kSplitItems;
-  const std::vector<size_t> chunks = plan_chunks(ctx.plan, n, small || lease.alone, part_cap);
+  const std::vector<size_t> chunks = plan_chunks(ctx.plan, n, small || lease.alone, part_cap, heavy);
   const size_t nchunks = chunks.size();
   size_t chunk = 0;  // the largest chunk: slot capacity
   for (size_t c : chunks) chunk = c > chunk ? c : chunk;
@@ -276,6 +278,8 @@ int run_pipelined(Context& ctx, const HostIn (&ins)[NIN], uint8_t* ok, size_t n,
     t_chunk_first = h.first;
     const double t2 = now();
     uint8_t* dev = slot.stage;
+    // (r06 tried the verify kernels writing their verdicts straight into the slot's pinned host block — no copy,
+    //  one stream hop less: equal on every scheme and on the 1024-item call, same box, alternating runs)
     uint8_t* dok = dev + h.ok_off;
     std::lock_guard<std::mutex> enq(ctx.enq_mu);
     hipStream_t s_out = small ? ctx.pipe_small : ctx.pipe_out;

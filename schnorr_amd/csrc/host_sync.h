@@ -268,7 +268,8 @@ struct PlanParams {
 //     and whole chunks cost fewer launches (two in flight: 14.2 against 14.9 ms per 2^20 with 2^16).
 // A remainder of at most a quarter chunk (or half a sub-batch) is merged into the last chunk instead of
 // trailing behind it as a part of its own on ONE lane.
-inline std::vector<size_t> plan_chunks(const PlanParams& p, size_t n, bool ramp, size_t unit = kSplitItems) {
+inline std::vector<size_t> plan_chunks(const PlanParams& p, size_t n, bool ramp, size_t unit = kSplitItems,
+                                       bool heavy = false) {
   std::vector<size_t> out;
   if (n <= kPipeSmallCall) {  // one small call: a single chunk
     out.push_back(n);
@@ -283,6 +284,13 @@ inline std::vector<size_t> plan_chunks(const PlanParams& p, size_t n, bool ramp,
     } else if (ramp && p.growth > 0) {  // DSV_PIPE_GROWTH: geometric from the first chunk
       want = align_up((size_t)want_f, 4096);
       want_f *= p.growth;
+    } else if (ramp && heavy) {
+      // double / var-generator items: two chunks of one sub-batch, then chunks of two.  Their kernels are
+      // latency-bound below a sub-batch (k_verify_var takes 1.2 ms for 2^15 items and 1.4 ms for 2^16), so
+      // the small first chunks that pay for single signatures only add launches here.  r06, same box, one-shot
+      // from typed objects: var-generator 2^18 items 7.01 -> 6.23 ms (0.69 -> 0.78 x the device-resident rate),
+      // double 2^20 items 28.98 -> 27.88 ms (0.835 -> 0.868 x); single signatures: equal or worse (15.4 -> 15.9)
+      want = c < 2 ? unit : 2 * unit;
     } else if (ramp) {
       // (chunks of TWO sub-batches, one per lane at a time, from a first chunk of 2 x 2^15: 17.3 against
       //  15.8 ms per 2^20 one-shot, same box — the staging latency of the larger chunks outweighs it)

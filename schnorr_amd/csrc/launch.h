@@ -33,6 +33,9 @@ constexpr int kWavesVerify = 2, kWavesHash = 2;               // resident waves 
 // ---- small batches: eight lanes per signature (k_quad.hip) ---------------------------------
 constexpr int kQuadBlock = 256;              // 32 signatures per workgroup
 constexpr size_t kQuadMaxItems = (size_t)1 << 14;
+// the var-generator scheme's sixteen-lanes-per-signature kernel (k_vargen.hip: k_verify_var_hex): launches of
+// at most this many items (2^13 items are 2048 waves: one per SIMD and a half)
+constexpr size_t kVarHexMaxItems = (size_t)1 << 13;
 
 // ---- mixed-batch split (k_misc.hip) ---------------------------------------------------------
 constexpr int kSplitThreads = 256;

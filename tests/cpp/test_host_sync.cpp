@@ -143,8 +143,9 @@ static void plans() {
       if (p.first_chunk > p.chunk) p.first_chunk = p.chunk;
     }
     const size_t n = 1 + rng() % (iter % 3 ? ((size_t)1 << 18) : ((size_t)1 << 23));
-    for (int ramp = 0; ramp < 2; ramp++) {
-      const std::vector<size_t> chunks = plan_chunks(p, n, ramp != 0);
+    for (int ramp = 0; ramp < 4; ramp++) {  // (2, 3: the plan of a heavy scheme — double, var-generator)
+      const bool heavy = ramp >= 2;
+      const std::vector<size_t> chunks = plan_chunks(p, n, (ramp & 1) != 0, kSplitItems, heavy);
       size_t sum = 0;
       for (size_t c : chunks) {
         CHECK(c > 0 && (n <= kPipeSmallCall || c <= p.chunk + p.chunk / 4 + kSplitItems / 2));
@@ -160,9 +161,12 @@ static void plans() {
       }
       CHECK(sum == n);
       if (n <= kPipeSmallCall) CHECK(chunks.size() == 1);
-      if (!ramp && n > kPipeSmallCall)  // behind another call: full chunks from the start
+      if (!(ramp & 1) && n > kPipeSmallCall)  // behind another call: full chunks from the start
         for (size_t k = 0; k + 1 < chunks.size(); k++) CHECK(chunks[k] == p.chunk);
-      if (ramp && n > 4 * kSplitItems && !p.plan_len) CHECK(chunks[0] == std::min(p.first_chunk, kSplitItems) && chunks[1] == chunks[0]);
+      if ((ramp & 1) && !heavy && n > 4 * kSplitItems && !p.plan_len)
+        CHECK(chunks[0] == std::min(p.first_chunk, kSplitItems) && chunks[1] == chunks[0]);
+      if ((ramp & 1) && heavy && n > 6 * kSplitItems && !p.plan_len)
+        CHECK(chunks[0] == kSplitItems && chunks[1] == kSplitItems && chunks[2] == std::min(2 * kSplitItems, p.chunk));
     }
   }
 }
