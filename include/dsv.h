@@ -95,7 +95,18 @@ int dsv_shutdown(void);               /* every initialised device */
 int dsv_shutdown_device(int device);
 int dsv_set_device(int device);       /* device of THIS thread's host entry points (must be initialised) */
 int dsv_get_device(void);             /* ... the current choice; -1 before any dsv_init */
-int dsv_initialized_devices(int *out, int cap); /* returns how many; fills out[0 .. min(cap, count)) */
+int dsv_initialized_devices(int *out, int cap);
+/* NUMA placement (an 8-GPU host has two sockets).  dsv_init reads the device's PCI address and, from
+ * /sys/bus/pci/devices/<address>/numa_node and /sys/devices/system/node/node<N>/cpulist, the cpus of the
+ * socket its PCIe root hangs off; the copy threads of that device's host calls and the library's own
+ * per-device worker threads (*_multi shards beyond the first, the drivers of submitted jobs) are bound to
+ * them (threads of the application never are).  Pinned staging needs nothing: hipHostMalloc allocates on
+ * the node nearest the current device.  DSV_NUMA=0 in the environment switches the binding off;
+ * DSV_SYSFS_ROOT points the lookup at another tree.  dsv_device_numa: *node (-1: unknown), up to `cap`
+ * cpus and the PCI address (bdf: NULL or >= 32 bytes) of an initialised device; returns the cpu count or a
+ * negative dsv_status.  dsv_debug_numa_lookup: the lookup alone, no device needed (tests). */
+int dsv_device_numa(int device, int *node, int *cpus, int cap, char *bdf);
+int dsv_debug_numa_lookup(const char *sysfs_root, const char *bdf, int *node, int *cpus, int cap); /* returns how many; fills out[0 .. min(cap, count)) */
 const char *dsv_version(void);
 const char *dsv_last_error(void);
 int dsv_device_count(void);

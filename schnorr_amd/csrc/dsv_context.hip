@@ -376,6 +376,23 @@ int dsv_init(int device) {
     g_err = why;
     return rc;
   }
+  {
+    // NUMA placement of this device's host-side threads (DSV_NUMA=0: none; DSV_SYSFS_ROOT: another sysfs tree)
+    char bdf[64] = {0};
+    ctx.pci_bdf.clear();
+    ctx.numa_node = -1;
+    ctx.numa_cpus.clear();
+    if (hipDeviceGetPCIBusId(bdf, (int)sizeof bdf, device) == hipSuccess) ctx.pci_bdf = bdf;
+    else (void)hipGetLastError();
+    const char* off = getenv("DSV_NUMA");
+    if (!(off && strcmp(off, "0") == 0) && !ctx.pci_bdf.empty()) {
+      const char* root = getenv("DSV_SYSFS_ROOT");
+      const std::string sys = root && *root ? root : "/sys";
+      ctx.numa_node = numa_node_of_pci(sys, ctx.pci_bdf);
+      ctx.numa_cpus = cpus_of_numa_node(sys, ctx.numa_node);
+    }
+    for (auto& pipe : ctx.pipes) pipe.copiers.set_affinity(ctx.numa_cpus);
+  }
   const char* split = getenv("DSV_SPLIT");
   ctx.split = !(split && strcmp(split, "0") == 0);
   const char* quad = getenv("DSV_QUAD");
@@ -501,6 +518,31 @@ int dsv_set_device(int device) {
   return DSV_OK;
 }
 int dsv_get_device(void) { return t_device >= 0 ? t_device : g_primary.load(); }
+// where a device's host-side work is placed: *node = NUMA node of its PCIe root (-1: unknown / DSV_NUMA=0),
+// cpus[0 .. min(count, cap)) = that node's cpus; bdf (may be null): its PCI address, at most 31 characters.
+// Returns the cpu count or a negative dsv_status.
+int dsv_device_numa(int device, int* node, int* cpus, int cap, char* bdf) {
+  if (device < 0 || device >= kMaxDevices || !g_ctx[device].ready.load(std::memory_order_acquire))
+    return fail(DSV_ERR_NOT_INITIALIZED, "device %d is not initialised", device);
+  const Context& ctx = g_ctx[device];
+  if (node) *node = ctx.numa_node;
+  for (int k = 0; cpus && k < cap && k < (int)ctx.numa_cpus.size(); k++) cpus[k] = ctx.numa_cpus[k];
+  if (bdf) {
+    strncpy(bdf, ctx.pci_bdf.c_str(), 31);
+    bdf[31] = 0;
+  }
+  return (int)ctx.numa_cpus.size();
+}
+// the lookup itself, without a device (tests: a fake sysfs tree): node and cpus of the PCI device `bdf`
+// under `sysfs_root`; returns the cpu count
+int dsv_debug_numa_lookup(const char* sysfs_root, const char* bdf, int* node, int* cpus, int cap) {
+  if (!sysfs_root || !bdf) return fail(DSV_ERR_INVALID_ARGUMENT, "null pointer");
+  const int nd = numa_node_of_pci(sysfs_root, bdf);
+  const std::vector<int> list = cpus_of_numa_node(sysfs_root, nd);
+  if (node) *node = nd;
+  for (int k = 0; cpus && k < cap && k < (int)list.size(); k++) cpus[k] = list[k];
+  return (int)list.size();
+}
 int dsv_initialized_devices(int* out, int cap) {
   int n = 0;
   for (int d = 0; d < kMaxDevices; d++)

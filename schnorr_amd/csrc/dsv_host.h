@@ -99,6 +99,12 @@ struct Pipe {
 struct Context {
   std::atomic<bool> ready{false};
   int device = -1;
+  // where the device hangs off the host (r06): PCI address, NUMA node of its root (-1: unknown or DSV_NUMA=0)
+  // and that node's cpus — the copy threads of this device's pipes and the library's own per-device worker
+  // threads run there (host_sync.h: "NUMA placement")
+  std::string pci_bdf;
+  int numa_node = -1;
+  std::vector<int> numa_cpus;
   bool split = true;         // DSV_SPLIT=0: one stream, whole batch per launch
   bool fuse_double = true;   // DSV_DOUBLE_FUSED=0: two single-equation launches per double batch (r01; A/B)
   bool quad = true;          // DSV_QUAD=0: batches of <= 2^14 items also take the one-lane-per-signature kernel

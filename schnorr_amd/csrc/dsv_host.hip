@@ -468,6 +468,10 @@ int submit_mont_cols(int kind, const dsv_column* cols, size_t n, uint8_t* ok, ds
         j->started = true;
       }
       j->cv.notify_all();
+      {  // the driver gathers the first shard itself: next to the device that takes it
+        const int d = t_device >= 0 ? t_device : g_primary.load(std::memory_order_acquire);
+        if (d >= 0 && d < kMaxDevices) (void)pin_this_thread(g_ctx[d].numa_cpus);
+      }
       j->rc = verify_mont_cols(j->kind, j->cols, j->n, j->ok, true);
       if (j->rc) j->err = g_err;  // the text lives in this thread's thread-local
       j->finished.store(true, std::memory_order_release);

@@ -420,6 +420,7 @@ int run_multi(size_t n, Part part) {
   std::string msg[kMaxDevices];
   std::vector<std::thread> th;
   auto work = [&](int k) {
+    if (k) (void)pin_this_thread(devs[k]->numa_cpus);  // (the library's own threads; shard 0 runs on the caller's)
     const size_t lo = n * (size_t)k / (size_t)nd, hi = n * (size_t)(k + 1) / (size_t)nd;
     rc[k] = hi > lo ? part(*devs[k], lo, hi - lo) : (int)DSV_OK;
     if (rc[k]) msg[k] = g_err;  // the error text lives in the worker's thread-local

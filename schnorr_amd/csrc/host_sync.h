@@ -5,6 +5,8 @@
 // not available on this pool, and this is exactly the code where a data race would hide.
 #pragma once
 #include <immintrin.h>
+#include <pthread.h>
+#include <sched.h>
 
 #include <atomic>
 #include <condition_variable>
@@ -14,6 +16,7 @@
 #include <cstring>
 #include <functional>
 #include <mutex>
+#include <string>
 #include <thread>
 #include <vector>
 
@@ -24,6 +27,75 @@ constexpr size_t kSplitItems = (size_t)1 << 16;      // one sub-batch: 1024 wave
 constexpr size_t kPipeSmallCall = (size_t)1 << 16;   // up to here a call is ONE chunk on one stream
 
 inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+// ---- NUMA placement of a device's host-side work (r06) --------------------------------------------
+// An 8-GPU host has two sockets; a GPU's copy threads should run — and its pinned staging lie — on the
+// socket its PCIe root hangs off, or every gathered byte crosses the socket interconnect once more on
+// its way to the DMA engine.  The mapping comes from sysfs: bus/pci/devices/<bdf>/numa_node and
+// devices/system/node/node<N>/cpulist under `root` (normally /sys; tests point it at a fake tree).
+// Plain file reads, no libnuma.  Pinned staging needs no code here: hipHostMalloc already allocates on
+// the node nearest the current device unless hipHostMallocNumaUser is passed.
+inline bool read_small_file(const std::string& path, std::string& out) {
+  FILE* f = fopen(path.c_str(), "r");
+  if (!f) return false;
+  char buf[4096];
+  const size_t got = fread(buf, 1, sizeof buf - 1, f);
+  fclose(f);
+  buf[got] = 0;
+  out = buf;
+  return true;
+}
+// NUMA node of a PCI device ("0000:c1:00.0"); -1: unknown (no such file, or the kernel says -1)
+inline int numa_node_of_pci(const std::string& root, const std::string& bdf) {
+  std::string lower = bdf, text;
+  for (auto& ch : lower) ch = (char)tolower((unsigned char)ch);
+  if (!read_small_file(root + "/bus/pci/devices/" + lower + "/numa_node", text)) return -1;
+  char* end = nullptr;
+  const long v = strtol(text.c_str(), &end, 10);
+  return end == text.c_str() || v < 0 ? -1 : (int)v;
+}
+// "0-15,64-79" -> cpu numbers (empty on any parse error: the caller then pins nothing)
+inline std::vector<int> parse_cpulist(const std::string& text) {
+  std::vector<int> cpus;
+  const char* p = text.c_str();
+  while (*p && *p != '\n') {
+    char* end = nullptr;
+    const long lo = strtol(p, &end, 10);
+    if (end == p || lo < 0) return {};
+    long hi = lo;
+    p = end;
+    if (*p == '-') {
+      hi = strtol(p + 1, &end, 10);
+      if (end == p + 1 || hi < lo) return {};
+      p = end;
+    }
+    if (hi - lo > 4096) return {};
+    for (long c = lo; c <= hi; c++) cpus.push_back((int)c);
+    if (*p == ',') p++;
+    else if (*p && *p != '\n') return {};
+  }
+  return cpus;
+}
+inline std::vector<int> cpus_of_numa_node(const std::string& root, int node) {
+  std::string text;
+  if (node < 0 || !read_small_file(root + "/devices/system/node/node" + std::to_string(node) + "/cpulist", text)) return {};
+  return parse_cpulist(text);
+}
+// restrict the CALLING thread to `cpus` (those of them the process may use at all); false: nothing changed
+inline bool pin_this_thread(const std::vector<int>& cpus) {
+  if (cpus.empty()) return false;
+  cpu_set_t allowed, want;
+  if (sched_getaffinity(0, sizeof allowed, &allowed) != 0) return false;
+  CPU_ZERO(&want);
+  int n = 0;
+  for (int c : cpus)
+    if (c >= 0 && c < CPU_SETSIZE && CPU_ISSET(c, &allowed)) {
+      CPU_SET(c, &want);
+      n++;
+    }
+  if (n == 0) return false;  // (a container's cpuset on the other socket: leave the thread where it may run)
+  return pthread_setaffinity_np(pthread_self(), sizeof want, &want) == 0;
+}
 
 // Copy threads of the host path: the caller's (pageable) arrays are gathered into pinned staging
 // by several threads at once, so the DMA engine is fed faster than one memcpy stream can.
@@ -58,6 +130,12 @@ class CopyPool {
       done_.wait(lk, [this] { return pending_.load(std::memory_order_acquire) == 0; });
     job_ = nullptr;  // (under the lock: a worker that does not take part in this job may be reading it)
   }
+  // the workers (not the caller, thread 0 of a job: its placement is the application's) run on these cpus
+  // from their next start on; call before the first run()
+  void set_affinity(const std::vector<int>& cpus) {
+    std::unique_lock<std::mutex> lk(m_);
+    cpus_ = cpus;
+  }
   void stop() {
     {
       std::unique_lock<std::mutex> lk(m_);
@@ -74,6 +152,14 @@ class CopyPool {
   static constexpr int kSpin = 20000;  // ~0.2 - 0.4 ms of pause instructions
   static void cpu_relax() { __builtin_ia32_pause(); }
   void loop(int id) {
+    {
+      std::vector<int> cpus;
+      {
+        std::unique_lock<std::mutex> lk(m_);
+        cpus = cpus_;
+      }
+      (void)pin_this_thread(cpus);
+    }
     uint64_t seen = gen_.load(std::memory_order_acquire) - 1;  // started while a job is being posted: take it
     for (;;) {
       for (int spin = 0; spin < kSpin && gen_.load(std::memory_order_acquire) == seen; spin++) cpu_relax();
@@ -97,6 +183,7 @@ class CopyPool {
     }
   }
   std::vector<std::thread> th_;
+  std::vector<int> cpus_;
   std::mutex m_;
   std::condition_variable go_, done_;
   const std::function<void(int, int)>* job_ = nullptr;

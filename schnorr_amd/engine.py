@@ -46,6 +46,28 @@ def initialized_devices():
     return [buf[i] for i in range(min(n, 16))]
 
 
+def device_numa(device=0):
+    """dsv_device_numa: {"bdf": PCI address, "node": NUMA node of the device's PCIe root (-1: unknown or
+    DSV_NUMA=0), "cpus": that node's cpus} — where the device's copy threads are bound"""
+    cpus = (ctypes.c_int * 1024)()
+    node = ctypes.c_int(-1)
+    bdf = ctypes.create_string_buffer(32)
+    n = _lib.load().dsv_device_numa(ctypes.c_int(device), ctypes.byref(node), cpus, 1024, bdf)
+    if n < 0:
+        _lib.check(n)
+    return {"bdf": bdf.value.decode(), "node": node.value, "cpus": [cpus[i] for i in range(min(n, 1024))]}
+
+
+def numa_lookup(sysfs_root, bdf):
+    """dsv_debug_numa_lookup: (node, cpus) of a PCI device under a sysfs tree; no device needed"""
+    cpus = (ctypes.c_int * 4096)()
+    node = ctypes.c_int(-1)
+    n = _lib.load().dsv_debug_numa_lookup(sysfs_root.encode(), bdf.encode(), ctypes.byref(node), cpus, 4096)
+    if n < 0:
+        _lib.check(n)
+    return node.value, [cpus[i] for i in range(min(n, 4096))]
+
+
 def shutdown(device=None):
     """dsv_shutdown (all devices) or dsv_shutdown_device."""
     if not _initialised:

@@ -202,3 +202,31 @@ def test_mixed_batch_beyond_one_group_per_kind(engine):
     assert not engine.verify_mixed_rlc_dev(*args, ok, ws)
     assert int(ok.sum()) == n - 1 and int(ok[victim]) == 0
     engine.rlc_history(0, 1)
+
+
+@pytest.mark.parametrize("n", [1, 15, 16, 17, 1000, 8192, 8193])
+def test_var_generator_sixteen_lane_kernel(engine, n):
+    """`PublicKeyVarGen::verify` (/root/reference/src/keys/public.rs:401-415) through k_verify_var_hex (launches of
+    at most 2^13 items: sixteen lanes per signature) and, one item beyond, through the one-lane kernel: the
+    oracle's verdicts on the harness's tamper classes, on malformed items and on the identity as key"""
+    base = 700
+    d = _signed(min(n, base), 640 + n % 97, "vargen")
+    if n > base:
+        reps = -(-n // base)
+        d = {k: np.tile(v, (reps, 1))[:n].copy() for k, v in d.items()}
+    if n >= 16:
+        H.tamper(d, period=5)
+        d["u"][3] = 0xFF                         # u >= r
+        d["PK"][7, 31] |= 0x80                   # a coordinate >= q
+        d["Gen"][9, :32] = 0
+        d["Gen"][9, 32:] = 0
+        d["Gen"][9, 32] = 1                      # the identity as generator
+    want = _oracle(d, "vargen")
+    t = [torch.from_numpy(np.ascontiguousarray(d[k])).to(DEV) for k in COLS["vargen"]]
+    ok = torch.full((n,), 7, dtype=torch.uint8, device=DEV)
+    ws = torch.empty(engine.workspace_bytes(n), dtype=torch.uint8, device=DEV)
+    engine.verify_vargen_dev(*t, ok, ws)
+    torch.cuda.synchronize()
+    assert np.array_equal(ok.cpu().numpy(), want)
+    if n >= 16:
+        assert 0 < want.sum() < n

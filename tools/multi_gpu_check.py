@@ -73,6 +73,17 @@ def main():
         times.append(time.perf_counter() - t0)
     step("1. dsv_init on every device", sorted(E.initialized_devices()) == list(range(ngpu)),
          "init ms per device: " + " ".join("%.0f" % (t * 1e3) for t in times))
+    # ---- 1b. where each device's host-side threads run (include/dsv.h: dsv_device_numa)
+    nodes = set()
+    for d in range(ngpu):
+        info = E.device_numa(d)
+        cpus = info["cpus"]
+        span = ("%d cpus %d..%d" % (len(cpus), cpus[0], cpus[-1])) if cpus else "no binding"
+        print("       device %d  pci %s  numa node %d  copy threads: %s" % (d, info["bdf"], info["node"], span), flush=True)
+        nodes.add(info["node"])
+    step("1b. NUMA placement known for every device", -1 not in nodes or os.environ.get("DSV_NUMA") == "0",
+         "nodes in use: %s%s" % (sorted(nodes), " (unknown: the copy threads float; a container that hides /sys/bus/pci)"
+                                 if -1 in nodes else ""))
 
     n = 1 << args.log2_batch
     b = W.gen_single(n, seed=2321, device="cuda:0")
