@@ -298,6 +298,13 @@ pub fn try_verify_batch_var_gen_fast(sigs: &[SignatureVarGen], pks: &[PublicKeyV
 
 /// A batch in flight.  Borrows the slices it was started from (the engine reads the objects in place
 /// until `wait` returns); dropping it unwaited waits.
+///
+/// SOUNDNESS.  The engine's driver thread reads the borrowed objects until the job has been waited for,
+/// and the only thing that makes it wait is `wait()` or `Drop`.  `core::mem::forget(job)` (or a leak
+/// through an `Rc` cycle) ends the borrow without either — safe code could then free the slices under
+/// the engine: the pre-1.0 `thread::scoped` hole.  The functions that hand out a `BatchJob` are therefore
+/// `unsafe fn` (contract: the job is waited for or dropped, never leaked); the safe form of the same
+/// thing is [`batch_scope`], which joins every job before it returns, as `std::thread::scope` does.
 pub struct BatchJob<'a> {
     job: *mut c_void,
     ok: Vec<u8>,
@@ -333,7 +340,12 @@ fn submit<'a>(f: SubmitFn, cols: &[Column], n: usize, soa: Option<Box<dyn core::
 }
 /// Start `verify_batch` and return at once.  Keep two in flight per GPU:
 /// `let a = submit(b0); let b = submit(b1); a.wait(); let c = submit(b2); b.wait(); ...`
-pub fn verify_batch_submit<'a>(sigs: &'a [Signature], pks: &'a [PublicKey], msgs: &'a [BlsScalar])
+///
+/// # Safety
+/// The returned job must be waited for or dropped before `sigs`, `pks` and `msgs` go away; it must never
+/// be leaked (`mem::forget`, an `Rc` cycle): the engine reads the slices in place until then.  Safe
+/// alternative: [`batch_scope`].  (The same holds for the `_double` and `_var_gen` forms.)
+pub unsafe fn verify_batch_submit<'a>(sigs: &'a [Signature], pks: &'a [PublicKey], msgs: &'a [BlsScalar])
     -> Result<BatchJob<'a>, EngineError> {
     assert!(sigs.len() == pks.len() && sigs.len() == msgs.len());
     let n = sigs.len();
@@ -349,7 +361,7 @@ pub fn verify_batch_submit<'a>(sigs: &'a [Signature], pks: &'a [PublicKey], msgs
         submit(dsv_verify_single_mont_cols_submit, &cols, n, Some(soa as Box<dyn core::any::Any>))
     }
 }
-pub fn verify_batch_double_submit<'a>(sigs: &'a [SignatureDouble], pks: &'a [PublicKeyDouble], msgs: &'a [BlsScalar])
+pub unsafe fn verify_batch_double_submit<'a>(sigs: &'a [SignatureDouble], pks: &'a [PublicKeyDouble], msgs: &'a [BlsScalar])
     -> Result<BatchJob<'a>, EngineError> {
     assert!(sigs.len() == pks.len() && sigs.len() == msgs.len());
     let n = sigs.len();
@@ -367,7 +379,7 @@ pub fn verify_batch_double_submit<'a>(sigs: &'a [SignatureDouble], pks: &'a [Pub
         submit(dsv_verify_double_mont_cols_submit, &cols, n, Some(soa as Box<dyn core::any::Any>))
     }
 }
-pub fn verify_batch_var_gen_submit<'a>(sigs: &'a [SignatureVarGen], pks: &'a [PublicKeyVarGen], msgs: &'a [BlsScalar])
+pub unsafe fn verify_batch_var_gen_submit<'a>(sigs: &'a [SignatureVarGen], pks: &'a [PublicKeyVarGen], msgs: &'a [BlsScalar])
     -> Result<BatchJob<'a>, EngineError> {
     assert!(sigs.len() == pks.len() && sigs.len() == msgs.len());
     let n = sigs.len();
@@ -384,6 +396,127 @@ pub fn verify_batch_var_gen_submit<'a>(sigs: &'a [SignatureVarGen], pks: &'a [Pu
         let cols = soa.cols();
         submit(dsv_verify_vargen_mont_cols_submit, &cols, n, Some(soa as Box<dyn core::any::Any>))
     }
+}
+
+
+/// Batches in flight behind a SAFE interface: every job started through the scope is joined before
+/// `batch_scope` returns (also when the closure panics), so leaking a ticket leaks nothing the engine
+/// still uses — the verdict buffers and, on the layout-agnostic path, the dense copies belong to the scope.
+/// ```ignore
+/// let verdicts = batch_scope(|s| {
+///     let a = s.verify_batch(&sigs0, &pks0, &msgs0)?;      // two in flight per GPU
+///     let b = s.verify_batch(&sigs1, &pks1, &msgs1)?;
+///     Ok::<_, EngineError>((s.wait(a)?, s.wait(b)?))
+/// })?;
+/// ```
+pub struct BatchScope<'env> {
+    slots: core::cell::RefCell<Vec<ScopedSlot>>,
+    _env: core::marker::PhantomData<&'env ()>,
+}
+struct ScopedSlot {
+    job: *mut c_void,
+    ok: Box<[u8]>,                          // (its heap block does not move when `slots` grows)
+    _soa: Option<Box<dyn core::any::Any>>,  // the dense copies of the layout-agnostic path, if taken
+}
+/// A ticket for one job of a [`BatchScope`]; redeem it with [`BatchScope::wait`].
+pub struct ScopedJob(usize);
+impl<'env> BatchScope<'env> {
+    fn start(&self, f: SubmitFn, cols: &[Column], n: usize, soa: Option<Box<dyn core::any::Any>>)
+        -> Result<ScopedJob, EngineError> {
+        let mut slot = ScopedSlot { job: core::ptr::null_mut(), ok: vec![0u8; n].into_boxed_slice(), _soa: soa };
+        if n != 0 {
+            init_all()?;
+            check(unsafe { f(cols.as_ptr(), n, slot.ok.as_mut_ptr(), &mut slot.job) })?;
+        }
+        let mut slots = self.slots.borrow_mut();
+        slots.push(slot);
+        Ok(ScopedJob(slots.len() - 1))
+    }
+    /// `verify_batch`, started now; the slices must outlive the scope (`'env`)
+    pub fn verify_batch(&self, sigs: &'env [Signature], pks: &'env [PublicKey], msgs: &'env [BlsScalar])
+        -> Result<ScopedJob, EngineError> {
+        assert!(sigs.len() == pks.len() && sigs.len() == msgs.len());
+        let n = sigs.len();
+        if n == 0 {
+            return self.start(dsv_verify_single_mont_cols_submit, &[], 0, None);
+        }
+        if layout_ok() {
+            let cols = [col(sigs[0].u(), sigs), col(sigs[0].R(), sigs), col(pks[0].as_ref(), pks), col(&msgs[0], msgs)];
+            self.start(dsv_verify_single_mont_cols_submit, &cols, n, None)
+        } else {
+            let soa = Box::new(fallback::Soa::gather(n, |i| sigs[i].u(), |i| [sigs[i].R(), pks[i].as_ref()], |i| &msgs[i]));
+            let cols = soa.cols();
+            self.start(dsv_verify_single_mont_cols_submit, &cols, n, Some(soa as Box<dyn core::any::Any>))
+        }
+    }
+    /// `verify_batch_double`, started now
+    pub fn verify_batch_double(&self, sigs: &'env [SignatureDouble], pks: &'env [PublicKeyDouble], msgs: &'env [BlsScalar])
+        -> Result<ScopedJob, EngineError> {
+        assert!(sigs.len() == pks.len() && sigs.len() == msgs.len());
+        let n = sigs.len();
+        if n == 0 {
+            return self.start(dsv_verify_double_mont_cols_submit, &[], 0, None);
+        }
+        if layout_ok() {
+            let cols = [col(sigs[0].u(), sigs), col(sigs[0].R(), sigs), col(sigs[0].R_prime(), sigs),
+                        col(pks[0].pk(), pks), col(pks[0].pk_prime(), pks), col(&msgs[0], msgs)];
+            self.start(dsv_verify_double_mont_cols_submit, &cols, n, None)
+        } else {
+            let soa = Box::new(fallback::Soa::gather(n, |i| sigs[i].u(),
+                |i| [sigs[i].R(), sigs[i].R_prime(), pks[i].pk(), pks[i].pk_prime()], |i| &msgs[i]));
+            let cols = soa.cols();
+            self.start(dsv_verify_double_mont_cols_submit, &cols, n, Some(soa as Box<dyn core::any::Any>))
+        }
+    }
+    /// `verify_batch_var_gen`, started now
+    pub fn verify_batch_var_gen(&self, sigs: &'env [SignatureVarGen], pks: &'env [PublicKeyVarGen], msgs: &'env [BlsScalar])
+        -> Result<ScopedJob, EngineError> {
+        assert!(sigs.len() == pks.len() && sigs.len() == msgs.len());
+        let n = sigs.len();
+        if n == 0 {
+            return self.start(dsv_verify_vargen_mont_cols_submit, &[], 0, None);
+        }
+        if layout_ok() {
+            let cols = [col(sigs[0].u(), sigs), col(sigs[0].R(), sigs), col(pks[0].public_key(), pks),
+                        col(pks[0].generator(), pks), col(&msgs[0], msgs)];
+            self.start(dsv_verify_vargen_mont_cols_submit, &cols, n, None)
+        } else {
+            let soa = Box::new(fallback::Soa::gather(n, |i| sigs[i].u(),
+                |i| [sigs[i].R(), pks[i].public_key(), pks[i].generator()], |i| &msgs[i]));
+            let cols = soa.cols();
+            self.start(dsv_verify_vargen_mont_cols_submit, &cols, n, Some(soa as Box<dyn core::any::Any>))
+        }
+    }
+    /// Blocks until the job's verdicts are there.
+    pub fn wait(&self, job: ScopedJob) -> Result<Vec<bool>, EngineError> {
+        let handle = {
+            let mut slots = self.slots.borrow_mut();
+            core::mem::replace(&mut slots[job.0].job, core::ptr::null_mut())
+        };
+        if !handle.is_null() {
+            check(unsafe { dsv_job_wait(handle) })?;
+        }
+        // (a null handle: an empty batch — tickets are neither Copy nor Clone, so none is redeemed twice)
+        let slots = self.slots.borrow();
+        Ok(verdicts(slots[job.0].ok.to_vec()))
+    }
+}
+impl<'env> Drop for BatchScope<'env> {
+    fn drop(&mut self) {
+        for slot in self.slots.get_mut().iter_mut() {
+            if !slot.job.is_null() {
+                unsafe { dsv_job_wait(slot.job) };  // joins the engine's driver thread: nothing reads 'env data after this
+                slot.job = core::ptr::null_mut();
+            }
+        }
+    }
+}
+/// Runs `f` with a scope for batches in flight and joins every job it started before returning — on the
+/// normal path and on unwind (the scope is a local of this function: `f` only ever sees a reference to it).
+pub fn batch_scope<'env, T>(f: impl FnOnce(&BatchScope<'env>) -> T) -> T {
+    let scope = BatchScope { slots: core::cell::RefCell::new(Vec::new()), _env: core::marker::PhantomData };
+    f(&scope)
+    // (`scope` is dropped here, or during unwinding: Drop waits for whatever is still in flight)
 }
 
 /// Layout-agnostic path: limb COPIES through the public accessors (`get_u().0`: a field read, no
@@ -480,9 +613,23 @@ mod tests {
         pks.swap(3, 4); // two wrong keys
         let gpu = verify_batch(&sigs, &pks, &msgs);
         assert_eq!(try_verify_batch(&sigs, &pks, &msgs).expect("engine"), gpu);
-        // two batches in flight give the same verdicts
-        let (a, b) = (verify_batch_submit(&sigs, &pks, &msgs).expect("engine"),
-                      verify_batch_submit(&sigs, &pks, &msgs).expect("engine"));
+        // two batches in flight give the same verdicts: through the scope ...
+        let (va, vb) = batch_scope(|s| {
+            let a = s.verify_batch(&sigs, &pks, &msgs).expect("engine");
+            let b = s.verify_batch(&sigs, &pks, &msgs).expect("engine");
+            (s.wait(a).expect("engine"), s.wait(b).expect("engine"))
+        });
+        assert!(va == gpu && vb == gpu);
+        // ... a ticket that is never redeemed is still joined when the scope ends
+        batch_scope(|s| {
+            let t = s.verify_batch(&sigs, &pks, &msgs).expect("engine");
+            core::mem::forget(t);
+        });
+        // ... and through the unscoped jobs (unsafe: the caller promises to wait for them)
+        let (a, b) = unsafe {
+            (verify_batch_submit(&sigs, &pks, &msgs).expect("engine"),
+             verify_batch_submit(&sigs, &pks, &msgs).expect("engine"))
+        };
         assert_eq!(a.wait().expect("engine"), gpu);
         assert_eq!(b.wait().expect("engine"), gpu);
         for i in 0..sigs.len() {
@@ -492,10 +639,12 @@ mod tests {
         // the fast accept: same verdicts, decided item by item (two wrong keys) ...
         let (fast, accepted) = verify_batch_fast(&sigs, &pks, &msgs);
         assert!(fast == gpu && !accepted);
-        // ... and by the aggregate once the keys are back in place
+        // ... also once the keys are back in place: 256 items are below the size from which an aggregate pays
+        // (schnorr_amd/csrc/rlc.h: kRlcMinAuto = 2^17; smaller batches take the per-signature kernels and
+        // report accepted = false) — the verdicts are what counts
         pks.swap(3, 4);
         let (fast, accepted) = verify_batch_fast(&sigs, &pks, &msgs);
-        assert!(accepted && fast.iter().all(|&b| b));
+        assert!(!accepted && fast.iter().all(|&b| b));
         pks.swap(3, 4);
         // the layout-agnostic path gives the same verdicts
         let soa = fallback::Soa::gather(sigs.len(), |i| sigs[i].u(),

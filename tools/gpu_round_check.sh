@@ -9,6 +9,14 @@ mkdir -p gpurun_out
 echo "[final] tests"
 timeout -k 10 900 python3 -m pytest tests -m gpu -x -q --timeout 300 > gpurun_out/${R}_round_tests.log 2>&1 || { tail -15 gpurun_out/${R}_round_tests.log; exit 1; }
 tail -3 gpurun_out/${R}_round_tests.log
+# the Rust shim's own tests, where a toolchain and the crates exist (they were never run)
+if command -v cargo >/dev/null 2>&1; then
+  echo "[final] cargo test (rust/dusk-schnorr-gpu)"
+  (cd rust/dusk-schnorr-gpu && timeout -k 10 900 cargo test --release --offline) > gpurun_out/${R}_cargo_test.log 2>&1 \
+    && tail -3 gpurun_out/${R}_cargo_test.log || { echo "[final] cargo test FAILED (or no registry)"; tail -5 gpurun_out/${R}_cargo_test.log; }
+else
+  echo "[final] no cargo on this box: the Rust shim stays uncompiled (DESIGN.md, parity status)"
+fi
 echo "[final] profiles"
 rm -rf gpurun_out/prof_round
 bash tools/profile_bench.sh gpurun_out/prof_round 2>&1 | grep "profile_bench" || exit 1
