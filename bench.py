@@ -30,7 +30,7 @@ checked after the timed region, and at N = 1 samples are re-verified by the CPU 
 Prints ONE JSON line on rank 0.  `roofline` is SURVEY.md §8(d)'s figure for the dominant kernel
 k_verify_fixed_half: v_mad_u64_u32 lane-operations per verdict x verdicts / the kernel's launch
 duration (HIP events, one whole-batch launch on the current stream, right after the timed region),
-against the measured MAD issue peak.  DESIGN.md §4 has the instruction model.
+against the measured MAD issue peak.  DESIGN.md §3 (in full: HISTORY.md §4) has the instruction model.
 Riding along at N = 1: `double` (configs[2]), `vargen` (configs[3]), `mixed` (configs[4] shape),
 `sign`, `ext` (projective inputs, to_hash_inputs on the device), `wire` (serialized records,
 decompression on the device), `host_path` / `host_path_ext` / `wire.host` (PCIe-inclusive, never the
@@ -54,7 +54,7 @@ sys.path.insert(0, ROOT)
 
 METRIC = "Schnorr verifies/sec (single + double) at batch=2^20; 1/2/4/8 MI355X"  # BASELINE.json
 
-# ---- work model (tools/isa_hist.py -> profiles/r02/isa_hist.json) ---------------
+# ---- work model (HISTORY.md §4; tools/isa_hist.py -> profiles/r02/isa_hist.json) ---------------
 # v_mad_u64_u32 and total VALU instructions of one field operation, as hipcc emits them
 MUL_MAD, MUL_ALL = 153, 189            # 81 + 72 MADs; + 36 digit / shift instructions
 SQR_MAD, SQR_ALL = 117, 161            # 45 + 72 MADs; + 8 doublings + 36

@@ -30,7 +30,7 @@
 //
 // HBM traffic per signature is 193 B (single) / 321 B (double) / 257 B (vargen) in, 1 B out, plus
 // 33 B of c/valid between the two kernels and the window-table workspace: the path is VALU-bound
-// by orders of magnitude, not HBM-bound (DESIGN.md §4).
+// by orders of magnitude, not HBM-bound (DESIGN.md §3).
 #define DSV_HOST_TABLES 1
 #include "dsv_constants.h"
 #include "dsv_host.h"

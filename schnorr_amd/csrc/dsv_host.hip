@@ -41,13 +41,13 @@ int verify_double_host(Context& ctx, const uint8_t* u, const uint8_t* R_uv, cons
                        uint8_t* ok) {
   const HostIn ins[6] = {{u, 32}, {R_uv, 64}, {Rp_uv, 64}, {PK_uv, 64}, {PKp_uv, 64}, {m, 32}};
   Context* cp = &ctx;
-  return run_pipelined(ctx, ins, ok, n, 0, 0, NoPrep{}, DSV_PART(1), true);
+  return run_pipelined(ctx, ins, ok, n, 0, 0, NoPrep{}, DSV_PART(1), kPipeHeavy);
 }
 int verify_vargen_host(Context& ctx, const uint8_t* u, const uint8_t* R_uv, const uint8_t* PK_uv,
                        const uint8_t* Gen_uv, const uint8_t* m, size_t n, uint8_t* ok) {
   const HostIn ins[5] = {{u, 32}, {R_uv, 64}, {PK_uv, 64}, {Gen_uv, 64}, {m, 32}};
   Context* cp = &ctx;
-  return run_pipelined(ctx, ins, ok, n, 0, 0, NoPrep{}, DSV_PART(2), true);
+  return run_pipelined(ctx, ins, ok, n, 0, 0, NoPrep{}, DSV_PART(2), kPipeHeavy);
 }
 }  // namespace
 
@@ -202,7 +202,7 @@ int verify_ext_host(Context& ctx, int kind, const HostIn (&ins)[NIN], size_t n, 
                        [kind, cp](const void* const* d, size_t cnt, Stager& x, hipStream_t st, Staged& g) {
                          return prep_normalize(*cp, kind, d, cnt, x, st, g);
                        },
-                       DSV_PART(kind), kind != 0);
+                       DSV_PART(kind), kind != 0 ? kPipeHeavy : 0u);
 }
 int verify_single_ext_host(Context& ctx, const uint8_t* u, const uint8_t* R, const uint8_t* PK,
                            const uint8_t* m, size_t n, uint8_t* ok) {
@@ -361,7 +361,7 @@ int verify_mont_host(Context& ctx, int kind, const HostIn (&ins)[NIN], size_t n,
                          (void)np;
                          return prep_normalize(*cp, kind, d, cnt, x, st, g, cu, cm, true);  // ONE launch
                        },
-                       DSV_PART(kind), kind != 0);
+                       DSV_PART(kind), kind != 0 ? kPipeHeavy : 0u);
 }
 }  // namespace
 namespace dsvh {

@@ -7,6 +7,8 @@
 
 namespace dsvh {
 
+enum : unsigned { kPipeHeavy = 1, kPipeNoVerdicts = 2 };  // run_pipelined's flags
+
 // Chunked host path shared by the verify entry points.
 //   ins[k] = {host array, bytes per item[, stride]}; launch(dev_ptrs, count, dok, ws, extra, stream)
 //   enqueues the kernels for `count` items on `stream` (it is handed sub-batches, not chunks).
@@ -72,14 +74,17 @@ struct NoPrep {};
 //     chunk's first sub-batch (the other lane waits for its event), results in the slot's own
 //     scratch (prep_item_bytes per item).  Per SUB-BATCH these kernels would be 128 waves each in
 //     front of every hash: 16 low-occupancy phases per 2^20 items instead of 4.
-//   heavy: the scheme does about twice a single signature's device work per item (double, var-generator):
-//     the ramp of a call that finds the GPU idle then uses larger chunks (host_sync.h: plan_chunks)
+//   flags: kPipeHeavy — the scheme does about twice a single signature's device work per item (double,
+//     var-generator): the ramp of a call that finds the GPU idle then uses larger chunks (host_sync.h:
+//     plan_chunks); kPipeNoVerdicts — the parts write no verdict bytes (the fast accept's arena fills): no
+//     verdict copy per chunk, `ok` is left alone (it used to receive stale device bytes)
 //   part(staged, offset, count, dok, ws, extra, stream): one sub-batch; `extra`: scratch of
 //     extra_item_bytes per item behind the lane's verify workspace (the wire path decompresses per
 //     sub-batch: full-occupancy kernels, no reason to serialise a chunk's worth on one lane).
 template <size_t NIN, class Prep, class Part>
 int run_pipelined(Context& ctx, const HostIn (&ins)[NIN], uint8_t* ok, size_t n, size_t prep_item_bytes,
-                  size_t extra_item_bytes, Prep prep, Part part, bool heavy = false) {
+                  size_t extra_item_bytes, Prep prep, Part part, unsigned flags = 0) {
+  const bool heavy = (flags & kPipeHeavy) != 0, no_verdicts = (flags & kPipeNoVerdicts) != 0;
   constexpr bool has_prep = !std::is_same<Prep, NoPrep>::value;
   const bool small = n <= kPipeSmallCall;  // transfer, kernels and verdicts on ONE stream, a work area of its own
   TurnTicket turn(ctx.pipe_sync);          // (on an error path its destructor still passes the turn on, in order)
@@ -150,7 +155,7 @@ int run_pipelined(Context& ctx, const HostIn (&ins)[NIN], uint8_t* ok, size_t n,
     if (!h.cnt) return DSV_OK;
     if (small) HIP_TRY(hipStreamSynchronize(ctx.pipe_small));  // (the one-stream path of a small call)
     else HIP_TRY(hipEventSynchronize(pipe.slot[sl].ev_done));
-    memcpy(ok + h.first, pipe.slot[sl].host + h.ok_off, h.cnt);
+    if (!no_verdicts) memcpy(ok + h.first, pipe.slot[sl].host + h.ok_off, h.cnt);
     h.cnt = 0;
     if (h.parts_on[0] | h.parts_on[1]) {
       std::lock_guard<std::mutex> enq(ctx.enq_mu);
@@ -353,7 +358,7 @@ int run_pipelined(Context& ctx, const HostIn (&ins)[NIN], uint8_t* ok, size_t n,
             return fail(DSV_ERR_HIP, "event record / wait failed");
         }
     }
-    if (hipMemcpyAsync(slot.host + h.ok_off, dok, cnt, hipMemcpyDeviceToHost, s_out) != hipSuccess ||
+    if ((!no_verdicts && hipMemcpyAsync(slot.host + h.ok_off, dok, cnt, hipMemcpyDeviceToHost, s_out) != hipSuccess) ||
         (!small && hipEventRecord(slot.ev_done, s_out) != hipSuccess))
       return fail(DSV_ERR_HIP, "verdict copy failed: %s", hipGetErrorString(hipGetLastError()));
     h.enqueued = true;

@@ -552,7 +552,8 @@ int fill_arena(Context& ctx, int kind, const HostIn (&ins)[NIN], size_t n, uint8
                          g.p[1 + np] + 32 * off, cnt, w.c + 32 * at, w.valid + at, st, g.valid + off);
         HIP_TRY(hipGetLastError());
         return (int)DSV_OK;
-      });
+      },
+      kPipeNoVerdicts | (kind != 0 ? kPipeHeavy : 0u));
 }
 // one shard of n <= kRlcMaxGroup items on one device, ONE group: take an arena, let `fill(arena, workspace
 // carve)` run the pipeline that leaves u, the affine points and c / valid resident, then the aggregate
@@ -774,7 +775,7 @@ int verify_wire_rlc_host(int kind, const uint8_t* sig, const uint8_t* pk, const 
                        g.p[2] + 32 * off, cnt, w.c + 32 * at, w.valid + at, st, valid);
       HIP_TRY(hipGetLastError());
       return (int)DSV_OK;
-    });
+    }, kPipeNoVerdicts);
   });
 }
 }  // namespace

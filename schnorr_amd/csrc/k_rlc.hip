@@ -5,7 +5,7 @@
 // The reference's equation is cofactorless, u*G + c*PK == R, and its types hold points with a
 // small-order component (`from_bytes` checks the curve equation only, src/keys/public.rs:94-100), so
 // a plain  sum z_i (u_i G + c_i PK_i - R_i) == O  is NOT the reference's verdict: torsion defects
-// cancel (DESIGN.md §7).  What this path accepts instead is the conjunction of
+// cancel (DESIGN.md §5).  What this path accepts instead is the conjunction of
 //   (1) every PK_i and R_i that enters the sum lies in the prime-order subgroup, and
 //   (2) (sum z_i u_i) G + sum (z_i c_i) PK_i - sum z_i R_i == O     with secret random 128-bit z_i,
 // under which every per-signature verdict is `true` (error <= 2^-112: see below).  If either fails

@@ -123,7 +123,7 @@ inline size_t normalize_prefix_bytes(size_t n, int npoints) {
   return (size_t)npoints * (n + kNormalizePerLane) * kLimbs * 4;
 }
 // want_per_lane / block: 0 = the defaults above / 256 threads (the host pipeline asks for few,
-// single-wave workgroups: DESIGN.md §3 "Host pipeline")
+// single-wave workgroups: DESIGN.md §4)
 void launch_normalize_uvz(const NormalizeArgs& a, int npoints, size_t n, uint8_t* valid,
                           uint32_t* prefix, hipStream_t s, int want_per_lane = 0, int block = 0);
 void launch_sign_finish(const uint8_t* r, const uint8_t* c, const uint8_t* sk, size_t n, uint8_t* u_out,

@@ -1,6 +1,6 @@
 // Does an i8 MFMA stream hide behind a v_mad_u64_u32 stream on gfx950?
 //
-// Question behind it: the linear layers of Hades multiply the state by CONSTANT
+// Question behind it (HISTORY.md §6): the linear layers of Hades multiply the state by CONSTANT
 // field elements -- over a batch that is a constant (Toeplitz-of-bytes) matrix times a matrix of
 // state bytes, i.e. MFMA-shaped work, while everything else in the engine is 64-bit integer MADs
 // on the VALU.  It only pays if the matrix pipe runs beside the VALU instead of taking its issue

@@ -79,7 +79,7 @@ DEF_KERNEL_U32(not_b32, "v_not_b32 %0, %0")
 DEF_KERNEL_U32(mov_b32, "v_mov_b32 %0, %1")
 DEF_KERNEL_U32(bitop3, "v_bitop3_b32 %0, %0, %1, %0 bitop3:0xc")
 DEF_KERNEL_U32(add_u32_nop, "v_add_u32 %0, %0, %1\n s_nop 0")
-// selects and quad exchanges (costing a 4-lanes-per-signature group law)
+// selects and quad exchanges (costing a 4-lanes-per-signature group law, HISTORY.md §6)
 DEF_KERNEL_U32(cndmask_sgpr, "v_cndmask_b32 %0, %0, %1, s[10:11]")
 DEF_KERNEL_U32(mov_dpp_quad, "v_mov_b32_dpp %0, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf")
 

@@ -5,7 +5,7 @@
 
 Everything below has been built and rehearsed on one GPU (contiguous shards wrapped over one device,
 gloo world sizes 2 .. 8 on the CPU) but has never seen a device ordinal other than 0 nor RCCL with more
-than one rank (DESIGN.md §5).  On a node with N >= 2 visible GPUs this script runs, in order, and prints
+than one rank (DESIGN.md §7).  On a node with N >= 2 visible GPUs this script runs, in order, and prints
 PASS / FAIL per step with the figures that matter; it stops at the first FAIL (no GPU step is started
 after a failed one):
 
