@@ -335,7 +335,7 @@ using namespace dsvh;
 
 extern "C" {
 
-const char* dsv_version(void) { return "dsv 0.5.1 (gfx950, fe29)"; }
+const char* dsv_version(void) { return "dsv 0.6.0 (gfx950, fe29)"; }
 const char* dsv_last_error(void) { return g_err.c_str(); }
 
 int dsv_device_count(void) {

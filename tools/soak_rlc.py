@@ -15,6 +15,9 @@ Every fourth round runs the TYPED-OBJECT form instead (dsv_verify_*_mont_cols_rl
 Rust structs, Montgomery limbs, random z, planted encodings the types cannot hold: tests/mont_cases.py):
 tampered -> not accepted; its valid + malformed items alone -> accepted.  Every eighth round: the batch as
 serialized records in host memory (dsv_verify_*_wire_rlc) against the oracle's from_bytes + verify.
+r06: every round also draws the sub-group count (automatic, or 1 .. 16 forced: dsv_debug_rlc_subgroups) and the
+device's history counter (0: one sub-group, no sample; 8: sub-groups + the sample check), and every third
+device-pointer round takes `accepted` through a pinned word (the enqueue-only form) instead of a host int.
 Verdicts always equal the oracle's (the oracle is test infrastructure; nothing here is timed)."""
 import os
 import sys
@@ -46,6 +49,10 @@ t0 = time.time()
 for rd in range(rounds):
     scheme = ("single", "double", "vargen")[int(rng.integers(0, 3))]
     n = int(SIZES[int(rng.integers(0, len(SIZES)))])
+    forced = int((0, 0, 0, 1, 2, 3, 4, 8, 16)[int(rng.integers(0, 9))])
+    hist = int((0, 8)[int(rng.integers(0, 2))])
+    E.rlc_subgroups(forced)
+    E.rlc_history(0, hist)
     if rd % 4 == 3:
         cols, want = C.mont_case(scheme, 300, int(rng.integers(1, 1 << 30)), period=int(rng.integers(4, 40)))
         tamper_free = bool(rng.integers(0, 2))
@@ -141,17 +148,24 @@ for rd in range(rounds):
     t = [torch.from_numpy(x).to("cuda:0") for x in a]
     ok = torch.full((n,), 9, dtype=torch.uint8, device="cuda:0")
     ws = torch.empty(E.rlc_workspace_bytes(n, bits), dtype=torch.uint8, device="cuda:0")
-    accepted = getattr(E, "verify_%s_rlc_dev" % scheme)(*t, ok, ws, window_bits=bits)
+    if rd % 3 == 1:
+        word = torch.full((1,), 7, dtype=torch.int32).pin_memory()
+        assert getattr(E, "verify_%s_rlc_dev" % scheme)(*t, ok, ws, window_bits=bits, accepted_out=word) is None
+        torch.cuda.synchronize()
+        accepted = bool(int(word[0]))
+    else:
+        accepted = getattr(E, "verify_%s_rlc_dev" % scheme)(*t, ok, ws, window_bits=bits)
     got = ok.cpu().numpy()
     expect_accept = kind in ("clean", "malformed") and (bits != 0 or n >= 1 << 17)   # automatic bits: small groups skip it
     diff = int((got != twant).sum())
     wrong_accept = accepted != expect_accept
     total += n
     bad += diff + (1 if wrong_accept else 0)
-    print("round %d: %s n=%d bits=%d %-9s accepted=%d valid=%d/%d%s  (%.0f s)" % (
-        rd, scheme, n, bits, kind, accepted, int(twant.sum()), n,
+    print("round %d: %s n=%d bits=%d sub-groups=%s history=%d %-9s accepted=%d valid=%d/%d%s  (%.0f s)" % (
+        rd, scheme, n, bits, forced or "auto", hist, kind, accepted, int(twant.sum()), n,
         "  DIFFERENT: %d verdicts%s" % (diff, ", acceptance" if wrong_accept else "") if diff or wrong_accept else "",
         time.time() - t0), flush=True)
     del ws, ok, t
+E.rlc_subgroups(0)
 print("soak_rlc: %d verdicts compared with the oracle, %d different / wrongly accepted" % (total, bad))
 sys.exit(1 if bad else 0)
