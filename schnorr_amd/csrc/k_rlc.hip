@@ -703,37 +703,79 @@ DSV_DEV Quad exchange(u32* sh, int& buf, int wave, int lane, const Fe& mine) {
   buf ^= 1;  // the next round writes the other buffer: nobody is still reading it (one barrier back)
   return q;
 }
-// (limb by limb: a select between whole structs becomes an array in scratch memory indexed by `wave`)
-DSV_DEV Fe pick(int wave, const Fe& a, const Fe& b, const Fe& c, const Fe& d) {
-  return fe_select(wave < 2, fe_select(wave == 0, a, b), fe_select(wave == 2, c, d));
-}
-DSV_DEV Xp xp_finish(u32* sh, int& buf, int wave, int lane, const Fe& cu, const Fe& ct, const Fe& cv, const Fe& cz,
-                     const Fe& zl, const Fe& t2) {
-  // u = cu ct, v = cv cz, z = zl ct, tt = cu t2
-  const Fe x = pick(wave, cu, cv, zl, cu), y = pick(wave, ct, cz, ct, t2);
+// Which wave multiplies what is decided by UNIFORM BRANCHES on the wave number (a scalar: readfirstlane), each
+// arm preparing only its own two operands; the multiplication itself exists once, behind the arms.  (r05
+// computed every operand in every wave and selected limb by limb: 81 v_cndmask per doubling, 108 per
+// addition, of 672 / 700 instructions — a tenth of a kernel that is one dependent chain.  The empty asm
+// statements keep the compiler from folding the arms back into selects.)
+#define DSV_ARM() asm volatile("" ::: "memory")
+DSV_DEV Xp xp_finish(u32* sh, int& buf, int wave, int lane, const Fe& x, const Fe& y) {
   const Quad q = exchange(sh, buf, wave, lane, fe_mul(x, y));
   Xp r;
   r.u = q.r[0], r.v = q.r[1], r.z = q.r[2], r.tt = q.r[3];
   return r;
 }
 DSV_DEV Xp xp_double(u32* sh, int& buf, int wave, int lane, const Xp& p) {
-  const Quad q = exchange(sh, buf, wave, lane, fe_sqr(pick(wave, p.u, p.v, p.z, fe_add(p.u, p.v))));
-  const Fe zz2 = fe_dbl(q.r[2]);
-  const Fe vpu = fe_add(q.r[1], q.r[0]);
-  const Fe cu = fe_sub4w(q.r[3], vpu);       // 2uv (ext_two_uv)
-  const Fe vmu = fe_sub2_raw(q.r[1], q.r[0]);
-  const Fe ct = fe_sub4w(zz2, vmu);
-  return xp_finish(sh, buf, wave, lane, cu, ct, vpu, vmu, vmu, vpu);  // (ext_double: u = cu ct, v = vpu vmu, z = vmu ct; t1 t2 = cu vpu)
+  Fe x;
+  if (wave == 0) { DSV_ARM(); x = p.u; }
+  else if (wave == 1) { DSV_ARM(); x = p.v; }
+  else if (wave == 2) { DSV_ARM(); x = p.z; }
+  else { DSV_ARM(); x = fe_add(p.u, p.v); }
+  const Quad q = exchange(sh, buf, wave, lane, fe_sqr(x));
+  // ext_double: u = cu ct, v = vpu vmu, z = vmu ct; t1 t2 = cu vpu, with
+  //   vpu = vv + uu, cu = (u + v)^2 - vpu (2uv, ext_two_uv), vmu = vv - uu, ct = 2 zz - vmu
+  Fe a, b;
+  if (wave == 0) {
+    DSV_ARM();
+    const Fe vpu = fe_add(q.r[1], q.r[0]);
+    a = fe_sub4w(q.r[3], vpu);
+    b = fe_sub4w(fe_dbl(q.r[2]), fe_sub2_raw(q.r[1], q.r[0]));
+  } else if (wave == 1) {
+    DSV_ARM();
+    a = fe_add(q.r[1], q.r[0]);
+    b = fe_sub2_raw(q.r[1], q.r[0]);
+  } else if (wave == 2) {
+    DSV_ARM();
+    a = fe_sub2_raw(q.r[1], q.r[0]);
+    b = fe_sub4w(fe_dbl(q.r[2]), a);
+  } else {
+    DSV_ARM();
+    b = fe_add(q.r[1], q.r[0]);
+    a = fe_sub4w(q.r[3], b);
+  }
+  return xp_finish(sh, buf, wave, lane, a, b);
 }
 DSV_DEV Xp xp_add(u32* sh, int& buf, int wave, int lane, const Xp& p, const Niels& n) {
-  const Fe x = pick(wave, fe_sub2_raw(p.v, p.u), fe_add(p.v, p.u), p.tt, p.z);
-  const Fe y = pick(wave, n.vmu, n.vpu, n.t2d, n.z);
+  Fe x, y;
+  if (wave == 0) { DSV_ARM(); x = fe_sub2_raw(p.v, p.u); y = n.vmu; }
+  else if (wave == 1) { DSV_ARM(); x = fe_add(p.v, p.u); y = n.vpu; }
+  else if (wave == 2) { DSV_ARM(); x = p.tt; y = n.t2d; }
+  else { DSV_ARM(); x = p.z; y = n.z; }
   const Quad q = exchange(sh, buf, wave, lane, fe_mul(x, y));  // a, b, c, z nz
-  const Fe d = fe_dbl(q.r[3]);
-  const Fe cu = fe_sub2_raw(q.r[1], q.r[0]), cv = fe_add(q.r[1], q.r[0]);
-  const Fe cz = fe_add(d, q.r[2]), ct = fe_sub2(d, q.r[2]);
-  return xp_finish(sh, buf, wave, lane, cu, ct, cv, cz, cz, cv);  // (ext_add_tail: u = cu ct, v = cv cz, z = cz ct; t1 t2 = cu cv)
+  // ext_add_tail: u = cu ct, v = cv cz, z = cz ct; t1 t2 = cu cv, with d = 2 z nz,
+  //   cu = b - a, cv = b + a, cz = d + c, ct = d - c
+  Fe a, b;
+  if (wave == 0) {
+    DSV_ARM();
+    a = fe_sub2_raw(q.r[1], q.r[0]);
+    b = fe_sub2(fe_dbl(q.r[3]), q.r[2]);
+  } else if (wave == 1) {
+    DSV_ARM();
+    a = fe_add(q.r[1], q.r[0]);
+    b = fe_add(fe_dbl(q.r[3]), q.r[2]);
+  } else if (wave == 2) {
+    DSV_ARM();
+    const Fe d = fe_dbl(q.r[3]);
+    a = fe_add(d, q.r[2]);
+    b = fe_sub2(d, q.r[2]);
+  } else {
+    DSV_ARM();
+    a = fe_sub2_raw(q.r[1], q.r[0]);
+    b = fe_add(q.r[1], q.r[0]);
+  }
+  return xp_finish(sh, buf, wave, lane, a, b);
 }
+#undef DSV_ARM
 DSV_DEV Xp xp_identity() {
   Xp r;
   r.u = fe_zero(), r.v = fe_one(), r.z = fe_one(), r.tt = fe_zero();
@@ -791,7 +833,7 @@ k_rlc_scale(const u32* __restrict__ S, size_t S_stride, const u32* __restrict__ 
   fsum += (size_t)blockIdx.y * 16;
   u32* flags = gflags + 4 + 4 * blockIdx.y;
   const u32 lanes = (u32)p.windows * p.c, g = (lanes + 63) / 64;
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
   const bool weigh = blockIdx.x >= g && blockIdx.x < 2 * g, fixed_base = blockIdx.x == 2 * g;
   if (fixed_base) {
     if (threadIdx.x == 0) {
