@@ -1041,11 +1041,28 @@ def main():
             pass
         # every hardware thread this process may run on (the affinity count, no cap): north_star's "the reference
         # CPU verify loop timed on the same box's host cores (core count stated)" — as far as a port can state it
+        # ... bounded by the container's cpu quota when there is one (cgroup v2 cpu.max / v1 cfs quota): 256 visible
+        # hardware threads under a 16-cpu quota only thrash (measured: 27.7 k/s on 256 threads, 50 k/s on 16)
+        quota = None
+        try:
+            with open("/sys/fs/cgroup/cpu.max") as f:
+                q_, p_ = f.read().split()[:2]
+                quota = None if q_ == "max" else max(1, int(round(int(q_) / int(p_))))
+        except Exception:
+            try:
+                with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as f, open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as g:
+                    q_, p_ = int(f.read()), int(g.read())
+                    quota = None if q_ <= 0 else max(1, int(round(q_ / p_)))
+            except Exception:
+                quota = None
+        affinity_threads = all_cores
+        if quota is not None:
+            all_cores = min(all_cores, quota)
         all_block = None
         if all_cores > cores:
             # (2048 items per thread: a thread's start-up must not weigh — 256 items each measured LESS than 16
             #  threads did; what the figure then shows is the box's cpu quota, not its socket count)
-            smp = min(n, 2048 * all_cores)
+            smp = min(n, 2048 * all_cores, 4 * sample)   # (bounded: ~10 s even where more threads do not help)
             au, aR, aPK, am = (h(batch[k], smp) for k in ("u", "R", "PK", "m"))
             ta0 = time.perf_counter()
             a_ok = O.verify_single(au, aR, aPK, am, nthreads=all_cores)
@@ -1055,7 +1072,8 @@ def main():
             all_block = {"value": smp / ta, "threads": all_cores, "items": smp, "wall_s": ta}
             del au, aR, aPK, am
         else:
-            all_block = {"value": sample / tc, "threads": cores, "items": sample, "wall_s": tc}
+            all_block = {"value": sample / tc, "threads": cores, "items": sample, "wall_s": tc,
+                         "note": "the process may use no more cpus than `cores` (affinity and cpu quota): same measurement as `value`"}
         # the other two schemes' port rates, same thread count as `value`
         other = {}
         kd = 1024 * cores
@@ -1074,6 +1092,7 @@ def main():
         out["cpu_baseline"] = {
             "value": sample / tc, "unit": "verifies/s", "cores": cores, "kind": "port",
             "cpu": cpu_model, "all_cores": all_block, "schemes": other,
+            "host": {"affinity_threads": affinity_threads, "cpu_quota": quota},
             "sample": "first %d items of the same batch, %d threads, %.1f s wall; "
                       "1 thread: %.0f verifies/s on %d items; configs[0] shape (1024 x keygen+sign, "
                       "1 thread): %.0f /s" % (sample, cores, tc, one / t1, one, 1024 / t_sign),

@@ -218,7 +218,7 @@ int verify_rlc_on(Context& ctx, int scheme, const void* u, const void* R_uv, con
     const size_t cnt = n - off < group ? n - off : group;
     if (k >= kRlcMaxGroupsPerCall) return fail(DSV_ERR_TOO_LARGE, "more than %zu groups", kRlcMaxGroupsPerCall);
     va.ngroups = (u32)k + 1;
-    if (!window_bits && cnt < kRlcMinAuto && !have_challenges) {
+    if (!window_bits && cnt < rlc_min_auto(scheme) && !have_challenges) {
       // too small for an aggregate to pay: the per-signature entry point as it is
       va.subs[k] = 0;
       traced[k] = Traced{off, cnt, RlcPlan{}, false};

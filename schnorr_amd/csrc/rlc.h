@@ -46,8 +46,13 @@ struct RlcPlan {
 constexpr size_t kRlcMaxGroup = (size_t)1 << 22;  // point indices (at most 4 per item) are packed into 24 bits
 constexpr int kRlcMaxSub = 16;                    // sub-groups per group: at most
 // below this an aggregate is slower than the per-signature kernels (its tail does not shrink with the
-// batch): with automatic window bits such groups skip it
+// batch): with automatic window bits such groups skip it.  The host forms (typed objects, records in host
+// memory) use kRlcMinAuto for every scheme; device-resident calls rlc_min_auto(scheme): a double or
+// var-generator signature is twice the per-signature work, and their kernels are latency-bound below 2^16
+// items (r06, same box, all valid, 12-bit windows: double 2^14 items 1.15 x, 2^15 1.39 x, 2^16 1.40 x;
+// var-generator 1.28 / 1.25 / 1.23 x; single 2^16 items 0.96 x, 2^17 1.36 x)
 constexpr size_t kRlcMinAuto = (size_t)1 << 17;
+inline size_t rlc_min_auto(int scheme) { return scheme == 0 ? kRlcMinAuto : (size_t)1 << 14; }
 constexpr int kRlcFsumBlocks = 64;
 constexpr int kRlcTile = 8192;  // digits one workgroup of k_rlc_part1 partitions
 // flags of one sub-group (4 words): [0] defects, [1] = 1 once the chain of kernels ran to its end.

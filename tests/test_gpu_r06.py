@@ -230,3 +230,24 @@ def test_var_generator_sixteen_lane_kernel(engine, n):
     assert np.array_equal(ok.cpu().numpy(), want)
     if n >= 16:
         assert 0 < want.sum() < n
+
+
+@pytest.mark.parametrize("scheme", ["double", "vargen"])
+def test_double_and_var_generator_aggregates_start_at_2_14_items(engine, scheme):
+    """automatic window bits: a device-resident double / var-generator batch is decided by its aggregate from
+    2^14 items on (rlc.h: rlc_min_auto; a single-signature batch from 2^17), one item fewer takes the
+    per-signature kernels; verdicts are the oracle's either way"""
+    base = _signed(1024, 650, scheme)
+    for n, expect in (((1 << 14) - 1, False), (1 << 14, True), ((1 << 14) + 333, True)):
+        d = {k: np.tile(v, (-(-n // 1024), 1))[:n].copy() for k, v in base.items()}
+        engine.rlc_history(0, 0)
+        acc, ok = _run(engine, d, scheme)
+        assert acc == expect and ok.all(), n
+        d["m"][n // 3, 4] ^= 1
+        want = np.ones(n, np.uint8)
+        want[n // 3] = 0
+        acc, ok = _run(engine, d, scheme)
+        assert not acc and np.array_equal(ok, want), n
+        cut = slice(n // 3 - 20, n // 3 + 20)
+        assert np.array_equal(_oracle({k: v[cut] for k, v in d.items()}, scheme), want[cut])
+    engine.rlc_history(0, 1)

@@ -156,7 +156,8 @@ for rd in range(rounds):
     else:
         accepted = getattr(E, "verify_%s_rlc_dev" % scheme)(*t, ok, ws, window_bits=bits)
     got = ok.cpu().numpy()
-    expect_accept = kind in ("clean", "malformed") and (bits != 0 or n >= 1 << 17)   # automatic bits: small groups skip it
+    # automatic bits: small groups skip the aggregate (rlc.h: rlc_min_auto — 2^17 single, 2^14 double / var-generator)
+    expect_accept = kind in ("clean", "malformed") and (bits != 0 or n >= (1 << 17 if scheme == "single" else 1 << 14))
     diff = int((got != twant).sum())
     wrong_accept = accepted != expect_accept
     total += n
