@@ -324,6 +324,7 @@ def _verify_batch_e2e(E, hu, hR, hPK, hm, expected, cores):
                                "value": cnt.value / (times[0] * 1e-3), "accepted_by_aggregate": bool(acc.value)}
             fast["all_valid"]["vs_verify_batch_one_shot"] = fast["all_valid"]["value"] / res["one_shot"]["value"]
             if hasattr(L, "vb_e2e_run_fast_streamed"):   # two calls in flight (two threads on the blocking entry point)
+                E.rlc_history(0, 0)   # (the graded batch above left the device in "batches fail" mode: steady state again)
                 best = None
                 for rep in range(3):
                     if L.vb_e2e_run_fast_streamed(p(np.ascontiguousarray(expected)), ctypes.c_int(8), ctypes.c_int(2),
@@ -916,6 +917,27 @@ def main():
                       "workload": "2^%d single signatures, R and PK as (u, v, z) with random z: "
                                   "dsv_verify_single_ext_dev (k_normalize_uvz: one inversion per eight "
                                   "signatures, then the affine path)" % args.log2_batch}
+        # the same for the other two schemes (r06): the device-resident rate of the INPUT FORM verify_batch_double /
+        # verify_batch_var_gen hand over (projective points) — what their one-shot figures are fairly compared with
+        for sch_, cols_, fn_ in (("double", ("R", "Rp", "PK", "PKp"), E.verify_double_ext_dev),
+                                 ("vargen", ("R", "PK", "Gen"), E.verify_vargen_ext_dev)):
+            if sch_ not in sample_checks:
+                continue
+            b_, _ = sample_checks[sch_]
+            n_ = b_["u"].shape[0]
+            hz_ = hz[:n_]
+            pr_ = lambda pt: torch.from_numpy(np.concatenate(
+                [E.debug_fq_mul(np.ascontiguousarray(hh(pt)[:, :32]), hz_),
+                 E.debug_fq_mul(np.ascontiguousarray(hh(pt)[:, 32:]), hz_), hz_], axis=1)).to(dev)
+            pts_ = [pr_(b_[k]) for k in cols_]
+            wse2 = torch.empty(E.ext_workspace_bytes(n_), dtype=torch.uint8, device=dev)
+            fe2 = lambda: fn_(b_["u"], *pts_, b_["m"], oke[:n_], wse2)
+            te2 = timed(fe2, reps, 1)
+            if int((oke[:n_] != b_["expected"]).sum().item()):
+                raise SystemExit("projective-input verdicts (%s) differ from the expected pattern" % sch_)
+            out[sch_]["ext"] = {"value": n_ * reps / te2, "unit": "verifies/s", "items": n_,
+                                "workload": "the same batch with every point as (u, v, z), random z: dsv_verify_%s_ext_dev" % sch_}
+            del pts_, wse2
         del wse
 
         # ---- wire records (Signature 64 B + PublicKey 32 B per item): decompression on the device
@@ -1229,11 +1251,15 @@ def main():
                 e2d = _verify_batch_e2e_double(E, sample_checks["double"][0], cores)
                 if e2d:
                     ratios(e2d, out["double"]["value"], "device_resident_double")
+                    if "ext" in out["double"]:
+                        ratios(e2d, out["double"]["ext"]["value"], "device_resident_double_ext")
                     e2e["double"] = e2d
             if "vargen" in sample_checks:
                 e2v = _verify_batch_e2e_vargen(E, sample_checks["vargen"][0], cores)
                 if e2v:
                     ratios(e2v, out["vargen"]["value"], "device_resident_vargen")
+                    if "ext" in out["vargen"]:
+                        ratios(e2v, out["vargen"]["ext"]["value"], "device_resident_vargen_ext")
                     e2e["vargen"] = e2v
             e2e["note"] = ("one-shot: a single verify_batch call on an idle GPU (ramp and tail included); "
                            "streamed.two_in_flight: a caller with a stream of batches keeps two in flight "
