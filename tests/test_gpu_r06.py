@@ -251,3 +251,68 @@ def test_double_and_var_generator_aggregates_start_at_2_14_items(engine, scheme)
         cut = slice(n // 3 - 20, n // 3 + 20)
         assert np.array_equal(_oracle({k: v[cut] for k, v in d.items()}, scheme), want[cut])
     engine.rlc_history(0, 1)
+
+
+def test_two_groups_in_sub_groups(engine):
+    """2^22 + 2^18 + 5 signatures while the history says "batches fail": two groups, each cut into sub-groups (the
+    last one ragged), one wrong signature in each group — the construction pattern; then all valid -> accepted"""
+    from schnorr_amd import workload as W
+    n = (1 << 22) + (1 << 18) + 5
+    b = W.gen_single(n, seed=9, tamper=False)
+    ws = torch.empty(engine.rlc_workspace_bytes(n), dtype=torch.uint8, device=DEV)
+    ok = torch.zeros(n, dtype=torch.uint8, device=DEV)
+    engine.rlc_history(0, 8)
+    assert engine.verify_single_rlc_dev(b["u"], b["R"], b["PK"], b["m"], ok, ws)
+    assert bool(ok.all())
+    want = torch.ones(n, dtype=torch.uint8, device=DEV)
+    for victim in (1_234_567, n - 2):
+        b["m"][victim, 7] ^= 0x08
+        want[victim] = 0
+    ok.zero_()
+    engine.rlc_history(0, 8)
+    assert not engine.verify_single_rlc_dev(b["u"], b["R"], b["PK"], b["m"], ok, ws)
+    assert torch.equal(ok, want)
+    engine.rlc_history(0, 1)
+
+
+def test_device_calls_from_several_threads_and_streams(engine):
+    """four host threads, each with its own stream, workspace and verdict buffer, enqueue fast-accept calls at the
+    same time (valid and invalid batches alternating): every call's verdicts and `accepted` are its own"""
+    import threading
+    n = 6000
+    d = _signed(n, 660)
+    bad = {k: v.copy() for k, v in d.items()}
+    bad["u"][4321, 9] ^= 0x80
+    want_bad = _oracle(bad, "single")
+    assert want_bad.sum() == n - 1
+    dev = {name: [torch.from_numpy(np.ascontiguousarray(x[k])).to(DEV) for k in COLS["single"]]
+           for name, x in (("good", d), ("bad", bad))}
+    errors = []
+
+    def worker(t):
+        try:
+            stream = torch.cuda.Stream(device=DEV)
+            ok = torch.zeros(n, dtype=torch.uint8, device=DEV)
+            ws = torch.empty(engine.rlc_workspace_bytes(n, 8), dtype=torch.uint8, device=DEV)
+            word = torch.zeros(1, dtype=torch.int32).pin_memory()
+            for call in range(6):
+                which = "bad" if (call + t) & 1 else "good"
+                with torch.cuda.stream(stream):
+                    ok.fill_(9)
+                    engine.verify_single_rlc_dev(*dev[which], ok, ws, stream=stream, window_bits=8, accepted_out=word)
+                stream.synchronize()
+                got = ok.cpu().numpy()
+                exp = want_bad if which == "bad" else np.ones(n, np.uint8)
+                if int(word[0]) != (which == "good") or not np.array_equal(got, exp):
+                    errors.append("thread %d call %d (%s): accepted=%d, %d verdicts differ" % (
+                        t, call, which, int(word[0]), int((got != exp).sum())))
+        except Exception as e:  # noqa: BLE001
+            errors.append("thread %d: %r" % (t, e))
+
+    threads = [threading.Thread(target=worker, args=(t,)) for t in range(4)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    assert not errors, errors
+    engine.rlc_history(0, 1)
