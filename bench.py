@@ -810,17 +810,20 @@ def main():
         one_b["u"][victim, 3] ^= 0x10
         one_b["expected"][victim] = 0
         # label, batch, history the device is put into before every call (None: as the calls themselves leave it)
+        # hist: (short, long) history the device is put into before every call; None: as the calls themselves leave it
         cases = (("all_valid", valid_b, None, n >= RLC_MIN),
-                 ("one_bad_first_call", one_b, 0, False),          # the first bad batch of a caller: whole-group fallback
-                 ("one_bad_in_batch", one_b, None, False),         # ... and the following ones: sub-groups localise it
-                 ("graded_workload", batch, None, False))          # wrong items throughout: the sample skips the aggregates
+                 ("one_bad_never_seen_before", one_b, (0, 0), False),   # a caller whose batches never failed: whole-group fallback
+                 ("one_bad_first_in_a_while", one_b, (0, 128), False),  # ... failed within the last 128 calls: guarded, a second stage localises it
+                 ("one_bad_in_batch", one_b, None, False),              # ... within the last 8 calls: sub-groups up front
+                 ("graded_workload", batch, None, False))               # wrong items throughout: the sample skips the aggregates
         for label, b_, hist, expect_acc in cases:
             accs = []
 
             def f_():
                 if hist is not None:
                     torch.cuda.synchronize(dev)
-                    E.rlc_history(dev_index, hist)
+                    E.rlc_history(dev_index, hist[0])
+                    E.rlc_history_long(dev_index, hist[1])
                 E.verify_single_rlc_dev(b_["u"], b_["R"], b_["PK"], b_["m"], okr, wsr, accepted_out=acc_word)
                 torch.cuda.synchronize(dev)
                 accs.append(int(acc_word[0]))
@@ -851,6 +854,7 @@ def main():
             E.verify_single_rlc_dev(valid_b["u"], valid_b["R"], valid_b["PK"], valid_b["m"], o_, w_, stream=streams[k],
                                     accepted_out=a_)
         E.rlc_history(dev_index, 0)
+        E.rlc_history_long(dev_index, 0)
         tt_ = timed(two_streams, 2 * reps, 2)
         if not bool(okr.all()) or not bool(okr2.all()) or int(acc2[0]) != int(n >= RLC_MIN) or int(acc2[1]) != int(n >= RLC_MIN):
             raise SystemExit("rlc (two streams): verdicts / acceptance differ from the expected pattern")
@@ -859,6 +863,7 @@ def main():
         del wsr2, okr2
         rlc["one_bad_in_2^20"] = rlc["one_bad_in_batch"] if n == 1 << 20 else None
         E.rlc_history(dev_index, 0)
+        E.rlc_history_long(dev_index, 0)
         del valid_b, one_b
         # the other two schemes at their configuration sizes, all-valid batches
         for label, gen_, cols_, fn_, n_, ref_ in (

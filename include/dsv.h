@@ -324,6 +324,12 @@ int dsv_rlc_plan_info(int scheme, size_t n, int window_bits, int groups, uint64_
 /* the device's history counter (see above; tests and tools): returns it, or a negative dsv_status;
  * set >= 0 overrides it */
 int dsv_debug_rlc_history(int device, int set);
+/* the device's LONG history counter (128 after a call that held a rejected aggregate, one less after a call
+ * whose aggregates all accepted): while it is > 0 and the short one is 0, groups run "guarded" — one aggregate
+ * as in the steady state plus, behind it, a second stage of sub-group aggregates that a kernel switches off
+ * when the first accepted (+0.03 ms on an accepted 2^20-item call), so that the first rejected batch after a run of valid
+ * ones is localised too instead of paying both paths in full.  DSV_RLC_GUARD=0 switches that off. */
+int dsv_debug_rlc_history_long(int device, int set);
 /* sub-groups per group, process-wide: groups >= 1 forces that many (whatever the history says),
  * 0 = automatic, < 0 = leave; returns the previous setting ($DSV_RLC_SUBGROUPS initialises it) */
 int dsv_debug_rlc_subgroups(int groups);

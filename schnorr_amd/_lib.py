@@ -46,7 +46,7 @@ SYMBOLS = [
     "dsv_verify_vargen_mont_cols_submit", "dsv_job_wait", "dsv_job_done", "dsv_max_in_flight",
     # r05: random-linear-combination fast accept in front of the per-signature kernels
     "dsv_rlc_workspace_bytes", "dsv_verify_single_rlc_dev", "dsv_verify_double_rlc_dev",
-    "dsv_verify_vargen_rlc_dev", "dsv_rlc_plan_info", "dsv_debug_rlc_history", "dsv_debug_rlc_subgroups", "dsv_device_numa", "dsv_debug_numa_lookup",
+    "dsv_verify_vargen_rlc_dev", "dsv_rlc_plan_info", "dsv_debug_rlc_history", "dsv_debug_rlc_history_long", "dsv_debug_rlc_subgroups", "dsv_device_numa", "dsv_debug_numa_lookup",
     "dsv_verify_single_mont_cols_rlc", "dsv_verify_double_mont_cols_rlc", "dsv_verify_vargen_mont_cols_rlc",
     "dsv_wire_rlc_workspace_bytes", "dsv_verify_single_wire_rlc_dev", "dsv_verify_double_wire_rlc_dev",
     "dsv_verify_vargen_wire_rlc_dev",

@@ -28,6 +28,18 @@ extern "C" {
 // that the verdict kernel itself maintains (8 after a call with a rejected sub-group, one less after an
 // accepted call; 1 after dsv_init): the host reads it, possibly one call late, and never waits for it.
 // While it is > 0 a SAMPLE is verified first as well (below).
+//
+// The FIRST rejected batch after a run of valid ones would still pay both paths in full (one sub-group:
+// 15.4 ms against 12.3 per 2^20).  A second, slower counter (128 after a rejected aggregate, one less per
+// accepted call) marks callers whose batches do fail now and then: while it is > 0 and the short one is 0, a
+// group of at least four sub-groups runs GUARDED — its single aggregate as in the steady state, and behind it,
+// enqueued unconditionally, a second stage of sub-group aggregates that a one-thread kernel (k_rlc_chain)
+// switches off when the first one accepted (its kernels and the per-signature launches behind it then return
+// at once: ~25 early exits, +0.03 ms on an accepted 2^20-item call); when the first stage rejects, the second
+// localises the failure and only one sub-group reaches the per-signature kernels: 9.4 instead of 15.8 ms
+// (1.31 x the per-signature path instead of 0.78 x; double 16.9 instead of 30.3 ms).  It pays from one failing
+// batch in ~200 on, hence the counter's 128.  A caller whose batches never fail never enqueues it;
+// DSV_RLC_GUARD=0 switches it off.
 extern "C++" {
 namespace {
 // Before an aggregate is paid for, the per-signature kernel (eight lanes per signature: 0.26 ms)
@@ -43,7 +55,7 @@ constexpr size_t kRlcSample = 1024;
 struct RlcCarve {
   Workspace w;  // the per-signature path's own workspace comes first: the fallback uses it as it is
   RlcBuffers b;
-  u32* flags_area;     // kRlcMaxGroupsPerCall flag blocks (b.flags = this group's)
+  u32* flags_area;     // kRlcFlagBlocks flag blocks, two per group (b.flags = the one in use)
   uint8_t* sample_ok;  // kRlcSample verdicts of the pre-check
   void* sample_ws;     // ... and its per-signature workspace
   size_t bytes;
@@ -57,7 +69,7 @@ RlcCarve carve_rlc(void* ws, size_t nmax, size_t cnt, const RlcPlan& p) {
   auto words = [&](size_t count) { return reinterpret_cast<u32*>(st.take(count * 4)); };
   const size_t G = p.groups, sub = p.sub;
   // fixed places first: the same whatever the plan
-  r.flags_area = words(kRlcMaxGroupsPerCall * kRlcGroupFlagWords);
+  r.flags_area = words(kRlcFlagBlocks * kRlcGroupFlagWords);
   r.b.flags = r.flags_area;
   r.sample_ok = st.take(kRlcSample);
   r.sample_ws = st.take(dsv_workspace_bytes(kRlcSample));
@@ -131,15 +143,15 @@ int rlc_random_key(ChaChaKey& key) {
 }
 // sub-groups per group, forced (DSV_RLC_SUBGROUPS, dsv_debug_rlc_subgroups; tests and tools); 0: by the history
 std::atomic<int> g_rlc_force_groups{getenv("DSV_RLC_SUBGROUPS") ? atoi(getenv("DSV_RLC_SUBGROUPS")) : 0};
-// pinned host words the device writes: [0] the history counter, [1] calls completed, [2 ..] a ring of
-// verdict slots for callers whose `accepted` is pageable memory
-constexpr u32 kRlcSlots = 62;
+// pinned host words the device writes: [0] the history counter, [1] calls completed, [2] the long history
+// counter, [4 ..] a ring of verdict slots for callers whose `accepted` is pageable memory
+constexpr u32 kRlcSlots = 60, kRlcSlot0 = 4;
 int ensure_rlc_pinned(Context& ctx) {
   std::lock_guard<std::mutex> lk(ctx.rlc_pinned_mu);
   if (ctx.rlc_pinned) return DSV_OK;
   u32* p = nullptr;
-  HIP_TRY(hipHostMalloc((void**)&p, (2 + kRlcSlots) * sizeof(u32), hipHostMallocDefault));
-  for (u32 k = 0; k < 2 + kRlcSlots; k++) p[k] = 0;
+  HIP_TRY(hipHostMalloc((void**)&p, (kRlcSlot0 + kRlcSlots) * sizeof(u32), hipHostMallocDefault));
+  for (u32 k = 0; k < kRlcSlot0 + kRlcSlots; k++) p[k] = 0;
   p[0] = 1;  // the first call of a device checks a sample and runs in sub-groups
   ctx.rlc_pinned = p;
   return DSV_OK;
@@ -165,7 +177,7 @@ int rlc_verdict_target(Context& ctx, int* accepted, RlcVerdictTarget& t) {
   (void)hipGetLastError();  // a failed query leaves a sticky "invalid value"
   if (int r = ensure_rlc_pinned(ctx)) return r;
   const u32 k = ctx.rlc_slot.fetch_add(1) % kRlcSlots;
-  t.slot = ctx.rlc_pinned + 2 + k;
+  t.slot = ctx.rlc_pinned + kRlcSlot0 + k;
   t.dev = t.slot;
   t.out = accepted;
   return DSV_OK;
@@ -207,11 +219,13 @@ int verify_rlc_on(Context& ctx, int scheme, const void* u, const void* R_uv, con
   const int force_groups = g_rlc_force_groups.load(std::memory_order_relaxed);
   // what the device's recent calls say (written by the verdict kernels; read without waiting for anything)
   const u32 history = *reinterpret_cast<volatile u32*>(ctx.rlc_pinned);
+  const u32 history_long = *reinterpret_cast<volatile u32*>(ctx.rlc_pinned + 2);
+  static const bool guard_on = !(getenv("DSV_RLC_GUARD") && atoi(getenv("DSV_RLC_GUARD")) == 0);
   RlcVerdictArgs va = {};
   u32* flags_area = nullptr;
   struct Traced {
     size_t off, cnt;
-    RlcPlan plan;
+    RlcPlan plan, plan2;  // plan2.groups != 0: the second stage of a guarded group
     bool sampled;
   } traced[kRlcMaxGroupsPerCall];
   for (size_t off = 0, k = 0; off < n; off += group, k++) {
@@ -221,7 +235,7 @@ int verify_rlc_on(Context& ctx, int scheme, const void* u, const void* R_uv, con
     if (!window_bits && cnt < rlc_min_auto(scheme) && !have_challenges) {
       // too small for an aggregate to pay: the per-signature entry point as it is
       va.subs[k] = 0;
-      traced[k] = Traced{off, cnt, RlcPlan{}, false};
+      traced[k] = Traced{off, cnt, RlcPlan{}, RlcPlan{}, false};
       int r;
       const uint8_t* vin = valid_in ? valid_in + off : nullptr;
       if (scheme == 0)
@@ -235,20 +249,30 @@ int verify_rlc_on(Context& ctx, int scheme, const void* u, const void* R_uv, con
       if (r) return r;
       continue;
     }
-    int G = 1;
-    if (staged) G = 1;  // (its first range is on the stream already, planned as one sub-group)
-    else if (force_groups > 0) G = force_groups;
-    else if (history > 0) G = rlc_split_groups(cnt, window_bits);
+    // how this group runs (file header): plain, split (sub-groups + sample) or guarded (two stages)
+    int G = 1, G2 = 0;
+    if (staged) {
+      G = 1;  // (its first range is on the stream already, planned as one sub-group)
+    } else if (history == 0 && history_long > 0 && guard_on) {
+      G2 = force_groups > 0 ? force_groups : rlc_split_groups(cnt, window_bits);
+      if (G2 < 4) G2 = 0;  // (two sub-groups: the second stage costs what it saves — 2^18 items: 4.41 against 4.40 ms)
+      if (!G2 && force_groups > 0) G = force_groups;
+    } else if (force_groups > 0) {
+      G = force_groups;
+    } else if (history > 0) {
+      G = rlc_split_groups(cnt, window_bits);
+    }
     const RlcPlan plan = rlc_group_plan(scheme, cnt, window_bits, G);
     RlcCarve cv = carve_rlc(workspace, group, cnt, plan);
     flags_area = cv.flags_area;
-    cv.b.flags = cv.flags_area + k * kRlcGroupFlagWords;
+    cv.b.flags = cv.flags_area + (2 * k) * kRlcGroupFlagWords;
     va.subs[k] = (uint8_t)plan.groups;
+    va.second[k] = 0;
     ChaChaKey key;
     if (staged) key = staged->key;  // (one group: the bucket pass of its first items is on the stream already)
     else if (int r = rlc_random_key(key)) return r;
-    const bool do_sample = !window_bits && sample_on && (ctx.quad || scheme == 2) && history > 0;
-    traced[k] = Traced{off, cnt, plan, do_sample};
+    const bool do_sample = !window_bits && sample_on && (ctx.quad || scheme == 2) && history > 0 && !G2;
+    traced[k] = Traced{off, cnt, plan, RlcPlan{}, do_sample};
     if (!staged) HIP_TRY(launch_rlc_begin(cv.b, s));  // (staged: the hook did, before the first range)
     // (have_challenges: one group whose c / valid are in the workspace already — the host form hashes
     //  chunk by chunk while the transfers run)
@@ -289,14 +313,34 @@ int verify_rlc_on(Context& ctx, int scheme, const void* u, const void* R_uv, con
       HIP_TRY(launch_rlc_buckets(scheme, plan, cv.b, in, key, pok + off, false, s));
       HIP_TRY(launch_rlc_finish(plan, cv.b, ctx.table[0], ctx.table[1], false, s));
     }
+    // what decides the per-signature launches: this stage's flag words, or (guarded) those of a second stage
+    // of sub-group aggregates over the same challenges, with fresh weights, in the first stage's buffers
+    const u32* gflags = cv.b.flags;
+    size_t sub = plan.sub;
+    bool split_fallback = plan.groups > 1;
+    if (G2) {
+      const RlcPlan plan2 = rlc_group_plan(scheme, cnt, window_bits, G2);
+      RlcCarve cv2 = carve_rlc(workspace, group, cnt, plan2);
+      cv2.b.flags = cv2.flags_area + (2 * k + 1) * kRlcGroupFlagWords;
+      ChaChaKey key2;
+      if (int r2 = rlc_random_key(key2)) return r2;
+      HIP_TRY(launch_rlc_begin(cv2.b, s));
+      launch_rlc_chain(cv.b.flags, cv2.b.flags, plan2.groups, s);
+      HIP_TRY(launch_rlc_buckets(scheme, plan2, cv2.b, in, key2, pok + off, false, s));
+      HIP_TRY(launch_rlc_finish(plan2, cv2.b, ctx.table[0], ctx.table[1], false, s));
+      gflags = cv2.b.flags;
+      sub = plan2.sub;
+      split_fallback = false;  // (one gated launch per sub-group on the caller's stream: they are expected to return at once)
+      va.subs[k] = (uint8_t)plan2.groups;
+      va.second[k] = 1;
+      traced[k].plan2 = plan2;
+    }
     // the per-signature kernels, from the challenges already in the workspace (run_split carves it the same
     // way), each launch gated by its sub-group's flag words: no work where the aggregate accepted.
     // ONE sub-group — the steady state, where the aggregate is expected to accept —: one launch over the whole
     // group (sixteen gated sub-batch launches cost 0.05 ms of an accepted call's 5.3; a rejected group loses
     // the few percent the sub-batch split returns, once: the next call runs in sub-groups).
     Context* cp = &ctx;
-    const u32* gflags = cv.b.flags;
-    const size_t sub = plan.sub;
     auto fallback = [=](size_t o, size_t part, const Workspace& w, hipStream_t ps) {
       // (sub-groups are whole sub-batches; an unsplit launch covers one sub-group or is cut here)
       for (size_t done = 0; done < part;) {
@@ -317,7 +361,7 @@ int verify_rlc_on(Context& ctx, int scheme, const void* u, const void* R_uv, con
       }
     };
     int r = DSV_OK;
-    if (plan.groups == 1) {
+    if (!split_fallback) {
       fallback((size_t)0, cnt, cv.w, s);
       HIP_TRY(hipGetLastError());
     } else {
@@ -332,7 +376,7 @@ int verify_rlc_on(Context& ctx, int scheme, const void* u, const void* R_uv, con
   HIP_TRY(hipGetLastError());
   if (trace) {
     HIP_TRY(hipStreamSynchronize(s));
-    std::vector<u32> f(kRlcMaxGroupsPerCall * kRlcGroupFlagWords);
+    std::vector<u32> f(kRlcFlagBlocks * kRlcGroupFlagWords);
     HIP_TRY(hipMemcpy(f.data(), flags_area, f.size() * sizeof(u32), hipMemcpyDeviceToHost));
     for (u32 k = 0; k < va.ngroups; k++) {
       const Traced& t = traced[k];
@@ -341,18 +385,24 @@ int verify_rlc_on(Context& ctx, int scheme, const void* u, const void* R_uv, con
                      t.off, t.off + t.cnt);
         continue;
       }
-      const u32* gf = f.data() + (size_t)k * kRlcGroupFlagWords;
-      if (gf[0])
-        std::fprintf(stderr, "[dsv rlc] scheme %d items %zu..%zu: a wrong item in the sample, no aggregate\n", scheme, t.off,
-                     t.off + t.cnt);
-      for (u32 g = 0; g < va.subs[k] && !gf[0]; g++) {
-        const u32* fl = gf + 4 + 4 * g;
-        const size_t lo = t.off + (size_t)g * t.plan.sub, hi = lo + t.plan.sub < t.off + t.cnt ? lo + t.plan.sub : t.off + t.cnt;
-        std::fprintf(stderr, "[dsv rlc] scheme %d items %zu..%zu c=%d sub-group %u/%u%s (history %u): %s%s%s%s%s\n", scheme, lo, hi,
-                     t.plan.c, g + 1, (u32)va.subs[k], t.sampled ? " sampled" : "", history,
-                     fl[1] == 1 ? "" : "chain incomplete ", fl[0] & kRlcOffCurve ? "off-curve " : "",
-                     fl[0] & kRlcTorsion ? "subgroup-test " : "", fl[0] & kRlcOverflow ? "bin-overflow " : "",
-                     fl[0] & kRlcSum ? "sum " : (fl[0] == 0 && fl[1] == 1 ? "accepted" : ""));
+      for (int stage = 0; stage < (t.plan2.groups ? 2 : 1); stage++) {
+        const RlcPlan& pl = stage ? t.plan2 : t.plan;
+        const u32* gf = f.data() + ((size_t)2 * k + stage) * kRlcGroupFlagWords;
+        if (gf[0] && !stage)
+          std::fprintf(stderr, "[dsv rlc] scheme %d items %zu..%zu: a wrong item in the sample, no aggregate\n", scheme, t.off,
+                       t.off + t.cnt);
+        if (gf[0] && stage)
+          std::fprintf(stderr, "[dsv rlc] scheme %d items %zu..%zu: second stage not needed\n", scheme, t.off, t.off + t.cnt);
+        for (u32 g = 0; g < pl.groups && !gf[0]; g++) {
+          const u32* fl = gf + 4 + 4 * g;
+          const size_t lo = t.off + (size_t)g * pl.sub, hi = lo + pl.sub < t.off + t.cnt ? lo + pl.sub : t.off + t.cnt;
+          std::fprintf(stderr, "[dsv rlc] scheme %d items %zu..%zu c=%d %ssub-group %u/%u%s (history %u / %u): %s%s%s%s%s\n", scheme,
+                       lo, hi, pl.c, t.plan2.groups ? (stage ? "second stage, " : "first stage, ") : "", g + 1, pl.groups,
+                       t.sampled ? " sampled" : "", history, history_long,
+                       fl[1] == 1 ? "" : "chain incomplete ", fl[0] & kRlcOffCurve ? "off-curve " : "",
+                       fl[0] & kRlcTorsion ? "subgroup-test " : "", fl[0] & kRlcOverflow ? "bin-overflow " : "",
+                       fl[0] & kRlcSum ? "sum " : (fl[0] == 0 && fl[1] == 1 ? "accepted" : ""));
+        }
       }
     }
   }
@@ -410,6 +460,16 @@ int dsv_debug_rlc_history(int device, int set) {
   const int h = rlc_history(ctx);
   if (h < 0) return DSV_ERR_HIP;
   if (set >= 0) *reinterpret_cast<volatile u32*>(ctx.rlc_pinned) = (u32)set;
+  return h;
+}
+int dsv_debug_rlc_history_long(int device, int set) {
+  if (device < 0 || device >= kMaxDevices || !g_ctx[device].ready.load(std::memory_order_acquire))
+    return fail(DSV_ERR_NOT_INITIALIZED, "device %d is not initialised", device);
+  Context& ctx = g_ctx[device];
+  DSV_ON_DEVICE(ctx);
+  if (rlc_history(ctx) < 0) return DSV_ERR_HIP;
+  const int h = (int)*reinterpret_cast<volatile u32*>(ctx.rlc_pinned + 2);
+  if (set >= 0) *reinterpret_cast<volatile u32*>(ctx.rlc_pinned + 2) = (u32)set;
   return h;
 }
 int dsv_debug_rlc_subgroups(int groups) {

@@ -940,7 +940,7 @@ __global__ void k_rlc_verdict(const u32* __restrict__ flags, RlcVerdictArgs a, u
   if (threadIdx.x || blockIdx.x) return;
   bool all = true, rejected = false, any = false;
   for (u32 k = 0; k < a.ngroups; k++) {
-    const u32* f = flags + (size_t)k * kRlcGroupFlagWords;
+    const u32* f = flags + ((size_t)2 * k + a.second[k]) * kRlcGroupFlagWords;
     for (u32 g = 0; g < a.subs[k]; g++) {
       const bool acc = f[4 + 4 * g] == 0u && f[4 + 4 * g + 1] == 1u;
       rejected |= !acc;
@@ -952,13 +952,25 @@ __global__ void k_rlc_verdict(const u32* __restrict__ flags, RlcVerdictArgs a, u
   if (accepted) *accepted = (all && (!a.and_into || *accepted != 0u)) ? 1u : 0u;
   if (history) {
     const u32 h = history[0];
-    if (rejected) history[0] = 8u;
-    else if (any && h > 0) history[0] = h - 1;
+    const u32 h2 = history[2];
+    if (rejected) history[0] = 8u, history[2] = 128u;
+    else if (any) history[0] = h > 0 ? h - 1 : 0u, history[2] = h2 > 0 ? h2 - 1 : 0u;
     history[1] += 1u;
   }
 }
 
+__global__ void k_rlc_chain(const u32* __restrict__ first, u32* __restrict__ second, u32 subs) {
+  if (threadIdx.x || blockIdx.x) return;
+  if (first[0] == 0u && first[4] == 0u && first[5] == 1u) {  // (no sample in a guarded call; one sub-group in the first stage)
+    second[0] = 1u;
+    for (u32 g = 0; g < subs; g++) second[4 + 4 * g + 1] = 1u;
+  }
+}
+
 // ---- host side ----------------------------------------------------------------------------------------
+void launch_rlc_chain(const uint32_t* first, uint32_t* second, uint32_t subs, hipStream_t s) {
+  hipLaunchKernelGGL(k_rlc_chain, dim3(1), dim3(64), 0, s, first, second, subs);
+}
 void launch_rlc_sample_decide(const uint8_t* sample_ok, const uint8_t* valid, const uint8_t* u, const uint8_t* pk0,
                               const uint8_t* pk1, size_t first, size_t count, uint32_t* flags, hipStream_t s) {
   if (!count) return;

@@ -63,6 +63,9 @@ enum : uint32_t { kRlcOffCurve = 1, kRlcTorsion = 2, kRlcSum = 4, kRlcOverflow =
 // 4 + 4 g .. the flags of sub-group g
 constexpr int kRlcGroupFlagWords = 4 + 4 * kRlcMaxSub;
 constexpr size_t kRlcMaxGroupsPerCall = 64;  // DSV_MAX_BATCH / kRlcMaxGroup
+// a group owns TWO flag blocks: [2k] its aggregate(s), [2k + 1] the sub-group aggregates of a second stage that
+// runs only where the first one rejected (dsv_rlc.hip: "guarded" calls)
+constexpr size_t kRlcFlagBlocks = 2 * kRlcMaxGroupsPerCall;
 inline int rlc_default_bits(size_t n) {
   return n >= ((size_t)1 << 19) ? 16 : n >= ((size_t)1 << 17) ? 14 : n >= ((size_t)1 << 14) ? 12 : 8;
 }
@@ -185,13 +188,18 @@ void launch_rlc_sample_decide(const uint8_t* sample_ok, const uint8_t* valid, co
                               const uint8_t* pk1, size_t first, size_t count, uint32_t* flags, hipStream_t s);
 // The call's verdict from the flag blocks of its groups (kRlcGroupFlagWords apart): *accepted = every
 // sub-group of every group accepted (device-accessible memory, may be null); `history` (may be null; pinned
-// host memory the context owns): [0] = 8 after a call with a rejected sub-group, one less (not below 0) after
-// a call whose aggregates all accepted, unchanged if the call ran none; [1] += 1.
+// host memory the context owns): [0] = 8 and [2] = 128 after a call with a rejected sub-group, one less each (not
+// below 0) after a call whose aggregates all accepted, unchanged if the call ran none; [1] += 1.
 struct RlcVerdictArgs {
   uint32_t ngroups;
-  uint32_t and_into;                   // *accepted &= ... (the second kind of a mixed batch)
-  uint8_t subs[kRlcMaxGroupsPerCall];  // sub-groups of each group; 0: the group took the per-signature path as it is
+  uint32_t and_into;                     // *accepted &= ... (the second kind of a mixed batch)
+  uint8_t subs[kRlcMaxGroupsPerCall];    // sub-groups of each group's DECISIVE stage; 0: the group took the per-signature path as it is
+  uint8_t second[kRlcMaxGroupsPerCall];  // 1: the decisive flag block is the group's second one
 };
 void launch_rlc_verdict(const uint32_t* flags, RlcVerdictArgs a, uint32_t* accepted, uint32_t* history, hipStream_t s);
+// Between the two stages of a guarded group: if the first stage's (single) aggregate ACCEPTED, mark the second
+// stage's block "skip" and its `subs` sub-groups accepted — its kernels and the per-signature launches gated by
+// it then return at once; else leave it zeroed: the second stage runs.  One thread; `second` zeroed beforehand.
+void launch_rlc_chain(const uint32_t* first, uint32_t* second, uint32_t subs, hipStream_t s);
 
 }  // namespace dsv

@@ -600,6 +600,14 @@ def rlc_history(device=0, set_to=-1):
     return r
 
 
+def rlc_history_long(device=0, set_to=-1):
+    """dsv_debug_rlc_history_long: the slow counter behind "guarded" calls; returns the value before the call"""
+    r = _lib.load().dsv_debug_rlc_history_long(ctypes.c_int(device), ctypes.c_int(set_to))
+    if r < 0:
+        _lib.check(r)
+    return r
+
+
 def rlc_subgroups(groups=-1):
     """dsv_debug_rlc_subgroups: force `groups` sub-groups per group (0: automatic); returns the previous setting"""
     return int(_lib.load().dsv_debug_rlc_subgroups(ctypes.c_int(groups)))

@@ -316,3 +316,81 @@ def test_device_calls_from_several_threads_and_streams(engine):
         th.join()
     assert not errors, errors
     engine.rlc_history(0, 1)
+
+
+@pytest.mark.parametrize("scheme", ["single", "double", "vargen"])
+def test_guarded_groups(engine, scheme):
+    """history 0, long history > 0 ("batches fail now and then"): one aggregate plus a second stage of sub-group
+    aggregates that runs only where the first rejected.  Verdicts = the oracle's; `accepted` and both counters
+    follow the decisive stage."""
+    n = 5000 + 13
+    d = _signed(n, 670, scheme)
+    bad = {k: v.copy() for k, v in d.items()}
+    bad["u"][n - 7, 11] ^= 0x04
+    want = _oracle(bad, scheme)
+    assert want.sum() == n - 1
+    engine.rlc_history(0, 0)
+    engine.rlc_history_long(0, 20)
+    engine.rlc_subgroups(5)       # (the second stage's sub-groups; the first stage is one aggregate)
+    acc, ok = _run(engine, d, scheme, 8)
+    assert acc and ok.all()
+    assert engine.rlc_history(0) == 0 and engine.rlc_history_long(0) == 19
+    acc, ok = _run(engine, bad, scheme, 8)
+    assert not acc and np.array_equal(ok, want)
+    assert engine.rlc_history(0) == 8 and engine.rlc_history_long(0) == 128
+    # tampered throughout, guarded again
+    engine.rlc_history(0, 0)
+    a = {k: v.copy() for k, v in d.items()}
+    H.tamper(a, period=13)
+    want = _oracle(a, scheme)
+    acc, ok = _run(engine, a, scheme, 12)
+    assert not acc and np.array_equal(ok, want)
+    engine.rlc_subgroups(0)
+    engine.rlc_history(0, 1)
+    engine.rlc_history_long(0, 0)
+
+
+def test_guarded_second_stage_runs_only_after_a_reject():
+    """seen through DSV_RLC_TRACE: a valid batch -> first stage accepted, second stage not needed; one wrong item ->
+    first stage rejected ("sum"), the second stage's sub-groups all accepted but the one that holds it"""
+    code = r"""
+import sys
+sys.path.insert(0, "tests")
+import numpy as np, torch
+import oracle_lib as O
+from schnorr_amd import engine as E
+E.init(0)
+n = 4000
+d = O.keygen_sign_single(n, 671, nthreads=8)
+cols = ("u", "R", "PK", "m")
+ok = torch.zeros(n, dtype=torch.uint8, device="cuda:0")
+ws = torch.empty(E.rlc_workspace_bytes(n, 8), dtype=torch.uint8, device="cuda:0")
+E.rlc_subgroups(4)
+for label, victim in (("valid", None), ("one", 3100)):
+    a = {k: d[k].copy() for k in cols}
+    if victim is not None:
+        a["m"][victim, 0] ^= 1
+    E.rlc_history(0, 0); E.rlc_history_long(0, 32)
+    sys.stderr.write("CALL %s\n" % label); sys.stderr.flush()
+    t = [torch.from_numpy(np.ascontiguousarray(a[k])).to("cuda:0") for k in cols]
+    acc = E.verify_single_rlc_dev(*t, ok, ws, window_bits=8)
+    want = np.ones(n, np.uint8)
+    if victim is not None:
+        want[victim] = 0
+    assert acc == (victim is None) and np.array_equal(ok.cpu().numpy(), want)
+print("done")
+"""
+    env = dict(os.environ, DSV_RLC_TRACE="1")
+    r = subprocess.run([sys.executable, "-c", code], cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, (r.stdout[-800:], r.stderr[-2000:])
+    calls, cur = {}, None
+    for line in r.stderr.splitlines():
+        if line.startswith("CALL "):
+            cur = line[5:]
+            calls[cur] = []
+        elif "[dsv rlc]" in line and cur:
+            calls[cur].append(line)
+    assert any("first stage" in x and "accepted" in x for x in calls["valid"]) and any("not needed" in x for x in calls["valid"])
+    assert any("first stage" in x and " sum" in x for x in calls["one"])
+    second = [x for x in calls["one"] if "second stage" in x]
+    assert len(second) == 4 and sum("accepted" in x for x in second) == 3 and sum(" sum" in x for x in second) == 1, second

@@ -5,8 +5,10 @@
 
 Workloads (verdicts checked against the construction-time pattern every time):
   all valid          steady state of a caller whose batches are valid: one aggregate per group decides
+  all valid, guarded the same for a caller whose batches fail now and then: a second stage is enqueued and switched off
   all valid, split   the same while the device's history says "batches fail": sub-groups + sample
-  one wrong, first   ONE wrong signature, history 0 (the first such batch): whole-group fallback
+  one wrong, unguarded  ONE wrong signature for a caller that never saw one: whole-group fallback
+  one wrong, guarded    ... the first one after a run of valid batches: the second stage localises it
   one wrong, split   ONE wrong signature while the history says so: only its sub-group takes the fallback
   1/16 tampered      the graded workload (wrong items throughout): the sample skips the aggregates
 The calls are enqueue-only (accepted comes back through a pinned word); the timing loop synchronises
@@ -64,9 +66,13 @@ best0, med0 = timed(lambda: plain(*[good[k] for k in COLS], ok, ws))
 assert torch.equal(ok, good["expected"])
 print("%s n=2^%d bits=%d per-signature path          %.3f ms (median %.3f) = %.1f M/s" % (
     scheme, n.bit_length() - 1, bits, best0, med0, n / best0 / 1e3), flush=True)
-for label, b, history, expect in (("all valid", good, 0, big), ("all valid, split", good, 8, big),
-                                  ("one wrong, first", one, 0, False), ("one wrong, split", one, 8, False),
-                                  ("1/16 tampered", graded, 8, False)):
+# (history, long history): (0, 0) steady state of a caller whose batches never fail; (0, 128) "guarded": batches
+# fail now and then; (8, 128) "split": one failed within the last eight calls
+for label, b, history, expect in (("all valid", good, (0, 0), big), ("all valid, guarded", good, (0, 128), big),
+                                  ("all valid, split", good, (8, 128), big),
+                                  ("one wrong, unguarded", one, (0, 0), False), ("one wrong, guarded", one, (0, 128), False),
+                                  ("one wrong, split", one, (8, 128), False),
+                                  ("1/16 tampered", graded, (8, 128), False)):
     cols = [b[k] for k in COLS]
     accs = []
 
@@ -80,7 +86,8 @@ for label, b, history, expect in (("all valid", good, 0, big), ("all valid, spli
     ok.zero_()
     ts = []
     for _ in range(reps + 1):
-        E.rlc_history(0, history)
+        E.rlc_history(0, history[0])
+        E.rlc_history_long(0, history[1])
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         call()
@@ -91,5 +98,5 @@ for label, b, history, expect in (("all valid", good, 0, big), ("all valid, spli
     ts = sorted(ts[1:])
     assert all(a == int(expect) for a in accs), (label, accs)
     best, med = ts[0], ts[len(ts) // 2]
-    print("%s n=2^%d bits=%d %-18s rlc %.3f ms (median %.3f) = %.1f M/s | x%.2f the per-signature path" % (
+    print("%s n=2^%d bits=%d %-21s rlc %.3f ms (median %.3f) = %.1f M/s | x%.2f the per-signature path" % (
         scheme, n.bit_length() - 1, bits, label, best, med, n / best / 1e3, best0 / best), flush=True)
