@@ -28,6 +28,10 @@ for path in sys.argv[1:]:
             r["all_valid"]["value"] / 1e6, r["all_valid"]["vs_per_signature"],
             r.get("double_all_valid", {}).get("value", 0) / 1e6, r.get("vargen_all_valid", {}).get("value", 0) / 1e6,
             r["graded_workload"]["value"] / 1e6, r["graded_workload"]["vs_per_signature"]))
+        ob = lambda k: "%.2f ms x%.2f" % (r[k]["ms_per_call"], r[k]["vs_per_signature"]) if k in r else "-"
+        print("    one wrong signature in the batch: failed within 8 calls %s | within 128 calls (guarded) %s | never before %s | two streams, all valid %.1f M/s" % (
+            ob("one_bad_in_batch"), ob("one_bad_first_in_a_while"), ob("one_bad_never_seen_before"),
+            r["all_valid"].get("two_streams", {}).get("value", 0) / 1e6))
         print("    typed objects %.1f M/s (two in flight %.1f)  wire records %.1f M/s in HBM, %.1f M/s from host memory" % (
             f.get("all_valid", {}).get("value", 0) / 1e6, f.get("all_valid_two_in_flight", {}).get("value", 0) / 1e6,
             w.get("fast_accept_all_valid", {}).get("value", 0) / 1e6,

@@ -16,7 +16,8 @@ Rust structs, Montgomery limbs, random z, planted encodings the types cannot hol
 tampered -> not accepted; its valid + malformed items alone -> accepted.  Every eighth round: the batch as
 serialized records in host memory (dsv_verify_*_wire_rlc) against the oracle's from_bytes + verify.
 r06: every round also draws the sub-group count (automatic, or 1 .. 16 forced: dsv_debug_rlc_subgroups) and the
-device's history counter (0: one sub-group, no sample; 8: sub-groups + the sample check), and every third
+device's history counters (short 0: one sub-group, no sample; 8: sub-groups + the sample check; long 128 with short 0:
+guarded groups, a gated second stage of sub-group aggregates), and every third
 device-pointer round takes `accepted` through a pinned word (the enqueue-only form) instead of a host int.
 Verdicts always equal the oracle's (the oracle is test infrastructure; nothing here is timed)."""
 import os
@@ -51,8 +52,10 @@ for rd in range(rounds):
     n = int(SIZES[int(rng.integers(0, len(SIZES)))])
     forced = int((0, 0, 0, 1, 2, 3, 4, 8, 16)[int(rng.integers(0, 9))])
     hist = int((0, 8)[int(rng.integers(0, 2))])
+    hist_long = int((0, 128)[int(rng.integers(0, 2))])   # (with hist 0: "guarded" groups, a gated second stage)
     E.rlc_subgroups(forced)
     E.rlc_history(0, hist)
+    E.rlc_history_long(0, hist_long)
     if rd % 4 == 3:
         cols, want = C.mont_case(scheme, 300, int(rng.integers(1, 1 << 30)), period=int(rng.integers(4, 40)))
         tamper_free = bool(rng.integers(0, 2))
@@ -162,11 +165,12 @@ for rd in range(rounds):
     wrong_accept = accepted != expect_accept
     total += n
     bad += diff + (1 if wrong_accept else 0)
-    print("round %d: %s n=%d bits=%d sub-groups=%s history=%d %-9s accepted=%d valid=%d/%d%s  (%.0f s)" % (
-        rd, scheme, n, bits, forced or "auto", hist, kind, accepted, int(twant.sum()), n,
+    print("round %d: %s n=%d bits=%d sub-groups=%s history=%d/%d %-9s accepted=%d valid=%d/%d%s  (%.0f s)" % (
+        rd, scheme, n, bits, forced or "auto", hist, hist_long, kind, accepted, int(twant.sum()), n,
         "  DIFFERENT: %d verdicts%s" % (diff, ", acceptance" if wrong_accept else "") if diff or wrong_accept else "",
         time.time() - t0), flush=True)
     del ws, ok, t
 E.rlc_subgroups(0)
+E.rlc_history_long(0, 0)
 print("soak_rlc: %d verdicts compared with the oracle, %d different / wrongly accepted" % (total, bad))
 sys.exit(1 if bad else 0)
