@@ -297,9 +297,9 @@ int dsv_verify_vargen_dev(const void *u, const void *R_uv, const void *PK_uv, co
  * Failure localisation.  A rejected group costs both paths, so the library adapts per device: a counter
  * kept by the device itself (8 after a call that held a rejected aggregate, one less after a call whose
  * aggregates all accepted, 1 after dsv_init; the host reads it without waiting, possibly one call late)
- * decides how the NEXT calls run.  While it is > 0 a group is cut into sub-groups of ~2^18 items that
- * share the hash and one set of launches, each with its own aggregate — one wrong signature in 2^20 then
- * sends 2^18 items to the per-signature kernels, not 2^20 —, and 1024 consecutive items at a position
+ * decides how the NEXT calls run.  While it is > 0 a group is cut into up to 16 sub-groups of >= 2^16 items
+ * that share the hash and one set of launches, each with its own aggregate — one wrong signature in 2^20
+ * then sends 2^16 items to the per-signature kernels, not 2^20 —, and 1024 consecutive items at a position
  * drawn from the call's secret key are verified first: a wrong one among them skips the aggregates
  * altogether (a batch tampered with throughout pays hash + sample + per-signature path; a heuristic,
  * DSV_RLC_SAMPLE=0 switches it off, DSV_RLC_SUB_LOG2 / DSV_RLC_SUBGROUPS tune / force the sub-groups).

@@ -22,7 +22,7 @@ extern "C" {
 //
 // Failure localisation (SURVEY's "bisect on failure", done the way this chip allows): not sequential
 // halving — every level would pay the aggregate's latency-bound tail again — but sub-groups UP FRONT while
-// the device's recent calls give reason to: a group is cut into 2^k sub-groups of ~2^18 items that share
+// the device's recent calls give reason to: a group is cut into up to 16 sub-groups of >= 2^16 items that share
 // the hash pass and ONE set of launches (blockIdx.y = sub-group), so the tail is paid once; only a
 // failing sub-group's per-signature kernels do any work.  "Reason to" is a counter in pinned host memory
 // that the verdict kernel itself maintains (8 after a call with a rejected sub-group, one less after an
@@ -108,11 +108,11 @@ size_t rlc_group_items(size_t n) {
   return (n + groups - 1) / groups;
 }
 // sub-groups a group of cnt items is cut into while the history says "batches fail": sub-groups of
-// 2^17 items (DSV_RLC_SUB_LOG2; measured: 2^20 items with one wrong signature 7.2 ms in eight sub-groups, 8.1 in four, 10.8 in two), at least two from 2^18 items on, at most kRlcMaxSub
+// 2^16 items (DSV_RLC_SUB_LOG2; measured, 2^20 items with one wrong signature: 6.5 ms in sixteen sub-groups, 7.1 in eight, 8.1 in four, 10.8 in two; 2^18 items: 2.96 ms in four, 3.48 in two), at least two from 2^18 items on, at most kRlcMaxSub
 int rlc_split_groups(size_t cnt, int window_bits) {
   static const int sub_log2 = [] {
     const char* e = getenv("DSV_RLC_SUB_LOG2");
-    const int v = e ? atoi(e) : 17;
+    const int v = e ? atoi(e) : 16;
     return v < 10 ? 10 : (v > 22 ? 22 : v);
   }();
   size_t g = cnt >> sub_log2;
