@@ -304,8 +304,9 @@ int dsv_verify_vargen_dev(const void *u, const void *R_uv, const void *PK_uv, co
  * altogether (a batch tampered with throughout pays hash + sample + per-signature path; a heuristic,
  * DSV_RLC_SAMPLE=0 switches it off, DSV_RLC_SUB_LOG2 / DSV_RLC_SUBGROUPS tune / force the sub-groups).
  * A caller whose batches are valid runs one aggregate per group and nothing else.
- * window_bits: 0 = chosen from n — and groups below 2^17 items, where an aggregate does not pay, go
- * straight to the per-signature kernels —, else one of 4, 6, 8, 12, 14, 16 (bucket windows; tests).
+ * window_bits: 0 = chosen from n — and groups below 2^17 items (single signatures; double and
+ * var-generator batches: below 2^14), where an aggregate does not pay, go straight to the per-signature
+ * kernels —, else one of 4, 6, 8, 12, 14, 16 (bucket windows; tests).
  * accepted (may be NULL): receives 1 if every group was decided by its aggregates, else 0.  If it points
  * to memory the device can write — device memory, or host memory from hipHostMalloc / hipHostRegister —
  * it is written by a kernel when `stream` gets there and the call does not block; if it is ordinary
