@@ -312,7 +312,10 @@ int dsv_verify_vargen_dev(const void *u, const void *R_uv, const void *PK_uv, co
  * it is written by a kernel when `stream` gets there and the call does not block; if it is ordinary
  * host memory the call waits for `stream` at its end and stores the value itself.
  * workspace: dsv_rlc_workspace_bytes(n, window_bits) device bytes, 256-byte aligned (never less for a
- * larger n: a workspace sized for n serves any smaller batch). */
+ * larger n: a workspace sized for n serves any smaller batch).
+ * Do NOT capture these calls into a hipGraph: the 32-byte weight key is drawn on the host (getrandom) per
+ * call and passed by value — a replayed graph would reuse it, and predictable weights void the soundness
+ * of the aggregate (the per-signature entry points have no such state and may be captured). */
 size_t dsv_rlc_workspace_bytes(size_t n, int window_bits);
 /* geometry of one group's aggregate (tests, sizing; works without a GPU): scheme 0 single / 1 double /
  * 2 var-generator, `groups` sub-groups (0 or 1: one); out[24] = window bits c, c/2, key windows, nonce
