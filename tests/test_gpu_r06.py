@@ -272,7 +272,15 @@ def test_two_groups_in_sub_groups(engine):
     engine.rlc_history(0, 8)
     assert not engine.verify_single_rlc_dev(b["u"], b["R"], b["PK"], b["m"], ok, ws)
     assert torch.equal(ok, want)
+    # the same two groups guarded: each runs its single aggregate, then (rejected) its second stage
+    ok.zero_()
+    engine.rlc_history(0, 0)
+    engine.rlc_history_long(0, 100)
+    assert not engine.verify_single_rlc_dev(b["u"], b["R"], b["PK"], b["m"], ok, ws)
+    assert torch.equal(ok, want)
+    assert engine.rlc_history(0) == 8 and engine.rlc_history_long(0) == 128
     engine.rlc_history(0, 1)
+    engine.rlc_history_long(0, 0)
 
 
 def test_device_calls_from_several_threads_and_streams(engine):

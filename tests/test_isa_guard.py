@@ -140,7 +140,7 @@ def test_batch_fast_accept_kernels_stay_in_registers(isa):
     that the compiler turned into a scratch array indexed by the wave number (1.45 ms instead of 0.57) —
     and the bucket accumulation keeps four waves per SIMD."""
     info = {k: v for k, v in isa["info"]["rlc"].items() if "k_rlc_" in k}
-    assert len(info) >= 12, sorted(info)          # prep x 3, fsum, starts, counts, accumulate, sum x 4, scale, final
+    assert len(info) >= 16, sorted(info)          # prep x 3, part1, part2, lenhist, order, accumulate, merge, sum x 4, scale, sample_decide, verdict, chain
     for name, k in info.items():
         assert k["scratch"] == 0 and k["vgpr_spill_count"] == 0, (name, k)
     acc = _find(info, "k_rlc_accumulate")
