@@ -102,8 +102,8 @@ def test_workspace_size_never_drops_with_the_batch_size():
 
 
 def test_default_window_widths_follow_the_batch_size():
-    assert [E.rlc_plan_info("single", n)["c"] for n in (100, (1 << 14) - 1, 1 << 14, 1 << 17, 1 << 19, 1 << 22)] == \
-        [8, 8, 12, 14, 16, 16]
+    assert [E.rlc_plan_info("single", n)["c"] for n in (100, (1 << 14) - 1, 1 << 14, 1 << 17, 1 << 19, 1 << 20, 1 << 22)] == \
+        [8, 8, 12, 14, 14, 16, 16]
 
 
 def test_plan_argument_checks():
