@@ -402,3 +402,26 @@ print("done")
     assert any("first stage" in x and " sum" in x for x in calls["one"])
     second = [x for x in calls["one"] if "second stage" in x]
     assert len(second) == 4 and sum("accepted" in x for x in second) == 3 and sum(" sum" in x for x in second) == 1, second
+
+
+def test_tiny_and_empty_batches_through_the_fast_accept(engine, forced_groups):
+    """n = 0 (nothing enqueued, `accepted` cleared wherever it lives), n = 1 .. 5 with more sub-groups asked for than
+    there are items, explicit window bits: the oracle's verdicts"""
+    d = _signed(5, 680)
+    t_all = {k: torch.from_numpy(np.ascontiguousarray(d[k])).to(DEV) for k in COLS["single"]}
+    ws = torch.empty(engine.rlc_workspace_bytes(8, 8), dtype=torch.uint8, device=DEV)
+    ok = torch.zeros(8, dtype=torch.uint8, device=DEV)
+    for word in (torch.full((1,), 7, dtype=torch.int32).pin_memory(), torch.full((1,), 7, dtype=torch.int32, device=DEV)):
+        empty = [t_all[k][:0] for k in COLS["single"]]
+        assert engine.verify_single_rlc_dev(*empty, ok[:0], ws, window_bits=8, accepted_out=word) is None
+        torch.cuda.synchronize()
+        assert int(word.cpu()[0]) == 0
+    assert engine.verify_single_rlc_dev(*[t_all[k][:0] for k in COLS["single"]], ok[:0], ws, window_bits=8) is False
+    forced_groups(16)
+    for n in (1, 2, 3, 5):
+        cut = {k: d[k][:n].copy() for k in COLS["single"]}
+        acc, got = _run(engine, cut, "single", 8)
+        assert acc and got.all(), n
+        cut["u"][n - 1, 0] ^= 1
+        acc, got = _run(engine, cut, "single", 8)
+        assert not acc and np.array_equal(got, _oracle(cut, "single")), n
