@@ -201,33 +201,137 @@ int rlc_verdict_wait(const RlcVerdictTarget& t, hipStream_t s) {
   *t.out = (int)*reinterpret_cast<volatile u32*>(t.slot);
   return DSV_OK;
 }
-// scheme 0 single (R, PK), 1 double (R, R', PK, PK'), 2 var-generator (R, PK, Gen): unused pointers null.
+}  // namespace dsvh
+namespace {
+// one call's arguments, as the pieces below need them
+struct RlcCall {
+  Context& ctx;
+  int scheme;  // 0 single (R, PK), 1 double (R, R', PK, PK'), 2 var-generator (R, PK, Gen): unused pointers null
+  const uint8_t *u, *R, *Rp, *PK, *PKp, *G, *m;
+  uint8_t* ok;
+  void* workspace;
+  hipStream_t s;
+};
+struct RlcTraced {  // what DSV_RLC_TRACE reports about one group
+  size_t off, cnt;
+  RlcPlan plan, plan2;  // plan2.groups != 0: the second stage of a guarded group
+  bool sampled;
+};
+// the sample check of the group at `off`: kRlcSample consecutive items at a position drawn from the key through
+// the per-signature kernel, then the one-wave decision into the group's flag block
+void rlc_enqueue_sample(const RlcCall& c, const RlcCarve& cv, const ChaChaKey& key, size_t off, size_t cnt) {
+  // (beside the hash on a stream of its own it costs MORE — 0.4 ms: a small kernel next to one that fills
+  //  the chip — than in line behind it: 0.26 ms)
+  const size_t sn = cnt < kRlcSample ? cnt : kRlcSample;
+  const size_t at = off + (size_t)(key.w[7] % (u32)((cnt - sn) / 64 + 1)) * 64;  // (the key's last word: no weight uses it)
+  const size_t rel = at - off;
+  u32* tables = carve(cv.sample_ws, sn).tables;
+  if (c.scheme == 0)
+    launch_verify_fixed(c.ctx, false, c.u + 32 * at, cv.w.c + 32 * rel, c.PK + 64 * at, c.R + 64 * at, 0, cv.w.valid + rel, sn,
+                        cv.sample_ok, tables, c.s);
+  else if (c.scheme == 1)
+    launch_verify_fixed_double(c.ctx, c.u + 32 * at, cv.w.c + 32 * rel, c.PK + 64 * at, c.R + 64 * at, c.PKp + 64 * at,
+                               c.Rp + 64 * at, cv.w.valid + rel, sn, cv.sample_ok, tables, c.s);
+  else  // (one lane per signature beyond 2^13 items, sixteen below: ~0.4 ms for the sample)
+    launch_verify_var(c.u + 32 * at, cv.w.c + 32 * rel, c.PK + 64 * at, c.G + 64 * at, c.R + 64 * at, cv.w.valid + rel, sn,
+                      cv.sample_ok, tables, c.s);
+  // a WRONG item counts, a malformed one does not (`valid` covers what the hash reads — R, R', m; u and
+  // the keys are range-checked here as the verify kernel does)
+  launch_rlc_sample_decide(cv.sample_ok, cv.w.valid + rel, c.u + 32 * at, c.PK + 64 * at,
+                           c.scheme == 0 ? (const uint8_t*)nullptr : (c.scheme == 1 ? c.PKp : c.G) + 64 * at, 0, sn, cv.b.flags,
+                           c.s);
+}
+// The per-signature kernels of the group at `off`, from the challenges already in the workspace (run_split
+// carves it the same way), each launch gated by its sub-group's flag words in `gflags`: no work where the
+// aggregate accepted.  split: sub-batches alternating between the two internal streams (what a rejected
+// sub-group wants); else one launch per sub-group on the caller's stream (what launches that are expected to
+// return at once want: sixteen gated sub-batch launches cost 0.05 ms of an accepted call's 5.3).
+int rlc_enqueue_fallback(const RlcCall& c, const Workspace& w0, const u32* gflags, size_t sub, bool split, size_t off,
+                         size_t cnt) {
+  Context* cp = &c.ctx;
+  const RlcCall call = c;
+  auto fallback = [=](size_t o, size_t part, const Workspace& w, hipStream_t ps) {
+    // (sub-groups are whole sub-batches; an unsplit launch covers one sub-group or is cut here)
+    for (size_t done = 0; done < part;) {
+      const size_t at = off + o + done, g = (o + done) / sub;
+      size_t take = (g + 1) * sub - (o + done);
+      if (take > part - done) take = part - done;
+      const u32* gate = gflags + 4 + 4 * g;
+      if (call.scheme == 0)
+        launch_verify_fixed(*cp, false, call.u + 32 * at, w.c + 32 * done, call.PK + 64 * at, call.R + 64 * at, 0, w.valid + done,
+                            take, call.ok + at, w.tables, ps, false, gate);
+      else if (call.scheme == 1)
+        launch_verify_fixed_double(*cp, call.u + 32 * at, w.c + 32 * done, call.PK + 64 * at, call.R + 64 * at,
+                                   call.PKp + 64 * at, call.Rp + 64 * at, w.valid + done, take, call.ok + at, w.tables, ps, false,
+                                   gate);
+      else
+        launch_verify_var(call.u + 32 * at, (const uint8_t*)w.c + 32 * done, call.PK + 64 * at, call.G + 64 * at,
+                          call.R + 64 * at, (const uint8_t*)w.valid + done, take, call.ok + at, w.tables, ps, gate);
+      done += take;
+    }
+  };
+  if (split) return run_split(c.ctx, cnt, c.workspace, c.s, fallback);
+  fallback((size_t)0, cnt, w0, c.s);
+  HIP_TRY(hipGetLastError());
+  return DSV_OK;
+}
+// DSV_RLC_TRACE: waits for the stream and prints, per group, stage and sub-group, why it was (not) accepted
+int rlc_trace(const RlcCall& c, const u32* flags_area, const RlcVerdictArgs& va, const RlcTraced* traced, u32 history,
+              u32 history_long) {
+  HIP_TRY(hipStreamSynchronize(c.s));
+  std::vector<u32> f(kRlcFlagBlocks * kRlcGroupFlagWords);
+  HIP_TRY(hipMemcpy(f.data(), flags_area, f.size() * sizeof(u32), hipMemcpyDeviceToHost));
+  for (u32 k = 0; k < va.ngroups; k++) {
+    const RlcTraced& t = traced[k];
+    if (!va.subs[k]) {
+      std::fprintf(stderr, "[dsv rlc] scheme %d items %zu..%zu: too small for an aggregate, per-signature path\n", c.scheme,
+                   t.off, t.off + t.cnt);
+      continue;
+    }
+    for (int stage = 0; stage < (t.plan2.groups ? 2 : 1); stage++) {
+      const RlcPlan& pl = stage ? t.plan2 : t.plan;
+      const u32* gf = f.data() + ((size_t)2 * k + stage) * kRlcGroupFlagWords;
+      if (gf[0] && !stage)
+        std::fprintf(stderr, "[dsv rlc] scheme %d items %zu..%zu: a wrong item in the sample, no aggregate\n", c.scheme, t.off,
+                     t.off + t.cnt);
+      if (gf[0] && stage)
+        std::fprintf(stderr, "[dsv rlc] scheme %d items %zu..%zu: second stage not needed\n", c.scheme, t.off, t.off + t.cnt);
+      for (u32 g = 0; g < pl.groups && !gf[0]; g++) {
+        const u32* fl = gf + 4 + 4 * g;
+        const size_t lo = t.off + (size_t)g * pl.sub, hi = lo + pl.sub < t.off + t.cnt ? lo + pl.sub : t.off + t.cnt;
+        std::fprintf(stderr, "[dsv rlc] scheme %d items %zu..%zu c=%d %ssub-group %u/%u%s (history %u / %u): %s%s%s%s%s\n", c.scheme,
+                     lo, hi, pl.c, t.plan2.groups ? (stage ? "second stage, " : "first stage, ") : "", g + 1, pl.groups,
+                     t.sampled ? " sampled" : "", history, history_long,
+                     fl[1] == 1 ? "" : "chain incomplete ", fl[0] & kRlcOffCurve ? "off-curve " : "",
+                     fl[0] & kRlcTorsion ? "subgroup-test " : "", fl[0] & kRlcOverflow ? "bin-overflow " : "",
+                     fl[0] & kRlcSum ? "sum " : (fl[0] == 0 && fl[1] == 1 ? "accepted" : ""));
+      }
+    }
+  }
+  return DSV_OK;
+}
+}  // namespace
+namespace dsvh {
 // Enqueues everything on `s` and returns; *accepted_dev (device-accessible, may be null) = every group was
 // decided by its aggregates (and_into: ... AND what the word held: the second kind of a mixed batch).
 int verify_rlc_on(Context& ctx, int scheme, const void* u, const void* R_uv, const void* Rp_uv, const void* PK_uv,
                   const void* PKp_uv, const void* Gen_uv, const void* m, size_t n, void* ok, void* workspace,
                   hipStream_t s, int window_bits, u32* accepted_dev, bool and_into, bool have_challenges,
                   const uint8_t* valid_in, const RlcStaged* staged) {
-  const uint8_t *pu = (const uint8_t*)u, *pR = (const uint8_t*)R_uv, *pRp = (const uint8_t*)Rp_uv,
-                *pPK = (const uint8_t*)PK_uv, *pPKp = (const uint8_t*)PKp_uv, *pG = (const uint8_t*)Gen_uv,
-                *pm = (const uint8_t*)m;
-  uint8_t* pok = (uint8_t*)ok;
+  const RlcCall c{ctx, scheme, (const uint8_t*)u, (const uint8_t*)R_uv, (const uint8_t*)Rp_uv, (const uint8_t*)PK_uv,
+                  (const uint8_t*)PKp_uv, (const uint8_t*)Gen_uv, (const uint8_t*)m, (uint8_t*)ok, workspace, s};
   if (int r = ensure_rlc_pinned(ctx)) return r;
   const size_t group = rlc_group_items(n);
   static const bool trace = getenv("DSV_RLC_TRACE") != nullptr;  // why a group was (not) accepted: makes the call synchronous
   static const bool sample_on = !(getenv("DSV_RLC_SAMPLE") && atoi(getenv("DSV_RLC_SAMPLE")) == 0);
+  static const bool guard_on = !(getenv("DSV_RLC_GUARD") && atoi(getenv("DSV_RLC_GUARD")) == 0);
   const int force_groups = g_rlc_force_groups.load(std::memory_order_relaxed);
   // what the device's recent calls say (written by the verdict kernels; read without waiting for anything)
   const u32 history = *reinterpret_cast<volatile u32*>(ctx.rlc_pinned);
   const u32 history_long = *reinterpret_cast<volatile u32*>(ctx.rlc_pinned + 2);
-  static const bool guard_on = !(getenv("DSV_RLC_GUARD") && atoi(getenv("DSV_RLC_GUARD")) == 0);
   RlcVerdictArgs va = {};
   u32* flags_area = nullptr;
-  struct Traced {
-    size_t off, cnt;
-    RlcPlan plan, plan2;  // plan2.groups != 0: the second stage of a guarded group
-    bool sampled;
-  } traced[kRlcMaxGroupsPerCall];
+  RlcTraced traced[kRlcMaxGroupsPerCall];
   for (size_t off = 0, k = 0; off < n; off += group, k++) {
     const size_t cnt = n - off < group ? n - off : group;
     if (k >= kRlcMaxGroupsPerCall) return fail(DSV_ERR_TOO_LARGE, "more than %zu groups", kRlcMaxGroupsPerCall);
@@ -235,17 +339,17 @@ int verify_rlc_on(Context& ctx, int scheme, const void* u, const void* R_uv, con
     if (!window_bits && cnt < rlc_min_auto(scheme) && !have_challenges) {
       // too small for an aggregate to pay: the per-signature entry point as it is
       va.subs[k] = 0;
-      traced[k] = Traced{off, cnt, RlcPlan{}, RlcPlan{}, false};
+      traced[k] = RlcTraced{off, cnt, RlcPlan{}, RlcPlan{}, false};
       int r;
       const uint8_t* vin = valid_in ? valid_in + off : nullptr;
       if (scheme == 0)
-        r = verify_single_on(ctx, pu + 32 * off, pR + 64 * off, pPK + 64 * off, pm + 32 * off, cnt, pok + off, workspace, s, vin);
+        r = verify_single_on(ctx, c.u + 32 * off, c.R + 64 * off, c.PK + 64 * off, c.m + 32 * off, cnt, c.ok + off, workspace, s, vin);
       else if (scheme == 1)
-        r = verify_double_on(ctx, pu + 32 * off, pR + 64 * off, pRp + 64 * off, pPK + 64 * off, pPKp + 64 * off,
-                             pm + 32 * off, cnt, pok + off, workspace, s, vin);
+        r = verify_double_on(ctx, c.u + 32 * off, c.R + 64 * off, c.Rp + 64 * off, c.PK + 64 * off, c.PKp + 64 * off,
+                             c.m + 32 * off, cnt, c.ok + off, workspace, s, vin);
       else
-        r = verify_vargen_on(ctx, pu + 32 * off, pR + 64 * off, pPK + 64 * off, pG + 64 * off, pm + 32 * off, cnt,
-                             pok + off, workspace, s, vin);
+        r = verify_vargen_on(ctx, c.u + 32 * off, c.R + 64 * off, c.PK + 64 * off, c.G + 64 * off, c.m + 32 * off, cnt,
+                             c.ok + off, workspace, s, vin);
       if (r) return r;
       continue;
     }
@@ -272,52 +376,32 @@ int verify_rlc_on(Context& ctx, int scheme, const void* u, const void* R_uv, con
     if (staged) key = staged->key;  // (one group: the bucket pass of its first items is on the stream already)
     else if (int r = rlc_random_key(key)) return r;
     const bool do_sample = !window_bits && sample_on && (ctx.quad || scheme == 2) && history > 0 && !G2;
-    traced[k] = Traced{off, cnt, plan, RlcPlan{}, do_sample};
+    traced[k] = RlcTraced{off, cnt, plan, RlcPlan{}, do_sample};
     if (!staged) HIP_TRY(launch_rlc_begin(cv.b, s));  // (staged: the hook did, before the first range)
     // (have_challenges: one group whose c / valid are in the workspace already — the host form hashes
     //  chunk by chunk while the transfers run)
     if (!have_challenges)
-      launch_challenge(scheme == 1, pR + 64 * off, scheme == 1 ? pRp + 64 * off : (const uint8_t*)nullptr,
-                       pm + 32 * off, cnt, cv.w.c, cv.w.valid, s, valid_in ? valid_in + off : nullptr);
-    if (do_sample) {
-      // (beside the hash on a stream of its own it costs MORE — 0.4 ms: a small kernel next to one that fills
-      //  the chip — than in line behind it: 0.26 ms)
-      const size_t sn = cnt < kRlcSample ? cnt : kRlcSample;
-      const size_t at = off + (size_t)(key.w[7] % (u32)((cnt - sn) / 64 + 1)) * 64;  // (the key's last word: no weight uses it)
-      const size_t rel = at - off;
-      u32* tables = carve(cv.sample_ws, sn).tables;
-      if (scheme == 0)
-        launch_verify_fixed(ctx, false, pu + 32 * at, cv.w.c + 32 * rel, pPK + 64 * at, pR + 64 * at, 0, cv.w.valid + rel, sn,
-                            cv.sample_ok, tables, s);
-      else if (scheme == 1)
-        launch_verify_fixed_double(ctx, pu + 32 * at, cv.w.c + 32 * rel, pPK + 64 * at, pR + 64 * at, pPKp + 64 * at,
-                                   pRp + 64 * at, cv.w.valid + rel, sn, cv.sample_ok, tables, s);
-      else  // (one lane per signature: ~1 ms for the sample — worth it only because it is rarely taken)
-        launch_verify_var(pu + 32 * at, cv.w.c + 32 * rel, pPK + 64 * at, pG + 64 * at, pR + 64 * at, cv.w.valid + rel, sn,
-                          cv.sample_ok, tables, s);
-      // a WRONG item counts, a malformed one does not (`valid` covers what the hash reads — R, R', m; u and
-      // the keys are range-checked here as the verify kernel does)
-      launch_rlc_sample_decide(cv.sample_ok, cv.w.valid + rel, pu + 32 * at, pPK + 64 * at,
-                               scheme == 0 ? (const uint8_t*)nullptr : (scheme == 1 ? pPKp : pG) + 64 * at, 0, sn, cv.b.flags, s);
-    }
+      launch_challenge(scheme == 1, c.R + 64 * off, scheme == 1 ? c.Rp + 64 * off : (const uint8_t*)nullptr, c.m + 32 * off, cnt,
+                       cv.w.c, cv.w.valid, s, valid_in ? valid_in + off : nullptr);
+    if (do_sample) rlc_enqueue_sample(c, cv, key, off, cnt);
     RlcInputs in = {};
-    in.u = pu + 32 * off, in.c = cv.w.c, in.valid = cv.w.valid;
-    in.pk[0] = pPK + 64 * off, in.r[0] = pR + 64 * off;
-    if (scheme == 1) in.pk[1] = pPKp + 64 * off, in.r[1] = pRp + 64 * off;
-    if (scheme == 2) in.gen = pG + 64 * off;
+    in.u = c.u + 32 * off, in.c = cv.w.c, in.valid = cv.w.valid;
+    in.pk[0] = c.PK + 64 * off, in.r[0] = c.R + 64 * off;
+    if (scheme == 1) in.pk[1] = c.PKp + 64 * off, in.r[1] = c.Rp + 64 * off;
+    if (scheme == 2) in.gen = c.G + 64 * off;
     if (staged) {
       HIP_TRY(launch_rlc_buckets(scheme, rlc_range(plan, staged->boundary, cnt - staged->boundary), cv.b, in, key,
-                                 pok + off, true, s));
+                                 c.ok + off, true, s));
       HIP_TRY(launch_rlc_finish(plan, cv.b, ctx.table[0], ctx.table[1], true, s));
     } else {
-      HIP_TRY(launch_rlc_buckets(scheme, plan, cv.b, in, key, pok + off, false, s));
+      HIP_TRY(launch_rlc_buckets(scheme, plan, cv.b, in, key, c.ok + off, false, s));
       HIP_TRY(launch_rlc_finish(plan, cv.b, ctx.table[0], ctx.table[1], false, s));
     }
     // what decides the per-signature launches: this stage's flag words, or (guarded) those of a second stage
     // of sub-group aggregates over the same challenges, with fresh weights, in the first stage's buffers
     const u32* gflags = cv.b.flags;
     size_t sub = plan.sub;
-    bool split_fallback = plan.groups > 1;
+    bool split_fallback = plan.groups > 1;  // (ONE sub-group — the steady state — expects to be accepted: one launch)
     if (G2) {
       const RlcPlan plan2 = rlc_group_plan(scheme, cnt, window_bits, G2);
       RlcCarve cv2 = carve_rlc(workspace, group, cnt, plan2);
@@ -326,7 +410,7 @@ int verify_rlc_on(Context& ctx, int scheme, const void* u, const void* R_uv, con
       if (int r2 = rlc_random_key(key2)) return r2;
       HIP_TRY(launch_rlc_begin(cv2.b, s));
       launch_rlc_chain(cv.b.flags, cv2.b.flags, plan2.groups, s);
-      HIP_TRY(launch_rlc_buckets(scheme, plan2, cv2.b, in, key2, pok + off, false, s));
+      HIP_TRY(launch_rlc_buckets(scheme, plan2, cv2.b, in, key2, c.ok + off, false, s));
       HIP_TRY(launch_rlc_finish(plan2, cv2.b, ctx.table[0], ctx.table[1], false, s));
       gflags = cv2.b.flags;
       sub = plan2.sub;
@@ -335,77 +419,14 @@ int verify_rlc_on(Context& ctx, int scheme, const void* u, const void* R_uv, con
       va.second[k] = 1;
       traced[k].plan2 = plan2;
     }
-    // the per-signature kernels, from the challenges already in the workspace (run_split carves it the same
-    // way), each launch gated by its sub-group's flag words: no work where the aggregate accepted.
-    // ONE sub-group — the steady state, where the aggregate is expected to accept —: one launch over the whole
-    // group (sixteen gated sub-batch launches cost 0.05 ms of an accepted call's 5.3; a rejected group loses
-    // the few percent the sub-batch split returns, once: the next call runs in sub-groups).
-    Context* cp = &ctx;
-    auto fallback = [=](size_t o, size_t part, const Workspace& w, hipStream_t ps) {
-      // (sub-groups are whole sub-batches; an unsplit launch covers one sub-group or is cut here)
-      for (size_t done = 0; done < part;) {
-        const size_t at = off + o + done, g = (o + done) / sub;
-        size_t take = (g + 1) * sub - (o + done);
-        if (take > part - done) take = part - done;
-        const u32* gate = gflags + 4 + 4 * g;
-        if (scheme == 0)
-          launch_verify_fixed(*cp, false, pu + 32 * at, w.c + 32 * done, pPK + 64 * at, pR + 64 * at, 0, w.valid + done, take,
-                              pok + at, w.tables, ps, false, gate);
-        else if (scheme == 1)
-          launch_verify_fixed_double(*cp, pu + 32 * at, w.c + 32 * done, pPK + 64 * at, pR + 64 * at, pPKp + 64 * at,
-                                     pRp + 64 * at, w.valid + done, take, pok + at, w.tables, ps, false, gate);
-        else
-          launch_verify_var(pu + 32 * at, (const uint8_t*)w.c + 32 * done, pPK + 64 * at, pG + 64 * at, pR + 64 * at,
-                            (const uint8_t*)w.valid + done, take, pok + at, w.tables, ps, gate);
-        done += take;
-      }
-    };
-    int r = DSV_OK;
-    if (!split_fallback) {
-      fallback((size_t)0, cnt, cv.w, s);
-      HIP_TRY(hipGetLastError());
-    } else {
-      r = run_split(ctx, cnt, workspace, s, fallback);
-    }
-    if (r) return r;
+    if (int r = rlc_enqueue_fallback(c, cv.w, gflags, sub, split_fallback, off, cnt)) return r;
   }
   if (!flags_area)
     flags_area = carve_rlc(workspace, group, group, rlc_group_plan(scheme, group, window_bits ? window_bits : 8, 1)).flags_area;
   va.and_into = and_into ? 1u : 0u;
   launch_rlc_verdict(flags_area, va, accepted_dev, ctx.rlc_pinned, s);
   HIP_TRY(hipGetLastError());
-  if (trace) {
-    HIP_TRY(hipStreamSynchronize(s));
-    std::vector<u32> f(kRlcFlagBlocks * kRlcGroupFlagWords);
-    HIP_TRY(hipMemcpy(f.data(), flags_area, f.size() * sizeof(u32), hipMemcpyDeviceToHost));
-    for (u32 k = 0; k < va.ngroups; k++) {
-      const Traced& t = traced[k];
-      if (!va.subs[k]) {
-        std::fprintf(stderr, "[dsv rlc] scheme %d items %zu..%zu: too small for an aggregate, per-signature path\n", scheme,
-                     t.off, t.off + t.cnt);
-        continue;
-      }
-      for (int stage = 0; stage < (t.plan2.groups ? 2 : 1); stage++) {
-        const RlcPlan& pl = stage ? t.plan2 : t.plan;
-        const u32* gf = f.data() + ((size_t)2 * k + stage) * kRlcGroupFlagWords;
-        if (gf[0] && !stage)
-          std::fprintf(stderr, "[dsv rlc] scheme %d items %zu..%zu: a wrong item in the sample, no aggregate\n", scheme, t.off,
-                       t.off + t.cnt);
-        if (gf[0] && stage)
-          std::fprintf(stderr, "[dsv rlc] scheme %d items %zu..%zu: second stage not needed\n", scheme, t.off, t.off + t.cnt);
-        for (u32 g = 0; g < pl.groups && !gf[0]; g++) {
-          const u32* fl = gf + 4 + 4 * g;
-          const size_t lo = t.off + (size_t)g * pl.sub, hi = lo + pl.sub < t.off + t.cnt ? lo + pl.sub : t.off + t.cnt;
-          std::fprintf(stderr, "[dsv rlc] scheme %d items %zu..%zu c=%d %ssub-group %u/%u%s (history %u / %u): %s%s%s%s%s\n", scheme,
-                       lo, hi, pl.c, t.plan2.groups ? (stage ? "second stage, " : "first stage, ") : "", g + 1, pl.groups,
-                       t.sampled ? " sampled" : "", history, history_long,
-                       fl[1] == 1 ? "" : "chain incomplete ", fl[0] & kRlcOffCurve ? "off-curve " : "",
-                       fl[0] & kRlcTorsion ? "subgroup-test " : "", fl[0] & kRlcOverflow ? "bin-overflow " : "",
-                       fl[0] & kRlcSum ? "sum " : (fl[0] == 0 && fl[1] == 1 ? "accepted" : ""));
-        }
-      }
-    }
-  }
+  if (trace) return rlc_trace(c, flags_area, va, traced, history, history_long);
   return DSV_OK;
 }
 }  // namespace dsvh
