@@ -594,9 +594,11 @@ k_rlc_merge(RlcPlan p, RlcBuffers bf) {
 //   MODE 2  lines -> segments of: sum of the lines whose index has bit j set
 //   MODE 3  segments -> S[w * c + kind * half + j], the subset sum of bit (kind * half + j) of window w
 // MODE 0 (196 k outputs of 16 inputs at c = 16: throughput) runs one lane per output.  MODES 1 - 3 (a few
-// thousand outputs: pure latency, 16 dependent additions of ~4 us each) run `count` lanes per output: every
-// lane takes one input and a butterfly of log2(count) exchanges (36 words through ds_bpermute) and additions
-// leaves the sum in all of them — 3 + 9 log2(count) multiplications deep instead of 8 count.
+// thousand outputs: pure latency, 16 dependent additions of ~4 us each) run up to FOUR lanes per output: every
+// lane adds count / 4 inputs, then a butterfly of two exchanges (36 words through ds_bpermute) and additions
+// leaves the sum in all four — 3 + 8 (count / 4 - 1) + 18 multiplications deep instead of 8 count.  (count
+// lanes per output and a butterfly of log2(count) levels is as deep, but every lane adds at every level: 5 x
+// the work, and with the 12 288 outputs of MODE 1 at c = 16 that is no longer latency: 73 against 64 us.)
 // `extra` workgroups behind the outputs' own run fsum_block (MODE 0: stage 0, MODE 1: stage 1).
 template <int MODE>
 __global__ void __launch_bounds__(64)
@@ -618,7 +620,8 @@ k_rlc_sum(const u32* __restrict__ in, size_t in_stride, RlcPlan p, u32* __restri
   else if (MODE == 2) total = (u32)p.windows * 2 * p.half * p.nseg2, count = side / 2 / p.nseg2;
   else total = (u32)p.windows * 2 * p.half, count = p.nseg2;
   const u32 t = blockIdx.x * 64 + threadIdx.x;
-  const u32 lanes_per = MODE == 0 ? 1u : count;  // a power of two <= 16 (tests/test_rlc_plan.py)
+  // count: a power of two <= 16 (tests/test_rlc_plan.py)
+  const u32 lanes_per = MODE == 0 ? 1u : (count < 4u ? count : 4u), per_lane = count / lanes_per;
   const u32 o_raw = t / lanes_per, lane = t % lanes_per;
   const bool live = o_raw < total;
   if (MODE == 0 && !live) return;
@@ -657,6 +660,8 @@ k_rlc_sum(const u32* __restrict__ in, size_t in_stride, RlcPlan p, u32* __restri
     return;
   }
   Ext acc = ext_from_niels(load_niels(in + addr(lane)));
+#pragma unroll 1
+  for (u32 k = 1; k < per_lane; k++) acc = ext_add_niels(acc, load_niels(in + addr(k * lanes_per + lane)));
 #pragma unroll 1
   for (u32 m = 1; m < lanes_per; m <<= 1) {
     const Niels mine = ext_to_niels(acc);
@@ -1012,9 +1017,10 @@ hipError_t launch_rlc_finish(const RlcPlan& p, const RlcBuffers& b, const uint32
   const unsigned side = 1u << p.half;
   // outputs x lanes per output (k_rlc_sum), + the workgroups that sum the fixed-base scalars beside them
   const unsigned g0 = grid_for((size_t)p.windows * 2 * side * p.nseg, 64);
-  const unsigned g1 = grid_for((size_t)p.windows * 2 * side * p.nseg, 64);
-  const unsigned g2 = grid_for((size_t)p.windows * 2 * p.half * p.nseg2 * (side / 2 / p.nseg2), 64);
-  const unsigned g3 = grid_for((size_t)p.windows * 2 * p.half * p.nseg2, 64);
+  auto per_out = [](unsigned count) { return count < 4u ? count : 4u; };  // lanes per output of k_rlc_sum<1..3>
+  const unsigned g1 = grid_for((size_t)p.windows * 2 * side * per_out(p.nseg), 64);
+  const unsigned g2 = grid_for((size_t)p.windows * 2 * p.half * p.nseg2 * per_out(side / 2 / p.nseg2), 64);
+  const unsigned g3 = grid_for((size_t)p.windows * 2 * p.half * per_out(p.nseg2), 64);
   hipLaunchKernelGGL(k_rlc_sum<0>, dim3(g0 + kRlcFsumBlocks * p.fixed, G), dim3(64), 0, s, b.buckets, b.bucket_stride, p,
                      b.tmp[0], b.tmp_stride[0], b, g0);
   hipLaunchKernelGGL(k_rlc_sum<1>, dim3(g1 + p.fixed, G), dim3(64), 0, s, b.tmp[0], b.tmp_stride[0], p, b.tmp[1],

@@ -53,7 +53,7 @@ constexpr int kRlcMaxSub = 16;                    // sub-groups per group: at mo
 // var-generator 1.28 / 1.25 / 1.23 x; single 2^16 items 0.96 x, 2^17 1.36 x)
 constexpr size_t kRlcMinAuto = (size_t)1 << 17;
 inline size_t rlc_min_auto(int scheme) { return scheme == 0 ? kRlcMinAuto : (size_t)1 << 14; }
-constexpr int kRlcFsumBlocks = 64;
+constexpr int kRlcFsumBlocks = 256;  // (64-thread workgroups riding on k_rlc_sum<0>: 64 of them took longer than the sums themselves)
 constexpr int kRlcTile = 8192;  // digits one workgroup of k_rlc_part1 partitions
 // flags of one sub-group (4 words): [0] defects, [1] = 1 once the chain of kernels ran to its end.
 // A sub-group is ACCEPTED iff [0] == 0 and [1] == 1: the per-signature kernels launched behind the
